@@ -1,0 +1,257 @@
+"""ctypes binding of the libdfx C ABI (``include/dfx.h``).
+
+The product loads ``difflexmm_amd/libdfx.so`` (hand-written HIP kernels for gfx950) and raises when it is
+missing -- there is no CPU fallback.  ``Engine`` is a thin, NumPy-only wrapper of one ``dfx_handle``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+DFX_MAX_FNS = 2
+DFX_FN_PARAMS = 5
+
+BOND_LINEARIZED, BOND_NONLINEAR = 0, 1
+CONTACT_NONE, CONTACT_ANGLE = 0, 1
+TABLEAU = {"dopri5": 0, "rk4": 1}
+FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_PULSE = range(7)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class dfx_special(C.Structure):
+    _fields_ = [("block", C.c_int32), ("con_mask", C.c_int32),
+                ("con_coef", (C.c_double * DFX_MAX_FNS) * 3), ("load_coef", (C.c_double * DFX_MAX_FNS) * 3)]
+
+
+class dfx_problem(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("n_npb", C.c_int32), ("n_bonds", C.c_int32), ("bonds", _ip),
+                ("bond_model", C.c_int32), ("contact", C.c_int32), ("n_special", C.c_int32),
+                ("special", C.POINTER(dfx_special)), ("n_fns", C.c_int32), ("fn_type", C.c_int32 * DFX_MAX_FNS),
+                ("batch", C.c_int32), ("tableau", C.c_int32), ("device", C.c_int32)]
+
+
+_PARAM_FIELDS = ["centroid_node_vectors", "reference_vector", "k_bond", "inertia", "damping", "void_angle0",
+                 "contact", "fn_params"]
+
+
+class dfx_params(C.Structure):
+    _fields_ = [(n, _dp) for n in _PARAM_FIELDS]
+
+
+class dfx_grads(C.Structure):
+    _fields_ = [(n, _dp) for n in _PARAM_FIELDS + ["state0"]]
+
+
+class dfx_stats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("rhs_evals", C.c_int64), ("launches", C.c_int64),
+                ("kernel_ms", C.c_double), ("stage_kernel_us", C.c_double)]
+
+
+EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_forward", "dfx_adjoint",
+           "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
+           "dfx_device_count", "dfx_version"]
+
+
+def declare(lib):
+    """Attach argument / result types to every entry point of include/dfx.h."""
+    H = C.c_void_p
+    lib.dfx_create.argtypes = [C.POINTER(dfx_problem), C.POINTER(H)]
+    lib.dfx_destroy.argtypes = [H]
+    lib.dfx_last_error.argtypes = [H]
+    lib.dfx_last_error.restype = C.c_char_p
+    lib.dfx_set_params.argtypes = [H, C.POINTER(dfx_params)]
+    lib.dfx_forward.argtypes = [H, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
+    lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
+    lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
+    lib.dfx_rhs.argtypes = [H, _dp, C.c_double, _dp]
+    lib.dfx_rhs_vjp.argtypes = [H, _dp, C.c_double, _dp, _dp, C.POINTER(dfx_grads)]
+    lib.dfx_energy.argtypes = [H, _dp, _dp]
+    lib.dfx_device_count.restype = C.c_int
+    lib.dfx_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("dfx_last_error", "dfx_version"):
+            getattr(lib, name).restype = C.c_int
+    return lib
+
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfx.so")
+
+
+def load_library():
+    """Load the HIP engine.  Fails loudly when it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"difflexmm_amd: {path} not found -- build the HIP engine first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C difflexmm_amd/csrc)")
+        _LIB = declare(C.CDLL(path))
+    return _LIB
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class Engine:
+    """One ``dfx_handle``: a lattice + boundary-condition pattern, ``batch`` members wide."""
+
+    def __init__(self, n_blocks, n_npb, bonds, bond_model, contact, special, fn_types, batch=1,
+                 tableau="dopri5", device=0, lib=None):
+        self.lib = lib if lib is not None else load_library()
+        self.n_blocks, self.n_npb, self.batch = int(n_blocks), int(n_npb), int(batch)
+        self.bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
+        self.n_bonds = len(self.bonds)
+        self.fn_types = list(fn_types)
+        self.n_fns = len(self.fn_types)
+        self.contact = int(contact)
+        spec = (dfx_special * max(1, len(special)))()
+        for i, (block, mask, con, load) in enumerate(special):
+            spec[i].block, spec[i].con_mask = int(block), int(mask)
+            for d in range(3):
+                for f in range(DFX_MAX_FNS):
+                    spec[i].con_coef[d][f] = float(con[d][f]) if f < self.n_fns else 0.0
+                    spec[i].load_coef[d][f] = float(load[d][f]) if f < self.n_fns else 0.0
+        prob = dfx_problem()
+        prob.n_blocks, prob.n_npb, prob.n_bonds = self.n_blocks, self.n_npb, self.n_bonds
+        prob.bonds = self.bonds.ctypes.data_as(_ip)
+        prob.bond_model, prob.contact = int(bond_model), self.contact
+        prob.n_special, prob.special = len(special), spec
+        prob.n_fns = self.n_fns
+        for f in range(DFX_MAX_FNS):
+            prob.fn_type[f] = int(self.fn_types[f]) if f < self.n_fns else 0
+        prob.batch, prob.tableau, prob.device = self.batch, TABLEAU[tableau], int(device)
+        self._h = C.c_void_p()
+        rc = self.lib.dfx_create(C.byref(prob), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("dfx_create failed: " + self.lib.dfx_last_error(None).decode())
+        self.n_timepoints = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.dfx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: " + self.lib.dfx_last_error(self._h).decode())
+
+    # -- parameters ---------------------------------------------------------------------------
+    def shapes(self):
+        B, nb, npb, nbd = self.batch, self.n_blocks, self.n_npb, self.n_bonds
+        return {"centroid_node_vectors": (B, nb, npb, 2), "reference_vector": (B, nbd, 2), "k_bond": (B, nbd, 3),
+                "inertia": (B, nb, 3), "damping": (B, nb, 3), "void_angle0": (B, nbd, 2), "contact": (B, 3),
+                "fn_params": (B, max(1, self.n_fns), DFX_FN_PARAMS), "state0": (B, 2, nb, 3)}
+
+    def set_params(self, **arrays):
+        """Arrays by ``dfx_params`` field name; shapes as in :meth:`shapes` (broadcast over batch)."""
+        sh = self.shapes()
+        p = dfx_params()
+        keep = []
+        for name in _PARAM_FIELDS:
+            a = arrays.get(name)
+            if a is None:
+                continue
+            a = _f64(a, sh[name])
+            keep.append(a)
+            setattr(p, name, _ptr(a))
+        self._check(self.lib.dfx_set_params(self._h, C.byref(p)), "dfx_set_params")
+
+    # -- solves -------------------------------------------------------------------------------
+    def forward(self, state0, timepoints, steps_per_interval, keep_trajectory=False, want_fields=True):
+        B, nb = self.batch, self.n_blocks
+        state0 = _f64(state0, (B, 2, nb, 3))
+        ts = _f64(timepoints)
+        T = len(ts)
+        fields = np.empty((B, T, 2, nb, 3)) if want_fields else None
+        st = dfx_stats()
+        self._check(self.lib.dfx_forward(self._h, _ptr(state0), _ptr(ts), T, int(steps_per_interval),
+                                         int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward")
+        self.n_timepoints = T
+        return fields, _stats(st)
+
+    def _grads(self, which):
+        sh = self.shapes()
+        g = dfx_grads()
+        out = {}
+        for name in which:
+            if name == "fn_params" and self.n_fns == 0:
+                continue
+            if name in ("void_angle0", "contact") and not self.contact:
+                continue
+            out[name] = np.zeros(sh[name])
+            setattr(g, name, _ptr(out[name]))
+        return g, out
+
+    ALL_GRADS = tuple(_PARAM_FIELDS + ["state0"])
+
+    def adjoint(self, fields_bar, which=ALL_GRADS):
+        B, nb = self.batch, self.n_blocks
+        fb = _f64(fields_bar, (B, self.n_timepoints, 2, nb, 3))
+        g, out = self._grads(which)
+        st = dfx_stats()
+        self._check(self.lib.dfx_adjoint(self._h, _ptr(fb), C.byref(g), C.byref(st)), "dfx_adjoint")
+        return out, _stats(st)
+
+    def objective_kinetic(self, target_blocks):
+        tb = np.ascontiguousarray(target_blocks, dtype=np.int32)
+        obj = np.zeros(self.batch)
+        self._check(self.lib.dfx_objective_kinetic(self._h, tb.ctypes.data_as(_ip), len(tb), _ptr(obj)),
+                    "dfx_objective_kinetic")
+        return obj
+
+    def adjoint_kinetic(self, target_blocks, which=ALL_GRADS):
+        tb = np.ascontiguousarray(target_blocks, dtype=np.int32)
+        g, out = self._grads(which)
+        st = dfx_stats()
+        self._check(self.lib.dfx_adjoint_kinetic(self._h, tb.ctypes.data_as(_ip), len(tb), C.byref(g), C.byref(st)),
+                    "dfx_adjoint_kinetic")
+        return out, _stats(st)
+
+    # -- test hooks ---------------------------------------------------------------------------
+    def rhs(self, y, t):
+        B, nb = self.batch, self.n_blocks
+        y = _f64(y, (B, 2, nb, 3))
+        dy = np.empty_like(y)
+        self._check(self.lib.dfx_rhs(self._h, _ptr(y), float(t), _ptr(dy)), "dfx_rhs")
+        return dy
+
+    def rhs_vjp(self, y, t, lam, which=tuple(_PARAM_FIELDS)):
+        B, nb = self.batch, self.n_blocks
+        y, lam = _f64(y, (B, 2, nb, 3)), _f64(lam, (B, 2, nb, 3))
+        y_bar = np.empty_like(y)
+        g, out = self._grads(which)
+        self._check(self.lib.dfx_rhs_vjp(self._h, _ptr(y), float(t), _ptr(lam), _ptr(y_bar), C.byref(g)), "dfx_rhs_vjp")
+        return y_bar, out
+
+    def energy(self, u):
+        u = _f64(u, (self.batch, self.n_blocks, 3))
+        e = np.zeros(self.batch)
+        self._check(self.lib.dfx_energy(self._h, _ptr(u), _ptr(e)), "dfx_energy")
+        return e
+
+
+def _stats(st):
+    return {"steps": st.steps, "rhs_evals": st.rhs_evals, "launches": st.launches, "kernel_ms": st.kernel_ms,
+            "stage_kernel_us": st.stage_kernel_us}

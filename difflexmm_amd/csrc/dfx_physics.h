@@ -1,0 +1,358 @@
+// dfx_physics.h -- per-ligament physics of the DifFlexMM hot path, hand-derived.
+//
+// One header, compiled for gfx950 device code (dfx_kernels.hip) and for the host
+// (oracle/cpu/dfx_cpu.cpp, the timed CPU port).  Everything is templated on the scalar
+// type T: T = double gives energy gradients (forces); T = Dual (first-order forward-mode
+// number) pushed through the SAME hand-written gradient gives, in the epsilon parts, the
+// Hessian-vector product and every mixed parameter derivative the adjoint sweep needs
+// (grad_{u,p} of  d/d eps E(u + eps w, p)).
+//
+// Reference formulas restated here (file:line relative to /root/reference):
+//   node kinematics      difflexmm/kinematics.py:13-31   U = u_xy + (R(theta) - I) r
+//   nonlinear ligament   difflexmm/energy.py:120-176
+//   linearised ligament  difflexmm/energy.py:70-117
+//   angle-based contact  difflexmm/energy.py:204-219,333-361 + geometry.py:181-253
+//   driving functions    problems/quads_focusing.py:211-222, tests/test_difflexmm.py:85-86,
+//                        scripts/pulse_RS.py:49-50, problems/hinge_characterization.py:134-139
+//
+// Algebraic restatements (mathematically identical, cheaper on the GPU):
+//  * shear strain  wrap(atan2(b) - atan2(R(tb) l0))  ==  atan2((R(tb) l0) x b, (R(tb) l0) . b)
+//    (differs from the reference's floor-mod only at exactly +-pi);
+//  * cos/sin of the mean rotation from the half-angle pair (cos(th/2), sin(th/2)) carried in
+//    the per-block stage record, so one sincos per block per RHS instead of three per bond;
+//  * a void angle is the angle between two edges of two rigid blocks, so it equals
+//    wrap(phi +- (theta_A - theta_B)) with phi the same angle in the undeformed design:
+//    block centroids and translations cancel exactly (energy.py:397-404 adds them, then
+//    geometry.py:196-199 subtracts them again).  phi is computed once per solve on the host.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define DFX_HD __host__ __device__ __forceinline__
+#else
+#define DFX_HD inline
+#endif
+
+namespace dfx {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 6.28318530717958647692;
+
+// ---------------------------------------------------------------------------------------
+// first-order forward-mode number
+// ---------------------------------------------------------------------------------------
+struct Dual {
+  double v, e;
+  DFX_HD Dual() : v(0.0), e(0.0) {}
+  DFX_HD Dual(double a) : v(a), e(0.0) {}
+  DFX_HD Dual(double a, double b) : v(a), e(b) {}
+};
+DFX_HD Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.e + b.e); }
+DFX_HD Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.e - b.e); }
+DFX_HD Dual operator-(Dual a) { return Dual(-a.v, -a.e); }
+DFX_HD Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.v * b.e + a.e * b.v); }
+DFX_HD Dual operator*(double a, Dual b) { return Dual(a * b.v, a * b.e); }
+DFX_HD Dual operator*(Dual a, double b) { return Dual(a.v * b, a.e * b); }
+DFX_HD Dual operator+(Dual a, double b) { return Dual(a.v + b, a.e); }
+DFX_HD Dual operator+(double a, Dual b) { return Dual(a + b.v, b.e); }
+DFX_HD Dual operator-(Dual a, double b) { return Dual(a.v - b, a.e); }
+DFX_HD Dual operator-(double a, Dual b) { return Dual(a - b.v, -b.e); }
+DFX_HD Dual operator/(Dual a, Dual b) {
+  double r = 1.0 / b.v;
+  double q = a.v * r;
+  return Dual(q, (a.e - q * b.e) * r);
+}
+DFX_HD Dual operator/(double a, Dual b) {
+  double r = 1.0 / b.v;
+  double q = a * r;
+  return Dual(q, -q * b.e * r);
+}
+
+DFX_HD double val(double a) { return a; }
+DFX_HD double val(Dual a) { return a.v; }
+DFX_HD double eps(double) { return 0.0; }
+DFX_HD double eps(Dual a) { return a.e; }
+
+DFX_HD double tsqrt(double a) { return sqrt(a); }
+DFX_HD Dual tsqrt(Dual a) {
+  double s = sqrt(a.v);
+  return Dual(s, 0.5 * a.e / s);
+}
+DFX_HD double tatan2(double y, double x) { return atan2(y, x); }
+DFX_HD Dual tatan2(Dual y, Dual x) {
+  return Dual(atan2(y.v, x.v), (x.v * y.e - y.v * x.e) / (x.v * x.v + y.v * y.v));
+}
+// wrap an angle into [-pi, pi] (value only; derivative 1)
+DFX_HD double twrap(double a) { return a - kTwoPi * rint(a * (1.0 / kTwoPi)); }
+DFX_HD Dual twrap(Dual a) { return Dual(twrap(a.v), a.e); }
+
+// ---------------------------------------------------------------------------------------
+// per-block stage record: (x, y, theta) plus the half-angle pair
+// ---------------------------------------------------------------------------------------
+template <class T>
+struct BlockRec {
+  T x, y, th, ch, sh;  // ch = cos(th/2), sh = sin(th/2)
+};
+
+DFX_HD BlockRec<Dual> seed_rec(const BlockRec<double>& r, double wx, double wy, double wth) {
+  BlockRec<Dual> d;
+  d.x = Dual(r.x, wx);
+  d.y = Dual(r.y, wy);
+  d.th = Dual(r.th, wth);
+  d.ch = Dual(r.ch, -0.5 * r.sh * wth);
+  d.sh = Dual(r.sh, 0.5 * r.ch * wth);
+  return d;
+}
+
+enum BondModel { kLinearized = 0, kNonlinear = 1 };
+
+// dE_bond / d(everything the OWN end of the bond owns) + bond parameters
+template <class T>
+struct BondGrad {
+  T fx, fy, fth;   // dE/d(x, y, theta) of the own block
+  T rx, ry;        // dE/d(centroid_node_vector of the own node)
+  T lx, ly;        // dE/d(reference_vector)   (total)
+  T ks, ksh, kr;   // dE/d(k_stretch, k_shear, k_rot)
+  T e;             // bond energy
+};
+
+// Bond (node1 on block A) -> (node2 on block B).  `o` is the own block, `p` the partner;
+// sgn = +1 when the own block holds node2 (end B), -1 when it holds node1 (end A).
+// (ro) / (rp) are the centroid->node vectors of the two bonded nodes, (lx,ly) the
+// reference vector oriented node1 -> node2.
+template <int MODEL, class T>
+DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, T rox, T roy, T rpx, T rpy,
+                      T lx, T ly, T ks, T ksh, T kr, double sgn, BondGrad<T>& g) {
+  // rotation of own / partner block from the half angles
+  T co = o.ch * o.ch - o.sh * o.sh, so = 2.0 * (o.sh * o.ch);
+  T cp = p.ch * p.ch - p.sh * p.sh, sp = 2.0 * (p.sh * p.ch);
+  // rotated node vectors and node displacements (kinematics.py:24-31)
+  T qox = co * rox - so * roy, qoy = so * rox + co * roy;
+  T qpx = cp * rpx - sp * rpy, qpy = sp * rpx + cp * rpy;
+  T dUx = sgn * ((o.x + qox - rox) - (p.x + qpx - rpx));
+  T dUy = sgn * ((o.y + qoy - roy) - (p.y + qpy - rpy));
+  T kap = sgn * (o.th - p.th);  // theta_2 - theta_1
+  T l02 = lx * lx + ly * ly;
+  T l0 = tsqrt(l02);
+  T gbx, gby, gtb;  // dE/d(dU), dE/d(mean rotation)
+  if (MODEL == kNonlinear) {
+    // energy.py:139-155,172-176
+    T cb = o.ch * p.ch - o.sh * p.sh, sb = o.sh * p.ch + o.ch * p.sh;  // cos/sin of (th_o+th_p)/2
+    T bx = dUx + lx, by = dUy + ly;
+    T L2 = bx * bx + by * by;
+    T Lb = tsqrt(L2);
+    T px = cb * lx - sb * ly, py = sb * lx + cb * ly;
+    T gam = tatan2(px * by - py * bx, px * bx + py * by);
+    T es = Lb - l0;
+    T iL2 = 1.0 / L2;
+    T iLb = Lb * iL2;
+    T kse = ks * es, kshg = ksh * gam;
+    T shear = kshg * l02;  // dE/dgamma
+    g.e = 0.5 * (kse * es) + 0.5 * (shear * gam) + 0.5 * (kr * kap * kap);
+    gbx = kse * bx * iLb - shear * by * iL2;
+    gby = kse * by * iLb + shear * bx * iL2;
+    gtb = -shear;
+    T il0 = 1.0 / l0;
+    g.lx = gbx - kse * lx * il0 + kshg * gam * lx + kshg * ly;
+    g.ly = gby - kse * ly * il0 + kshg * gam * ly - kshg * lx;
+    g.ks = 0.5 * (es * es);
+    g.ksh = 0.5 * (l02 * gam * gam);
+  } else {
+    // energy.py:88-96,113-117
+    T tb = 0.5 * (o.th + p.th);
+    T il0 = 1.0 / l0;
+    T dot = dUx * lx + dUy * ly;
+    T crs = lx * dUy - ly * dUx;
+    T es = dot * il0;
+    T esh = crs * il0 - tb * l0;
+    T kse = ks * es, kshe = ksh * esh;
+    g.e = 0.5 * (kse * es) + 0.5 * (kshe * esh) + 0.5 * (kr * kap * kap);
+    gbx = (kse * lx - kshe * ly) * il0;
+    gby = (kse * ly + kshe * lx) * il0;
+    gtb = -(kshe * l0);
+    T il02 = il0 * il0;
+    T c3 = crs * il0 * il02;
+    g.lx = kse * (dUx * il0 - es * lx * il02) + kshe * (dUy * il0 - c3 * lx - tb * lx * il0);
+    g.ly = kse * (dUy * il0 - es * ly * il02) + kshe * (-(dUx * il0) - c3 * ly - tb * ly * il0);
+    g.ks = 0.5 * (es * es);
+    g.ksh = 0.5 * (esh * esh);
+  }
+  g.kr = 0.5 * (kap * kap);
+  T krk = kr * kap;
+  g.fx = sgn * gbx;
+  g.fy = sgn * gby;
+  g.fth = sgn * (gby * qox - gbx * qoy) + 0.5 * gtb + sgn * krk;
+  g.rx = sgn * (co * gbx + so * gby - gbx);
+  g.ry = sgn * (co * gby - so * gbx - gby);
+}
+
+// Angle-based contact of one bond (energy.py:333-361 on the two void angles of energy.py:204-219).
+//   a1 = wrap(phi1 - kap), a2 = wrap(phi2 + kap), kap = theta_B - theta_A.
+template <class T>
+struct ContactGrad {
+  T dkap;        // dE/dkap
+  T p1, p2;      // dE/dphi1, dE/dphi2
+  T am, ac, kc;  // dE/d(min_angle, cutoff_angle, k_contact)
+  T e;
+};
+
+template <class T>
+DFX_HD void contact_one(T a, T am, T ac, T kc, T& e, T& da, T& dam, T& dac, T& dkc) {
+  a = twrap(a);
+  if (val(a) >= val(am) && val(a) < val(ac)) {
+    T D = ac - am;
+    T x = (a - ac) / D;
+    T ip = 1.0 / (x + 1.0), im = 1.0 / (x - 1.0);
+    T h = ip - im - 2.0;
+    T hp = im * im - ip * ip;
+    T qD = 0.25 * (kc * D);
+    e = qD * D * h;
+    da = qD * hp;
+    dac = qD * (2.0 * h - (1.0 + x) * hp);
+    dam = qD * (x * hp - 2.0 * h);
+    dkc = 0.25 * (D * D * h);
+  } else {
+    e = T(0.0); da = T(0.0); dam = T(0.0); dac = T(0.0); dkc = T(0.0);
+  }
+}
+
+template <class T>
+DFX_HD void contact_grad(T kap, T phi1, T phi2, T am, T ac, T kc, ContactGrad<T>& g) {
+  T e1, d1, m1, c1, k1, e2, d2, m2, c2, k2;
+  contact_one(phi1 - kap, am, ac, kc, e1, d1, m1, c1, k1);
+  contact_one(phi2 + kap, am, ac, kc, e2, d2, m2, c2, k2);
+  g.e = e1 + e2;
+  g.dkap = d2 - d1;
+  g.p1 = d1;
+  g.p2 = d2;
+  g.am = m1 + m2;
+  g.ac = c1 + c2;
+  g.kc = k1 + k2;
+}
+
+// ---------------------------------------------------------------------------------------
+// closed library of scalar time functions; value, d/dt and d/dparams
+// ---------------------------------------------------------------------------------------
+enum TimeFnType {
+  kFnZero = 0,
+  kFnPulse = 1,       // p = (A, f, t_d):  A/2 (1 - cos 2 pi f tau) on 0 < tau < 1/f, tau = t - t_d
+  kFnHarmonic = 2,    // same, on tau > 0
+  kFnRamp = 3,        // p = (A, r):       A * (t r  if t < 1/r else 1)
+  kFnSech2Tanh = 4,   // p = (A, s):       2A/s^2 sech^2(t/s - 3) tanh(3 - t/s)
+  kFnConstant = 5,    // p = (A)
+  kFnRampPulse = 6    // p = (A, f, t_d, S, r): S*min(t r,1) + pulse(t - t_d; A, f)   (static tuning)
+};
+constexpr int kMaxFnParams = 5;
+
+struct TimeFn {
+  int type;
+  int pad;
+  double p[kMaxFnParams];
+};
+
+// g = value, gt = dg/dt, gp[i] = dg/dp[i]
+DFX_HD void eval_time_fn(const TimeFn& f, double t, double& g, double& gt, double* gp) {
+  for (int i = 0; i < kMaxFnParams; ++i) gp[i] = 0.0;
+  g = 0.0;
+  gt = 0.0;
+  switch (f.type) {
+    case kFnPulse:
+    case kFnHarmonic:
+    case kFnRampPulse: {
+      double A = f.p[0], fr = f.p[1], tau = t - f.p[2];
+      bool on = (tau > 0.0) && (f.type == kFnHarmonic || tau * fr < 1.0);
+      if (on) {
+        double ph = kTwoPi * fr * tau;
+        double s = sin(ph), c = cos(ph);
+        g = 0.5 * A * (1.0 - c);
+        gt = A * kPi * fr * s;
+        gp[0] = 0.5 * (1.0 - c);
+        gp[1] = A * kPi * tau * s;
+        gp[2] = -gt;
+      }
+      if (f.type == kFnRampPulse) {
+        double S = f.p[3], r = f.p[4];
+        if (t * r < 1.0) { g += S * t * r; gt += S * r; gp[3] = t * r; gp[4] = S * t; }
+        else { g += S; gp[3] = 1.0; }
+      }
+    } break;
+    case kFnRamp: {
+      double A = f.p[0], r = f.p[1];
+      if (t * r < 1.0) { g = A * t * r; gt = A * r; gp[0] = t * r; gp[1] = A * t; }
+      else { g = A; gp[0] = 1.0; }
+    } break;
+    case kFnSech2Tanh: {
+      double A = f.p[0], s = f.p[1];
+      double z = t / s - 3.0;
+      double th = tanh(z), se2 = 1.0 - th * th;
+      double pre = 2.0 * A / (s * s);
+      g = -pre * se2 * th;                       // tanh(3 - t/s) = -tanh(z)
+      double dgdz = -pre * se2 * (1.0 - 3.0 * th * th);
+      gt = dgdz / s;
+      gp[0] = g / A;
+      gp[1] = -2.0 * g / s + dgdz * (-t / (s * s));
+    } break;
+    case kFnConstant:
+      g = f.p[0];
+      gp[0] = 1.0;
+      break;
+    default:
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// explicit Runge-Kutta tableaux in "acceleration form"
+//   k_j = (V_j, A_j);  V_i = v_n + h sum_j a_ij A_j;  Q_i = q_n + h c_i v_n + h^2 sum_l aa_il A_l
+//   with aa = a * a  (so only accelerations are stored between stages).
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxStages = 7;
+struct Tableau {
+  int s;                                 // stages per step (dopri5 fixed-step: 6, rk4: 4)
+  double c[kMaxStages + 1];              // stage times; c[s] = 1 (the step end)
+  double a[kMaxStages + 1][kMaxStages];  // rows 0..s-1: stage coefficients, row s: solution weights b
+  double aa[kMaxStages + 1][kMaxStages]; // (a*a) rows incl. the b row:  sum_j a_ij a_jl
+};
+
+inline Tableau make_tableau(int s, const double* c, const double* a /* (s+1) x s, last row = b */) {
+  Tableau t;
+  t.s = s;
+  for (int i = 0; i <= kMaxStages; ++i) {
+    t.c[i] = 0.0;
+    for (int j = 0; j < kMaxStages; ++j) { t.a[i][j] = 0.0; t.aa[i][j] = 0.0; }
+  }
+  for (int i = 0; i <= s; ++i) {
+    t.c[i] = (i < s) ? c[i] : 1.0;
+    for (int j = 0; j < s; ++j) t.a[i][j] = a[i * s + j];
+  }
+  for (int i = 0; i <= s; ++i)
+    for (int l = 0; l < s; ++l) {
+      double acc = 0.0;
+      for (int j = 0; j < s; ++j) acc += t.a[i][j] * t.a[j][l];
+      t.aa[i][l] = acc;
+    }
+  return t;
+}
+
+inline Tableau tableau_dopri5() {
+  // Dormand-Prince 5(4), fixed step: 6 stages, solution weights = row 7 of the tableau (FSAL)
+  static const double c[6] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0};
+  static const double a[7 * 6] = {
+      0, 0, 0, 0, 0, 0,
+      1.0 / 5, 0, 0, 0, 0, 0,
+      3.0 / 40, 9.0 / 40, 0, 0, 0, 0,
+      44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0,
+      19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0,
+      9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0,
+      35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+  return make_tableau(6, c, a);
+}
+
+inline Tableau tableau_rk4() {
+  static const double c[4] = {0.0, 0.5, 0.5, 1.0};
+  static const double a[5 * 4] = {0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 1.0, 0,
+                                  1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+  return make_tableau(4, c, a);
+}
+
+}  // namespace dfx

@@ -1,0 +1,184 @@
+// dfx_plan.h -- host-side problem plan shared by the HIP engine (dfx_engine.hip) and the CPU port
+// (oracle/cpu/dfx_cpu.cpp): turns the reference's bond list into the slot-indexed tables the
+// kernels read, packs ControlParams into that layout and scatters slot gradients back.
+//
+// Layout ("gather form", one lane per (block, node slot), 4 slots per block):
+//   slot = 4*block + local_node          (kagome blocks use slots 0..2, slot 3 is padding)
+//   slot_info[slot] = 2*partner_slot + own_is_end2   or -1 when the node carries no ligament
+// Every ligament is therefore evaluated by both of its ends; each end keeps only the derivatives
+// of quantities it owns, so forces and parameter gradients are accumulated without atomics and
+// bit-reproducibly.  Ligament parameters are duplicated to both slots (coalesced loads).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dfx.h"
+#include "dfx_physics.h"
+
+namespace dfx {
+
+constexpr int kSlots = 4;        // lanes per block
+constexpr int kRec = 8;          // doubles per block stage record: x y th cos(th/2) sin(th/2) vx vy vth
+constexpr int kSlotParams = 9;   // r(2) l0(2) k(3) phi(2)
+
+struct Plan {
+  int n_blocks = 0, n_npb = 0, n_bonds = 0, batch = 1, n_slots = 0;
+  int model = 0, contact = 0, n_fns = 0, n_special = 0;
+  int fn_type[DFX_MAX_FNS] = {0, 0};
+  Tableau tab;
+  std::vector<int32_t> slot_info;      // n_slots
+  std::vector<int32_t> slot_bond;      // n_slots, bond id or -1
+  std::vector<int32_t> block_special;  // n_blocks, index into special or -1
+  std::vector<dfx_special> special;
+};
+
+inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
+  if (!p || p->n_blocks <= 0 || (p->n_npb != 3 && p->n_npb != 4)) { err = "invalid problem: n_blocks/n_npb"; return 1; }
+  if (p->batch <= 0) { err = "invalid problem: batch must be >= 1"; return 1; }
+  if (p->n_fns < 0 || p->n_fns > DFX_MAX_FNS) { err = "invalid problem: n_fns out of range"; return 1; }
+  if (p->bond_model != DFX_BOND_LINEARIZED && p->bond_model != DFX_BOND_NONLINEAR) { err = "invalid bond_model"; return 1; }
+  if (p->contact != DFX_CONTACT_NONE && p->contact != DFX_CONTACT_ANGLE) { err = "invalid contact model"; return 1; }
+  pl.n_blocks = p->n_blocks; pl.n_npb = p->n_npb; pl.n_bonds = p->n_bonds; pl.batch = p->batch;
+  pl.n_slots = p->n_blocks * kSlots;
+  pl.model = p->bond_model; pl.contact = p->contact; pl.n_fns = p->n_fns; pl.n_special = p->n_special;
+  for (int i = 0; i < DFX_MAX_FNS; ++i) pl.fn_type[i] = i < p->n_fns ? p->fn_type[i] : 0;
+  if (p->tableau == DFX_TABLEAU_DOPRI5) pl.tab = tableau_dopri5();
+  else if (p->tableau == DFX_TABLEAU_RK4) pl.tab = tableau_rk4();
+  else { err = "invalid tableau"; return 1; }
+  pl.slot_info.assign(pl.n_slots, -1);
+  pl.slot_bond.assign(pl.n_slots, -1);
+  const int n_nodes = p->n_blocks * p->n_npb;
+  for (int b = 0; b < p->n_bonds; ++b) {
+    int n1 = p->bonds[2 * b], n2 = p->bonds[2 * b + 1];
+    if (n1 < 0 || n2 < 0 || n1 >= n_nodes || n2 >= n_nodes || n1 == n2) { err = "bond with invalid node id"; return 1; }
+    int s1 = (n1 / p->n_npb) * kSlots + n1 % p->n_npb;
+    int s2 = (n2 / p->n_npb) * kSlots + n2 % p->n_npb;
+    if (n1 / p->n_npb == n2 / p->n_npb) { err = "bond joins two nodes of one block"; return 1; }
+    if (pl.slot_info[s1] != -1 || pl.slot_info[s2] != -1) { err = "node with more than one ligament (unsupported)"; return 1; }
+    pl.slot_info[s1] = 2 * s2 + 0;
+    pl.slot_info[s2] = 2 * s1 + 1;
+    pl.slot_bond[s1] = b;
+    pl.slot_bond[s2] = b;
+  }
+  pl.block_special.assign(p->n_blocks, -1);
+  pl.special.assign(p->special, p->special + p->n_special);
+  for (int i = 0; i < p->n_special; ++i) {
+    int blk = p->special[i].block;
+    if (blk < 0 || blk >= p->n_blocks) { err = "special block id out of range"; return 1; }
+    if (pl.block_special[blk] != -1) { err = "block listed twice in special"; return 1; }
+    pl.block_special[blk] = i;
+  }
+  return 0;
+}
+
+// Packed per-member parameter image (host copy; the HIP engine uploads it verbatim).
+struct PackedParams {
+  std::vector<double> slot;     // batch * n_slots * kSlotParams
+  std::vector<double> inv_m;    // batch * n_blocks * 3
+  std::vector<double> damping;  // batch * n_blocks * 3
+  std::vector<double> contact;  // batch * 3
+  std::vector<TimeFn> fns;      // batch * DFX_MAX_FNS
+};
+
+inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, std::string& err) {
+  if (!q || !q->centroid_node_vectors || !q->reference_vector || !q->k_bond || !q->inertia) {
+    err = "set_params: centroid_node_vectors, reference_vector, k_bond and inertia are required"; return 1;
+  }
+  if (pl.contact && (!q->void_angle0 || !q->contact)) { err = "set_params: contact model needs void_angle0 and contact"; return 1; }
+  if (pl.n_fns && !q->fn_params) { err = "set_params: fn_params required"; return 1; }
+  const int B = pl.batch, NS = pl.n_slots, NB = pl.n_blocks;
+  out.slot.assign((size_t)B * NS * kSlotParams, 0.0);
+  out.inv_m.assign((size_t)B * NB * 3, 0.0);
+  out.damping.assign((size_t)B * NB * 3, 0.0);
+  out.contact.assign((size_t)B * 3, 0.0);
+  out.fns.assign((size_t)B * DFX_MAX_FNS, TimeFn{0, 0, {0, 0, 0, 0, 0}});
+  for (int m = 0; m < B; ++m) {
+    const double* cnv = q->centroid_node_vectors + (size_t)m * NB * pl.n_npb * 2;
+    const double* l0 = q->reference_vector + (size_t)m * pl.n_bonds * 2;
+    const double* kb = q->k_bond + (size_t)m * pl.n_bonds * 3;
+    const double* ph = q->void_angle0 ? q->void_angle0 + (size_t)m * pl.n_bonds * 2 : nullptr;
+    double* sp = out.slot.data() + (size_t)m * NS * kSlotParams;
+    for (int b = 0; b < NB; ++b)
+      for (int k = 0; k < pl.n_npb; ++k) {
+        double* s = sp + (size_t)(b * kSlots + k) * kSlotParams;
+        s[0] = cnv[(b * pl.n_npb + k) * 2];
+        s[1] = cnv[(b * pl.n_npb + k) * 2 + 1];
+        int bond = pl.slot_bond[b * kSlots + k];
+        if (bond >= 0) {
+          s[2] = l0[2 * bond]; s[3] = l0[2 * bond + 1];
+          s[4] = kb[3 * bond]; s[5] = kb[3 * bond + 1]; s[6] = kb[3 * bond + 2];
+          if (ph) { s[7] = ph[2 * bond]; s[8] = ph[2 * bond + 1]; }
+        }
+      }
+    for (int i = 0; i < NB * 3; ++i) {
+      double mass = q->inertia[(size_t)m * NB * 3 + i];
+      if (!(mass > 0.0)) { err = "set_params: inertia must be positive"; return 1; }
+      out.inv_m[(size_t)m * NB * 3 + i] = 1.0 / mass;
+      out.damping[(size_t)m * NB * 3 + i] = q->damping ? q->damping[(size_t)m * NB * 3 + i] : 0.0;
+    }
+    if (q->contact) for (int i = 0; i < 3; ++i) out.contact[m * 3 + i] = q->contact[m * 3 + i];
+    for (int f = 0; f < pl.n_fns; ++f) {
+      TimeFn& tf = out.fns[(size_t)m * DFX_MAX_FNS + f];
+      tf.type = pl.fn_type[f];
+      for (int i = 0; i < DFX_FN_PARAMS; ++i) tf.p[i] = q->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i];
+    }
+  }
+  return 0;
+}
+
+// Gradient accumulators in device layout (host mirror); unpacked into dfx_grads.
+//   slot_g:  batch * n_slots * kSlotGrads :  r(2) | l0(2) k(3) phi(2) contact(3)  (bond part only on end-1 slots)
+//   blk_g:   batch * n_blocks * 6         :  d/d m (3), d/d damping (3)
+//   spec_g:  batch * n_special * 3 * 2    :  u_bar of constrained DOFs folded with fn partials is done
+//            on the fly: fn_g = batch * DFX_MAX_FNS * DFX_FN_PARAMS per special block
+constexpr int kSlotGrads = 12;
+
+inline void unpack_grads(const Plan& pl, const std::vector<double>& slot_g, const std::vector<double>& blk_g,
+                         const std::vector<double>& fn_g /* batch * max(1,n_special) * MAX_FNS*FN_PARAMS */,
+                         const std::vector<double>& inv_m, dfx_grads* g) {
+  const int B = pl.batch, NS = pl.n_slots, NB = pl.n_blocks;
+  for (int m = 0; m < B; ++m) {
+    const double* sg = slot_g.data() + (size_t)m * NS * kSlotGrads;
+    if (g->centroid_node_vectors)
+      for (int b = 0; b < NB; ++b)
+        for (int k = 0; k < pl.n_npb; ++k)
+          for (int c = 0; c < 2; ++c)
+            g->centroid_node_vectors[((size_t)m * NB * pl.n_npb + b * pl.n_npb + k) * 2 + c] =
+                sg[(size_t)(b * kSlots + k) * kSlotGrads + c];
+    double con[3] = {0, 0, 0};
+    if (g->reference_vector) memset(g->reference_vector + (size_t)m * pl.n_bonds * 2, 0, sizeof(double) * pl.n_bonds * 2);
+    if (g->k_bond) memset(g->k_bond + (size_t)m * pl.n_bonds * 3, 0, sizeof(double) * pl.n_bonds * 3);
+    if (g->void_angle0) memset(g->void_angle0 + (size_t)m * pl.n_bonds * 2, 0, sizeof(double) * pl.n_bonds * 2);
+    for (int s = 0; s < NS; ++s) {
+      int info = pl.slot_info[s];
+      if (info < 0 || (info & 1)) continue;  // bond parameters live on the end-1 slot
+      int bond = pl.slot_bond[s];
+      const double* q = sg + (size_t)s * kSlotGrads;
+      if (g->reference_vector) { g->reference_vector[((size_t)m * pl.n_bonds + bond) * 2] = q[2]; g->reference_vector[((size_t)m * pl.n_bonds + bond) * 2 + 1] = q[3]; }
+      if (g->k_bond) for (int c = 0; c < 3; ++c) g->k_bond[((size_t)m * pl.n_bonds + bond) * 3 + c] = q[4 + c];
+      if (g->void_angle0) { g->void_angle0[((size_t)m * pl.n_bonds + bond) * 2] = q[7]; g->void_angle0[((size_t)m * pl.n_bonds + bond) * 2 + 1] = q[8]; }
+      for (int c = 0; c < 3; ++c) con[c] += q[9 + c];
+    }
+    if (g->contact) for (int c = 0; c < 3; ++c) g->contact[m * 3 + c] = con[c];
+    for (int i = 0; i < NB * 3; ++i) {
+      int b = i / 3, d = i % 3;
+      if (g->inertia) g->inertia[(size_t)m * NB * 3 + i] = blk_g[((size_t)m * NB + b) * 6 + d];
+      if (g->damping) g->damping[(size_t)m * NB * 3 + i] = blk_g[((size_t)m * NB + b) * 6 + 3 + d];
+    }
+    if (g->fn_params) {
+      const int W = DFX_MAX_FNS * DFX_FN_PARAMS;
+      for (int f = 0; f < pl.n_fns; ++f)
+        for (int i = 0; i < DFX_FN_PARAMS; ++i) {
+          double acc = 0.0;
+          for (int sidx = 0; sidx < pl.n_special; ++sidx) acc += fn_g[((size_t)m * pl.n_special + sidx) * W + f * DFX_FN_PARAMS + i];
+          g->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i] = acc;
+        }
+    }
+  }
+  (void)inv_m;
+}
+
+}  // namespace dfx

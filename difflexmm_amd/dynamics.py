@@ -1,0 +1,231 @@
+"""``setup_dynamic_solver`` with the reference's signature (``difflexmm/dynamics.py:60-186``) on top of the HIP
+engine.  The returned ``solve_dynamics(state0, timepoints, control_params)`` has the reference's shapes,
+``(T, 2, n_blocks, 3)``, and additionally ``solve_dynamics.vjp(fields_bar)`` -- the counterpart of taking
+``jax.grad`` through the reference solver -- returning a ``ControlParams``-shaped gradient tree.
+
+Differences that are inherent to running inside hand-written kernels (all keyword-only, all with defaults):
+  * the integrator is the reference's Dormand-Prince tableau on a FIXED step grid, ``steps_per_interval`` steps
+    between consecutive ``timepoints`` (default: chosen from a stiffness bound so that h*omega_max <= 0.5);
+    ``rtol``/``atol`` are accepted for signature compatibility and ignored by the fixed grid;
+  * ``energy_fn``, ``loading_fn`` and ``constrained_DOFs_fn`` must come from ``difflexmm_amd.energy`` /
+    ``difflexmm_amd.loading`` (declarative specs), otherwise ``TypeError`` at setup;
+  * ``batch=B`` integrates B members (list of B ``ControlParams``) side by side.
+"""
+from typing import Optional
+
+import numpy as np
+
+from . import _binding as _b
+from .energy import _EnergyFn
+from .geometry import (DOFsInfo, compute_inertia, compute_inertia_vjp, void_angles0, void_angles0_vjp)
+from .loading import as_time_function, zero
+from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentParams, MechanicalParams)
+
+
+def _bcast(x, n):
+    return np.broadcast_to(np.asarray(x, dtype=float), (n,)).copy()
+
+
+class DynamicSolver:
+    """Callable returned by :func:`setup_dynamic_solver`."""
+
+    def __init__(self, geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
+                 constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, lib):
+        if not isinstance(energy_fn, _EnergyFn) or energy_fn.spec.bond_model is None:
+            raise TypeError("energy_fn must be built with difflexmm_amd.energy.build_strain_energy "
+                            "(optionally combined with build_contact_energy)")
+        self.geometry = geometry
+        self.spec = energy_fn.spec
+        self.n_blocks, self.n_npb = geometry.n_blocks, geometry.n_npb
+        self.bonds = self.spec.bond_connectivity
+        self.rtol, self.atol = rtol, atol
+        self.steps_per_interval = steps_per_interval
+        self.batch = int(batch)
+        self.damped_blocks = None if damped_blocks is None else np.asarray(damped_blocks, dtype=np.int64)
+        self.constrained_pairs = np.asarray(constrained_block_DOF_pairs, dtype=np.int64).reshape(-1, 2)
+        self.free_DOF_ids, self.constrained_DOF_ids, _ = DOFsInfo(self.n_blocks, self.constrained_pairs)
+        self.constraint_fn = as_time_function(constrained_DOFs_fn, "constrained_DOFs_fn")
+        if loaded_block_DOF_pairs is not None and loading_fn is not None:
+            self.loaded_pairs = np.asarray(loaded_block_DOF_pairs, dtype=np.int64).reshape(-1, 2)
+            self.loading_fn = as_time_function(loading_fn, "loading_fn")
+        else:
+            self.loaded_pairs = np.zeros((0, 2), dtype=np.int64)
+            self.loading_fn = zero
+        # time-function slots: constraint terms first, then loading terms
+        self.con_terms, self.load_terms = self.constraint_fn.terms, self.loading_fn.terms
+        n_fns = len(self.con_terms) + len(self.load_terms)
+        if n_fns > _b.DFX_MAX_FNS:
+            raise ValueError(f"at most {_b.DFX_MAX_FNS} time functions (constraint + loading terms) are supported")
+        fn_types = [f.type_id for f in self.con_terms + self.load_terms]
+        # blocks with constrained or loaded DOFs
+        special = {}
+
+        def entry(block):
+            return special.setdefault(int(block), [0, np.zeros((3, _b.DFX_MAX_FNS)), np.zeros((3, _b.DFX_MAX_FNS))])
+
+        n_con = len(self.constrained_pairs)
+        for j, (blk, d) in enumerate(self.constrained_pairs):
+            e = entry(blk)
+            e[0] |= 1 << int(d)
+            for f, term in enumerate(self.con_terms):
+                e[1][d, f] = _bcast(term.vector, n_con)[j]
+        n_load = len(self.loaded_pairs)
+        for j, (blk, d) in enumerate(self.loaded_pairs):
+            e = entry(blk)
+            for f, term in enumerate(self.load_terms):
+                e[2][d, len(self.con_terms) + f] = _bcast(term.vector, n_load)[j]
+        self._special = [(blk, e[0], e[1], e[2]) for blk, e in sorted(special.items())]
+        self.engine = _b.Engine(self.n_blocks, self.n_npb, self.bonds, self.spec.bond_model,
+                                _b.CONTACT_ANGLE if self.spec.contact else _b.CONTACT_NONE, self._special, fn_types,
+                                batch=self.batch, tableau=integrator, device=device, lib=lib)
+        self._last = None
+
+    # -- ControlParams -> engine arrays -------------------------------------------------------------
+    def _flatten(self, cp: ControlParams):
+        gp, mp = cp.geometrical_params, cp.mechanical_params
+        cnv = np.asarray(gp.centroid_node_vectors, dtype=float)
+        nbd = len(self.bonds)
+        bp = mp.bond_params
+        out = {
+            "centroid_node_vectors": cnv,
+            "reference_vector": np.broadcast_to(np.asarray(bp.reference_vector, dtype=float), (nbd, 2)),
+            "k_bond": np.stack([_bcast(bp.k_stretch, nbd), _bcast(bp.k_shear, nbd), _bcast(bp.k_rot, nbd)], 1),
+        }
+        if mp.inertia is None:   # dynamics.py:157-163
+            out["inertia"] = compute_inertia(cnv, mp.density)
+        else:
+            out["inertia"] = np.asarray(mp.inertia, dtype=float).reshape(self.n_blocks, 3)
+        damping = np.zeros((self.n_blocks, 3))
+        if self.damped_blocks is not None:   # loading.py:71-106
+            damping[self.damped_blocks] = np.broadcast_to(np.asarray(mp.damping, dtype=float), (len(self.damped_blocks), 3))
+        out["damping"] = damping
+        if self.spec.contact:
+            c = mp.contact_params
+            out["void_angle0"] = void_angles0(cnv, self.bonds)
+            out["contact"] = np.array([c.min_angle, c.cutoff_angle, c.k_contact], dtype=float)
+        fnp = [f.resolve(cp.constraint_params) for f in self.con_terms] + [f.resolve(cp.loading_params) for f in self.load_terms]
+        if fnp:
+            out["fn_params"] = np.stack(fnp)
+        return out
+
+    def _members(self, control_params):
+        cps = list(control_params) if isinstance(control_params, (list, tuple)) and not isinstance(control_params, ControlParams) \
+            else [control_params]
+        if len(cps) == 1 and self.batch > 1:
+            cps = cps * self.batch
+        if len(cps) != self.batch:
+            raise ValueError(f"expected {self.batch} ControlParams, got {len(cps)}")
+        return cps
+
+    def estimate_steps_per_interval(self, flat, timepoints):
+        """Fixed grid from a Gershgorin-type bound on the largest natural frequency: h * omega_max <= 0.5."""
+        inertia, k, cnv = flat["inertia"], flat["k_bond"], flat["centroid_node_vectors"]
+        l02 = (flat["reference_vector"] ** 2).sum(1)
+        n_b = np.zeros(self.n_blocks)
+        kt = np.zeros(self.n_blocks); kr = np.zeros(self.n_blocks)
+        r2 = (cnv ** 2).sum(-1).max(1)
+        for end in (0, 1):
+            blk = self.bonds[:, end] // self.n_npb
+            np.add.at(kt, blk, 2 * (k[:, 0] + k[:, 1]))
+            np.add.at(kr, blk, 2 * ((k[:, 0] + k[:, 1]) * r2[blk] + k[:, 2] + k[:, 1] * l02 / 4))
+            np.add.at(n_b, blk, 1)
+        w2 = max((kt / inertia[:, 0]).max(), (kr / inertia[:, 2]).max())
+        dt = 0.5 / np.sqrt(w2)
+        span = np.diff(np.asarray(timepoints, dtype=float)).max() if len(timepoints) > 1 else 0.0
+        return max(1, int(np.ceil(span / dt)))
+
+    # -- solve -----------------------------------------------------------------------------------------
+    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None):
+        cps = self._members(control_params)
+        flats = [self._flatten(cp) for cp in cps]
+        self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
+        spi = steps_per_interval or self.steps_per_interval
+        if spi is None:
+            spi = max(self.estimate_steps_per_interval(f, timepoints) for f in flats)
+        state0 = np.asarray(state0, dtype=float)
+        if state0.ndim == 3:
+            state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
+        fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory)
+        self._last = (cps, flats, np.asarray(timepoints, dtype=float))
+        self.stats = dict(stats, steps_per_interval=spi)
+        return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
+
+    # -- reverse mode ------------------------------------------------------------------------------------
+    def vjp(self, fields_bar):
+        """Gradient of sum(fields_bar * fields) w.r.t. every ControlParams leaf and state0.
+        Requires the last call to have used ``keep_trajectory=True``.  Returns (ControlParams tree(s), state0_bar)."""
+        if self._last is None:
+            raise RuntimeError("vjp: call the solver with keep_trajectory=True first")
+        fb = np.asarray(fields_bar, dtype=float)
+        if fb.ndim == 4:
+            fb = fb[None]
+        grads, stats = self.engine.adjoint(fb)
+        self.adjoint_stats = stats
+        return self._unflatten_grads(grads, fb)
+
+    def kinetic_energy_value_and_vjp(self, target_blocks):
+        """objective = sum_t sum_{b in target} m v^2/2 (energy.py:494-499 over problems/quads_focusing.py:461-467),
+        evaluated and differentiated on the device."""
+        obj = self.engine.objective_kinetic(target_blocks)
+        grads, stats = self.engine.adjoint_kinetic(target_blocks)
+        self.adjoint_stats = stats
+        trees, s0 = self._unflatten_grads(grads, None)
+        return (obj[0] if self.batch == 1 else obj), trees, s0
+
+    def _unflatten_grads(self, g, fields_bar):
+        cps, flats, ts = self._last
+        trees = []
+        for m, (cp, flat) in enumerate(zip(cps, flats)):
+            gp, mp = cp.geometrical_params, cp.mechanical_params
+            cnv = flat["centroid_node_vectors"]
+            cnv_bar = g["centroid_node_vectors"][m].copy()
+            if self.spec.contact:
+                cnv_bar += void_angles0_vjp(cnv, self.bonds, g["void_angle0"][m])
+            density_bar, inertia_bar = None, None
+            if mp.inertia is None:
+                vb, density_bar = compute_inertia_vjp(cnv, mp.density, g["inertia"][m])
+                cnv_bar += vb
+            else:
+                inertia_bar = g["inertia"][m].reshape(np.shape(mp.inertia))
+            kb = g["k_bond"][m]
+
+            def like(x, full):
+                return full.sum() if np.ndim(x) == 0 else full
+            damping_bar = 0.0
+            if self.damped_blocks is not None:
+                rows = g["damping"][m][self.damped_blocks]
+                damping_bar = rows.sum() if np.ndim(mp.damping) == 0 else rows.reshape(np.shape(mp.damping)) \
+                    if np.shape(mp.damping) == rows.shape else rows.sum(0)
+            contact_bar = None
+            if self.spec.contact:
+                c = g["contact"][m]
+                contact_bar = ContactParams(min_angle=c[0], cutoff_angle=c[1], k_contact=c[2])
+            con_bar, load_bar = {}, {}
+            for f, term in enumerate(self.con_terms):
+                term.scatter_grad(g["fn_params"][m][f], con_bar)
+            for f, term in enumerate(self.load_terms):
+                term.scatter_grad(g["fn_params"][m][len(self.con_terms) + f], load_bar)
+            trees.append(ControlParams(
+                geometrical_params=GeometricalParams(block_centroids=np.zeros_like(np.asarray(gp.block_centroids, dtype=float)),
+                                                     centroid_node_vectors=cnv_bar),
+                mechanical_params=MechanicalParams(
+                    bond_params=LigamentParams(k_stretch=like(mp.bond_params.k_stretch, kb[:, 0]),
+                                               k_shear=like(mp.bond_params.k_shear, kb[:, 1]),
+                                               k_rot=like(mp.bond_params.k_rot, kb[:, 2]),
+                                               reference_vector=g["reference_vector"][m]),
+                    density=density_bar, inertia=inertia_bar, damping=damping_bar, contact_params=contact_bar),
+                loading_params=load_bar, constraint_params=con_bar))
+        state0_bar = g["state0"]
+        if self.batch == 1:
+            return trees[0], state0_bar[0]
+        return trees, state0_bar
+
+
+def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loading_fn=None,
+                         constrained_block_DOF_pairs=np.array([]), constrained_DOFs_fn=zero,
+                         damped_blocks=None, rtol: float = 1e-8, atol: float = 1e-8, *,
+                         integrator: str = "dopri5", steps_per_interval: Optional[int] = None,
+                         batch: int = 1, device: int = 0, _lib=None):
+    """Same positional/keyword arguments as ``difflexmm.dynamics.setup_dynamic_solver`` (dynamics.py:60-69)."""
+    return DynamicSolver(geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
+                         constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, _lib)

@@ -1,0 +1,356 @@
+"""Host-side geometry of the solver: design variables -> (block_centroids, centroid_node_vectors,
+bond_connectivity, reference_bond_vectors), block inertia, DOF bookkeeping and the undeformed void
+angles, each with the vector-Jacobian product the adjoint needs.  NumPy only.
+
+Counterpart of the reference's ``difflexmm/geometry.py`` (run once per design, not per time step).
+Derivatives of the small per-block polygon formulas are taken with the complex-step method
+(exact to rounding, no subtraction), the index maps design -> nodes are linear and transpose to
+scatter-adds.
+"""
+import math
+
+import numpy as np
+
+_CSTEP = 1e-40
+
+
+def rotation_matrix(angle):
+    """geometry.py:17-23."""
+    c, s = np.cos(angle), np.sin(angle)
+    return np.array([[c, -s], [s, c]])
+
+
+# -- polygons (geometry.py:71-160) -------------------------------------------------------------
+
+def polygon_props(v):
+    """area, centroid, polar moment about the centroid of CCW polygons v (..., n, 2).
+    Works for complex input (used by the complex-step Jacobians): |S| is sign(Re S) * S."""
+    v1 = np.roll(v, 1, axis=-2)
+    cr = v1[..., 0] * v[..., 1] - v1[..., 1] * v[..., 0]
+    S = cr.sum(-1)
+    area = np.where(S.real < 0, -1.0, 1.0) * S / 2                      # geometry.py:84
+    s = v1 + v
+    cen = np.stack([(s[..., 0] * cr).sum(-1), (s[..., 1] * cr).sum(-1)], -1) / (6 * area)[..., None]  # :103-106
+    a = v1 - cen[..., None, :]
+    b = v - cen[..., None, :]
+    crc = a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    q = a[..., 0] ** 2 + a[..., 0] * b[..., 0] + b[..., 0] ** 2 + a[..., 1] ** 2 + a[..., 1] * b[..., 1] + b[..., 1] ** 2
+    M = (crc * q).sum(-1) / 12
+    ip = np.where(M.real < 0, -1.0, 1.0) * M                              # geometry.py:123-127
+    return area, cen, ip
+
+
+def polygon_area(v):
+    return polygon_props(np.asarray(v, dtype=float))[0]
+
+
+def polygon_centroid(v):
+    return polygon_props(np.asarray(v, dtype=float))[1]
+
+
+def polygon_polar_moment(v):
+    return polygon_props(np.asarray(v, dtype=float))[2]
+
+
+def polygon_props_jac(v):
+    """Jacobians of (area, centroid, polar moment) w.r.t. the vertices, per polygon.
+    Returns dA (nb,n,2), dC (nb,2,n,2), dI (nb,n,2)."""
+    v = np.asarray(v, dtype=float)
+    nb, n, _ = v.shape
+    dA = np.empty((nb, n, 2)); dC = np.empty((nb, 2, n, 2)); dI = np.empty((nb, n, 2))
+    for k in range(n):
+        for c in range(2):
+            vc = v.astype(complex)
+            vc[:, k, c] += 1j * _CSTEP
+            a, cen, ip = polygon_props(vc)
+            dA[:, k, c] = a.imag / _CSTEP
+            dC[:, :, k, c] = cen.imag / _CSTEP
+            dI[:, k, c] = ip.imag / _CSTEP
+    return dA, dC, dI
+
+
+def compute_inertia(vertices, density):
+    """geometry.py:144-160 -> (n_blocks, 3) = [rho A, rho A, rho I_p]."""
+    area, _, ip = polygon_props(np.asarray(vertices, dtype=float))
+    m = density * area
+    return np.column_stack((m, m, density * ip))
+
+
+def compute_inertia_vjp(vertices, density, inertia_bar):
+    """(vertices_bar, density_bar) for a cotangent of compute_inertia's result."""
+    vertices = np.asarray(vertices, dtype=float)
+    area, _, ip = polygon_props(vertices)
+    dA, _, dI = polygon_props_jac(vertices)
+    gm = inertia_bar[:, 0] + inertia_bar[:, 1]
+    rho = np.broadcast_to(np.asarray(density, dtype=float), area.shape)
+    v_bar = (rho * gm)[:, None, None] * dA + (rho * inertia_bar[:, 2])[:, None, None] * dI
+    rho_bar = gm * area + inertia_bar[:, 2] * ip
+    return v_bar, (rho_bar.sum() if np.ndim(density) == 0 else rho_bar)
+
+
+def DOFsInfo(n_blocks, constrained_block_DOF_pairs):
+    """geometry.py:163-178, vectorised (O(n) instead of the reference's O(n_dof * n_constrained))."""
+    pairs = np.asarray(constrained_block_DOF_pairs, dtype=np.int64).reshape(-1, 2)
+    constrained = pairs[:, 0] * 3 + pairs[:, 1]
+    all_ids = np.arange(n_blocks * 3)
+    mask = np.ones(n_blocks * 3, dtype=bool)
+    mask[constrained] = False
+    return all_ids[mask], constrained, all_ids
+
+
+def compute_edge_lengths(cnv):
+    """geometry.py:205-218."""
+    return np.linalg.norm(np.roll(cnv, 1, axis=1) - cnv, axis=2)
+
+
+# -- void angles of the undeformed design (energy.py:204-219 + geometry.py:181-253 at u = 0) -----
+
+def _edge_pairs(cnv, bonds):
+    n = cnv.shape[1]
+    b1, l1 = bonds[:, 0] // n, bonds[:, 0] % n
+    b2, l2 = bonds[:, 1] // n, bonds[:, 1] % n
+    idx = (b1, l1, (l1 + 1) % n, (l1 - 1) % n, b2, l2, (l2 + 1) % n, (l2 - 1) % n)
+    e1p = cnv[b1, idx[2]] - cnv[b1, l1]   # edge node1 -> next node   (block_1_node_1, unnormalised)
+    e1m = cnv[b1, idx[3]] - cnv[b1, l1]   # edge node1 -> previous node
+    e2p = cnv[b2, idx[6]] - cnv[b2, l2]
+    e2m = cnv[b2, idx[7]] - cnv[b2, l2]
+    return idx, e1p, e1m, e2p, e2m
+
+
+def _angle(u, w):
+    return np.arctan2(u[:, 0] * w[:, 1] - u[:, 1] * w[:, 0], u[:, 0] * w[:, 0] + u[:, 1] * w[:, 1])
+
+
+def void_angles0(cnv, bonds):
+    """(n_bonds, 2): the two void angles of every bond in the undeformed design.  During the motion the
+    angles are  wrap(phi1 + th_A - th_B), wrap(phi2 + th_B - th_A)  (rigid blocks: translations cancel)."""
+    cnv = np.asarray(cnv, dtype=float)
+    bonds = np.asarray(bonds, dtype=np.int64)
+    _, e1p, e1m, e2p, e2m = _edge_pairs(cnv, bonds)
+    return np.stack([_angle(e2m, e1p), _angle(e1m, e2p)], 1)   # geometry.py:248-249
+
+
+def void_angles0_vjp(cnv, bonds, phi_bar):
+    """cnv_bar for a cotangent (n_bonds, 2) of void_angles0."""
+    cnv = np.asarray(cnv, dtype=float)
+    bonds = np.asarray(bonds, dtype=np.int64)
+    (b1, l1, n1, p1, b2, l2, n2, p2), e1p, e1m, e2p, e2m = _edge_pairs(cnv, bonds)
+    out = np.zeros_like(cnv)
+
+    def back(u, w, gbar):
+        # phi = atan2(u x w, u . w): dphi/du = -perp(u)/|u|^2 , dphi/dw = perp(w)/|w|^2, perp(a) = (-a_y, a_x)
+        du = -np.stack([-u[:, 1], u[:, 0]], 1) / (u ** 2).sum(1)[:, None] * gbar[:, None]
+        dw = np.stack([-w[:, 1], w[:, 0]], 1) / (w ** 2).sum(1)[:, None] * gbar[:, None]
+        return du, dw
+
+    du, dw = back(e2m, e1p, phi_bar[:, 0])      # phi1: u = e2m, w = e1p
+    np.add.at(out, (b2, p2), du); np.add.at(out, (b2, l2), -du)
+    np.add.at(out, (b1, n1), dw); np.add.at(out, (b1, l1), -dw)
+    du, dw = back(e1m, e2p, phi_bar[:, 1])      # phi2: u = e1m, w = e2p
+    np.add.at(out, (b1, p1), du); np.add.at(out, (b1, l1), -du)
+    np.add.at(out, (b2, n2), dw); np.add.at(out, (b2, l2), -dw)
+    return out
+
+
+def compute_edge_angles(nodes, bonds):
+    """geometry.py:234-253 on explicit node positions (n_blocks, n_npb, 2): void_1, void_2, block_1, block_2."""
+    nodes = np.asarray(nodes, dtype=float)
+    bonds = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
+    _, e1p, e1m, e2p, e2m = _edge_pairs(nodes, bonds)
+    return _angle(e2m, e1p), _angle(e1m, e2p), _angle(e1p, e1m), _angle(e2p, e2m)
+
+
+# -- lattices ---------------------------------------------------------------------------------------
+
+class Geometry:
+    """Common part of the lattice classes (reference: ``Geometry``/``LatticeGeometry``, geometry.py:272-351)."""
+    n_blocks: int
+    n_npb: int
+
+    def get_parametrization(self):
+        """geometry.py:319-328."""
+        return self.block_centroids, self.centroid_node_vectors, self.bond_connectivity, self.reference_bond_vectors
+
+    def get_reference_geometry(self, *design):
+        return self.centroid_node_vectors(*design) + self.block_centroids(*design)[:, None, :]
+
+    # centred node vectors / centroids from the un-centred reference node vectors
+    def _centre(self, ref):
+        cen = polygon_props(ref)[1]
+        return ref - cen[:, None, :], cen
+
+    def _centre_vjp(self, ref, cnv_bar, centroid_bar):
+        _, dC, _ = polygon_props_jac(ref)
+        g = (centroid_bar if centroid_bar is not None else 0.0) - cnv_bar.sum(1)   # cotangent of the centroid
+        return cnv_bar + np.einsum("bc,bcnk->bnk", g, dC)
+
+
+def _square_grid(n1, n2):
+    n2s, n1s = np.meshgrid(np.arange(n2), np.arange(n1), indexing="ij")
+    return n1s.reshape(-1), n2s.reshape(-1)
+
+
+def _quad_bonds(n1b, n2b):
+    h = [[n1b * n2 * 4 + n1 * 4, n1b * n2 * 4 + (n1 + 1) * 4 + 2] for n2 in range(n2b) for n1 in range(n1b - 1)]
+    v = [[n1b * n2 * 4 + n1 * 4 + 1, n1b * (n2 + 1) * 4 + n1 * 4 + 3] for n2 in range(n2b - 1) for n1 in range(n1b)]
+    return np.array(h + v, dtype=np.int32).reshape(-1, 2)
+
+
+def _quad_ref_vectors(n1b, n2b, l):
+    return np.concatenate([np.tile([l, 0.0], ((n1b - 1) * n2b, 1)), np.tile([0.0, l], ((n2b - 1) * n1b, 1))])
+
+
+class QuadGeometry(Geometry):
+    """Aperiodic lattice of quadrilaterals, design = (horizontal_shifts (n1+1,n2,2), vertical_shifts (n1,n2+1,2)).
+    Reference: geometry.py:804-952 (block id = n2*n1_blocks + n1; nodes 0:+x 1:+y 2:-x 3:-y)."""
+
+    def __init__(self, n1_blocks, n2_blocks, spacing=1.0, bond_length=0.1):
+        self.n1_blocks, self.n2_blocks = int(n1_blocks), int(n2_blocks)
+        self.n1_cells, self.n2_cells = self.n1_blocks, self.n2_blocks
+        self.spacing, self.bond_length = float(spacing), float(bond_length)
+        self.n_blocks = self.n1_blocks * self.n2_blocks
+        self.n_npb = 4
+        self.n_nodes = 4 * self.n_blocks
+        self._n1s, self._n2s = _square_grid(self.n1_blocks, self.n2_blocks)
+        r = (self.spacing - self.bond_length) / 2
+        self._v0s = np.array([[r, 0.0], [0.0, r], [-r, 0.0], [0.0, -r]])
+
+    def design_shapes(self):
+        return (self.n1_blocks + 1, self.n2_blocks, 2), (self.n1_blocks, self.n2_blocks + 1, 2)
+
+    def reference_node_vectors(self, horizontal_shifts, vertical_shifts):
+        hs, vs = np.asarray(horizontal_shifts, dtype=float), np.asarray(vertical_shifts, dtype=float)
+        n1, n2 = self._n1s, self._n2s
+        return self._v0s[None] + np.stack([hs[n1 + 1, n2], vs[n1, n2 + 1], hs[n1, n2], vs[n1, n2]], 1)
+
+    def centroid_node_vectors(self, horizontal_shifts, vertical_shifts):
+        return self._centre(self.reference_node_vectors(horizontal_shifts, vertical_shifts))[0]
+
+    def reference_points(self):
+        return self.spacing * np.stack([self._n1s, self._n2s], -1).astype(float)
+
+    def block_centroids(self, horizontal_shifts, vertical_shifts):
+        return self.reference_points() + self._centre(self.reference_node_vectors(horizontal_shifts, vertical_shifts))[1]
+
+    def bond_connectivity(self):
+        return _quad_bonds(self.n1_blocks, self.n2_blocks)
+
+    def reference_bond_vectors(self):
+        return _quad_ref_vectors(self.n1_blocks, self.n2_blocks, self.bond_length)
+
+    def vjp(self, design, cnv_bar, centroid_bar=None):
+        """Cotangents of (centroid_node_vectors, block_centroids) -> cotangents of the design tuple."""
+        hs, vs = design
+        ref_bar = self._centre_vjp(self.reference_node_vectors(hs, vs), cnv_bar, centroid_bar)
+        n1, n2 = self._n1s, self._n2s
+        hb = np.zeros(self.design_shapes()[0]); vb = np.zeros(self.design_shapes()[1])
+        np.add.at(hb, (n1 + 1, n2), ref_bar[:, 0]); np.add.at(vb, (n1, n2 + 1), ref_bar[:, 1])
+        np.add.at(hb, (n1, n2), ref_bar[:, 2]); np.add.at(vb, (n1, n2), ref_bar[:, 3])
+        return hb, vb
+
+    def get_design_from_rotated_square(self, angle):
+        """geometry.py:928-952."""
+        r = self.spacing - self.bond_length
+
+        def base(n1, n2):
+            a = (-1.0) ** (n1 + n2) * angle
+            return r / (2 * math.cos(a)) * np.array([math.cos(a), math.sin(a)]) - np.array([r / 2, 0.0])
+
+        hs = np.array([[base(n1, n2) for n2 in range(self.n2_blocks)] for n1 in range(self.n1_blocks + 1)])
+        rot = rotation_matrix(np.pi / 2)
+        vs = np.array([[rot @ base(n1, n2) for n2 in range(self.n2_blocks + 1)] for n1 in range(self.n1_blocks)])
+        return hs, vs
+
+
+class RotatedSquareGeometry(Geometry):
+    """Rotated-squares lattice, design = (angle,).  Reference: geometry.py:354-443."""
+
+    def __init__(self, n1_cells, n2_cells, spacing=1.0, bond_length=0.1):
+        self.n1_cells, self.n2_cells = int(n1_cells), int(n2_cells)
+        self.spacing, self.bond_length = float(spacing), float(bond_length)
+        self.n1_blocks, self.n2_blocks = 2 * self.n1_cells, 2 * self.n2_cells
+        self.n_blocks = self.n1_blocks * self.n2_blocks
+        self.n_npb = 4
+        self.n_nodes = 4 * self.n_blocks
+        self._n1s, self._n2s = _square_grid(self.n1_blocks, self.n2_blocks)
+
+    def centroid_node_vectors(self, angle):
+        a = (-1.0) ** (self._n1s + self._n2s) * angle
+        v0 = ((self.spacing - self.bond_length) / (2 * np.cos(a)))[:, None] * np.stack([np.cos(a), np.sin(a)], -1)
+        rots = np.stack([rotation_matrix(t) for t in np.linspace(0.0, 3 * np.pi / 2, 4)])
+        return np.einsum("kij,bj->bki", rots, v0)
+
+    def block_centroids(self, angle=None):
+        return self.spacing * np.stack([self._n1s, self._n2s], -1).astype(float)
+
+    def bond_connectivity(self):
+        return _quad_bonds(self.n1_blocks, self.n2_blocks)
+
+    def reference_bond_vectors(self):
+        return _quad_ref_vectors(self.n1_blocks, self.n2_blocks, self.bond_length)
+
+
+class KagomeGeometry(Geometry):
+    """Non-periodic kagome lattice (2 triangles per cell), design = (shifts_1 (n1+1,n2,2), shifts_2 (n1,n2+1,2),
+    shifts_3 (n1,n2,2)).  Reference: geometry.py:607-801."""
+
+    def __init__(self, n1_cells, n2_cells, direct_basis=None, bond_length=0.1):
+        if direct_basis is None:
+            direct_basis = np.array([[1.0, 0.0], [math.cos(math.pi / 3), math.sin(math.pi / 3)]])
+        self.n1_cells, self.n2_cells = int(n1_cells), int(n2_cells)
+        self.direct_basis = np.asarray(direct_basis, dtype=float)
+        self.bond_length = float(bond_length)
+        self.n_cells = self.n1_cells * self.n2_cells
+        self.n_bpc, self.n_npb = 2, 3
+        self.n_blocks = 2 * self.n_cells
+        self.n_nodes = 3 * self.n_blocks
+        l = self.bond_length
+        self._ri = l * np.array([math.cos(math.pi / 6), math.sin(math.pi / 6)])
+        self._r1 = l * np.array([0.0, -1.0])
+        self._r2 = l * np.array([-math.cos(math.pi / 6), math.sin(math.pi / 6)])
+        a1, a2 = self.direct_basis
+        self._b1 = np.array([a1 / 2, a1 / 2 + a2 / 2, a2 / 2]) - 0.5 * np.array([self._r1, self._ri, self._r2])
+        self._b2 = np.array([a1 / 2 + a2 / 2, a1 + a2 / 2, a1 / 2 + a2]) + 0.5 * np.array([self._ri, self._r2, self._r1])
+
+    def design_shapes(self):
+        n1, n2 = self.n1_cells, self.n2_cells
+        return (n1 + 1, n2, 2), (n1, n2 + 1, 2), (n1, n2, 2)
+
+    def reference_node_vectors(self, shifts_1, shifts_2, shifts_3):
+        s1, s2, s3 = (np.asarray(s, dtype=float) for s in (shifts_1, shifts_2, shifts_3))
+        blk1 = self._b1[None, None] + np.stack([s2[:, :-1], s3, s1[:-1]], 2)     # nodes (0) (1) (2)
+        blk2 = self._b2[None, None] + np.stack([s3, s1[1:], s2[:, 1:]], 2)       # nodes (3) (4) (5)
+        cells = np.stack([blk1, blk2], 2)                                          # (n1, n2, 2, 3, 2)
+        return cells.transpose(1, 0, 2, 3, 4).reshape(self.n_blocks, 3, 2)
+
+    def centroid_node_vectors(self, shifts_1, shifts_2, shifts_3):
+        return self._centre(self.reference_node_vectors(shifts_1, shifts_2, shifts_3))[0]
+
+    def reference_points(self):
+        n1s, n2s = _square_grid(self.n1_cells, self.n2_cells)
+        pts = n1s[:, None] * self.direct_basis[0] + n2s[:, None] * self.direct_basis[1]
+        return np.repeat(pts, 2, axis=0)
+
+    def block_centroids(self, shifts_1, shifts_2, shifts_3):
+        return self.reference_points() + self._centre(self.reference_node_vectors(shifts_1, shifts_2, shifts_3))[1]
+
+    def bond_connectivity(self):
+        n1c, n2c = self.n1_cells, self.n2_cells
+        internal = [[1 + 6 * (n2 * n1c + n1), 3 + 6 * (n2 * n1c + n1)] for n2 in range(n2c) for n1 in range(n1c)]
+        bnd1 = [[6 * ((n2 + 1) * n1c + n1), 5 + 6 * (n2 * n1c + n1)] for n2 in range(n2c - 1) for n1 in range(n1c)]
+        bnd2 = [[2 + 6 * (n2 * n1c + n1 + 1), 4 + 6 * (n2 * n1c + n1)] for n2 in range(n2c) for n1 in range(n1c - 1)]
+        return np.array(internal + bnd1 + bnd2, dtype=np.int32).reshape(-1, 2)
+
+    def reference_bond_vectors(self):
+        n1c, n2c = self.n1_cells, self.n2_cells
+        return np.concatenate([np.tile(self._ri, (n1c * n2c, 1)), np.tile(self._r1, (n1c * (n2c - 1), 1)),
+                               np.tile(self._r2, ((n1c - 1) * n2c, 1))])
+
+    def vjp(self, design, cnv_bar, centroid_bar=None):
+        ref_bar = self._centre_vjp(self.reference_node_vectors(*design), cnv_bar, centroid_bar)
+        n1, n2 = self.n1_cells, self.n2_cells
+        cells = ref_bar.reshape(n2, n1, 2, 3, 2).transpose(1, 0, 2, 3, 4)        # (n1, n2, 2, 3, 2)
+        s1b, s2b, s3b = (np.zeros(s) for s in self.design_shapes())
+        s2b[:, :-1] += cells[:, :, 0, 0]; s3b += cells[:, :, 0, 1]; s1b[:-1] += cells[:, :, 0, 2]
+        s3b += cells[:, :, 1, 0]; s1b[1:] += cells[:, :, 1, 1]; s2b[:, 1:] += cells[:, :, 1, 2]
+        return s1b, s2b, s3b

@@ -1,0 +1,157 @@
+"""Time functions for prescribed displacements (``constrained_DOFs_fn``) and external forces (``loading_fn``).
+
+The reference takes arbitrary Python callables here (``kinematics.py:40-81``, ``loading.py:12-47``); a HIP
+kernel cannot call Python, so the engine supports the closed library of time functions that the reference's
+``problems/``, ``scripts/`` and ``tests/`` actually use.  An object of this module is still a
+callable with the reference's signature -- ``fn(t, **constraint_params)`` or ``fn(state, t, **loading_params)`` --
+so host code can evaluate it, and it carries the declarative ``spec`` the engine consumes.
+
+Every parameter is either a number (a constant baked into the solver) or a string naming the entry of
+``control_params.constraint_params`` / ``loading_params`` that holds it (then it is differentiable).
+"""
+import numpy as np
+
+from ._binding import (DFX_FN_PARAMS, FN_CONSTANT, FN_HARMONIC, FN_PULSE, FN_RAMP, FN_RAMP_PULSE,
+                       FN_SECH2TANH, FN_ZERO)
+
+
+class TimeFunction:
+    """vector * g(t; params).  ``vector`` is a scalar or one coefficient per constrained / loaded DOF."""
+    type_id = FN_ZERO
+    param_names = ()
+
+    def __init__(self, vector=1.0, **params):
+        self.vector = np.asarray(vector, dtype=float)
+        unknown = set(params) - set(self.param_names)
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unknown parameters {sorted(unknown)}")
+        # default: look the parameter up under its own name
+        self.params = {n: params.get(n, n) for n in self.param_names}
+
+    def resolve(self, params_dict):
+        """5 numbers for the engine from a constraint_params / loading_params dict."""
+        out = np.zeros(DFX_FN_PARAMS)
+        for i, n in enumerate(self.param_names):
+            v = self.params[n]
+            if isinstance(v, str):
+                if v not in params_dict:
+                    raise KeyError(f"{type(self).__name__}: parameter '{v}' missing from the params dict")
+                v = params_dict[v]
+            out[i] = float(v)
+        return out
+
+    def scatter_grad(self, grad5, out_dict):
+        """Add d/d(params) (5 numbers from the engine) to a dict keyed like the params dict."""
+        for i, n in enumerate(self.param_names):
+            v = self.params[n]
+            if isinstance(v, str):
+                out_dict[v] = out_dict.get(v, 0.0) + float(grad5[i])
+
+    def value(self, t, p):
+        return 0.0
+
+    def _eval(self, t, kwargs):
+        return self.vector * self.value(float(t), self.resolve(kwargs))
+
+    def __call__(self, *args, **kwargs):
+        # fn(t, **params)  or  fn(state, t, **params)
+        t = args[-1]
+        return self._eval(t, kwargs)
+
+    @property
+    def terms(self):
+        return [self]
+
+    def __add__(self, other):
+        return SumOfTimeFunctions(self.terms + other.terms)
+
+
+class SumOfTimeFunctions(TimeFunction):
+    def __init__(self, terms):
+        self._terms = list(terms)
+
+    @property
+    def terms(self):
+        return self._terms
+
+    def _eval(self, t, kwargs):
+        return sum(f._eval(t, kwargs) for f in self._terms)
+
+
+class Zero(TimeFunction):
+    """The reference's default ``lambda t: 0`` (dynamics.py:66)."""
+
+    @property
+    def terms(self):
+        return []
+
+
+class Pulse(TimeFunction):
+    """amplitude/2 (1 - cos 2 pi f tau) on 0 < tau < 1/f, tau = t - input_delay (problems/quads_focusing.py:211-222)."""
+    type_id = FN_PULSE
+    param_names = ("amplitude", "loading_rate", "input_delay")
+
+    def value(self, t, p):
+        tau = t - p[2]
+        return p[0] * 0.5 * (1 - np.cos(2 * np.pi * p[1] * tau)) if (tau > 0 and tau * p[1] < 1) else 0.0
+
+
+class Harmonic(Pulse):
+    """Same wave switched on at tau > 0 and never off (problems/quads_spin.py:210-222)."""
+    type_id = FN_HARMONIC
+
+    def value(self, t, p):
+        tau = t - p[2]
+        return p[0] * 0.5 * (1 - np.cos(2 * np.pi * p[1] * tau)) if tau > 0 else 0.0
+
+
+class Ramp(TimeFunction):
+    """amplitude * min(t * rate, 1)  (tests/test_difflexmm.py:85-86, problems/hinge_characterization.py:134-139)."""
+    type_id = FN_RAMP
+    param_names = ("amplitude", "rate")
+
+    def value(self, t, p):
+        return p[0] * (t * p[1] if t * p[1] < 1 else 1.0)
+
+
+class Sech2Tanh(TimeFunction):
+    """2A/s^2 sech^2(t/s - 3) tanh(3 - t/s)  (scripts/pulse_RS.py:49-50)."""
+    type_id = FN_SECH2TANH
+    param_names = ("amplitude", "width")
+
+    def value(self, t, p):
+        z = t / p[1] - 3.0
+        return -2 * p[0] / p[1] ** 2 * (1 - np.tanh(z) ** 2) * np.tanh(z)
+
+
+class Constant(TimeFunction):
+    type_id = FN_CONSTANT
+    param_names = ("amplitude",)
+
+    def value(self, t, p):
+        return p[0]
+
+
+class RampPulse(TimeFunction):
+    """static ramp + delayed pulse (problems/quads_kinetic_energy_static_tuning.py:176-196)."""
+    type_id = FN_RAMP_PULSE
+    param_names = ("amplitude", "loading_rate", "input_delay", "static", "static_rate")
+
+    def value(self, t, p):
+        tau = t - p[2]
+        pulse = p[0] * 0.5 * (1 - np.cos(2 * np.pi * p[1] * tau)) if (tau > 0 and tau * p[1] < 1) else 0.0
+        return pulse + p[3] * (t * p[4] if t * p[4] < 1 else 1.0)
+
+
+zero = Zero()
+
+
+def as_time_function(fn, what):
+    """Accept the library objects (and None); anything else cannot run on the device."""
+    if fn is None:
+        return zero
+    if isinstance(fn, TimeFunction):
+        return fn
+    raise TypeError(
+        f"{what} must be built from difflexmm_amd.loading (Pulse, Harmonic, Ramp, Sech2Tanh, Constant, RampPulse, "
+        f"zero, or a sum of them): an arbitrary Python callable cannot be evaluated inside a HIP kernel")

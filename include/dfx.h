@@ -1,0 +1,154 @@
+/* dfx.h -- C ABI of libdfx, the MI355X engine for DifFlexMM's hot path.
+ *
+ * The library replaces, for one lattice, what the reference builds in Python/JAX:
+ *
+ *   dfx_create      <->  setup_dynamic_solver(...)            difflexmm/dynamics.py:60-136
+ *                        (static data: connectivity, bond model, contact on/off, which DOFs are
+ *                        constrained / loaded and by which time function)
+ *   dfx_set_params  <->  the ControlParams pytree passed to solve_dynamics
+ *                                                            difflexmm/utils.py:48-163
+ *   dfx_forward     <->  solve_dynamics(state0, timepoints, control_params)
+ *                                                            difflexmm/dynamics.py:138-184
+ *                        (odeint call at dynamics.py:166 + reconstruction :169-182)
+ *   dfx_adjoint     <->  the VJP jax.grad takes through solve_dynamics
+ *                        (problems/quads_focusing.py:565; jax.experimental.ode._odeint_rev)
+ *   dfx_rhs         <->  rhs(state, t, control_params, inertia)  difflexmm/dynamics.py:33-55
+ *   dfx_rhs_vjp     <->  jax.vjp(rhs, ...)                     (test hook for the adjoint kernel)
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (message via
+ * dfx_last_error).  All arrays are C-contiguous float64 / int32 HOST buffers owned by the
+ * caller; the library copies what it needs and keeps no caller pointer after a call returns.
+ * Device memory lives inside the handle.  A handle belongs to one (process, device) and is not
+ * thread safe.  `batch` independent members (designs / inputs of one lattice) are integrated
+ * side by side; every per-member array has a leading batch axis.
+ *
+ * DOF layout (geometry.py:174-175): dof = 3*block + {0:x, 1:y, 2:theta};  node = n_npb*block + local.
+ */
+#ifndef DFX_H
+#define DFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFX_MAX_FNS 2         /* time functions per problem                                   */
+#define DFX_FN_PARAMS 5       /* parameters per time function                                 */
+
+enum { DFX_BOND_LINEARIZED = 0, DFX_BOND_NONLINEAR = 1 };       /* energy.py:99 / energy.py:158 */
+enum { DFX_CONTACT_NONE = 0, DFX_CONTACT_ANGLE = 1 };           /* energy.py:364 (angle_based)  */
+enum { DFX_TABLEAU_DOPRI5 = 0, DFX_TABLEAU_RK4 = 1 };
+/* time-function library; parameters p[] in this order */
+enum {
+  DFX_FN_ZERO = 0,
+  DFX_FN_PULSE = 1,        /* (A, f, t_d)   problems/quads_focusing.py:211-222                   */
+  DFX_FN_HARMONIC = 2,     /* (A, f, t_d)   problems/quads_spin.py:210-222                       */
+  DFX_FN_RAMP = 3,         /* (A, r)        tests/test_difflexmm.py:85-86                        */
+  DFX_FN_SECH2TANH = 4,    /* (A, s)        scripts/pulse_RS.py:49-50                            */
+  DFX_FN_CONSTANT = 5,     /* (A)                                                                 */
+  DFX_FN_RAMP_PULSE = 6    /* (A, f, t_d, S, r) problems/quads_kinetic_energy_static_tuning.py:176-196 */
+};
+
+/* A block that has constrained and/or force-loaded DOFs.  u[dof] = sum_m con_coef[d][m] * g_m(t)
+ * for constrained DOFs (kinematics.py:68-73); F_load[dof] = sum_m load_coef[d][m] * g_m(t)
+ * (loading.py:36-45). */
+typedef struct dfx_special {
+  int32_t block;
+  int32_t con_mask;                       /* bit d set: DOF d of the block is constrained       */
+  double con_coef[3][DFX_MAX_FNS];
+  double load_coef[3][DFX_MAX_FNS];
+} dfx_special;
+
+typedef struct dfx_problem {
+  int32_t n_blocks;
+  int32_t n_npb;                          /* nodes per block: 3 (kagome) or 4 (quads)           */
+  int32_t n_bonds;
+  const int32_t* bonds;                   /* (n_bonds, 2) node ids, geometry.bond_connectivity() */
+  int32_t bond_model;                     /* DFX_BOND_*                                          */
+  int32_t contact;                        /* DFX_CONTACT_*                                       */
+  int32_t n_special;
+  const dfx_special* special;
+  int32_t n_fns;                          /* <= DFX_MAX_FNS                                      */
+  int32_t fn_type[DFX_MAX_FNS];           /* DFX_FN_*                                            */
+  int32_t batch;                          /* ensemble members integrated together                */
+  int32_t tableau;                        /* DFX_TABLEAU_*                                       */
+  int32_t device;                         /* HIP device ordinal (ignored by the CPU port)        */
+} dfx_problem;
+
+/* ControlParams, flattened (utils.py:48-163).  Leading axis of every array = batch. */
+typedef struct dfx_params {
+  const double* centroid_node_vectors;    /* (batch, n_blocks, n_npb, 2)                         */
+  const double* reference_vector;         /* (batch, n_bonds, 2)                                 */
+  const double* k_bond;                   /* (batch, n_bonds, 3) = k_stretch, k_shear, k_rot     */
+  const double* inertia;                  /* (batch, n_blocks, 3)  [m, m, J]                     */
+  const double* damping;                  /* (batch, n_blocks, 3)  per-DOF viscous coefficient   */
+  const double* void_angle0;              /* (batch, n_bonds, 2) undeformed void angles or NULL  */
+  const double* contact;                  /* (batch, 3) min_angle, cutoff_angle, k_contact / NULL */
+  const double* fn_params;                /* (batch, n_fns, DFX_FN_PARAMS)                       */
+} dfx_params;
+
+/* Gradient of  L = sum(fields_bar * fields)  with respect to everything in dfx_params and the
+ * initial state.  Any pointer may be NULL (that gradient is then not accumulated). */
+typedef struct dfx_grads {
+  double* centroid_node_vectors;          /* (batch, n_blocks, n_npb, 2)                         */
+  double* reference_vector;               /* (batch, n_bonds, 2)                                 */
+  double* k_bond;                         /* (batch, n_bonds, 3)                                 */
+  double* inertia;                        /* (batch, n_blocks, 3)                                */
+  double* damping;                        /* (batch, n_blocks, 3)                                */
+  double* void_angle0;                    /* (batch, n_bonds, 2)                                 */
+  double* contact;                        /* (batch, 3)                                          */
+  double* fn_params;                      /* (batch, n_fns, DFX_FN_PARAMS)                       */
+  double* state0;                         /* (batch, 2, n_blocks, 3)                             */
+} dfx_grads;
+
+typedef struct dfx_stats {
+  int64_t steps;                          /* RK steps taken per member                           */
+  int64_t rhs_evals;                      /* RHS evaluations per member (forward)                */
+  int64_t launches;                       /* kernel launches issued                              */
+  double kernel_ms;                       /* device time of the integration loop (HIP events)    */
+  double stage_kernel_us;                 /* mean duration of one stage-kernel launch incl. gap  */
+} dfx_stats;
+
+typedef struct dfx_handle dfx_handle;
+
+int dfx_create(const dfx_problem* problem, dfx_handle** out);
+int dfx_destroy(dfx_handle* h);
+const char* dfx_last_error(const dfx_handle* h);  /* h may be NULL: error of the last failed create */
+
+int dfx_set_params(dfx_handle* h, const dfx_params* params);
+
+/* Integrate from timepoints[0] with `steps_per_interval` equal RK steps between consecutive
+ * timepoints.  state0: (batch, 2, n_blocks, 3); fields: (batch, T, 2, n_blocks, 3), row 0 is the
+ * reconstructed initial state.  keep_trajectory != 0 checkpoints every step state in HBM so that
+ * dfx_adjoint can run afterwards. */
+int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats);
+
+/* Reverse sweep over the checkpointed trajectory of the last dfx_forward(keep_trajectory=1).
+ * fields_bar: (batch, T, 2, n_blocks, 3) cotangent of `fields`. */
+int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_stats* stats);
+
+/* Device-resident variants for benchmarking: the forward keeps the (T, ...) fields on the device and
+ * the cotangent is the target-kinetic-energy objective  sum_t sum_{b in target} m_bd v_bd^2 / 2
+ * (energy.py:494-499, problems/quads_focusing.py:447-467), evaluated on the device. */
+int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective);
+int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, dfx_grads* grads,
+                        dfx_stats* stats);
+
+/* Test hooks: one RHS evaluation and its vector-Jacobian product on full-DOF arrays.
+ * y, dy, lam, y_bar: (batch, 2, n_blocks, 3).  Constrained DOFs of y are ignored (they follow the
+ * driving functions); their dy / y_bar entries are returned as 0. */
+int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy);
+int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, double* y_bar, dfx_grads* grads);
+
+/* Potential energy of a full-DOF configuration, (batch, n_blocks, 3) -> (batch,)  (test hook) */
+int dfx_energy(dfx_handle* h, const double* u, double* energy);
+
+int dfx_device_count(void);
+const char* dfx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_H */

@@ -1,0 +1,23 @@
+"""Loader of the CPU port (oracle/cpu/libdfx_cpu.so) -- test infrastructure / CPU baseline only."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libdfx_cpu.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return so
+
+
+def load():
+    """ctypes handle with the same ABI as libdfx (include/dfx.h), argument types declared."""
+    global _LIB
+    if _LIB is None:
+        from difflexmm_amd._binding import declare
+        _LIB = declare(ctypes.CDLL(build()))
+    return _LIB

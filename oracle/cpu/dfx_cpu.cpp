@@ -1,0 +1,405 @@
+// dfx_cpu.cpp -- C++17 CPU port of the engine (TEST INFRASTRUCTURE + timed CPU baseline).
+//
+// Exports the same C ABI as libdfx (include/dfx.h) so the same Python binding can drive it, but it
+// is built into oracle/cpu/libdfx_cpu.so and is only ever loaded by tests/, smoke() and bench.py's
+// cpu_baseline leg.  The product (difflexmm_amd) never loads it.
+//
+// It runs the algorithm of the reference's hot path -- rhs (difflexmm/dynamics.py:33-55) inside a
+// Dormand-Prince step (jax.experimental.ode.runge_kutta_step) -- on host cores, with the force
+// hand-derived instead of obtained by autodiff.  The per-ligament formulas are the ones in
+// difflexmm_amd/csrc/dfx_physics.h (also compiled into the GPU kernels); their independent check is
+// the torch-autograd restatement in oracle/ref_*.py.  Parallelism: OpenMP over blocks.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../difflexmm_amd/csrc/dfx_stage.h"
+
+using namespace dfx;
+
+static std::string g_create_error;
+
+struct dfx_handle {
+  Plan pl;
+  PackedParams pp;
+  bool have_params = false;
+  std::string err;
+  // last forward
+  std::vector<double> traj;       // batch * (N+1) * n_blocks * kRec   (when kept)
+  std::vector<double> fields;     // batch * T * 2 * n_blocks * 3
+  std::vector<double> ts;
+  int spi = 0;
+  bool have_traj = false;
+};
+
+static Tables member_tables(const dfx_handle* h, int m) {
+  const Plan& pl = h->pl;
+  Tables tb;
+  tb.n_blocks = pl.n_blocks; tb.n_fns = pl.n_fns; tb.model = pl.model; tb.contact = pl.contact;
+  tb.slot_info = pl.slot_info.data();
+  tb.block_special = pl.block_special.data();
+  tb.special = pl.special.data();
+  tb.slot_p = h->pp.slot.data() + (size_t)m * pl.n_slots * kSlotParams;
+  tb.inv_m = h->pp.inv_m.data() + (size_t)m * pl.n_blocks * 3;
+  tb.damping = h->pp.damping.data() + (size_t)m * pl.n_blocks * 3;
+  tb.contact_p = h->pp.contact.data() + (size_t)m * 3;
+  tb.fns = h->pp.fns.data() + (size_t)m * DFX_MAX_FNS;
+  return tb;
+}
+
+template <int MODEL, int CONTACT>
+static void fwd_stage_t(const Tables& tb, const Tableau& T, const FwdStage& st, double* energy) {
+  double etot = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : etot)
+  for (int b = 0; b < tb.n_blocks; ++b) {
+    double f[3] = {0, 0, 0};
+    for (int k = 0; k < kSlots; ++k) {
+      double fx, fy, fth, e;
+      fwd_slot<MODEL, CONTACT>(tb, st.S_in, b * kSlots + k, fx, fy, fth, &e);
+      f[0] += fx; f[1] += fy; f[2] += fth;
+      etot += e;
+    }
+    if (st.A)
+      for (int d = 0; d < 3; ++d) fwd_dof(tb, T, st, b, d, f[d]);
+  }
+  if (energy) *energy = etot;
+}
+
+static void fwd_stage(const Tables& tb, const Tableau& T, const FwdStage& st, double* energy = nullptr) {
+  if (tb.model == kNonlinear) { if (tb.contact) fwd_stage_t<kNonlinear, 1>(tb, T, st, energy); else fwd_stage_t<kNonlinear, 0>(tb, T, st, energy); }
+  else { if (tb.contact) fwd_stage_t<kLinearized, 1>(tb, T, st, energy); else fwd_stage_t<kLinearized, 0>(tb, T, st, energy); }
+}
+
+template <int MODEL, int CONTACT>
+static void adj_stage_t(const Tables& tb, const Tableau& T, const AdjStage& st, const GradAcc& acc) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < tb.n_blocks; ++b) {
+    double hsum[3] = {0, 0, 0};
+    for (int k = 0; k < kSlots; ++k) {
+      double hx, hy, hth;
+      adj_slot<MODEL, CONTACT>(tb, st.S, st.W, b * kSlots + k, acc, hx, hy, hth);
+      hsum[0] += hx; hsum[1] += hy; hsum[2] += hth;
+    }
+    for (int d = 0; d < 3; ++d) adj_dof(tb, T, st, acc, b, d, hsum[d]);
+  }
+}
+
+static void adj_stage(const Tables& tb, const Tableau& T, const AdjStage& st, const GradAcc& acc) {
+  if (tb.model == kNonlinear) { if (tb.contact) adj_stage_t<kNonlinear, 1>(tb, T, st, acc); else adj_stage_t<kNonlinear, 0>(tb, T, st, acc); }
+  else { if (tb.contact) adj_stage_t<kLinearized, 1>(tb, T, st, acc); else adj_stage_t<kLinearized, 0>(tb, T, st, acc); }
+}
+
+static void snapshot(const double* S, int nb, double* out /* (2, nb, 3) */) {
+  for (int b = 0; b < nb; ++b)
+    for (int d = 0; d < 3; ++d) {
+      out[b * 3 + d] = S[(size_t)b * kRec + d];
+      out[nb * 3 + b * 3 + d] = S[(size_t)b * kRec + 5 + d];
+    }
+}
+
+extern "C" {
+
+int dfx_create(const dfx_problem* problem, dfx_handle** out) {
+  dfx_handle* h = new dfx_handle();
+  if (build_plan(problem, h->pl, h->err)) { g_create_error = h->err; delete h; return 1; }
+  *out = h;
+  return 0;
+}
+
+int dfx_destroy(dfx_handle* h) { delete h; return 0; }
+
+const char* dfx_last_error(const dfx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dfx_set_params(dfx_handle* h, const dfx_params* params) {
+  if (pack_params(h->pl, params, h->pp, h->err)) return 1;
+  h->have_params = true;
+  h->have_traj = false;
+  return 0;
+}
+
+int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
+  if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
+  if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+  const Plan& pl = h->pl;
+  const Tableau& T = pl.tab;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = n_timepoints, spi = steps_per_interval;
+  const size_t rec = (size_t)nb * kRec;
+  const int64_t N = (int64_t)(Tn - 1) * spi;
+  auto t_begin = std::chrono::steady_clock::now();
+  h->ts.assign(timepoints, timepoints + Tn);
+  h->spi = spi;
+  h->have_traj = keep_trajectory != 0;
+  h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
+  if (keep_trajectory) h->traj.assign((size_t)B * (N + 1) * rec, 0.0);
+  std::vector<double> Ybuf(2 * rec), Sbuf(2 * rec), A((size_t)T.s * nb * 3);
+  for (int m = 0; m < B; ++m) {
+    Tables tb = member_tables(h, m);
+    double* fm = h->fields.data() + (size_t)m * Tn * nb * 6;
+    double* tr = keep_trajectory ? h->traj.data() + (size_t)m * (N + 1) * rec : nullptr;
+    double* Y = tr ? tr : Ybuf.data();
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) init_dof(tb, state0 + (size_t)m * nb * 6, timepoints[0], Y, b, d);
+    snapshot(Y, nb, fm);
+    int64_t n = 0;
+    for (int k = 0; k + 1 < Tn; ++k) {
+      const double hh = (timepoints[k + 1] - timepoints[k]) / spi;
+      for (int j = 0; j < spi; ++j, ++n) {
+        const double t = timepoints[k] + j * hh;
+        double* Ynext = tr ? tr + (size_t)(n + 1) * rec : (Y == Ybuf.data() ? Ybuf.data() + rec : Ybuf.data());
+        for (int i = 0; i < T.s; ++i) {
+          FwdStage st;
+          st.S_in = i == 0 ? Y : Sbuf.data() + (size_t)(i & 1) * rec;
+          st.S_out = i == T.s - 1 ? Ynext : Sbuf.data() + (size_t)((i + 1) & 1) * rec;
+          st.Y = Y; st.A = A.data(); st.i = i; st.h = hh;
+          st.t_i = t + T.c[i] * hh; st.t_next = t + T.c[i + 1] * hh;
+          fwd_stage(tb, T, st);
+        }
+        Y = Ynext;
+      }
+      snapshot(Y, nb, fm + (size_t)(k + 1) * nb * 6);
+    }
+  }
+  if (fields) memcpy(fields, h->fields.data(), sizeof(double) * h->fields.size());
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->steps = N; stats->rhs_evals = N * T.s; stats->launches = 0;
+    stats->kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return 0;
+}
+
+static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T*nb*6 [q(3) v(3)] per block */,
+                       dfx_grads* grads, dfx_stats* stats) {
+  if (!h->have_traj) { h->err = "adjoint: run forward with keep_trajectory=1 first"; return 1; }
+  const Plan& pl = h->pl;
+  const Tableau& T = pl.tab;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size(), spi = h->spi;
+  const size_t rec = (size_t)nb * kRec;
+  const int64_t N = (int64_t)(Tn - 1) * spi;
+  auto t_begin = std::chrono::steady_clock::now();
+  const int nsp = pl.n_special > 0 ? pl.n_special : 1;
+  std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0);
+  std::vector<double> Sst((size_t)T.s * rec), A((size_t)T.s * nb * 3), YB((size_t)T.s * nb * 6), LAM((size_t)nb * 6),
+      W(2 * (size_t)nb * 3), KQ(2 * (size_t)nb * 3);
+  for (int m = 0; m < B; ++m) {
+    Tables tb = member_tables(h, m);
+    GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS};
+    const double* tr = h->traj.data() + (size_t)m * (N + 1) * rec;
+    const double* G = Gall.data() + (size_t)m * Tn * nb * 6;
+    int cur = 0;
+    const double h_last = Tn > 1 ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / spi : 0.0;
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d)
+        adj_begin_dof(tb, T, G + (size_t)(Tn - 1) * nb * 6, h_last, LAM.data(), W.data() + (size_t)cur * nb * 3, KQ.data() + (size_t)cur * nb * 3, b, d);
+    for (int k = Tn - 2; k >= 0; --k) {
+      const double hh = (h->ts[k + 1] - h->ts[k]) / spi;
+      for (int j = spi - 1; j >= 0; --j) {
+        const int64_t n = (int64_t)k * spi + j;
+        const double t = h->ts[k] + j * hh;
+        const double* Y = tr + (size_t)n * rec;
+        // recompute the stage records of step n
+        for (int i = 0; i < T.s; ++i) {
+          FwdStage st;
+          st.S_in = i == 0 ? Y : Sst.data() + (size_t)i * rec;
+          st.S_out = i == T.s - 1 ? nullptr : Sst.data() + (size_t)(i + 1) * rec;
+          st.Y = Y; st.A = A.data(); st.i = i; st.h = hh;
+          st.t_i = t + T.c[i] * hh; st.t_next = t + T.c[i + 1] * hh;
+          fwd_stage(tb, T, st);
+        }
+        for (int i = T.s - 1; i >= 0; --i) {
+          AdjStage st;
+          st.S = i == 0 ? Y : Sst.data() + (size_t)i * rec;
+          st.A = A.data();
+          st.W = W.data() + (size_t)cur * nb * 3; st.KQ = KQ.data() + (size_t)cur * nb * 3;
+          st.W_out = W.data() + (size_t)(1 - cur) * nb * 3; st.KQ_out = KQ.data() + (size_t)(1 - cur) * nb * 3;
+          st.YB = YB.data(); st.LAM = LAM.data();
+          st.G = (i == 0 && j == 0) ? G + (size_t)k * nb * 6 : nullptr;
+          st.i = i; st.t_i = t + T.c[i] * hh; st.h = hh;
+          st.h_prev = j > 0 ? hh : (k > 0 ? (h->ts[k] - h->ts[k - 1]) / spi : 0.0);
+          adj_stage(tb, T, st, acc);
+          cur = 1 - cur;
+        }
+      }
+    }
+    if (Tn == 1) {
+      // no steps: lambda_0 = G_0 (already placed by adj_begin_dof)
+    }
+    if (grads && grads->state0)
+      for (int b = 0; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) {
+          grads->state0[(size_t)m * nb * 6 + b * 3 + d] = LAM[b * 6 + d];
+          grads->state0[(size_t)m * nb * 6 + nb * 3 + b * 3 + d] = LAM[b * 6 + 3 + d];
+        }
+  }
+  if (grads) unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, grads);
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->steps = N; stats->rhs_evals = N * T.s;
+    stats->kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return 0;
+}
+
+int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_stats* stats) {
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  std::vector<double> G((size_t)B * Tn * nb * 6);
+  for (int m = 0; m < B; ++m)
+    for (int k = 0; k < Tn; ++k) {
+      const double* fb = fields_bar + ((size_t)m * Tn + k) * nb * 6;
+      double* g = G.data() + ((size_t)m * Tn + k) * nb * 6;
+      for (int b = 0; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) { g[b * 6 + d] = fb[b * 3 + d]; g[b * 6 + 3 + d] = fb[nb * 3 + b * 3 + d]; }
+    }
+  return run_adjoint(h, G, grads, stats);
+}
+
+int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective) {
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  if (h->fields.empty()) { h->err = "objective: run forward first"; return 1; }
+  for (int m = 0; m < B; ++m) {
+    double acc = 0.0;
+    for (int k = 0; k < Tn; ++k)
+      for (int i = 0; i < n_target; ++i)
+        for (int d = 0; d < 3; ++d) {
+          int dof = target_blocks[i] * 3 + d;
+          double v = h->fields[((size_t)m * Tn + k) * nb * 6 + nb * 3 + dof];
+          acc += 0.5 * v * v / h->pp.inv_m[(size_t)m * nb * 3 + dof];
+        }
+    objective[m] = acc;
+  }
+  return 0;
+}
+
+int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, dfx_grads* grads, dfx_stats* stats) {
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  if (h->fields.empty()) { h->err = "adjoint_kinetic: run forward first"; return 1; }
+  std::vector<double> G((size_t)B * Tn * nb * 6, 0.0);
+  for (int m = 0; m < B; ++m)
+    for (int k = 0; k < Tn; ++k)
+      for (int i = 0; i < n_target; ++i)
+        for (int d = 0; d < 3; ++d) {
+          int b = target_blocks[i], dof = b * 3 + d;
+          double v = h->fields[((size_t)m * Tn + k) * nb * 6 + nb * 3 + dof];
+          G[((size_t)m * Tn + k) * nb * 6 + b * 6 + 3 + d] = v / h->pp.inv_m[(size_t)m * nb * 3 + dof];
+        }
+  int rc = run_adjoint(h, G, grads, stats);
+  if (rc) return rc;
+  // explicit dependence of the objective on the inertia: d/dm sum m v^2/2 = v^2/2
+  if (grads && grads->inertia)
+    for (int m = 0; m < B; ++m)
+      for (int k = 0; k < Tn; ++k)
+        for (int i = 0; i < n_target; ++i)
+          for (int d = 0; d < 3; ++d) {
+            int dof = target_blocks[i] * 3 + d;
+            double v = h->fields[((size_t)m * Tn + k) * nb * 6 + nb * 3 + dof];
+            grads->inertia[(size_t)m * nb * 3 + dof] += 0.5 * v * v;
+          }
+  return 0;
+}
+
+int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
+  if (!h->have_params) { h->err = "rhs: set_params first"; return 1; }
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks;
+  std::vector<double> S((size_t)nb * kRec), A((size_t)pl.tab.s * nb * 3);
+  for (int m = 0; m < pl.batch; ++m) {
+    Tables tb = member_tables(h, m);
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) init_dof(tb, y + (size_t)m * nb * 6, t, S.data(), b, d);
+    FwdStage st;
+    st.S_in = S.data(); st.S_out = nullptr; st.Y = S.data(); st.A = A.data(); st.i = 0; st.h = 0.0; st.t_i = t; st.t_next = t;
+    fwd_stage(tb, pl.tab, st);
+    double* o = dy + (size_t)m * nb * 6;
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) {
+        int sidx = pl.block_special[b];
+        bool con = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1);
+        o[b * 3 + d] = con ? 0.0 : S[(size_t)b * kRec + 5 + d];
+        o[nb * 3 + b * 3 + d] = A[b * 3 + d];
+      }
+  }
+  return 0;
+}
+
+int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, double* y_bar, dfx_grads* grads) {
+  if (!h->have_params) { h->err = "rhs_vjp: set_params first"; return 1; }
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks, B = pl.batch;
+  const int nsp = pl.n_special > 0 ? pl.n_special : 1;
+  std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0);
+  std::vector<double> S((size_t)nb * kRec), A((size_t)pl.tab.s * nb * 3), W((size_t)nb * 3);
+  for (int m = 0; m < B; ++m) {
+    Tables tb = member_tables(h, m);
+    GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS};
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) init_dof(tb, y + (size_t)m * nb * 6, t, S.data(), b, d);
+    FwdStage st;
+    st.S_in = S.data(); st.S_out = nullptr; st.Y = S.data(); st.A = A.data(); st.i = 0; st.h = 0.0; st.t_i = t; st.t_next = t;
+    fwd_stage(tb, pl.tab, st);
+    const double* lm = lam + (size_t)m * nb * 6;
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) {
+        int sidx = pl.block_special[b];
+        bool con = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1);
+        W[b * 3 + d] = con ? 0.0 : lm[nb * 3 + b * 3 + d] * tb.inv_m[b * 3 + d];
+      }
+    double* yb = y_bar + (size_t)m * nb * 6;
+    for (int b = 0; b < nb; ++b) {
+      double hs[3] = {0, 0, 0};
+      for (int k = 0; k < kSlots; ++k) {
+        double hx, hy, hth;
+        if (tb.model == kNonlinear) { if (tb.contact) adj_slot<kNonlinear, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<kNonlinear, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); }
+        else { if (tb.contact) adj_slot<kLinearized, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<kLinearized, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); }
+        hs[0] += hx; hs[1] += hy; hs[2] += hth;
+      }
+      for (int d = 0; d < 3; ++d) {
+        bool con; double ybq, ybv;
+        adj_dof_local(tb, acc, b, d, t, hs[d], W[b * 3 + d], lm[b * 3 + d], S[(size_t)b * kRec + 5 + d], A[b * 3 + d], con, ybq, ybv);
+        yb[b * 3 + d] = ybq;
+        yb[nb * 3 + b * 3 + d] = ybv;
+      }
+    }
+  }
+  if (grads) {
+    dfx_grads g = *grads;
+    g.state0 = nullptr;
+    unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g);
+  }
+  return 0;
+}
+
+int dfx_energy(dfx_handle* h, const double* u, double* energy) {
+  if (!h->have_params) { h->err = "energy: set_params first"; return 1; }
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks;
+  std::vector<double> S((size_t)nb * kRec, 0.0);
+  for (int m = 0; m < pl.batch; ++m) {
+    Tables tb = member_tables(h, m);
+    for (int b = 0; b < nb; ++b) {
+      double* r = S.data() + (size_t)b * kRec;
+      for (int d = 0; d < 3; ++d) r[d] = u[(size_t)m * nb * 3 + b * 3 + d];
+      r[3] = cos(0.5 * r[2]); r[4] = sin(0.5 * r[2]);
+    }
+    FwdStage st;
+    st.S_in = S.data(); st.S_out = nullptr; st.Y = S.data(); st.A = nullptr; st.i = 0; st.h = 0; st.t_i = 0; st.t_next = 0;
+    fwd_stage(tb, pl.tab, st, energy + m);
+  }
+  return 0;
+}
+
+int dfx_device_count(void) { return 0; }
+const char* dfx_version(void) { return "dfx-cpu-port 0.1.0"; }
+
+}  // extern "C"
