@@ -1,0 +1,133 @@
+"""Shared builders for the parity tests: the same seeded problem once for the engine under test
+(HIP library, or the CPU port for the no-GPU suite) and once for the torch/NumPy oracle."""
+import math
+
+import numpy as np
+import torch
+
+import difflexmm_amd as dm
+from difflexmm_amd import energy as en_mod
+from difflexmm_amd import geometry as geo_mod
+from difflexmm_amd import loading as ld
+from difflexmm_amd.dynamics import setup_dynamic_solver
+from oracle import ref_dynamics as OD
+from oracle import ref_energy as OE
+from oracle import ref_geometry as OG
+
+# constants of notebooks/quads_focusing_multi_input_3dp_pla_shims.ipynb cell 7, mm-N-s-Mg
+SPACING, BOND_LENGTH = 15.0, 2.25
+K_STRETCH, K_SHEAR, K_ROT, DENSITY = 120.0, 1.19, 1.5, 6.18e-9
+PULSE = dict(amplitude=7.5, loading_rate=30.0, input_delay=0.1 / 30.0)
+
+
+def paper_damping(spacing=SPACING):
+    return 0.0186 * np.array([2 * math.sqrt(0.36125 * DENSITY * spacing ** 2 * K_SHEAR),
+                              2 * math.sqrt(0.36125 * DENSITY * spacing ** 2 * K_SHEAR),
+                              2 * math.sqrt(0.02175026 * DENSITY * spacing ** 4 * K_ROT)])
+
+
+def torch_pulse(vector):
+    vt = torch.as_tensor(np.asarray(vector, dtype=float))
+
+    def fn(t, amplitude, loading_rate, input_delay):
+        tau = torch.as_tensor(t, dtype=torch.float64) - input_delay
+        on = (tau > 0) & (tau < 1 / loading_rate)
+        return amplitude * torch.where(on, (1 - torch.cos(2 * math.pi * loading_rate * tau)) / 2,
+                                       torch.zeros((), dtype=torch.float64)) * vt
+    return fn
+
+
+class Case:
+    """A lattice + BCs + parameters, materialised for the engine (NumPy) and for the oracle (torch)."""
+
+    def __init__(self, lattice="quads", n=4, nonlinear=True, contact=False, damping=True, seed=0, lib=None,
+                 cutoff_deg=-10.0, min_deg=-15.0, batch=1, integrator="dopri5", per_bond_k=False, perturb=0.02):
+        rng = np.random.default_rng(seed)
+        self.rng = rng
+        if lattice == "quads":
+            self.geo = geo_mod.QuadGeometry(n, n, SPACING, BOND_LENGTH)
+            self.ogeo = OG.QuadGeometry(n, n, SPACING, BOND_LENGTH)
+            base = self.geo.get_design_from_rotated_square(25 * math.pi / 180)
+            self.design = tuple(b + rng.uniform(-perturb * SPACING, perturb * SPACING, b.shape) for b in base)
+            nb1 = n
+            # 1 driven block on the left edge (x driven, y/theta held) + a clamped corner block
+            mid = (n // 2) * nb1
+            con = [[mid, 0], [mid, 1], [mid, 2], [0, 0], [0, 1], [0, 2], [n * n - 1, 1]]
+            vec = [1.0, 0, 0, 0, 0, 0, 0]
+        else:
+            cell = 20.0
+            basis = cell * np.array([[1.0, 0.0], [math.cos(math.pi / 3), math.sin(math.pi / 3)]])
+            self.geo = geo_mod.KagomeGeometry(n, n, basis, BOND_LENGTH)
+            self.ogeo = OG.KagomeGeometry(n, n, basis, BOND_LENGTH)
+            self.design = tuple(rng.uniform(-0.3, 0.3, s) for s in self.geo.design_shapes())
+            mid = 2 * n * (n // 2)
+            con = [[mid, 0], [mid, 1], [mid, 2], [0, 0], [0, 1], [0, 2]]
+            vec = [1.0, 0, 0, 0, 0, 0]
+        self.con = np.array(con)
+        self.vec = np.array(vec)
+        self.bonds = self.geo.bond_connectivity()
+        nbd = len(self.bonds)
+        self.cnv = self.geo.centroid_node_vectors(*self.design)
+        self.cen = self.geo.block_centroids(*self.design)
+        self.refv = self.geo.reference_bond_vectors()
+        ks = K_STRETCH * (1 + 0.1 * rng.uniform(-1, 1, nbd)) if per_bond_k else K_STRETCH
+        ksh = K_SHEAR * (1 + 0.1 * rng.uniform(-1, 1, nbd)) if per_bond_k else K_SHEAR
+        kr = K_ROT * (1 + 0.1 * rng.uniform(-1, 1, nbd)) if per_bond_k else K_ROT
+        self.contact = contact
+        self.damped = np.arange(self.geo.n_blocks) if damping else None
+        dval = paper_damping() * np.ones((self.geo.n_blocks, 1)) if damping else 0.0
+        self.contact_params = (min_deg * math.pi / 180, cutoff_deg * math.pi / 180, 1.5)
+        efn = en_mod.ligament_energy if nonlinear else en_mod.ligament_energy_linearized
+        energy = en_mod.build_strain_energy(self.bonds, efn)
+        if contact:
+            energy = en_mod.combine_block_energies(energy, en_mod.build_contact_energy(self.bonds))
+        self.solver = setup_dynamic_solver(self.geo, energy, constrained_block_DOF_pairs=self.con,
+                                           constrained_DOFs_fn=ld.Pulse(self.vec), damped_blocks=self.damped,
+                                           integrator=integrator, batch=batch, _lib=lib)
+        self.cp = dm.ControlParams(
+            dm.GeometricalParams(self.cen, self.cnv),
+            dm.MechanicalParams(dm.LigamentParams(ks, ksh, kr, self.refv), DENSITY, None, dval,
+                                dm.ContactParams(*self.contact_params) if contact else None),
+            constraint_params=dict(PULSE))
+        # oracle twin
+        ofn = OE.ligament_energy if nonlinear else OE.ligament_energy_linearized
+        oenergy = OE.build_strain_energy(self.bonds, ofn)
+        if contact:
+            oenergy = OE.combine_block_energies(oenergy, OE.build_contact_energy(self.bonds))
+        self.oenergy = oenergy
+        self.osolver_args = dict(constrained_block_DOF_pairs=self.con, constrained_DOFs_fn=torch_pulse(self.vec),
+                                 damped_blocks=self.damped)
+        self.ks, self.ksh, self.kr, self.dval = ks, ksh, kr, dval
+
+    def oracle_solver(self, **kw):
+        return OD.setup_dynamic_solver(self.ogeo, self.oenergy, **self.osolver_args, **kw)
+
+    def oracle_cp(self, leaves=None):
+        """Oracle ControlParams; ``leaves`` (dict name -> torch tensor) overrides entries so autograd can track them."""
+        def T(x):
+            return torch.as_tensor(np.asarray(x, dtype=np.float64))
+        lv = dict(cnv=T(self.cnv), cen=T(self.cen), refv=T(self.refv),
+                  ks=T(self.ks), ksh=T(self.ksh), kr=T(self.kr),
+                  density=T(DENSITY), damping=T(self.dval),
+                  min_angle=T(self.contact_params[0]), cutoff_angle=T(self.contact_params[1]),
+                  k_contact=T(self.contact_params[2]),
+                  amplitude=T(PULSE["amplitude"]), loading_rate=T(PULSE["loading_rate"]),
+                  input_delay=T(PULSE["input_delay"]), inertia=None)
+        if leaves:
+            lv.update(leaves)
+        return OE.ControlParams(
+            OE.GeometricalParams(lv["cen"], lv["cnv"]),
+            OE.MechanicalParams(OE.LigamentParams(lv["ks"], lv["ksh"], lv["kr"], lv["refv"]), lv["density"], lv["inertia"],
+                                lv["damping"],
+                                OE.ContactParams(lv["min_angle"], lv["cutoff_angle"], lv["k_contact"]) if self.contact else None),
+            constraint_params=dict(amplitude=lv["amplitude"], loading_rate=lv["loading_rate"], input_delay=lv["input_delay"]))
+
+    def random_state(self, scale_q=0.4, scale_th=0.15, scale_v=50.0):
+        y = self.rng.normal(size=(2, self.geo.n_blocks, 3)) * np.array([scale_q, scale_q, scale_th])
+        y[1] *= scale_v
+        return y
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
