@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- timesteps x rigid-units / s of the hot path (forward + discrete adjoint) on MI355X.
+
+Workload (BASELINE.json configs[2], SURVEY 8(d) "C3"): 128x128 quad lattice (16 384 rigid units), nonlinear
+ligaments + viscous damping + angle-based contact, raised-cosine displacement pulse on 2 left-edge blocks,
+clamped corners, Dormand-Prince tableau on a fixed grid with dt = (2/f)/50 000, one output every 250 steps,
+objective = kinetic energy of the 2x2 target blocks, gradient w.r.t. the 66 048 geometry parameters.
+One "step" = one RK step (6 RHS evaluations) of one member, forward AND reverse.  `--steps K` times exactly K
+steps (K is rounded to a multiple of 250); the full config is K = 50 000.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--members M] [--size 128]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank integrates its own design (weak
+scaling, no data-path collective), objectives are gathered with one RCCL all_gather.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SPI = 250                     # steps between outputs: 50 000 steps / 200 output intervals
+FREQ = 30.0
+DT = (2.0 / FREQ) / 50000.0
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md, chip-level parameters
+# algorithmic bytes per rigid unit per launch
+BYTES_FWD_STAGE = 272 + 72    # one RHS evaluation (quads + contact) + its share of the stage combine (432/6)
+BYTES_ADJ_STAGE = 272 + 96 + 256  # stage data + lambda/Ybar read-write + parameter-gradient RMW
+
+
+def c3_problem(size, seed, members, lib=None, device=0):
+    from difflexmm_amd.problems import QuadsFocusingForward, TargetKineticEnergy
+    spacing, bond = 15.0, 2.25
+    rho, ksh, kr = 6.18e-9, 1.19, 1.5
+    damping = 0.0186 * np.array([2 * math.sqrt(0.36125 * rho * spacing ** 2 * ksh),
+                                 2 * math.sqrt(0.36125 * rho * spacing ** 2 * ksh),
+                                 2 * math.sqrt(0.02175026 * rho * spacing ** 4 * kr)]) * np.ones((size * size, 1))
+    fw = QuadsFocusingForward(
+        n1_blocks=size, n2_blocks=size, spacing=spacing, bond_length=bond, k_stretch=120.0, k_shear=ksh, k_rot=kr,
+        density=rho, damping=damping, amplitude=7.5, loading_rate=FREQ, input_delay=0.1 / FREQ, n_excited_blocks=2,
+        loaded_side="left", input_shift=0, simulation_time=2.0 / FREQ, n_timepoints=201, use_contact=True,
+        k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180, steps_per_interval=SPI,
+        batch=members, device=device, _lib=lib)
+    fw.setup()
+    obj = TargetKineticEnergy(fw, (2, 2), (size // 6, size // 5))
+    designs = []
+    for m in range(members):
+        rng = np.random.default_rng(seed + m)
+        base = fw.geometry.get_design_from_rotated_square(25 * math.pi / 180)
+        designs.append(tuple(b + rng.uniform(-0.02 * spacing, 0.02 * spacing, b.shape) for b in base))
+    return fw, obj, designs
+
+
+def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
+    """Forward (+ reverse) of n_steps steps with inputs resident in HBM; returns device milliseconds + stats."""
+    T = n_steps // spi + 1
+    fw.timepoints = np.arange(T) * (spi * DT)
+    sd = fw.solve_dynamics
+    cps = [fw.control_params(d) for d in designs]
+    flats = [sd._flatten(cp) for cp in cps]
+    eng = sd.engine
+    eng.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
+    sd._last = (cps, flats, fw.timepoints)
+    _, st_f = eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), fw.timepoints, spi, keep_trajectory=adjoint,
+                          want_fields=False)
+    out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "objective": None, "adj_ms": 0.0, "adj_launches": 0}
+    if adjoint:
+        out["objective"] = eng.objective_kinetic(obj.target_blocks)
+        grads, st_a = eng.adjoint_kinetic(obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
+        out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
+        out["grad_norm"] = float(np.linalg.norm(grads["centroid_node_vectors"]))
+    return out
+
+
+def cpu_baseline(size, seed, budget_s=20.0):
+    """The CPU port of the oracle (same algorithm, same tableau, OpenMP over blocks) on a bounded sample of the same
+    workload: forward + adjoint of a few steps of the same lattice."""
+    from oracle.cpu import load
+    lib = load()
+    fw, obj, designs = c3_problem(size, seed, 1, lib=lib)
+    t0 = time.perf_counter()
+    run_once(fw, obj, designs, 2, spi=2)
+    dt1 = time.perf_counter() - t0
+    n = int(max(2, min(400, (budget_s / max(dt1 / 2, 1e-6)) // 2 * 2)))
+    t0 = time.perf_counter()
+    run_once(fw, obj, designs, n, spi=2)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": n * size * size / dt, "unit": "timesteps*units/s", "cores": cores, "kind": "port",
+            "sample": f"{n} Dopri5 steps forward+adjoint of the same {size}x{size} lattice (C++ port of the oracle, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=250)
+    ap.add_argument("--members", type=int, default=1, help="ensemble members per GPU integrated in one launch")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    K = max(SPI, (args.steps // SPI) * SPI)
+    W = 0 if args.warmup <= 0 else max(SPI, (args.warmup // SPI) * SPI)
+    fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
+    fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 1, keep_trajectory=not args.forward_only)
+    if W:
+        run_once(fw, obj, designs, W, adjoint=not args.forward_only)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    res = run_once(fw, obj, designs, K, adjoint=not args.forward_only)
+    barrier()
+    wall = time.perf_counter() - t0
+    objective = res["objective"] if res["objective"] is not None else np.zeros(args.members)
+    if dist is not None:
+        tw = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+        mine = torch.tensor(np.asarray(objective, dtype=np.float64), device="cuda")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)          # the single collective of the path: objectives over xGMI
+        objective = torch.cat(gathered).cpu().numpy()
+    if rank == 0:
+        n_units = args.size * args.size
+        total_units_steps = K * n_units * args.members * world
+        fwd_us = 1e3 * res["fwd_ms"] / max(1, res["fwd_launches"])
+        roof_bytes = BYTES_FWD_STAGE * n_units * args.members
+        achieved = roof_bytes / (fwd_us * 1e-6) / 1e9
+        line = {
+            "metric": "timesteps*rigid-units/s (forward + adjoint)" if not args.forward_only else "timesteps*rigid-units/s (forward)",
+            "value": total_units_steps / wall, "unit": "timesteps*units/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * wall / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C3: {args.size}x{args.size} quads, nonlinear ligaments + damping + angle contact, "
+                                   f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
+                                   f"{'forward only' if args.forward_only else 'forward + adjoint wrt 66048 geometry params'}",
+                       "members_per_gpu": args.members, "integrator": "dopri5-fixed", "steps_per_output": SPI},
+            "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
+            "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
+            "launches": {"forward": res["fwd_launches"], "adjoint": res["adj_launches"]},
+            "objective": [float(x) for x in np.atleast_1d(objective)][:8],
+            "roofline": {"bound": "hbm", "kernel": "k_fwd_stage<nonlinear,contact>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
+                         "bytes_per_launch": roof_bytes, "launch_us": fwd_us},
+        }
+        if res["adj_launches"]:
+            s = 6
+            n_adj = res["adj_launches"] / 2.0
+            adj_us = max(1e-9, (1e3 * res["adj_ms"] - n_adj * fwd_us) / n_adj)
+            a2 = BYTES_ADJ_STAGE * n_units * args.members / (adj_us * 1e-6) / 1e9
+            line["roofline_adjoint_kernel"] = {"kernel": "k_adj_stage<nonlinear,contact>", "achieved": a2, "peak": HBM_PEAK_GBS,
+                                               "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS, "launch_us": adj_us}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size, 3)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or null."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("k_fwd_stage_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,7 @@ class dfx_stats(C.Structure):
                 ("kernel_ms", C.c_double), ("stage_kernel_us", C.c_double)]
 
 
-EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_forward", "dfx_adjoint",
+EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
 
@@ -62,6 +62,7 @@ def declare(lib):
     lib.dfx_last_error.argtypes = [H]
     lib.dfx_last_error.restype = C.c_char_p
     lib.dfx_set_params.argtypes = [H, C.POINTER(dfx_params)]
+    lib.dfx_reserve.argtypes = [H, C.c_int64, C.c_int32, C.c_int32]
     lib.dfx_forward.argtypes = [H, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, C.POINTER(dfx_stats)]
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
@@ -177,6 +178,9 @@ class Engine:
             keep.append(a)
             setattr(p, name, _ptr(a))
         self._check(self.lib.dfx_set_params(self._h, C.byref(p)), "dfx_set_params")
+
+    def reserve(self, max_steps, max_timepoints, keep_trajectory=True):
+        self._check(self.lib.dfx_reserve(self._h, int(max_steps), int(max_timepoints), int(bool(keep_trajectory))), "dfx_reserve")
 
     # -- solves -------------------------------------------------------------------------------
     def forward(self, state0, timepoints, steps_per_interval, keep_trajectory=False, want_fields=True):

@@ -215,6 +215,7 @@ struct AdjStage {
   double* KQ_out;
   const double* G;      // output cotangent to add to lambda_n at i == 0 (n_blocks*6) or null
   int i;
+  int local_only;       // 1: only Ybar_i + parameter accumulators (dfx_rhs_vjp test hook)
   double t_i, h, h_prev;  // h_prev: step size of the step that the NEXT reverse launch belongs to
 };
 
@@ -263,6 +264,7 @@ DFX_HD void adj_dof(const Tables& tb, const Tableau& T, const AdjStage& st, cons
                 st.A[(size_t)st.i * nd + dof], constrained, ybq, ybv);
   st.YB[(size_t)st.i * nd6 + b * 6 + d] = ybq;
   st.YB[(size_t)st.i * nd6 + b * 6 + 3 + d] = ybv;
+  if (st.local_only) return;
   double lq = st.LAM[b * 6 + d], lv = st.LAM[b * 6 + 3 + d];
   double kq, kv;
   if (st.i > 0) {

@@ -118,6 +118,11 @@ const char* dfx_last_error(const dfx_handle* h);  /* h may be NULL: error of the
 
 int dfx_set_params(dfx_handle* h, const dfx_params* params);
 
+/* Optional: pre-allocate device buffers for solves of up to `max_steps` RK steps and `max_timepoints`
+ * outputs (trajectory checkpoint only when keep_trajectory != 0), so that later dfx_forward / dfx_adjoint
+ * calls neither allocate nor re-instantiate their hipGraphs. */
+int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_t keep_trajectory);
+
 /* Integrate from timepoints[0] with `steps_per_interval` equal RK steps between consecutive
  * timepoints.  state0: (batch, 2, n_blocks, 3); fields: (batch, T, 2, n_blocks, 3), row 0 is the
  * reconstructed initial state.  keep_trajectory != 0 checkpoints every step state in HBM so that

@@ -121,6 +121,8 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
   return 0;
 }
 
+int dfx_reserve(dfx_handle*, int64_t, int32_t, int32_t) { return 0; }
+
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
@@ -221,7 +223,7 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
           st.W_out = W.data() + (size_t)(1 - cur) * nb * 3; st.KQ_out = KQ.data() + (size_t)(1 - cur) * nb * 3;
           st.YB = YB.data(); st.LAM = LAM.data();
           st.G = (i == 0 && j == 0) ? G + (size_t)k * nb * 6 : nullptr;
-          st.i = i; st.t_i = t + T.c[i] * hh; st.h = hh;
+          st.i = i; st.local_only = 0; st.t_i = t + T.c[i] * hh; st.h = hh;
           st.h_prev = j > 0 ? hh : (k > 0 ? (h->ts[k] - h->ts[k - 1]) / spi : 0.0);
           adj_stage(tb, T, st, acc);
           cur = 1 - cur;

@@ -1,0 +1,104 @@
+"""Parity checks shared by the CPU-port suite (no GPU) and the HIP suite (-m gpu): the engine under test
+against the torch-autograd / NumPy oracle on identical seeded inputs.  Tolerances are for fp64."""
+import numpy as np
+import torch
+
+from difflexmm_amd import geometry as geo
+from oracle import ref_dynamics as OD
+
+from .common import Case, relerr
+
+RTOL_RHS = 1e-12       # one RHS evaluation / one VJP
+RTOL_TRAJ = 1e-10      # short fixed-step trajectories (same tableau, same grid)
+RTOL_GRAD = 1e-9       # discrete-adjoint gradients vs autograd through the unrolled oracle
+
+
+def T64(x, grad=False):
+    return torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=grad)
+
+
+def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=True):
+    cut = (125.0 if lattice == "kagome" else 42.0)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, per_bond_k=per_bond_k)
+    s = c.solver
+    flat = s._flatten(c.cp)
+    s.engine.set_params(**{k: v[None] for k, v in flat.items()})
+    y = c.random_state()
+    lam = c.rng.normal(size=y.shape)
+    t = 0.012
+    dy = s.engine.rhs(y[None], t)[0]
+    yb, g = s.engine.rhs_vjp(y[None], t, lam[None])
+    names = ["cnv", "refv", "ks", "ksh", "kr", "damping", "amplitude", "loading_rate", "input_delay"]
+    src = dict(cnv=c.cnv, refv=c.refv, ks=c.ks, ksh=c.ksh, kr=c.kr, damping=c.dval, amplitude=7.5, loading_rate=30.0,
+               input_delay=0.1 / 30, min_angle=c.contact_params[0], cutoff_angle=c.contact_params[1],
+               k_contact=c.contact_params[2])
+    if contact:
+        names += ["min_angle", "cutoff_angle", "k_contact"]
+    leaves = {k: T64(src[k], True) for k in names}
+    inertia = T64(flat["inertia"], True)
+    leaves["inertia"] = inertia
+    osol = c.oracle_solver()
+    free = osol.free_DOF_ids
+    yf = T64(y.reshape(2, -1)[:, free], True)
+    r = osol.rhs(yf, t, c.oracle_cp(leaves), inertia.reshape(-1)[torch.as_tensor(free)], create_graph=True)
+    L = (r * T64(lam.reshape(2, -1)[:, free])).sum()
+    gr = torch.autograd.grad(L, [yf] + [leaves[k] for k in names] + [inertia], allow_unused=True)
+    og = dict(zip(names + ["inertia"], gr[1:]))
+    errs = {"rhs": relerr(dy.reshape(2, -1)[:, free], r.detach().numpy()),
+            "y_bar": relerr(yb[0].reshape(2, -1)[:, free], gr[0].numpy())}
+    cnv_bar = g["centroid_node_vectors"][0]
+    if contact:
+        cnv_bar = cnv_bar + geo.void_angles0_vjp(c.cnv, c.bonds, g["void_angle0"][0])
+    errs["cnv"] = relerr(cnv_bar, og["cnv"].numpy())
+    errs["refv"] = relerr(g["reference_vector"][0], og["refv"].numpy())
+    errs["k"] = relerr(g["k_bond"][0], np.stack([og["ks"].numpy(), og["ksh"].numpy(), og["kr"].numpy()], 1))
+    errs["inertia"] = relerr(g["inertia"][0], og["inertia"].numpy())
+    errs["damping"] = relerr(g["damping"][0], og["damping"].numpy())
+    errs["pulse"] = relerr(g["fn_params"][0][0][:3], np.array([og[k].item() for k in ("amplitude", "loading_rate", "input_delay")]))
+    if contact:
+        ref = np.array([og[k].item() for k in ("min_angle", "cutoff_angle", "k_contact")])
+        assert np.abs(ref).max() > 0, "contact inactive: the test would be vacuous"
+        errs["contact"] = relerr(g["contact"][0], ref)
+    # constrained DOFs report zero rate / cotangent
+    con = osol.constrained_DOF_ids
+    assert np.all(dy.reshape(2, -1)[:, con] == 0.0) and np.all(yb[0].reshape(2, -1)[:, con] == 0.0)
+    for k, v in errs.items():
+        assert v < RTOL_RHS, (lattice, nonlinear, contact, k, v)
+    return errs
+
+
+def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, contact=True, seed=5, spi=6, n_out=5, batch=1):
+    cut = (125.0 if lattice == "kagome" else 42.0)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, integrator=integrator)
+    fast = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)   # a full pulse inside the short window
+    c.cp = c.cp._replace(constraint_params=fast)
+    ts = np.linspace(0, 3e-4, n_out)
+    s = c.solver
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    fields = s(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=spi)
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi, tableau=integrator)
+    lv = dict(loading_rate=T64(3000.0), input_delay=T64(1e-5))
+    of = osol(y0, ts, c.oracle_cp(lv)).numpy()
+    e_fwd = relerr(fields, of)
+    assert e_fwd < RTOL_TRAJ, ("forward", lattice, integrator, e_fwd)
+    assert s.stats["steps"] == (n_out - 1) * spi
+    fb = c.rng.normal(size=fields.shape)
+    tree, s0 = s.vjp(fb)
+    design = [T64(d, True) for d in c.design]
+    cnv = c.ogeo.centroid_node_vectors(*design)
+    cen = c.ogeo.block_centroids(*design)
+    amp, y0t = T64(7.5, True), T64(y0, True)
+    free = osol.free_DOF_ids
+    hist, _ = OD.solve_fixed_differentiable(osol, c.ogeo, y0t, ts, c.oracle_cp(dict(cnv=cnv, cen=cen, amplitude=amp, **lv)),
+                                            spi, integrator)
+    L = (hist * T64(fb.reshape(len(ts), 2, -1)[:, :, free])).sum()
+    gr = torch.autograd.grad(L, design + [amp, y0t])
+    mine = c.geo.vjp(c.design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
+    errs = {"fwd": e_fwd}
+    for i, (a, b) in enumerate(zip(mine, gr)):
+        errs[f"design{i}"] = relerr(a, b.numpy())
+    errs["amplitude"] = abs(tree.constraint_params["amplitude"] - gr[len(design)].item()) / abs(gr[len(design)].item())
+    errs["state0"] = relerr(s0.reshape(2, -1)[:, free], gr[-1].numpy().reshape(2, -1)[:, free])
+    for k, v in errs.items():
+        assert v < RTOL_GRAD, (lattice, integrator, k, v)
+    return errs

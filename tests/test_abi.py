@@ -1,0 +1,47 @@
+"""The C-ABI library loads and exports every symbol include/dfx.h declares (no compute without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    return sorted(set(re.findall(r"\b(dfx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from difflexmm_amd._binding import EXPORTS
+    assert sorted(EXPORTS) == declared_symbols()
+
+
+def test_libdfx_exports_every_declared_symbol(hip_lib):
+    for name in declared_symbols():
+        assert hasattr(hip_lib, name), name
+    assert b"gfx950" in hip_lib.dfx_version()
+
+
+def test_cpu_port_exports_same_abi(cpu_lib):
+    for name in declared_symbols():
+        assert hasattr(cpu_lib, name), name
+
+
+def test_product_has_no_cpu_fallback(hip_lib):
+    """Without a HIP device the product must fail loudly instead of computing somewhere else."""
+    import numpy as np
+    if hip_lib.dfx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from difflexmm_amd import _binding as b
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        b.Engine(4, 4, np.array([[0, 6]]), 1, 0, [], [])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "difflexmm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/cpu/dfx_cpu.cpp", "").replace("(oracle/cpu", "(cpu-port") or f in ("dfx_stage.h", "dfx_plan.h", "dfx_physics.h", "dfx_engine.hip"), f

@@ -1,0 +1,108 @@
+"""-m gpu: the HIP engine (through the C ABI, libdfx.so) against the oracle on identical seeded inputs."""
+import numpy as np
+import pytest
+
+from . import parity
+from .common import Case, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lattice,n", [("quads", 4), ("quads", 9), ("kagome", 3), ("kagome", 5)])
+@pytest.mark.parametrize("nonlinear", [True, False])
+@pytest.mark.parametrize("contact", [False, True])
+def test_rhs_and_vjp_match_autograd(hip_lib, lattice, n, nonlinear, contact):
+    parity.check_rhs_and_vjp(None, lattice, n, nonlinear, contact)
+
+
+@pytest.mark.parametrize("lattice,n,integrator", [("quads", 4, "dopri5"), ("kagome", 3, "rk4"), ("quads", 3, "rk4"),
+                                                  ("kagome", 4, "dopri5")])
+def test_trajectory_and_discrete_adjoint(hip_lib, lattice, n, integrator):
+    parity.check_trajectory_and_adjoint(None, lattice, n, integrator)
+
+
+def test_linearized_no_contact_adjoint(hip_lib):
+    parity.check_trajectory_and_adjoint(None, "quads", 4, "dopri5", nonlinear=False, contact=False)
+
+
+def _solve(c, y0, ts, spi, target=None, keep=True):
+    fields = c.solver(y0, ts, c.cp, keep_trajectory=keep, steps_per_interval=spi)
+    return fields
+
+
+def test_hip_matches_cpu_port_32x32_with_segments(hip_lib, cpu_lib):
+    """32x32 quads (config C2 physics + contact), 600 steps per interval so that one interval spans several
+    hipGraph segments; HIP vs the CPU port of the oracle, forward fields and kinetic-energy gradient."""
+    ts = np.linspace(0.0, 2.4e-3, 3)
+    res = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("quads", 32, True, True, seed=2, lib=lib)
+        c.cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=800.0, input_delay=1e-5))
+        f = c.solver(np.zeros((2, 1024, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=600)
+        obj, tree, s0 = c.solver.kinetic_energy_value_and_vjp(np.array([16 * 32 + 2, 16 * 32 + 3]))
+        res[name] = (f, obj, tree.geometrical_params.centroid_node_vectors, tree.constraint_params["amplitude"])
+    assert np.abs(res["cpu"][0]).max() > 1e-3
+    assert relerr(res["hip"][0], res["cpu"][0]) < 1e-9
+    assert abs(res["hip"][1] - res["cpu"][1]) / abs(res["cpu"][1]) < 1e-9
+    assert relerr(res["hip"][2], res["cpu"][2]) < 1e-7
+    assert abs(res["hip"][3] - res["cpu"][3]) / abs(res["cpu"][3]) < 1e-7
+
+
+def test_graph_replay_equals_plain_launches(hip_lib, monkeypatch):
+    ts = np.linspace(0.0, 3e-4, 4)
+    outs = []
+    for no_graph in ("0", "1"):
+        monkeypatch.setenv("DFX_NO_GRAPH", no_graph)
+        c = Case("quads", 6, True, True, seed=4, lib=None, cutoff_deg=42.0)
+        y0 = c.random_state(0.05, 0.02, 5.0)
+        f = c.solver(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=7)
+        tree, s0 = c.solver.vjp(np.ones_like(f))
+        outs.append((f, tree.geometrical_params.centroid_node_vectors, s0))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)   # same kernels, same order: bit-identical
+
+
+def test_batch_members_are_independent(hip_lib):
+    """3 members with different designs in one launch == 3 separate solves (bit-identical)."""
+    ts = np.linspace(0.0, 3e-4, 3)
+    singles, cps = [], []
+    for seed in (21, 22, 23):
+        c = Case("quads", 5, True, True, seed=seed, lib=None, cutoff_deg=42.0)
+        f = c.solver(np.zeros((2, 25, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=8)
+        tree, _ = c.solver.vjp(np.ones_like(f))
+        singles.append((f, tree.geometrical_params.centroid_node_vectors))
+        cps.append(c.cp)
+    cb = Case("quads", 5, True, True, seed=21, lib=None, cutoff_deg=42.0, batch=3)
+    fb = cb.solver(np.zeros((2, 25, 3)), ts, cps, keep_trajectory=True, steps_per_interval=8)
+    trees, _ = cb.solver.vjp(np.ones_like(fb))
+    for m in range(3):
+        assert np.array_equal(fb[m], singles[m][0])
+        assert np.array_equal(trees[m].geometrical_params.centroid_node_vectors, singles[m][1])
+
+
+def test_full_size_128x128_properties(hip_lib):
+    """BASELINE config C3 size (128x128 quads, contact, damping): size-independent properties.
+    (a) clamped + undriven + at rest stays exactly at rest; (b) the solution is deterministic (two runs
+    bit-identical); (c) the adjoint passes the dot-product test  <fields_bar, J dp> = <J^T fields_bar, dp>
+    with a finite-difference directional derivative in the pulse amplitude."""
+    n = 128
+    c = Case("quads", n, True, True, seed=3, lib=None)
+    ts = np.linspace(0.0, 2e-4, 3)
+    rest = c.cp._replace(constraint_params=dict(amplitude=0.0, loading_rate=30.0, input_delay=0.0))
+    f0 = c.solver(np.zeros((2, n * n, 3)), ts, rest, steps_per_interval=10)
+    assert np.all(f0 == 0.0)
+    fast = dict(amplitude=7.5, loading_rate=5000.0, input_delay=1e-6)
+    cp = c.cp._replace(constraint_params=fast)
+    f1 = c.solver(np.zeros((2, n * n, 3)), ts, cp, keep_trajectory=True, steps_per_interval=10)
+    fb = np.random.default_rng(0).normal(size=f1.shape)
+    tree, _ = c.solver.vjp(fb)
+    f2 = c.solver(np.zeros((2, n * n, 3)), ts, cp, keep_trajectory=True, steps_per_interval=10)
+    assert np.array_equal(f1, f2)
+    eps = 1e-4
+    fp = c.solver(np.zeros((2, n * n, 3)), ts, cp._replace(constraint_params=dict(fast, amplitude=7.5 + eps)), steps_per_interval=10)
+    fm = c.solver(np.zeros((2, n * n, 3)), ts, cp._replace(constraint_params=dict(fast, amplitude=7.5 - eps)), steps_per_interval=10)
+    free = c.solver.free_DOF_ids
+    dfd = ((fp - fm) / (2 * eps)).reshape(len(ts), 2, -1)[:, :, free]
+    lhs = float((fb.reshape(len(ts), 2, -1)[:, :, free] * dfd).sum())
+    rhs = float(tree.constraint_params["amplitude"])
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6, (lhs, rhs)
