@@ -7,16 +7,19 @@
 //     quad shuffles; lanes 0..2 of the quad then own DOF x, y, theta for the integrator epilogue.
 //     No atomics anywhere: results are bit-reproducible.
 //   * one kernel launch per Runge-Kutta stage (the neighbour exchange of an explicit stage is a grid-wide
-//     dependency; a kernel boundary is the cheapest grid barrier on this chip).  The
-//     epilogue of stage i already assembles the stage record of stage i+1, so a launch only gathers
-//     finished 64-byte block records (x y th cos(th/2) sin(th/2) vx vy vth).
+//     dependency; a kernel boundary is the cheapest grid barrier on this chip).
+//   * a launch never chases an index: the epilogue of stage i assembles the stage record of stage i+1
+//     (64 B per unit: x y th cos(th/2) sin(th/2) vx vy vth) AND pushes the 5 numbers a neighbour needs
+//     into that neighbour's "mailbox" slot, so every load address of the next launch is known at wave
+//     start (one latency level instead of index -> gather).  All parameter tables are 16-byte rows
+//     indexed by the lane's own slot (coalesced dwordx4).
 //   * the time loop is replayed from hipGraphs (one graph = one segment of <= kMaxGraphSteps steps);
-//     everything that changes between replays (time, step size, checkpoint slot) is read from a small
-//     segment table in device memory, advanced by a 1-thread tick kernel at the head of each graph.
+//     what changes between replays (time, step size, checkpoint slot) is one 64-byte record in device
+//     memory, refreshed by a 1-thread tick kernel at the head of each graph.
 //   * the reverse sweep re-reads the checkpointed trajectory (one 64-B record per unit per step, kept in
 //     HBM), recomputes the stage records of a step and runs one Dual-number kernel per stage.
 //
-// The per-lane physics is shared with the CPU port through dfx_physics.h / dfx_stage.h.
+// The per-ligament physics (dfx_physics.h) is shared with the CPU port of the oracle.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -35,6 +38,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxGraphSteps = 256;
+constexpr int kPos = 6;   // doubles per unit position record: x y th cos(th/2) sin(th/2) pad   (three 16-byte chunks)
+constexpr int kStep = 9;  // doubles per unit in a trajectory checkpoint: position record + velocity (3)
 
 struct Seg {            // one graph replay worth of steps
   double t_interval;    // timepoints[k]
@@ -47,133 +52,295 @@ struct Seg {            // one graph replay worth of steps
   int pad;
 };
 
-// Everything a kernel needs; passed by value (kernarg).
+// next-stage coefficients of one launch, passed by value (lands in SGPRs)
+struct StageCoef {
+  double cv[kMaxStages];  // a[r][l]   : V_{r} = v_n + h sum_l cv[l] A_l
+  double cq[kMaxStages];  // (a*a)[r][l]: Q_{r} = q_n + h c_r v_n + h^2 sum_l cq[l] A_l
+  double c_i, c_next;     // stage times
+};
+
+// reverse-stage coefficients: kbar_{i-1} = h (b_{i-1} lambda + sum_{j>=i} a[j][i-1] Ybar_j)
+struct AdjCoef {
+  double col[kMaxStages + 1];  // col[j] = a[j][i-1] for j in i..s-1, col[s] = b_{i-1};  at i == 0: col[s] = b_{s-1}
+  double c_i;
+};
+
 struct DevCtx {
-  int n_blocks, n_slots, n_fns, batch, s;
+  int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
+  int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
-  // static tables
   const int32_t* slot_info;
   const int32_t* block_special;
   const dfx_special* special;
-  // per-member parameter images (member stride in elements)
-  const double* slot_p;
-  const double* inv_m;
-  const double* damping;
-  const double* contact_p;
+  // per-member parameter images, rows indexed by the lane's own slot / DOF (coalesced)
+  const double* p_r;      // n_slots*2   own centroid->node vector
+  const double* p_l;      // n_slots*2   reference vector of the slot's ligament
+  const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
+  const double* p_phi;    // n_slots*2   undeformed void angles
+  const double* cst;      // 8           min_angle cutoff_angle k_contact | uniform k_stretch k_shear k_rot
+  const double* inv_m;    // n_blocks*3
+  const double* damping;  // n_blocks*3
   const TimeFn* fns;
-  // time bookkeeping
-  const Seg* segs;
-  const int* seg_idx;
-  // state
-  double* traj;        // batch * (N+1) * n_blocks*kRec  (keep_trajectory) or null
-  double* Ypp;         // batch * 2 * n_blocks*kRec      ping-pong step states when traj == null
-  double* Sbuf;        // batch * (s+1) * n_blocks*kRec  stage records
-  double* A;           // batch * s * n_blocks*3
+  const Seg* cur;         // the segment being replayed
+  // state: (s+1) stage buffers per member; buffer 0 = current step state
+  double* traj;           // batch * traj_stride   checkpoints: per step [POS n_blocks*6 | VEL n_blocks*3]
+  double* POS;            // batch * (s+1) * n_blocks*kPos
+  double* VEL;            // batch * (s+1) * n_blocks*3
+  double* A;              // batch * s * n_blocks*3
   // reverse
-  double* YB;          // batch * s * n_blocks*6
-  double* LAM;         // batch * n_blocks*6
-  double* W;           // batch * 2 * n_blocks*3
-  double* KQ;          // batch * 2 * n_blocks*3
-  const double* G;     // T * batch * n_blocks*6 (time-major, so graph kernels do not depend on T)
-  int n_timepoints;
-  double* slot_g;      // batch * n_slots*kSlotGrads
-  double* blk_g;       // batch * n_blocks*6
-  double* fn_g;        // batch * n_special*MAX_FNS*FN_PARAMS
-  int n_special;
-  Tableau tab;
+  double* YB;             // batch * s * n_blocks*6
+  double* LAM;            // batch * n_blocks*6
+  double* W;              // batch * 2 * n_blocks*3
+  double* KQ;             // batch * 2 * n_blocks*3
+  const double* G;        // T * batch * n_blocks*6 (time-major)
+  double* g_r;            // batch * n_slots*2     d/d(own node vector)
+  double* g_phi;          // batch * n_slots*2     d/d(void angles)       (end-1 slots)
+  double* g_b;            // batch * n_slots*8     d/d(l0(2), k(3), contact(3)) (end-1 slots) or null
+  double* blk_g;          // batch * n_blocks*6
+  double* fn_g;           // batch * n_special*MAX_FNS*FN_PARAMS or null
 };
 
-__device__ __forceinline__ Tables dev_tables(const DevCtx& c, int m) {
-  Tables tb;
-  tb.n_blocks = c.n_blocks; tb.n_fns = c.n_fns; tb.model = 0; tb.contact = 0;
-  tb.slot_info = c.slot_info;
-  tb.block_special = c.block_special;
-  tb.special = c.special;
-  tb.slot_p = c.slot_p + (size_t)m * c.n_slots * kSlotParams;
-  tb.inv_m = c.inv_m + (size_t)m * c.n_blocks * 3;
-  tb.damping = c.damping + (size_t)m * c.n_blocks * 3;
-  tb.contact_p = c.contact_p + (size_t)m * 3;
-  tb.fns = c.fns + (size_t)m * DFX_MAX_FNS;
-  return tb;
+// ---- quad (4-lane) data movement on DPP: no LDS traffic, no bank conflicts --------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
-
 __device__ __forceinline__ double quad_sum(double v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
+  v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
   return v;
 }
+template <int J>
+__device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<J | (J << 2) | (J << 4) | (J << 6)>(v); }
 
-__device__ __forceinline__ double* step_state(const DevCtx& c, int m, long long n) {
-  const size_t rec = (size_t)c.n_blocks * kRec;
-  if (c.traj) return c.traj + (size_t)m * c.traj_stride + (size_t)n * rec;
-  return c.Ypp + ((size_t)m * 2 + (n & 1)) * rec;
+// XCD-aware workgroup order: hardware deals workgroups round-robin over the 8 XCDs (id % 8 share an L2);
+// give every XCD one contiguous band of the lattice so neighbour gathers mostly hit that XCD's own L2.
+__device__ __forceinline__ int logical_wg(int bid, int n_wg) {
+  const int x = bid & 7, q = bid >> 3, per = n_wg >> 3, rem = n_wg & 7;
+  return x * per + (x < rem ? x : rem) + q;
 }
 
-__global__ void k_tick(int* seg_idx, int delta) { *seg_idx += delta; }
+__device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
+  if (buf >= 0) return c.POS + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * kPos;
+  return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep;
+}
+__device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
+  if (buf >= 0) return c.VEL + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * 3;
+  return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep + (size_t)c.n_blocks * kPos;
+}
 
-// records of the initial state + row 0 of fields
-__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, double* rec_out /* batch stride n_blocks*kRec */) {
-  int m = blockIdx.y;
-  int tid = blockIdx.x * kThreads + threadIdx.x;
+__global__ void k_tick(const Seg* segs, int* seg_idx, int delta, Seg* cur) {
+  int i = *seg_idx + delta;
+  *seg_idx = i;
+  *cur = segs[i];
+}
+
+struct TimeVals { double g, gt; };
+
+// value of the prescribed displacement of DOF d of special block sp at time t (and its rate)
+__device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, const dfx_special& sp, int d, double t) {
+  TimeVals r{0.0, 0.0};
+  double gp[kMaxFnParams];
+  for (int f = 0; f < c.n_fns; ++f)
+    if (sp.con_coef[d][f] != 0.0) {
+      double g, gt;
+      eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t, g, gt, gp);
+      r.g += sp.con_coef[d][f] * g;
+      r.gt += sp.con_coef[d][f] * gt;
+    }
+  return r;
+}
+
+// records of a full (2, n_blocks, 3) state at time t0 -> stage buffer `buf`  (constrained DOFs follow c(t0), c'(t0))
+__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf) {
+  const int m = blockIdx.y;
+  const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
-  int b = tid >> 2, d = tid & 3;
+  const int b = tid >> 2, d = tid & 3;
   if (d == 3) return;
-  Tables tb = dev_tables(c, m);
-  init_dof(tb, state0 + (size_t)m * c.n_blocks * 6, t0, rec_out + (size_t)m * c.n_blocks * kRec, b, d);
+  const size_t nd = (size_t)c.n_blocks * 3;
+  double q = state0[(size_t)m * 2 * nd + b * 3 + d], v = state0[(size_t)m * 2 * nd + nd + b * 3 + d];
+  const int sidx = c.block_special[b];
+  if (sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1)) {
+    TimeVals tv = constrained_value(c, m, c.special[sidx], d, t0);
+    q = tv.g; v = tv.gt;
+  }
+  double* pr = c.POS + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * kPos + (size_t)b * kPos;
+  pr[d] = q;
+  c.VEL[((size_t)m * (c.s + 1) + buf) * nd + b * 3 + d] = v;
+  if (d == 2) {
+    double sn, cs;
+    sincos(0.5 * q, &sn, &cs);
+    pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
+  }
 }
 
-// fields[m, k] <- record (disp, vel)
-__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, const double* rec, size_t rec_member_stride, double* fields, int k) {
-  int m = blockIdx.y;
-  int tid = blockIdx.x * kThreads + threadIdx.x;
+// fields[m, k] <- (disp, vel) of stage buffer 0
+__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k) {
+  const int m = blockIdx.y;
+  const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * 3) return;
-  int b = tid / 3, d = tid % 3;
-  const double* r = rec + (size_t)m * rec_member_stride + (size_t)b * kRec;
+  const int b = tid / 3, d = tid % 3;
   double* f = fields + ((size_t)m * c.n_timepoints + k) * c.n_blocks * 6;
-  f[tid] = r[d];
-  f[(size_t)c.n_blocks * 3 + tid] = r[5 + d];
+  f[tid] = c.POS[(size_t)m * (c.s + 1) * c.n_blocks * kPos + (size_t)b * kPos + d];
+  f[(size_t)c.n_blocks * 3 + tid] = c.VEL[(size_t)m * (c.s + 1) * c.n_blocks * 3 + tid];
+}
+
+// copy stage buffer 0 into checkpoint slot n (only for the initial state)
+__global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
+  const int m = blockIdx.y;
+  const int tid = blockIdx.x * kThreads + threadIdx.x;
+  if (tid >= c.n_blocks * kStep) return;
+  double* t = c.traj + (size_t)m * c.traj_stride;
+  if (tid < c.n_blocks * kPos) t[tid] = c.POS[(size_t)m * (c.s + 1) * c.n_blocks * kPos + tid];
+  else t[tid] = c.VEL[(size_t)m * (c.s + 1) * c.n_blocks * 3 + (tid - c.n_blocks * kPos)];
+}
+
+struct LaneIn {
+  BlockRec<double> o, p;
+  double rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, phi1, phi2, am, ac, kc, sgn;
+  int info;
+};
+
+// Everything a lane needs for its ligament.  Own data: one coalesced 16-byte chunk per lane, spread over the
+// quad by DPP.  Partner data: gathered through slot_info from the same arrays (lines shared with the lanes
+// that own them, i.e. served by the XCD's L2).
+template <int CONTACT>
+__device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneIn& L) {
+  const int b = slot >> 2, k = slot & 3;
+  const int info = c.slot_info[slot];
+  L.info = info;
+  const size_t ps = (size_t)m * c.n_slots;
+  const double2 pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (size_t)b * kPos + 2 * k) : make_double2(0.0, 0.0);
+  const double2 ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
+  const double2 lv = *reinterpret_cast<const double2*>(c.p_l + (ps + slot) * 2);
+  const double* cst = c.cst + (size_t)m * 8;
+  if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
+  else { const double* pk = c.p_k + (ps + slot) * 4; L.ks = pk[0]; L.ksh = pk[1]; L.kr = pk[2]; }
+  if (CONTACT) {
+    const double2 ph = *reinterpret_cast<const double2*>(c.p_phi + (ps + slot) * 2);
+    L.phi1 = ph.x; L.phi2 = ph.y;
+    L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2];
+  }
+  // partner (dependent on info)
+  const int pslot = info < 0 ? slot : (info >> 1);
+  const double* pp = POSin + (size_t)(pslot >> 2) * kPos;
+  const double2 b0 = reinterpret_cast<const double2*>(pp)[0], b1 = reinterpret_cast<const double2*>(pp)[1];
+  const double b2 = pp[4];
+  const double2 rp = *reinterpret_cast<const double2*>(c.p_r + (ps + pslot) * 2);
+  L.o.x = quad_bcast<0>(pc.x); L.o.y = quad_bcast<0>(pc.y);
+  L.o.th = quad_bcast<1>(pc.x); L.o.ch = quad_bcast<1>(pc.y);
+  L.o.sh = quad_bcast<2>(pc.x);
+  L.p.x = b0.x; L.p.y = b0.y; L.p.th = b1.x; L.p.ch = b1.y; L.p.sh = b2;
+  L.rox = ro.x; L.roy = ro.y; L.rpx = rp.x; L.rpy = rp.y;
+  L.lx = lv.x; L.ly = lv.y;
+  const double l02 = lv.x * lv.x + lv.y * lv.y;
+  L.il0 = info < 0 ? 1.0 : rsqrt(l02);
+  L.l0 = l02 * L.il0;
+  L.sgn = (info & 1) ? 1.0 : -1.0;
 }
 
 // ---- forward stage ---------------------------------------------------------------------------
-// mode 0: regular time stepping (stage records ping-pong in Sbuf[0..1])
-// mode 1: recompute for the reverse sweep (stage records kept in Sbuf[1..s-1], no step-end write)
-// mode 2: test hook (single evaluation at stage 0, records in Sbuf[0], nothing written but A)
+//   in_buf  : stage buffer holding this stage's records, or -1: the checkpoint of step n (reverse recompute, i == 0)
+//   out_buf : buffer for the next stage's records (-1: none)
+//   y_buf   : 0: step base state (q_n, v_n) in buffer 0;  -1: in the checkpoint of step n
+//   write_traj: also store the new record into the checkpoint of step n+1 (last stage, keep_trajectory)
 template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, int i, int j, int mode) {
+__global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
+                                                        int y_buf, int write_traj) {
   const int m = blockIdx.y;
-  const int slot = blockIdx.x * kThreads + threadIdx.x;
+  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
-  const int b = slot >> 2, k = slot & 3;
-  Tables tb = dev_tables(c, m);
-  const size_t rec = (size_t)c.n_blocks * kRec;
-  const Seg sg = c.segs[*c.seg_idx];
+  if (c.ablate & 4) return;
+  const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
+  const Seg sg = *c.cur;
   const long long n = sg.base_step + j;
-  const double t = sg.t_interval + (sg.j0 + j) * sg.h;
-  double* Sm = c.Sbuf + (size_t)m * (c.s + 1) * rec;
-  FwdStage st;
-  st.i = i;
-  st.h = sg.h;
-  st.t_i = t + c.tab.c[i] * sg.h;
-  st.t_next = t + c.tab.c[i + 1] * sg.h;
-  st.A = c.A + (size_t)m * c.s * c.n_blocks * 3;
-  if (mode == 2) {
-    st.Y = Sm; st.S_in = Sm; st.S_out = nullptr;
-  } else {
-    st.Y = step_state(c, m, n);
-    if (mode == 0) {
-      st.S_in = i == 0 ? st.Y : Sm + (size_t)(i & 1) * rec;
-      st.S_out = i == c.s - 1 ? step_state(c, m, n + 1) : Sm + (size_t)((i + 1) & 1) * rec;
-    } else {
-      st.S_in = i == 0 ? st.Y : Sm + (size_t)i * rec;
-      st.S_out = i == c.s - 1 ? nullptr : Sm + (size_t)(i + 1) * rec;
+  const size_t nd = (size_t)c.n_blocks * 3;
+  // ---- load phase
+  const double* POSin = pos_in(c, m, in_buf, n);
+  LaneIn L;
+  load_lane<CONTACT>(c, m, slot, POSin, L);
+  const int dof = b * 3 + kd;
+  const double qn = pos_in(c, m, y_buf, n)[(size_t)b * kPos + kd];
+  const double vn = vel_in(c, m, y_buf, n)[dof];
+  const double v_i = vel_in(c, m, in_buf, n)[dof];
+  double* Am = c.A + (size_t)m * c.s * nd;
+  const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
+  const int sidx = c.block_special[b];
+  double sv = 0.0, sq = 0.0;
+  for (int l = 0; l < i; ++l) {
+    const double al = Am[(size_t)l * nd + dof];
+    sv += sc.cv[l] * al;
+    sq += sc.cq[l] * al;
+  }
+  // ---- ligament + contact of this slot
+  double fx = 0.0, fy = 0.0, fth = 0.0;
+  if (c.ablate & 1) {
+    fx = L.o.x + L.p.x + L.rox + L.rpx + L.lx + L.l0; fy = L.o.y + L.p.y + L.roy + L.rpy + L.ly + L.il0;
+    fth = L.o.th + L.p.th + L.o.ch + L.p.ch + L.o.sh + L.p.sh + (CONTACT ? L.phi1 + L.phi2 : 0.0);
+  } else if (L.info >= 0) {
+    BondGrad<double> g;
+    bond_grad<MODEL, double>(L.o, L.p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
+    fx = g.fx; fy = g.fy; fth = g.fth;
+    if (CONTACT) {
+      ContactGrad<double> cg;
+      contact_grad<double>(L.sgn * (L.o.th - L.p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
+      fth += L.sgn * cg.dkap;
     }
   }
-  double fx, fy, fth;
-  fwd_slot<MODEL, CONTACT>(tb, st.S_in, slot, fx, fy, fth, nullptr);
   fx = quad_sum(fx);
   fy = quad_sum(fy);
   fth = quad_sum(fth);
-  if (k < 3) fwd_dof(tb, c.tab, st, b, k, k == 0 ? fx : (k == 1 ? fy : fth));
+  // ---- DOF epilogue on lanes 0..2
+  const double h = sg.h;
+  const double t = sg.t_interval + (sg.j0 + j) * h;
+  double qnext = 0.0, vnext = 0.0;
+  if (k < 3) {
+    const double dE = k == 0 ? fx : (k == 1 ? fy : fth);
+    bool constrained = false;
+    double fload = 0.0;
+    if (sidx >= 0) {
+      const dfx_special& sp = c.special[sidx];
+      constrained = (sp.con_mask >> k) & 1;
+      if (!constrained) {
+        double gp[kMaxFnParams];
+        for (int f = 0; f < c.n_fns; ++f)
+          if (sp.load_coef[k][f] != 0.0) {
+            double g, gt;
+            eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t + sc.c_i * h, g, gt, gp);
+            fload += sp.load_coef[k][f] * g;
+          }
+      }
+    }
+    const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
+    Am[(size_t)i * nd + dof] = a;
+    sv += sc.cv[i] * a;
+    sq += sc.cq[i] * a;
+    qnext = qn + h * (sc.c_next * vn + h * sq);
+    vnext = vn + h * sv;
+    if (constrained && out_buf >= 0) {
+      TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
+      qnext = tv.g; vnext = tv.gt;
+    }
+  }
+  if (out_buf < 0) return;
+  // ---- publish the next stage record: lanes 0..2 each store one aligned 16-byte chunk (x,y) (th,ch) (sh,0)
+  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
+  double sn, cs;
+  sincos(0.5 * th2, &sn, &cs);
+  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
+  if (k < 3 && !(c.ablate & 2)) {
+    *reinterpret_cast<double2*>(c.POS + ((size_t)m * (c.s + 1) + out_buf) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
+    c.VEL[((size_t)m * (c.s + 1) + out_buf) * nd + dof] = vnext;
+    if (write_traj) {
+      double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)(n + 1) * c.n_blocks * kStep;
+      *reinterpret_cast<double2*>(tr + (size_t)b * kPos + 2 * k) = chunk;
+      tr[(size_t)c.n_blocks * kPos + dof] = vnext;
+    }
+  }
 }
 
 template <int MODEL, int CONTACT>
@@ -181,68 +348,175 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
   const int m = blockIdx.y;
   const int slot = blockIdx.x * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
-  Tables tb = dev_tables(c, m);
-  const size_t rec = (size_t)c.n_blocks * kRec;
-  double fx, fy, fth, e;
-  fwd_slot<MODEL, CONTACT>(tb, c.Sbuf + (size_t)m * (c.s + 1) * rec, slot, fx, fy, fth, &e);
+  LaneIn L;
+  load_lane<CONTACT>(c, m, slot, pos_in(c, m, 0, 0), L);
+  double e = 0.0;
+  if (L.info >= 0 && !(L.info & 1)) {
+    BondGrad<double> g;
+    bond_grad<MODEL, double>(L.o, L.p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
+    e = g.e;
+    if (CONTACT) {
+      ContactGrad<double> cg;
+      contact_grad<double>(L.sgn * (L.o.th - L.p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
+      e += cg.e;
+    }
+  }
   e_slot[(size_t)m * c.n_slots + slot] = e;
 }
 
 // ---- reverse stage ---------------------------------------------------------------------------
+//   in_buf: stage buffer with the stage records (recomputed), or -1: the checkpoint of step n (i == 0)
+//   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, int i, int j, int local_only) {
+__global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
+                                                        int local_only) {
   const int m = blockIdx.y;
-  const int slot = blockIdx.x * kThreads + threadIdx.x;
+  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
-  const int b = slot >> 2, k = slot & 3;
-  Tables tb = dev_tables(c, m);
-  const size_t rec = (size_t)c.n_blocks * kRec;
-  const size_t nd = (size_t)c.n_blocks * 3;
-  const Seg sg = c.segs[*c.seg_idx];
+  const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
+  const Seg sg = *c.cur;
   const long long n = sg.base_step + j;
-  const double t = sg.t_interval + (sg.j0 + j) * sg.h;
-  double* Sm = c.Sbuf + (size_t)m * (c.s + 1) * rec;
-  // ping-pong parity of the (w, kbar_q) buffers: ordinal of this launch in the reverse sweep
-  // forward ordinal of this stage; the reverse sweep visits ordinals in decreasing order, so parity alternates
-  const int in = local_only ? 0 : (int)((n * c.s + i) & 1);
-  AdjStage st;
-  st.i = i;
-  st.local_only = local_only;
-  st.S = (i == 0 && !local_only) ? step_state(c, m, n) : Sm + (size_t)i * rec;
-  st.A = c.A + (size_t)m * c.s * nd;
-  st.W = c.W + ((size_t)m * 2 + in) * nd;
-  st.KQ = c.KQ + ((size_t)m * 2 + in) * nd;
-  st.W_out = c.W + ((size_t)m * 2 + (in ^ 1)) * nd;
-  st.KQ_out = c.KQ + ((size_t)m * 2 + (in ^ 1)) * nd;
-  st.YB = c.YB + (size_t)m * c.s * c.n_blocks * 6;
-  st.LAM = c.LAM + (size_t)m * c.n_blocks * 6;
-  const bool first_of_interval = (sg.j0 + j) == 0;
-  st.G = (i == 0 && first_of_interval && c.G) ? c.G + ((size_t)sg.interval * c.batch + m) * c.n_blocks * 6 : nullptr;
-  st.t_i = t + c.tab.c[i] * sg.h;
-  st.h = sg.h;
-  st.h_prev = first_of_interval ? sg.h_prev : sg.h;
-  GradAcc acc;
-  acc.slot_g = c.slot_g ? c.slot_g + (size_t)m * c.n_slots * kSlotGrads : nullptr;
-  acc.blk_g = c.blk_g ? c.blk_g + (size_t)m * c.n_blocks * 6 : nullptr;
-  acc.fn_g = c.fn_g ? c.fn_g + (size_t)m * c.n_special * DFX_MAX_FNS * DFX_FN_PARAMS : nullptr;
-  double hx, hy, hth;
-  adj_slot<MODEL, CONTACT>(tb, st.S, st.W, slot, acc, hx, hy, hth);
+  // the reverse sweep visits forward ordinals n*s+i in decreasing order, so the buffer parity alternates
+  const int win = wbuf_static >= 0 ? wbuf_static : (int)((n * c.s + i) & 1);
+  const size_t nd = (size_t)c.n_blocks * 3, nd6 = (size_t)c.n_blocks * 6;
+  // ---- load phase
+  const double* POSin = pos_in(c, m, in_buf, n);
+  LaneIn L;
+  load_lane<CONTACT>(c, m, slot, POSin, L);
+  const int dof = b * 3 + kd;
+  const double* Win = c.W + ((size_t)m * 2 + win) * nd;
+  const double w_d = Win[dof];
+  const int pb = (L.info < 0 ? slot : (L.info >> 1)) >> 2;
+  const double wpx = Win[(size_t)pb * 3], wpy = Win[(size_t)pb * 3 + 1], wpth = Win[(size_t)pb * 3 + 2];
+  const double v_i = vel_in(c, m, in_buf, n)[dof];
+  const double a_i = c.A[(size_t)m * c.s * nd + (size_t)i * nd + dof];
+  const double kq_in = c.KQ[((size_t)m * 2 + win) * nd + dof];
+  const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
+  const int sidx = c.block_special[b];
+  double* YBm = c.YB + (size_t)m * c.s * nd6;
+  double* LAMm = c.LAM + (size_t)m * nd6;
+  double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
+  if (!local_only) {
+    lq = LAMm[b * 6 + kd]; lv = LAMm[b * 6 + 3 + kd];
+    for (int jj = i + 1; jj < c.s; ++jj) {
+      const double yq = YBm[(size_t)jj * nd6 + b * 6 + kd], yv = YBm[(size_t)jj * nd6 + b * 6 + 3 + kd];
+      const double cf = i > 0 ? ac.col[jj] : 1.0;
+      sq += cf * yq;
+      sv += cf * yv;
+    }
+  }
+  const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
+  // ---- Hessian-vector product + mixed parameter derivatives of this slot
+  double hx = 0.0, hy = 0.0, hth = 0.0;
+  if (L.info >= 0) {
+    BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
+    BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);
+    BondGrad<Dual> g;
+    bond_grad<MODEL, Dual>(o, p, Dual(L.rox), Dual(L.roy), Dual(L.rpx), Dual(L.rpy), Dual(L.lx), Dual(L.ly), L.l0, L.il0,
+                           Dual(L.ks), Dual(L.ksh), Dual(L.kr), L.sgn, g);
+    hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
+    ContactGrad<Dual> cg;
+    if (CONTACT) {
+      contact_grad<Dual>(L.sgn * (o.th - p.th), Dual(L.phi1), Dual(L.phi2), Dual(L.am), Dual(L.ac), Dual(L.kc), cg);
+      hth += L.sgn * cg.dkap.e;
+    }
+    // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
+    const size_t gs = (size_t)m * c.n_slots + slot;
+    double2* gr = reinterpret_cast<double2*>(c.g_r + gs * 2);
+    double2 r = *gr;
+    r.x -= g.rx.e; r.y -= g.ry.e;
+    *gr = r;
+    if (!(L.info & 1)) {
+      if (CONTACT) {
+        double2* gp = reinterpret_cast<double2*>(c.g_phi + gs * 2);
+        double2 q = *gp;
+        q.x -= cg.p1.e; q.y -= cg.p2.e;
+        *gp = q;
+      }
+      if (c.g_b) {
+        double* q = c.g_b + gs * 8;
+        q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
+        if (CONTACT) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
+      }
+    }
+  }
   hx = quad_sum(hx);
   hy = quad_sum(hy);
   hth = quad_sum(hth);
-  if (k < 3) adj_dof(tb, c.tab, st, acc, b, k, k == 0 ? hx : (k == 1 ? hy : hth));
+  // ---- DOF epilogue
+  const double h = sg.h;
+  if (k < 3) {
+    const double hw = k == 0 ? hx : (k == 1 ? hy : hth);
+    bool constrained = false;
+    if (sidx >= 0) {
+      const dfx_special& sp = c.special[sidx];
+      constrained = (sp.con_mask >> k) & 1;
+      if (c.fn_g) {
+        const double t_i = sg.t_interval + (sg.j0 + j) * h + ac.c_i * h;
+        double gp[kMaxFnParams];
+        for (int f = 0; f < c.n_fns; ++f) {
+          const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
+          if (coef != 0.0) {
+            double g, gt;
+            eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
+            double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
+            for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) q[kk] += coef * gp[kk];
+          }
+        }
+      }
+    }
+    double ybq = 0.0, ybv = 0.0;
+    if (!constrained) {
+      ybq = -hw;
+      ybv = kq_in - damp * w_d;
+      double* q = c.blk_g + ((size_t)m * c.n_blocks + b) * 6;
+      q[k] -= w_d * a_i;
+      q[3 + k] -= w_d * v_i;
+    }
+    YBm[(size_t)i * nd6 + b * 6 + k] = ybq;
+    YBm[(size_t)i * nd6 + b * 6 + 3 + k] = ybv;
+    if (!local_only) {
+      double kq, kv;
+      if (i > 0) {
+        kq = h * (ac.col[c.s] * lq + ac.col[i] * ybq + sq);
+        kv = h * (ac.col[c.s] * lv + ac.col[i] * ybv + sv);
+      } else {
+        lq += ybq + sq;
+        lv += ybv + sv;
+        const bool first = (sg.j0 + j) == 0;
+        if (first && c.G && !constrained) {
+          const double* G = c.G + ((size_t)sg.interval * c.batch + m) * nd6;
+          lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
+        }
+        if (constrained) { lq = 0.0; lv = 0.0; }
+        LAMm[b * 6 + k] = lq;
+        LAMm[b * 6 + 3 + k] = lv;
+        const double hp = first ? sg.h_prev : h;
+        kq = hp * ac.col[c.s] * lq;
+        kv = hp * ac.col[c.s] * lv;
+      }
+      c.KQ[((size_t)m * 2 + (win ^ 1)) * nd + dof] = kq;
+      c.W[((size_t)m * 2 + (win ^ 1)) * nd + dof] = constrained ? 0.0 : kv * invm;
+    }
+  }
 }
 
-__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, int buf) {
+// start of the reverse sweep: lambda_N = G_last; kbar_{s-1} of the last step into buffer `buf`
+__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf) {
   const int m = blockIdx.y;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;
   if (d == 3) return;
-  Tables tb = dev_tables(c, m);
-  const size_t nd = (size_t)c.n_blocks * 3;
-  adj_begin_dof(tb, c.tab, c.G + ((size_t)(c.n_timepoints - 1) * c.batch + m) * c.n_blocks * 6, h_last,
-                c.LAM + (size_t)m * c.n_blocks * 6, c.W + ((size_t)m * 2 + buf) * nd, c.KQ + ((size_t)m * 2 + buf) * nd, b, d);
+  const size_t nd = (size_t)c.n_blocks * 3, nd6 = (size_t)c.n_blocks * 6;
+  const int sidx = c.block_special[b];
+  const bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
+  const double* G = c.G + ((size_t)(c.n_timepoints - 1) * c.batch + m) * nd6;
+  const double lq = con ? 0.0 : G[b * 6 + d], lv = con ? 0.0 : G[b * 6 + 3 + d];
+  c.LAM[(size_t)m * nd6 + b * 6 + d] = lq;
+  c.LAM[(size_t)m * nd6 + b * 6 + 3 + d] = lv;
+  c.KQ[((size_t)m * 2 + buf) * nd + b * 3 + d] = h_last * b_last * lq;
+  c.W[((size_t)m * 2 + buf) * nd + b * 3 + d] = con ? 0.0 : h_last * b_last * lv * c.inv_m[(size_t)m * nd + b * 3 + d];
 }
 
 // test hook: w = lam_v / m, kbar_q = lam_q  into buffer 0
@@ -252,24 +526,24 @@ __global__ __launch_bounds__(kThreads) void k_seed_vjp(DevCtx c, const double* l
   if (tid >= c.n_blocks * 3) return;
   const int b = tid / 3, d = tid % 3;
   const size_t nd = (size_t)c.n_blocks * 3;
-  int sidx = c.block_special[b];
-  bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
+  const int sidx = c.block_special[b];
+  const bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
   const double* l = lam + (size_t)m * c.n_blocks * 6;
   c.W[(size_t)m * 2 * nd + tid] = con ? 0.0 : l[nd + tid] * c.inv_m[(size_t)m * nd + tid];
   c.KQ[(size_t)m * 2 * nd + tid] = l[tid];
 }
 
-// fields_bar (batch, T, 2, n_blocks, 3) -> G (batch, T, n_blocks, 6)
+// fields_bar (batch, T, 2, n_blocks, 3) -> G (T, batch, n_blocks, 6)
 __global__ __launch_bounds__(kThreads) void k_pack_G(DevCtx c, const double* fields_bar, double* G) {
   const size_t total = (size_t)c.batch * c.n_timepoints * c.n_blocks * 3;
-  size_t tid = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  const size_t tid = (size_t)blockIdx.x * kThreads + threadIdx.x;
   if (tid >= total) return;
-  size_t mk = tid / ((size_t)c.n_blocks * 3);
-  int r = (int)(tid % ((size_t)c.n_blocks * 3));
-  int b = r / 3, d = r % 3;
+  const size_t mk = tid / ((size_t)c.n_blocks * 3);
+  const int r = (int)(tid % ((size_t)c.n_blocks * 3));
+  const int b = r / 3, d = r % 3;
   const double* f = fields_bar + mk * c.n_blocks * 6;
   const size_t m_ = mk / c.n_timepoints, k_ = mk % c.n_timepoints;
-  double* g = G + (k_ * c.batch + m_) * c.n_blocks * 6;   // G is time-major: (T, batch, n_blocks, 6)
+  double* g = G + (k_ * c.batch + m_) * c.n_blocks * 6;
   g[b * 6 + d] = f[r];
   g[b * 6 + 3 + d] = f[(size_t)c.n_blocks * 3 + r];
 }
@@ -283,10 +557,10 @@ __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fi
   const int per_t = n_target * 3;
   const long long total = (long long)c.n_timepoints * per_t;
   for (long long idx = threadIdx.x; idx < total; idx += kThreads) {
-    int k = (int)(idx / per_t), r = (int)(idx % per_t);
-    int b = target[r / 3], d = r % 3;
-    double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
-    double mass = 1.0 / c.inv_m[(size_t)m * c.n_blocks * 3 + b * 3 + d];
+    const int k = (int)(idx / per_t), r = (int)(idx % per_t);
+    const int b = target[r / 3], d = r % 3;
+    const double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
+    const double mass = 1.0 / c.inv_m[(size_t)m * c.n_blocks * 3 + b * 3 + d];
     acc += 0.5 * mass * v * v;
     if (G) G[((size_t)k * c.batch + m) * c.n_blocks * 6 + b * 6 + 3 + d] = mass * v;
   }
@@ -302,12 +576,12 @@ __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fi
 // explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_g
 __global__ void k_kinetic_mass_grad(DevCtx c, const double* fields, const int32_t* target, int n_target) {
   const int m = blockIdx.y;
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_target * 3) return;
-  int b = target[r / 3], d = r % 3;
+  const int b = target[r / 3], d = r % 3;
   double acc = 0.0;
   for (int k = 0; k < c.n_timepoints; ++k) {
-    double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
+    const double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
     acc += 0.5 * v * v;
   }
   c.blk_g[((size_t)m * c.n_blocks + b) * 6 + d] += acc;
@@ -338,7 +612,7 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr; n = 0;
     hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess) n = count;
+    if (e == hipSuccess) n = std::max<size_t>(count, 1);
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
@@ -353,24 +627,20 @@ struct dfx_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_params = false, have_traj = false, have_fields = false;
   bool use_graph = true;
-  // static
+  bool want_bond_grads = true, want_fn_grads = true;
   DevBuf<int32_t> d_slot_info, d_block_special;
   DevBuf<dfx_special> d_special;
-  // params
-  DevBuf<double> d_slot_p, d_inv_m, d_damping, d_contact;
+  DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping;
   DevBuf<TimeFn> d_fns;
-  // time
-  DevBuf<Seg> d_segs;
+  DevBuf<Seg> d_segs, d_cur;
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
-  // state
-  DevBuf<double> d_traj, d_Ypp, d_Sbuf, d_A, d_state0, d_fields;
-  DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_slot_g, d_blk_g, d_fn_g, d_tmp, d_obj;
+  DevBuf<double> d_traj, d_POS, d_VEL, d_A, d_state0, d_fields;
+  DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_g, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
   int spi = 0;
   long long n_total = 0;
-  // graphs: key = (n_steps, kind) ; invalidated when buffers move
   std::map<std::pair<int, int>, hipGraphExec_t> graphs;
   DevCtx graph_ctx_snapshot;
   bool graph_ctx_valid = false;
@@ -388,59 +658,89 @@ static DevCtx make_ctx(dfx_handle* h) {
   DevCtx c;
   memset(&c, 0, sizeof(c));
   c.n_blocks = pl.n_blocks; c.n_slots = pl.n_slots; c.n_fns = pl.n_fns; c.batch = pl.batch; c.s = pl.tab.s;
-  c.traj_stride = h->pl.batch ? (long long)(h->d_traj.n / h->pl.batch) : 0;
+  { const char* a = getenv("DFX_ABLATE"); c.ablate = a ? atoi(a) : 0; }
+  c.n_wg = (pl.n_slots + kThreads - 1) / kThreads;
+  c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
+  c.traj_stride = pl.batch ? (long long)(h->d_traj.n / pl.batch) : 0;
   c.slot_info = h->d_slot_info.p; c.block_special = h->d_block_special.p; c.special = h->d_special.p;
-  c.slot_p = h->d_slot_p.p; c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.contact_p = h->d_contact.p;
-  c.fns = h->d_fns.p;
-  c.segs = h->d_segs.p; c.seg_idx = h->d_seg_idx.p;
+  c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;
+  c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.fns = h->d_fns.p;
+  c.cur = h->d_cur.p;
   c.traj = h->have_traj ? h->d_traj.p : nullptr;
-  c.Ypp = h->d_Ypp.p; c.Sbuf = h->d_Sbuf.p; c.A = h->d_A.p;
+  c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
-  c.n_timepoints = (int)h->ts.size();
-  c.slot_g = h->d_slot_g.p; c.blk_g = h->d_blk_g.p; c.fn_g = h->d_fn_g.p;
-  c.n_special = pl.n_special;
-  c.tab = pl.tab;
+  c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
+  c.blk_g = h->d_blk_g.p; c.fn_g = h->want_fn_grads ? h->d_fn_g.p : nullptr;
   return c;
 }
 
 static dim3 slot_grid(const dfx_handle* h) { return dim3((h->pl.n_slots + kThreads - 1) / kThreads, h->pl.batch); }
 
-template <int MODEL, int CONTACT>
-static void launch_fwd_t(dfx_handle* h, const DevCtx& c, int i, int j, int mode) {
-  hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT>), slot_grid(h), dim3(kThreads), 0, h->stream, c, i, j, mode);
+static StageCoef stage_coef(const Tableau& T, int i) {
+  StageCoef sc;
+  memset(&sc, 0, sizeof(sc));
+  const int r = i + 1;
+  for (int l = 0; l <= i; ++l) { sc.cv[l] = T.a[r][l]; sc.cq[l] = T.aa[r][l]; }
+  sc.c_i = T.c[i];
+  sc.c_next = T.c[r];
+  return sc;
 }
-static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int mode) {
+static AdjCoef adj_coef(const Tableau& T, int i) {
+  AdjCoef ac;
+  memset(&ac, 0, sizeof(ac));
+  if (i > 0) {
+    for (int j = i; j < T.s; ++j) ac.col[j] = T.a[j][i - 1];
+    ac.col[T.s] = T.a[T.s][i - 1];
+  } else {
+    ac.col[T.s] = T.a[T.s][T.s - 1];
+  }
+  ac.c_i = T.c[i];
+  return ac;
+}
+
+template <int MODEL, int CONTACT>
+static void launch_fwd_t(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int out_buf, int y_buf, int write_traj) {
+  hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT>), slot_grid(h), dim3(kThreads), 0, h->stream, c, stage_coef(h->pl.tab, i), i, j,
+                     in_buf, out_buf, y_buf, write_traj);
+}
+static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int out_buf, int y_buf, int write_traj) {
   const Plan& pl = h->pl;
-  if (pl.model == kNonlinear) { if (pl.contact) launch_fwd_t<kNonlinear, 1>(h, c, i, j, mode); else launch_fwd_t<kNonlinear, 0>(h, c, i, j, mode); }
-  else { if (pl.contact) launch_fwd_t<kLinearized, 1>(h, c, i, j, mode); else launch_fwd_t<kLinearized, 0>(h, c, i, j, mode); }
+  if (pl.model == kNonlinear) { if (pl.contact) launch_fwd_t<kNonlinear, 1>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); else launch_fwd_t<kNonlinear, 0>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); }
+  else { if (pl.contact) launch_fwd_t<kLinearized, 1>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); else launch_fwd_t<kLinearized, 0>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); }
   h->launches++;
 }
 template <int MODEL, int CONTACT>
-static void launch_adj_t(dfx_handle* h, const DevCtx& c, int i, int j, int local_only) {
-  hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT>), slot_grid(h), dim3(kThreads), 0, h->stream, c, i, j, local_only);
+static void launch_adj_t(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wbuf, int local_only) {
+  hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT>), slot_grid(h), dim3(kThreads), 0, h->stream, c, adj_coef(h->pl.tab, i), i, j, in_buf,
+                     wbuf, local_only);
 }
-static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int local_only) {
+static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wbuf, int local_only) {
   const Plan& pl = h->pl;
-  if (pl.model == kNonlinear) { if (pl.contact) launch_adj_t<kNonlinear, 1>(h, c, i, j, local_only); else launch_adj_t<kNonlinear, 0>(h, c, i, j, local_only); }
-  else { if (pl.contact) launch_adj_t<kLinearized, 1>(h, c, i, j, local_only); else launch_adj_t<kLinearized, 0>(h, c, i, j, local_only); }
+  if (pl.model == kNonlinear) { if (pl.contact) launch_adj_t<kNonlinear, 1>(h, c, i, j, in_buf, wbuf, local_only); else launch_adj_t<kNonlinear, 0>(h, c, i, j, in_buf, wbuf, local_only); }
+  else { if (pl.contact) launch_adj_t<kLinearized, 1>(h, c, i, j, in_buf, wbuf, local_only); else launch_adj_t<kLinearized, 0>(h, c, i, j, in_buf, wbuf, local_only); }
   h->launches++;
 }
+
+// forward: stage i reads buffer fin(i), writes fout(i); buffer 0 is the step state
+static int fin(int i) { return i == 0 ? 0 : 1 + ((i - 1) & 1); }
+static int fout(int i, int s) { return i == s - 1 ? 0 : 1 + (i & 1); }
 
 // enqueue one segment (kind 0: forward steps; kind 1: reverse steps) on h->stream
 static void enqueue_segment(dfx_handle* h, const DevCtx& c, int n_steps, int kind) {
   const int s = h->pl.tab.s;
+  hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p, kind == 0 ? 1 : -1, h->d_cur.p);
+  h->launches++;
   if (kind == 0) {
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->stream, h->d_seg_idx.p, 1);
     for (int j = 0; j < n_steps; ++j)
-      for (int i = 0; i < s; ++i) launch_fwd(h, c, i, j, 0);
+      for (int i = 0; i < s; ++i) launch_fwd(h, c, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->stream, h->d_seg_idx.p, -1);
     for (int j = n_steps - 1; j >= 0; --j) {
-      for (int i = 0; i < s; ++i) launch_fwd(h, c, i, j, 1);
-      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, i, j, 0);
+      // recompute the stage records of step n from its checkpoint: stage i -> buffer i+1
+      for (int i = 0; i < s - 1; ++i) launch_fwd(h, c, i, j, i == 0 ? -1 : i, i + 1, -1, 0);
+      launch_fwd(h, c, s - 1, j, s - 1, -1, -1, 0);
+      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, i, j, i == 0 ? -1 : i, -1, 0);
     }
   }
-  h->launches++;
 }
 
 static int run_segment(dfx_handle* h, const DevCtx& c, int n_steps, int kind) {
@@ -459,7 +759,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int n_steps, int kind) {
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    long long before = h->launches;
+    const long long before = h->launches;
     HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     enqueue_segment(h, c, n_steps, kind);
     HIP_OK(hipStreamEndCapture(h->stream, &graph));
@@ -489,6 +789,87 @@ static void build_segments(dfx_handle* h) {
   }
 }
 
+static int ensure_work_buffers(dfx_handle* h) {
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s;
+  HIP_OK(h->d_POS.ensure(B * (s + 1) * nb * kPos));
+  HIP_OK(h->d_VEL.ensure(B * (s + 1) * nb * 3));
+  HIP_OK(h->d_A.ensure(B * s * nb * 3));
+  HIP_OK(h->d_state0.ensure(B * nb * 6));
+  HIP_OK(h->d_cur.ensure(1));
+  return 0;
+}
+
+static int ensure_adjoint_buffers(dfx_handle* h) {
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s;
+  const size_t nsp = std::max(1, pl.n_special);
+  HIP_OK(h->d_YB.ensure(B * s * nb * 6));
+  HIP_OK(h->d_LAM.ensure(B * nb * 6));
+  HIP_OK(h->d_W.ensure(B * 2 * nb * 3));
+  HIP_OK(h->d_KQ.ensure(B * 2 * nb * 3));
+  HIP_OK(h->d_g_r.ensure(B * pl.n_slots * 2));
+  HIP_OK(h->d_g_phi.ensure(B * pl.n_slots * 2));
+  HIP_OK(h->d_g_b.ensure(B * pl.n_slots * 8));
+  HIP_OK(h->d_blk_g.ensure(B * nb * 6));
+  HIP_OK(h->d_fn_g.ensure(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS));
+  return 0;
+}
+
+static int zero_grad_accumulators(dfx_handle* h) {
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks;
+  const size_t nsp = std::max(1, pl.n_special);
+  HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_blk_g.p, 0, sizeof(double) * B * nb * 6, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
+  return 0;
+}
+
+// download the accumulators and scatter them into dfx_grads
+static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots;
+  const size_t nsp = std::max(1, pl.n_special);
+  std::vector<double> g_r(B * NS * 2), g_phi(B * NS * 2), g_b(B * NS * 8), blk_g(B * nb * 6), fn_g(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS),
+      lam(B * nb * 6);
+  HIP_OK(hipMemcpyAsync(g_r.data(), h->d_g_r.p, sizeof(double) * g_r.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(g_phi.data(), h->d_g_phi.p, sizeof(double) * g_phi.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(g_b.data(), h->d_g_b.p, sizeof(double) * g_b.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(blk_g.data(), h->d_blk_g.p, sizeof(double) * blk_g.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(fn_g.data(), h->d_fn_g.p, sizeof(double) * fn_g.size(), hipMemcpyDeviceToHost, h->stream));
+  if (with_state0) HIP_OK(hipMemcpyAsync(lam.data(), h->d_LAM.p, sizeof(double) * lam.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipGetLastError());
+  if (!grads) return 0;
+  std::vector<double> slot_g(B * NS * kSlotGrads, 0.0);
+  for (size_t i = 0; i < B * NS; ++i) {
+    double* q = slot_g.data() + i * kSlotGrads;
+    q[0] = g_r[i * 2]; q[1] = g_r[i * 2 + 1];
+    for (int c = 0; c < 5; ++c) q[2 + c] = g_b[i * 8 + c];
+    q[7] = g_phi[i * 2]; q[8] = g_phi[i * 2 + 1];
+    for (int c = 0; c < 3; ++c) q[9 + c] = g_b[i * 8 + 5 + c];
+  }
+  dfx_grads g = *grads;
+  if (!with_state0) g.state0 = nullptr;
+  unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g);
+  if (with_state0 && grads->state0)
+    for (size_t m = 0; m < B; ++m)
+      for (size_t b = 0; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) {
+          grads->state0[m * nb * 6 + b * 3 + d] = lam[m * nb * 6 + b * 6 + d];
+          grads->state0[m * nb * 6 + nb * 3 + b * 3 + d] = lam[m * nb * 6 + b * 6 + 3 + d];
+        }
+  return 0;
+}
+
+static void set_grad_wishes(dfx_handle* h, const dfx_grads* g) {
+  h->want_bond_grads = !g || g->reference_vector || g->k_bond || g->contact;
+  h->want_fn_grads = !g || g->fn_params;
+}
+
 extern "C" {
 
 int dfx_device_count(void) {
@@ -497,7 +878,7 @@ int dfx_device_count(void) {
   return n;
 }
 
-const char* dfx_version(void) { return "dfx-hip-gfx950 0.1.0"; }
+const char* dfx_version(void) { return "dfx-hip-gfx950 0.2.0"; }
 
 const char* dfx_last_error(const dfx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -518,7 +899,8 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   h->use_graph = !(g && g[0] == '1');
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
-            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(1) == hipSuccess;
+            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(1) == hipSuccess &&
+            h->d_cur.ensure(1) == hipSuccess;
   if (!ok) { h->err = "hipMalloc (static tables) failed"; return fail(2); }
   (void)hipMemcpy(h->d_slot_info.p, pl.slot_info.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
   (void)hipMemcpy(h->d_block_special.p, pl.block_special.data(), sizeof(int32_t) * pl.n_blocks, hipMemcpyHostToDevice);
@@ -534,11 +916,13 @@ int dfx_destroy(dfx_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release();
-  h->d_slot_p.release(); h->d_inv_m.release(); h->d_damping.release(); h->d_contact.release(); h->d_fns.release();
-  h->d_segs.release(); h->d_seg_idx.release();
-  h->d_traj.release(); h->d_Ypp.release(); h->d_Sbuf.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
+  h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release();
+  h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
+  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release();
+  h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
-  h->d_slot_g.release(); h->d_blk_g.release(); h->d_fn_g.release(); h->d_tmp.release(); h->d_obj.release(); h->d_target.release();
+  h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_g.release(); h->d_fn_g.release();
+  h->d_tmp.release(); h->d_obj.release(); h->d_target.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -546,43 +930,19 @@ int dfx_destroy(dfx_handle* h) {
   return 0;
 }
 
-static int ensure_work_buffers(dfx_handle* h) {
-  const Plan& pl = h->pl;
-  const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s, rec = nb * kRec;
-  HIP_OK(h->d_Ypp.ensure(B * 2 * rec));
-  HIP_OK(h->d_Sbuf.ensure(B * (s + 1) * rec));
-  HIP_OK(h->d_A.ensure(B * s * nb * 3));
-  HIP_OK(h->d_state0.ensure(B * nb * 6));
-  return 0;
-}
-
-static int ensure_adjoint_buffers(dfx_handle* h) {
-  const Plan& pl = h->pl;
-  const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s;
-  const size_t nsp = std::max(1, pl.n_special);
-  HIP_OK(h->d_YB.ensure(B * s * nb * 6));
-  HIP_OK(h->d_LAM.ensure(B * nb * 6));
-  HIP_OK(h->d_W.ensure(B * 2 * nb * 3));
-  HIP_OK(h->d_KQ.ensure(B * 2 * nb * 3));
-  HIP_OK(h->d_slot_g.ensure(B * pl.n_slots * kSlotGrads));
-  HIP_OK(h->d_blk_g.ensure(B * nb * 6));
-  HIP_OK(h->d_fn_g.ensure(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS));
-  return 0;
-}
-
 int dfx_set_params(dfx_handle* h, const dfx_params* params) {
   HIP_OK(hipSetDevice(h->device));
   if (pack_params(h->pl, params, h->pp, h->err)) return 1;
   const PackedParams& pp = h->pp;
-  HIP_OK(h->d_slot_p.ensure(pp.slot.size()));
-  HIP_OK(h->d_inv_m.ensure(pp.inv_m.size()));
-  HIP_OK(h->d_damping.ensure(pp.damping.size()));
-  HIP_OK(h->d_contact.ensure(pp.contact.size()));
+  auto up = [&](DevBuf<double>& d, const std::vector<double>& v) -> int {
+    HIP_OK(d.ensure(v.size()));
+    if (!v.empty()) HIP_OK(hipMemcpyAsync(d.p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, h->stream));
+    return 0;
+  };
+  if (up(h->d_p_r, pp.p_r) || up(h->d_p_l, pp.p_l) || up(h->d_p_k, pp.p_k) || up(h->d_p_phi, pp.p_phi) || up(h->d_cst, pp.cst) ||
+      up(h->d_inv_m, pp.inv_m) || up(h->d_damping, pp.damping))
+    return 2;
   HIP_OK(h->d_fns.ensure(pp.fns.size()));
-  HIP_OK(hipMemcpyAsync(h->d_slot_p.p, pp.slot.data(), sizeof(double) * pp.slot.size(), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(h->d_inv_m.p, pp.inv_m.data(), sizeof(double) * pp.inv_m.size(), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(h->d_damping.p, pp.damping.data(), sizeof(double) * pp.damping.size(), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(h->d_contact.p, pp.contact.data(), sizeof(double) * pp.contact.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_fns.p, pp.fns.data(), sizeof(TimeFn) * pp.fns.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   h->have_params = true;
@@ -594,7 +954,7 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
 int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_t keep_trajectory) {
   HIP_OK(hipSetDevice(h->device));
   const Plan& pl = h->pl;
-  const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kRec;
+  const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kStep;
   if (ensure_work_buffers(h)) return 2;
   if (ensure_adjoint_buffers(h)) return 2;
   HIP_OK(h->d_fields.ensure(B * (size_t)max_timepoints * nb * 6));
@@ -602,7 +962,7 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
   HIP_OK(h->d_tmp.ensure(B * (size_t)max_timepoints * nb * 6));
   HIP_OK(h->d_target.ensure(nb));
   HIP_OK(h->d_obj.ensure(B));
-  HIP_OK(h->d_segs.ensure((size_t)max_timepoints * (1 + (size_t)(max_steps / std::max(1, max_timepoints - 1)) / kMaxGraphSteps + 1)));
+  HIP_OK(h->d_segs.ensure((size_t)max_timepoints * (2 + (size_t)(max_steps / std::max(1, max_timepoints - 1)) / kMaxGraphSteps)));
   if (keep_trajectory) {
     hipError_t e = h->d_traj.ensure(B * (size_t)(max_steps + 1) * rec);
     if (e != hipSuccess) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
@@ -616,7 +976,7 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
   if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
   const Plan& pl = h->pl;
-  const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kRec;
+  const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kStep;
   const int Tn = n_timepoints;
   h->ts.assign(timepoints, timepoints + Tn);
   h->spi = steps_per_interval;
@@ -626,37 +986,32 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   h->have_traj = false;
   if (keep_trajectory) {
     hipError_t e = h->d_traj.ensure(B * (size_t)(h->n_total + 1) * rec);
-    if (e != hipSuccess) { h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string(B * (h->n_total + 1) * rec * 8 >> 20) + " MiB)"; return 2; }
+    if (e != hipSuccess) {
+      h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string((B * (h->n_total + 1) * rec * 8) >> 20) + " MiB)";
+      return 2;
+    }
     h->have_traj = true;
   }
   build_segments(h);
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
-  int minus1 = -1;
+  const int minus1 = -1;
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, &minus1, sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
   h->launches = 0;
-  // initial records: step 0 state
-  double* y0 = c.traj ? c.traj : c.Ypp;
-  const size_t y_stride = c.traj ? (size_t)c.traj_stride : 2 * rec;
-  // k_init writes with member stride n_blocks*kRec; write into Sbuf[0] then copy per member
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], h->d_Sbuf.p);
-  for (size_t m = 0; m < B; ++m)
-    HIP_OK(hipMemcpyAsync(y0 + m * y_stride, h->d_Sbuf.p + m * rec, sizeof(double) * rec, hipMemcpyDeviceToDevice, h->stream));
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0);
+  if (c.traj)
+    hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, (const double*)y0, y_stride, h->d_fields.p, 0);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
-    int rc = run_segment(h, c, sg.n_steps, 0);
-    if (rc) return rc;
-    if (sg.j0 + sg.n_steps == h->spi) {
-      const long long n_end = sg.base_step + sg.n_steps;
-      const double* yend = c.traj ? c.traj + (size_t)n_end * rec : c.Ypp + (size_t)(n_end & 1) * rec;
-      hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, yend, y_stride, h->d_fields.p, sg.interval + 1);
-    }
+    if (int rc = run_segment(h, c, sg.n_steps, 0)) return rc;
+    if (sg.j0 + sg.n_steps == h->spi)   // buffer 0 holds the state at the end of the interval
+      hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, sg.interval + 1);
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
@@ -676,48 +1031,29 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   return 0;
 }
 
-// reverse sweep with G already in h->d_G
+// reverse sweep with the output cotangents already in h->d_G
 static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool kinetic, int n_target) {
   const Plan& pl = h->pl;
-  const size_t B = pl.batch, nb = pl.n_blocks;
+  const size_t B = pl.batch;
   const int Tn = (int)h->ts.size();
-  const size_t nsp = std::max(1, pl.n_special);
+  set_grad_wishes(h, grads);
   DevCtx c = make_ctx(h);
   h->launches = 0;
-  HIP_OK(hipMemsetAsync(h->d_slot_g.p, 0, sizeof(double) * B * pl.n_slots * kSlotGrads, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_blk_g.p, 0, sizeof(double) * B * nb * 6, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
-  int nseg = (int)h->segs.size();
+  if (zero_grad_accumulators(h)) return 2;
+  const int nseg = (int)h->segs.size();
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, &nseg, sizeof(int), hipMemcpyHostToDevice, h->stream));
   const double h_last = Tn > 1 ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spi : 0.0;
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, (int)((h->n_total * pl.tab.s - 1) & 1));
-  for (int si = nseg - 1; si >= 0; --si) {
-    int rc = run_segment(h, c, h->segs[si].n_steps, 1);
-    if (rc) return rc;
-  }
+  const int wb = (int)((h->n_total * pl.tab.s - 1) & 1);
+  hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb);
+  for (int si = nseg - 1; si >= 0; --si)
+    if (int rc = run_segment(h, c, h->segs[si].n_steps, 1)) return rc;
   if (kinetic) {
     dim3 g((unsigned)((n_target * 3 + 63) / 64), (unsigned)B);
     hipLaunchKernelGGL(k_kinetic_mass_grad, g, dim3(64), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_target.p, n_target);
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
-  std::vector<double> slot_g(B * pl.n_slots * kSlotGrads), blk_g(B * nb * 6), fn_g(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS), lam(B * nb * 6);
-  HIP_OK(hipMemcpyAsync(slot_g.data(), h->d_slot_g.p, sizeof(double) * slot_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(blk_g.data(), h->d_blk_g.p, sizeof(double) * blk_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(fn_g.data(), h->d_fn_g.p, sizeof(double) * fn_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(lam.data(), h->d_LAM.p, sizeof(double) * lam.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipGetLastError());
-  if (grads) {
-    unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, grads);
-    if (grads->state0)
-      for (size_t m = 0; m < B; ++m)
-        for (size_t b = 0; b < nb; ++b)
-          for (int d = 0; d < 3; ++d) {
-            grads->state0[m * nb * 6 + b * 3 + d] = lam[m * nb * 6 + b * 6 + d];
-            grads->state0[m * nb * 6 + nb * 3 + b * 3 + d] = lam[m * nb * 6 + b * 6 + 3 + d];
-          }
-  }
+  if (int rc = collect_grads(h, grads, true)) return rc;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;
@@ -742,7 +1078,7 @@ int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_s
   HIP_OK(h->d_tmp.ensure(B * Tn * nb * 6));
   HIP_OK(hipMemcpyAsync(h->d_tmp.p, fields_bar, sizeof(double) * B * Tn * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
-  size_t total = B * Tn * nb * 3;
+  const size_t total = B * Tn * nb * 3;
   hipLaunchKernelGGL(k_pack_G, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream, c,
                      (const double*)h->d_tmp.p, h->d_G.p);
   return run_adjoint(h, grads, stats, false, 0);
@@ -793,23 +1129,15 @@ static int hook_prepare(dfx_handle* h, const double* y, double t) {
   if (ensure_work_buffers(h)) return 2;
   if (ensure_adjoint_buffers(h)) return 2;
   h->have_traj = false;
+  h->have_fields = false;
   h->ts.assign(1, t);
   h->n_total = 1;
   Seg sg;
   sg.t_interval = t; sg.h = 0.0; sg.h_prev = 0.0; sg.base_step = 0; sg.j0 = 0; sg.interval = 0; sg.n_steps = 1; sg.pad = 0;
-  HIP_OK(h->d_segs.ensure(1));
-  HIP_OK(hipMemcpyAsync(h->d_segs.p, &sg, sizeof(Seg), hipMemcpyHostToDevice, h->stream));
-  int zero = 0;
-  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->d_cur.p, &sg, sizeof(Seg), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, y, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
-  c.G = nullptr;
-  // records into Sbuf[0] of every member: k_init uses member stride n_blocks*kRec, Sbuf uses (s+1)*that
-  HIP_OK(h->d_tmp.ensure(B * nb * kRec));
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, t, h->d_tmp.p);
-  for (size_t m = 0; m < B; ++m)
-    HIP_OK(hipMemcpyAsync(h->d_Sbuf.p + m * (pl.tab.s + 1) * nb * kRec, h->d_tmp.p + m * nb * kRec, sizeof(double) * nb * kRec,
-                          hipMemcpyDeviceToDevice, h->stream));
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, t, 0);
   return 0;
 }
 
@@ -819,18 +1147,18 @@ int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   DevCtx c = make_ctx(h);
-  launch_fwd(h, c, 0, 0, 2);
-  std::vector<double> A(B * pl.tab.s * nb * 3), S(B * (pl.tab.s + 1) * nb * kRec);
+  launch_fwd(h, c, 0, 0, 0, -1, 0, 0);
+  std::vector<double> A(B * pl.tab.s * nb * 3), S(B * (pl.tab.s + 1) * nb * 3);
   HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(S.data(), h->d_Sbuf.p, sizeof(double) * S.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(S.data(), h->d_VEL.p, sizeof(double) * S.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) {
-        int sidx = pl.block_special[b];
-        bool con = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1);
-        dy[m * nb * 6 + b * 3 + d] = con ? 0.0 : S[m * (pl.tab.s + 1) * nb * kRec + b * kRec + 5 + d];
+        const int sidx = pl.block_special[b];
+        const bool con = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1);
+        dy[m * nb * 6 + b * 3 + d] = con ? 0.0 : S[m * (pl.tab.s + 1) * nb * 3 + b * 3 + d];
         dy[m * nb * 6 + nb * 3 + b * 3 + d] = A[m * pl.tab.s * nb * 3 + b * 3 + d];
       }
   return 0;
@@ -841,36 +1169,25 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   if (int rc = hook_prepare(h, y, t)) return rc;
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
-  const size_t nsp = std::max(1, pl.n_special);
+  set_grad_wishes(h, grads);
   DevCtx c = make_ctx(h);
   c.G = nullptr;
-  launch_fwd(h, c, 0, 0, 2);
-  HIP_OK(h->d_G.ensure(B * nb * 6));
-  HIP_OK(hipMemcpyAsync(h->d_G.p, lam, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_slot_g.p, 0, sizeof(double) * B * pl.n_slots * kSlotGrads, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_blk_g.p, 0, sizeof(double) * B * nb * 6, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
+  launch_fwd(h, c, 0, 0, 0, -1, 0, 0);
+  HIP_OK(h->d_tmp.ensure(B * nb * 6));
+  HIP_OK(hipMemcpyAsync(h->d_tmp.p, lam, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
+  if (zero_grad_accumulators(h)) return 2;
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_seed_vjp, g3, dim3(kThreads), 0, h->stream, c, (const double*)h->d_G.p);
-  launch_adj(h, c, 0, 0, 1);
-  std::vector<double> YB(B * pl.tab.s * nb * 6), slot_g(B * pl.n_slots * kSlotGrads), blk_g(B * nb * 6), fn_g(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS);
+  hipLaunchKernelGGL(k_seed_vjp, g3, dim3(kThreads), 0, h->stream, c, (const double*)h->d_tmp.p);
+  launch_adj(h, c, 0, 0, 0, 0, 1);
+  std::vector<double> YB(B * pl.tab.s * nb * 6);
   HIP_OK(hipMemcpyAsync(YB.data(), h->d_YB.p, sizeof(double) * YB.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(slot_g.data(), h->d_slot_g.p, sizeof(double) * slot_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(blk_g.data(), h->d_blk_g.p, sizeof(double) * blk_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(fn_g.data(), h->d_fn_g.p, sizeof(double) * fn_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipGetLastError());
+  if (int rc = collect_grads(h, grads, false)) return rc;
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) {
         y_bar[m * nb * 6 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + d];
         y_bar[m * nb * 6 + nb * 3 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + 3 + d];
       }
-  if (grads) {
-    dfx_grads g = *grads;
-    g.state0 = nullptr;
-    unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g);
-  }
   return 0;
 }
 
@@ -879,15 +1196,16 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   if (!h->have_params) { h->err = "energy: set_params first"; return 1; }
+  // records straight from u (no constraint override: the energy of the configuration as given)
   if (ensure_work_buffers(h)) return 2;
-  std::vector<double> S(B * (pl.tab.s + 1) * nb * kRec, 0.0);
+  std::vector<double> S(B * (pl.tab.s + 1) * nb * kPos, 0.0);
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b) {
-      double* r = S.data() + m * (pl.tab.s + 1) * nb * kRec + b * kRec;
+      double* r = S.data() + m * (pl.tab.s + 1) * nb * kPos + b * kPos;
       for (int d = 0; d < 3; ++d) r[d] = u[m * nb * 3 + b * 3 + d];
       r[3] = cos(0.5 * r[2]); r[4] = sin(0.5 * r[2]);
     }
-  HIP_OK(hipMemcpyAsync(h->d_Sbuf.p, S.data(), sizeof(double) * S.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->d_POS.p, S.data(), sizeof(double) * S.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_tmp.ensure(B * pl.n_slots));
   DevCtx c = make_ctx(h);
   if (pl.model == kNonlinear) {

@@ -81,6 +81,13 @@ struct PackedParams {
   std::vector<double> damping;  // batch * n_blocks * 3
   std::vector<double> contact;  // batch * 3
   std::vector<TimeFn> fns;      // batch * DFX_MAX_FNS
+  // GPU image (structure of arrays, 16-byte rows so every lane issues aligned dwordx4 loads):
+  std::vector<double> p_r;      // batch * n_slots * 2 : own node vector
+  std::vector<double> p_l;      // batch * n_slots * 2 : reference vector (oriented node1 -> node2)
+  std::vector<double> p_k;      // batch * n_slots * 4 : k_stretch, k_shear, k_rot, 0
+  std::vector<double> p_phi;    // batch * n_slots * 2 : undeformed void angles
+  std::vector<double> cst;      // batch * 8 : min_angle, cutoff_angle, k_contact, k_stretch, k_shear, k_rot (if uniform), 0, 0
+  bool k_uniform = true;        // every ligament of a member has the same three stiffnesses
 };
 
 inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, std::string& err) {
@@ -120,6 +127,31 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       out.damping[(size_t)m * NB * 3 + i] = q->damping ? q->damping[(size_t)m * NB * 3 + i] : 0.0;
     }
     if (q->contact) for (int i = 0; i < 3; ++i) out.contact[m * 3 + i] = q->contact[m * 3 + i];
+    // ---- GPU structure-of-arrays image
+    if (m == 0) {
+      out.p_r.assign((size_t)B * NS * 2, 0.0); out.p_l.assign((size_t)B * NS * 2, 0.0);
+      out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
+      out.cst.assign((size_t)B * 8, 0.0);
+      out.k_uniform = true;
+    }
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const double* s = sp + (size_t)s_ * kSlotParams;
+      double* r = out.p_r.data() + ((size_t)m * NS + s_) * 2;
+      double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
+      double* k = out.p_k.data() + ((size_t)m * NS + s_) * 4;
+      double* ph = out.p_phi.data() + ((size_t)m * NS + s_) * 2;
+      r[0] = s[0]; r[1] = s[1];
+      int info = pl.slot_info[s_];
+      if (info >= 0) {
+        if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { err = "set_params: zero-length reference vector"; return 1; }
+        l[0] = s[2]; l[1] = s[3];
+        k[0] = s[4]; k[1] = s[5]; k[2] = s[6];
+        ph[0] = s[7]; ph[1] = s[8];
+        if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) out.k_uniform = false;
+      }
+    }
+    if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 8 + i] = q->contact[m * 3 + i];
+    if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 8 + 3 + i] = kb[i];
     for (int f = 0; f < pl.n_fns; ++f) {
       TimeFn& tf = out.fns[(size_t)m * DFX_MAX_FNS + f];
       tf.type = pl.fn_type[f];

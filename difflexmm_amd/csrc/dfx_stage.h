@@ -55,7 +55,8 @@ DFX_HD void fwd_slot(const Tables& tb, const double* S_in, int slot, double& fx,
   const double* pp = tb.slot_p + (size_t)ps * kSlotParams;
   BlockRec<double> o = load_rec(S_in, slot >> 2), p = load_rec(S_in, ps >> 2);
   BondGrad<double> g;
-  bond_grad<MODEL, double>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], sp[4], sp[5], sp[6], sgn, g);
+  const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
+  bond_grad<MODEL, double>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], sgn, g);
   fx = g.fx; fy = g.fy; fth = g.fth;
   double e = g.e;
   if (CONTACT) {
@@ -179,7 +180,8 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
   BlockRec<Dual> o = seed_rec(ro, W[bo * 3], W[bo * 3 + 1], W[bo * 3 + 2]);
   BlockRec<Dual> p = seed_rec(rp, W[bp * 3], W[bp * 3 + 1], W[bp * 3 + 2]);
   BondGrad<Dual> g;
-  bond_grad<MODEL, Dual>(o, p, Dual(sp[0]), Dual(sp[1]), Dual(pp[0]), Dual(pp[1]), Dual(sp[2]), Dual(sp[3]),
+  const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
+  bond_grad<MODEL, Dual>(o, p, Dual(sp[0]), Dual(sp[1]), Dual(pp[0]), Dual(pp[1]), Dual(sp[2]), Dual(sp[3]), l0, 1.0 / l0,
                          Dual(sp[4]), Dual(sp[5]), Dual(sp[6]), sgn, g);
   hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
   ContactGrad<Dual> c;
