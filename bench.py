@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 SPI = 250                     # steps between outputs: 50 000 steps / 200 output intervals
 FREQ = 30.0
 DT = (2.0 / FREQ) / 50000.0
+MEMBERS_FOR_TRAFFIC = 1
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md, chip-level parameters
 # algorithmic bytes per rigid unit per launch
 BYTES_FWD_STAGE = 272 + 72    # one RHS evaluation (quads + contact) + its share of the stage combine (432/6)
@@ -81,20 +82,38 @@ def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
 
 def cpu_baseline(size, seed, budget_s=20.0):
     """The CPU port of the oracle (same algorithm, same tableau, OpenMP over blocks) on a bounded sample of the same
-    workload: forward + adjoint of a few steps of the same lattice."""
+    workload: forward + adjoint of a few steps of the same lattice.  Thread count: the best of a short sweep."""
+    import ctypes
     from oracle.cpu import load
     lib = load()
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
     fw, obj, designs = c3_problem(size, seed, 1, lib=lib)
-    t0 = time.perf_counter()
-    run_once(fw, obj, designs, 2, spi=2)
-    dt1 = time.perf_counter() - t0
-    n = int(max(2, min(400, (budget_s / max(dt1 / 2, 1e-6)) // 2 * 2)))
+    ncpu = os.cpu_count() or 1
+    run_once(fw, obj, designs, 2, spi=2)                      # touch everything once
+    best = (None, 0.0)
+    for nt in sorted({1, min(8, ncpu), min(32, ncpu), min(96, ncpu)}):
+        if gomp is not None:
+            gomp.omp_set_num_threads(nt)
+        elif nt != 1:
+            continue
+        t0 = time.perf_counter()
+        run_once(fw, obj, designs, 4, spi=2)
+        rate = 4 / (time.perf_counter() - t0)
+        if rate > best[1]:
+            best = (nt, rate)
+    nt, rate = best
+    if gomp is not None:
+        gomp.omp_set_num_threads(nt)
+    n = int(max(4, min(2000, (budget_s * rate) // 2 * 2)))
     t0 = time.perf_counter()
     run_once(fw, obj, designs, n, spi=2)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": n * size * size / dt, "unit": "timesteps*units/s", "cores": cores, "kind": "port",
-            "sample": f"{n} Dopri5 steps forward+adjoint of the same {size}x{size} lattice (C++ port of the oracle, OpenMP)"}
+    return {"value": n * size * size / dt, "unit": "timesteps*units/s", "cores": nt, "kind": "port",
+            "sample": f"{n} Dopri5 steps forward+adjoint of the same {size}x{size} lattice, 1 member "
+                      f"(C++ port of the oracle, OpenMP, {nt} threads = best of a sweep on {ncpu} logical CPUs)"}
 
 
 def main():
@@ -102,10 +121,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=250)
-    ap.add_argument("--members", type=int, default=1, help="ensemble members per GPU integrated in one launch")
+    ap.add_argument("--members", type=int, default=4, help="independent designs per GPU integrated side by side (grid.y)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the extra 1-member reference measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +137,8 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    global MEMBERS_FOR_TRAFFIC
+    MEMBERS_FOR_TRAFFIC = args.members
     K = max(SPI, (args.steps // SPI) * SPI)
     W = 0 if args.warmup <= 0 else max(SPI, (args.warmup // SPI) * SPI)
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
@@ -174,6 +196,22 @@ def main():
             a2 = BYTES_ADJ_STAGE * n_units * args.members / (adj_us * 1e-6) / 1e9
             line["roofline_adjoint_kernel"] = {"kernel": "k_adj_stage<nonlinear,contact>", "achieved": a2, "peak": HBM_PEAK_GBS,
                                                "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS, "launch_us": adj_us}
+        if args.members > 1 and not args.forward_only and not args.no_single:
+            # the same config with ONE design per GPU (latency-bound: one wave per SIMD), for reference
+            fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
+            K1 = min(K, 2500)
+            fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 1, keep_trajectory=True)
+            run_once(fw1, obj1, des1, SPI)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r1 = run_once(fw1, obj1, des1, K1)
+            torch.cuda.synchronize()
+            w1 = time.perf_counter() - t1
+            line["single_system"] = {"members_per_gpu": 1, "steps": K1, "value": K1 * n_units / w1,
+                                     "forward_only_value": K1 * n_units / (r1["fwd_ms"] * 1e-3),
+                                     "fwd_launch_us": 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]),
+                                     "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
+            del fw1, obj1
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, 3)
         print(json.dumps(line), flush=True)
@@ -187,7 +225,8 @@ def load_pmc_traffic():
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("k_fwd_stage_bytes_per_launch")
+            d = json.load(open(p))
+            return d.get("k_fwd_stage_bytes_per_member_launch") * MEMBERS_FOR_TRAFFIC
         except Exception:
             return None
     return None

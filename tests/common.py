@@ -131,3 +131,31 @@ class Case:
 def relerr(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def tensile_solver(lib, n1_cells, final_strain, nonlinear):
+    """The reference's tensile known-answer test (tests/test_difflexmm.py:35-146) on the engine API.
+    Returns (simulated end strain, solver)."""
+    g = geo_mod.RotatedSquareGeometry(n1_cells=n1_cells, n2_cells=1, spacing=1.0)
+    k_stretch = 1.0
+    k_shear = 1.851e-2 * k_stretch
+    k_rot = 1.534e-4 / 4 * k_stretch * g.spacing ** 2
+    mass = 1.0
+    Jrot = 1.815 ** -2 / 4 * mass * g.spacing ** 2
+    inertia = np.tile([mass, mass, Jrot], (g.n_blocks, 1))
+    damping = 0.05 * np.tile([(k_stretch * mass) ** 0.5, (k_stretch * mass) ** 0.5,
+                              (k_stretch * mass) ** 0.5 * g.spacing ** 2 / 4], (g.n_blocks, 1))
+    con = np.array([[0, 0], [g.n1_blocks, 0]])
+    final_load = final_strain * g.spacing * k_stretch
+    rate = 0.001 * (k_stretch / mass) ** 0.5
+    loaded = np.array([[g.n1_blocks - 1, 0], [g.n_blocks - 1, 0]])
+    energy = en_mod.build_strain_energy(g.bond_connectivity(),
+                                        en_mod.ligament_energy if nonlinear else en_mod.ligament_energy_linearized)
+    solver = setup_dynamic_solver(g, energy, loaded_block_DOF_pairs=loaded, loading_fn=ld.Ramp(amplitude=final_load, rate=rate),
+                                  constrained_block_DOF_pairs=con, damped_blocks=np.arange(g.n_blocks), _lib=lib)
+    cp = dm.ControlParams(dm.GeometricalParams(g.block_centroids(0.0), g.centroid_node_vectors(0.0)),
+                          dm.MechanicalParams(dm.LigamentParams(k_stretch, k_shear, k_rot, g.reference_bond_vectors()),
+                                              None, inertia, damping))
+    ts = np.linspace(0, 3 / rate, 100)
+    sol = solver(np.zeros((2, g.n_blocks, 3)), ts, cp)
+    return sol[-1, 0, g.n1_blocks - 1, 0] / (g.spacing * (g.n1_blocks - 1)), solver

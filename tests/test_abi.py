@@ -39,9 +39,16 @@ def test_product_has_no_cpu_fallback(hip_lib):
 
 
 def test_product_never_imports_the_oracle():
+    """Nothing under difflexmm_amd/ imports, includes or loads anything from oracle/."""
+    import re
     pkg = os.path.join(ROOT, "difflexmm_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("oracle/cpu/dfx_cpu.cpp", "").replace("(oracle/cpu", "(cpu-port") or f in ("dfx_stage.h", "dfx_plan.h", "dfx_physics.h", "dfx_engine.hip"), f
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                src = open(path).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), path
+                assert "libdfx_cpu" not in src, path
+            elif f.endswith((".h", ".hip", ".cpp")):
+                src = open(path).read()
+                assert not re.search(r'#include\s+"[^"]*oracle/', src), path

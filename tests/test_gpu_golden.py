@@ -1,0 +1,53 @@
+"""-m gpu: the HIP engine against the committed golden fixtures and the reference's tensile known-answer test."""
+import os
+
+import numpy as np
+import pytest
+
+from .common import Case, relerr, tensile_solver
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_golden_rhs(hip_lib):
+    gold = np.load(os.path.join(GOLD, "rhs.npz"))
+    for lattice, n, cut in (("quads", 4, 42.0), ("kagome", 3, 125.0)):
+        for nonlinear in (True, False):
+            key = f"{lattice}{n}_{'nl' if nonlinear else 'lin'}"
+            c = Case(lattice, n, nonlinear, True, seed=7, lib=None, cutoff_deg=cut)
+            y, free = gold[key + "_y"], gold[key + "_free"]
+            flat = c.solver._flatten(c.cp)
+            c.solver.engine.set_params(**{k: v[None] for k, v in flat.items()})
+            dy = c.solver.engine.rhs(y[None], 0.012)[0].reshape(2, -1)[:, free]
+            assert relerr(dy, gold[key + "_dy_free"]) < 1e-12
+
+
+def test_fixed_grid_converges_to_adaptive_reference(hip_lib):
+    gold = np.load(os.path.join(GOLD, "adaptive_8x8.npz"))
+    c = Case("quads", 8, False, False, damping=False, seed=1, lib=None)
+    cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=float(gold["loading_rate"]), input_delay=float(gold["input_delay"])))
+    f = c.solver(np.zeros((2, 64, 3)), gold["timepoints"], cp, steps_per_interval=200)
+    free = c.solver.free_DOF_ids
+    a = f.reshape(len(f), 2, -1)[:, :, free]
+    b = gold["fields"].reshape(len(f), 2, -1)[:, :, free]
+    assert relerr(a[:, 0], b[:, 0]) < 1e-6 and relerr(a[:, 1], b[:, 1]) < 1e-6   # stated tolerance vs the adaptive reference
+
+
+def test_golden_focusing_gradient(hip_lib):
+    gold = np.load(os.path.join(GOLD, "focusing_6x6.npz"))
+    c = Case("quads", 6, True, True, seed=9, lib=None, cutoff_deg=42.0)
+    cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+    c.solver(np.zeros((2, 36, 3)), gold["timepoints"], cp, keep_trajectory=True, steps_per_interval=int(gold["spi"]))
+    obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(gold["target"].astype(np.int32))
+    gh, gv = c.geo.vjp((gold["design_h"], gold["design_v"]), tree.geometrical_params.centroid_node_vectors,
+                       tree.geometrical_params.block_centroids)
+    assert abs(obj - float(gold["objective"])) / float(gold["objective"]) < 1e-10
+    assert relerr(gh, gold["grad_h"]) < 1e-9 and relerr(gv, gold["grad_v"]) < 1e-9
+
+
+@pytest.mark.parametrize("n1_cells,strain,nonlinear", [(5, 0.2, False), (5, 0.6, True), (20, 0.4, True), (10, 0.6, False)])
+def test_tensile_known_answer(hip_lib, n1_cells, strain, nonlinear):
+    """reference tests/test_difflexmm.py:35-146 through the HIP engine."""
+    got, _ = tensile_solver(None, n1_cells, strain, nonlinear)
+    assert abs(got - strain) / strain < 1e-4

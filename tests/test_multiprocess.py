@@ -1,0 +1,70 @@
+"""world_size-2 gloo test of the N>1 path (runs on CPU): designs sharded over ranks, no data-path collective,
+objectives combined by one all_gather, shared-design gradients by one all_reduce."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(lib):
+    import math
+    from difflexmm_amd.problems import QuadsFocusingForward, TargetKineticEnergy
+    fw = QuadsFocusingForward(
+        n1_blocks=6, n2_blocks=6, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5,
+        density=6.18e-9, damping=1e-4 * np.ones((36, 3)), amplitude=7.5, loading_rate=3000.0, input_delay=1e-5,
+        n_excited_blocks=2, loaded_side="left", input_shift=0, simulation_time=4e-4, n_timepoints=5,
+        use_contact=True, k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=42 * math.pi / 180,
+        steps_per_interval=10, _lib=lib)
+    fw.setup()
+    obj = TargetKineticEnergy(fw, (2, 2), (1, 1))
+    designs = []
+    for seed in range(4):
+        rng = np.random.default_rng(100 + seed)
+        base = fw.geometry.get_design_from_rotated_square(25 * math.pi / 180)
+        designs.append(tuple(b + rng.uniform(-0.3, 0.3, b.shape) for b in base))
+    return fw, obj, designs
+
+
+def _worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from difflexmm_amd import ensemble
+    from oracle.cpu import load
+    fw, obj, designs = _make(load())
+    values, grads, (lo, hi) = ensemble.evaluate_ensemble(obj, designs)
+    shared = ensemble.sum_shared_gradients([np.full((2, 3), float(rank + 1)), np.arange(4.0) * (rank + 1)])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), values=values, lo=lo, hi=hi, g0=grads[0][0], s0=shared[0], s1=shared[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_designs_and_gather_objectives(tmp_path, cpu_lib):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    fw, obj, designs = _make(cpu_lib)
+    ref = [obj.value_and_grad(d) for d in designs]
+    ref_vals = np.array([r[0] for r in ref])
+    assert np.all(ref_vals > 0)
+    for rank in range(2):
+        d = np.load(tmp_path / f"rank{rank}.npz")
+        np.testing.assert_allclose(d["values"], ref_vals, rtol=1e-12)          # every rank holds all objectives
+        assert (int(d["lo"]), int(d["hi"])) == ((0, 2), (2, 4))[rank]
+        np.testing.assert_allclose(d["g0"], ref[int(d["lo"])][1][0], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(d["s0"], np.full((2, 3), 3.0))               # 1 + 2
+        np.testing.assert_allclose(d["s1"], np.arange(4.0) * 3)
+
+
+def test_shard_bounds_cover_everything():
+    from difflexmm_amd.ensemble import shard_bounds
+    for n in (1, 7, 64, 256):
+        for ws in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, ws) for r in range(ws)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
