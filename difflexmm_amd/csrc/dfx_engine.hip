@@ -179,14 +179,17 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
 }
 
 // fields[m, k] <- (disp, vel) of stage buffer 0
-__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k) {
+__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad) {
   const int m = blockIdx.y;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * 3) return;
   const int b = tid / 3, d = tid % 3;
   double* f = fields + ((size_t)m * c.n_timepoints + k) * c.n_blocks * 6;
-  f[tid] = c.POS[(size_t)m * (c.s + 1) * c.n_blocks * kPos + (size_t)b * kPos + d];
-  f[(size_t)c.n_blocks * 3 + tid] = c.VEL[(size_t)m * (c.s + 1) * c.n_blocks * 3 + tid];
+  const double q = c.POS[(size_t)m * (c.s + 1) * c.n_blocks * kPos + (size_t)b * kPos + d];
+  const double v = c.VEL[(size_t)m * (c.s + 1) * c.n_blocks * 3 + tid];
+  f[tid] = q;
+  f[(size_t)c.n_blocks * 3 + tid] = v;
+  if (!isfinite(q) || !isfinite(v)) *bad = k + 1;   // any writer wins: only "some output row is not finite" matters
 }
 
 // copy stage buffer 0 into checkpoint slot n (only for the initial state)
@@ -822,7 +825,7 @@ static int zero_grad_accumulators(dfx_handle* h) {
   const size_t nsp = std::max(1, pl.n_special);
   HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
   HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
+  if (h->want_bond_grads) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
   HIP_OK(hipMemsetAsync(h->d_blk_g.p, 0, sizeof(double) * B * nb * 6, h->stream));
   HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
   return 0;
@@ -833,13 +836,13 @@ static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots;
   const size_t nsp = std::max(1, pl.n_special);
-  std::vector<double> g_r(B * NS * 2), g_phi(B * NS * 2), g_b(B * NS * 8), blk_g(B * nb * 6), fn_g(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS),
+  std::vector<double> g_r(B * NS * 2), g_phi(B * NS * 2), g_b(B * NS * 8, 0.0), blk_g(B * nb * 6), fn_g(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0),
       lam(B * nb * 6);
   HIP_OK(hipMemcpyAsync(g_r.data(), h->d_g_r.p, sizeof(double) * g_r.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(g_phi.data(), h->d_g_phi.p, sizeof(double) * g_phi.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(g_b.data(), h->d_g_b.p, sizeof(double) * g_b.size(), hipMemcpyDeviceToHost, h->stream));
+  if (h->want_bond_grads) HIP_OK(hipMemcpyAsync(g_b.data(), h->d_g_b.p, sizeof(double) * g_b.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(blk_g.data(), h->d_blk_g.p, sizeof(double) * blk_g.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(fn_g.data(), h->d_fn_g.p, sizeof(double) * fn_g.size(), hipMemcpyDeviceToHost, h->stream));
+  if (h->want_fn_grads) HIP_OK(hipMemcpyAsync(fn_g.data(), h->d_fn_g.p, sizeof(double) * fn_g.size(), hipMemcpyDeviceToHost, h->stream));
   if (with_state0) HIP_OK(hipMemcpyAsync(lam.data(), h->d_LAM.p, sizeof(double) * lam.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
@@ -899,7 +902,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   h->use_graph = !(g && g[0] == '1');
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
-            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(1) == hipSuccess &&
+            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2) == hipSuccess &&
             h->d_cur.ensure(1) == hipSuccess;
   if (!ok) { h->err = "hipMalloc (static tables) failed"; return fail(2); }
   (void)hipMemcpy(h->d_slot_info.p, pl.slot_info.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
@@ -939,7 +942,7 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
     if (!v.empty()) HIP_OK(hipMemcpyAsync(d.p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, h->stream));
     return 0;
   };
-  if (up(h->d_p_r, pp.p_r) || up(h->d_p_l, pp.p_l) || up(h->d_p_k, pp.p_k) || up(h->d_p_phi, pp.p_phi) || up(h->d_cst, pp.cst) ||
+  if (up(h->d_p_r, pp.p_r) || up(h->d_p_l, pp.p_l) || (!pp.k_uniform && up(h->d_p_k, pp.p_k)) || up(h->d_p_phi, pp.p_phi) || up(h->d_cst, pp.cst) ||
       up(h->d_inv_m, pp.inv_m) || up(h->d_damping, pp.damping))
     return 2;
   HIP_OK(h->d_fns.ensure(pp.fns.size()));
@@ -996,8 +999,8 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
-  const int minus1 = -1;
-  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, &minus1, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  const int minus1[2] = {-1, 0};   // segment cursor, non-finite flag
+  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, minus1, 2 * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
   h->launches = 0;
@@ -1005,19 +1008,26 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
     if (int rc = run_segment(h, c, sg.n_steps, 0)) return rc;
     if (sg.j0 + sg.n_steps == h->spi)   // buffer 0 holds the state at the end of the interval
-      hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, sg.interval + 1);
+      hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, sg.interval + 1, h->d_seg_idx.p + 1);
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
+  int bad = 0;
+  HIP_OK(hipMemcpyAsync(&bad, h->d_seg_idx.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
   h->have_fields = true;
+  if (bad) {
+    h->have_traj = false;
+    h->err = "forward: non-finite state at output " + std::to_string(bad - 1) + " (unstable step size or contact blow-up)";
+    return 3;
+  }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;

@@ -90,7 +90,7 @@ struct PackedParams {
   bool k_uniform = true;        // every ligament of a member has the same three stiffnesses
 };
 
-inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, std::string& err) {
+inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, std::string& err, bool gpu_image = true) {
   if (!q || !q->centroid_node_vectors || !q->reference_vector || !q->k_bond || !q->inertia) {
     err = "set_params: centroid_node_vectors, reference_vector, k_bond and inertia are required"; return 1;
   }
@@ -127,7 +127,13 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       out.damping[(size_t)m * NB * 3 + i] = q->damping ? q->damping[(size_t)m * NB * 3 + i] : 0.0;
     }
     if (q->contact) for (int i = 0; i < 3; ++i) out.contact[m * 3 + i] = q->contact[m * 3 + i];
+    for (int f = 0; f < pl.n_fns; ++f) {
+      TimeFn& tf = out.fns[(size_t)m * DFX_MAX_FNS + f];
+      tf.type = pl.fn_type[f];
+      for (int i = 0; i < DFX_FN_PARAMS; ++i) tf.p[i] = q->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i];
+    }
     // ---- GPU structure-of-arrays image
+    if (!gpu_image) continue;
     if (m == 0) {
       out.p_r.assign((size_t)B * NS * 2, 0.0); out.p_l.assign((size_t)B * NS * 2, 0.0);
       out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
@@ -152,11 +158,6 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     }
     if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 8 + i] = q->contact[m * 3 + i];
     if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 8 + 3 + i] = kb[i];
-    for (int f = 0; f < pl.n_fns; ++f) {
-      TimeFn& tf = out.fns[(size_t)m * DFX_MAX_FNS + f];
-      tf.type = pl.fn_type[f];
-      for (int i = 0; i < DFX_FN_PARAMS; ++i) tf.p[i] = q->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i];
-    }
   }
   return 0;
 }

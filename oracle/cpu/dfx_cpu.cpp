@@ -115,7 +115,7 @@ int dfx_destroy(dfx_handle* h) { delete h; return 0; }
 const char* dfx_last_error(const dfx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int dfx_set_params(dfx_handle* h, const dfx_params* params) {
-  if (pack_params(h->pl, params, h->pp, h->err)) return 1;
+  if (pack_params(h->pl, params, h->pp, h->err, false)) return 1;
   h->have_params = true;
   h->have_traj = false;
   return 0;

@@ -106,3 +106,11 @@ def test_full_size_128x128_properties(hip_lib):
     lhs = float((fb.reshape(len(ts), 2, -1)[:, :, free] * dfd).sum())
     rhs = float(tree.constraint_params["amplitude"])
     assert abs(lhs - rhs) / abs(lhs) < 1e-6, (lhs, rhs)
+
+
+def test_unstable_step_reports_an_error(hip_lib):
+    """SURVEY 8(b) errors: NaN/Inf in the state is a non-zero status + message (the reference would return NaNs silently)."""
+    c = Case("quads", 6, True, False, seed=1, lib=None)
+    c.cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=300.0, input_delay=0.0))
+    with pytest.raises(RuntimeError, match="non-finite"):
+        c.solver(np.zeros((2, 36, 3)), np.linspace(0, 0.5, 3), c.cp, steps_per_interval=20)   # h = 12.5 ms >> 1/omega_max
