@@ -49,7 +49,7 @@ class dfx_stats(C.Structure):
                 ("kernel_ms", C.c_double), ("stage_kernel_us", C.c_double)]
 
 
-EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_adjoint",
+EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_adaptive", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
 
@@ -64,6 +64,7 @@ def declare(lib):
     lib.dfx_set_params.argtypes = [H, C.POINTER(dfx_params)]
     lib.dfx_reserve.argtypes = [H, C.c_int64, C.c_int32, C.c_int32]
     lib.dfx_forward.argtypes = [H, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
     lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
@@ -192,6 +193,19 @@ class Engine:
         st = dfx_stats()
         self._check(self.lib.dfx_forward(self._h, _ptr(state0), _ptr(ts), T, int(steps_per_interval),
                                          int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward")
+        self.n_timepoints = T
+        return fields, _stats(st)
+
+    def forward_adaptive(self, state0, timepoints, rtol, atol, max_attempts=10_000_000):
+        """Adaptive Dormand-Prince with the reference's odeint semantics (forward only)."""
+        B, nb = self.batch, self.n_blocks
+        state0 = _f64(state0, (B, 2, nb, 3))
+        ts = _f64(timepoints)
+        T = len(ts)
+        fields = np.empty((B, T, 2, nb, 3))
+        st = dfx_stats()
+        self._check(self.lib.dfx_forward_adaptive(self._h, _ptr(state0), _ptr(ts), T, float(rtol), float(atol),
+                                                  int(max_attempts), _ptr(fields), C.byref(st)), "dfx_forward_adaptive")
         self.n_timepoints = T
         return fields, _stats(st)
 

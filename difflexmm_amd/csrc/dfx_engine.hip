@@ -52,6 +52,18 @@ struct Seg {            // one graph replay worth of steps
   int pad;
 };
 
+// adaptive mode: every member carries its own clock and step-size controller state
+struct Clock {
+  double t, h;            // start time and size of the step being attempted
+  double t_last, h_acc;   // start and size of the last accepted step (dense output)
+  long long attempts, accepted;
+  int state;              // 0 running, 1 finished, 2 non-finite error estimate, 3 step size underflow
+  int fin_next;           // the last output was produced in this round: finished from the next round on
+  int accept;             // decision of the last controller run
+  int out_lo, out_hi;     // outputs [out_lo, out_hi) lie inside the step just accepted
+  int out_idx;            // next output to produce
+};
+
 // next-stage coefficients of one launch, passed by value (lands in SGPRs)
 struct StageCoef {
   double cv[kMaxStages];  // a[r][l]   : V_{r} = v_n + h sum_l cv[l] A_l
@@ -82,6 +94,11 @@ struct DevCtx {
   const double* damping;  // n_blocks*3
   const TimeFn* fns;
   const Seg* cur;         // the segment being replayed
+  Clock* clock;           // per-member clocks (adaptive mode) or null
+  double* err_partial;    // batch * n_wg*4 per-wave partial sums of the squared error ratio
+  const double* ts_dev;   // output times (adaptive mode)
+  double* fields_dev;     // batch * T * n_blocks*6 (adaptive mode writes its dense output here)
+  double rtol, atol;
   // state: (s+1) stage buffers per member; buffer 0 = current step state
   double* traj;           // batch * traj_stride   checkpoints: per step [POS n_blocks*6 | VEL n_blocks*3]
   double* POS;            // batch * (s+1) * n_blocks*kPos
@@ -253,13 +270,24 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
 //   write_traj: also store the new record into the checkpoint of step n+1 (last stage, keep_trajectory)
 template <int MODEL, int CONTACT>
 __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
-                                                        int y_buf, int write_traj) {
+                                                        int y_buf, int mode) {
   const int m = blockIdx.y;
-  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
-  if (slot >= c.n_slots) return;
+  const int lwg = logical_wg(blockIdx.x, c.n_wg);
+  int slot = lwg * kThreads + threadIdx.x;
+  const int write_traj = mode & 1, err_mode = mode & 2;
+  const bool valid = slot < c.n_slots;
+  if (!valid) {
+    if (!err_mode) return;
+    slot = c.n_slots - 4 + (threadIdx.x & 3);   // keep the wave whole for the reduction: redo the last unit, contribute 0
+  }
   if (c.ablate & 4) return;
   const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
-  const Seg sg = *c.cur;
+  Seg sg = *c.cur;
+  if (c.clock) {          // adaptive: this member's own time and step
+    const Clock ck = c.clock[m];
+    if (ck.state | ck.fin_next) return;
+    sg.t_interval = ck.t; sg.h = ck.h; sg.j0 = 0; sg.base_step = 0; j = 0;
+  }
   const long long n = sg.base_step + j;
   const size_t nd = (size_t)c.n_blocks * 3;
   // ---- load phase
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
   const double qn = pos_in(c, m, y_buf, n)[(size_t)b * kPos + kd];
   const double vn = vel_in(c, m, y_buf, n)[dof];
   const double v_i = vel_in(c, m, in_buf, n)[dof];
-  double* Am = c.A + (size_t)m * c.s * nd;
+  double* Am = c.A + (size_t)m * (c.s + 1) * nd;
   const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
   const int sidx = c.block_special[b];
   double sv = 0.0, sq = 0.0;
@@ -324,10 +352,28 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
     sq += sc.cq[i] * a;
     qnext = qn + h * (sc.c_next * vn + h * sq);
     vnext = vn + h * sv;
+    if (err_mode) {
+      // i == 6 evaluated at the candidate y1: with (cv, cq) = (e, ee) the sums are the embedded error estimate
+      double r2 = 0.0;
+      if (!constrained) {
+        const double q1 = POSin[(size_t)b * kPos + k];
+        const double eq = h * h * sq, ev = h * sv;
+        const double tq = c.atol + c.rtol * fmax(fabs(qn), fabs(q1)), tv = c.atol + c.rtol * fmax(fabs(vn), fabs(v_i));
+        r2 = (eq / tq) * (eq / tq) + (ev / tv) * (ev / tv);
+      }
+      qnext = r2;
+    }
     if (constrained && out_buf >= 0) {
       TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
       qnext = tv.g; vnext = tv.gt;
     }
+  }
+  if (err_mode) {
+    // per-wave sum of the squared error ratios (fixed order -> deterministic); lane 0 of each wave stores it
+    double r2 = (k < 3 && valid) ? qnext : 0.0;
+    for (int off = 32; off > 0; off >>= 1) r2 += __shfl_down(r2, off, 64);
+    if ((threadIdx.x & 63) == 0) c.err_partial[((size_t)m * c.n_wg + lwg) * 4 + (threadIdx.x >> 6)] = r2;
+    return;
   }
   if (out_buf < 0) return;
   // ---- publish the next stage record: lanes 0..2 each store one aligned 16-byte chunk (x,y) (th,ch) (sh,0)
@@ -343,6 +389,124 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
       *reinterpret_cast<double2*>(tr + (size_t)b * kPos + 2 * k) = chunk;
       tr[(size_t)c.n_blocks * kPos + dof] = vnext;
     }
+  }
+}
+
+
+// ---- adaptive step control (jax.experimental.ode semantics) --------------------------------------
+// one workgroup per member: reduce the per-wave partials in a fixed order, decide, advance the clock
+__global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, double two_n_free, int n_timepoints) {
+  const int m = blockIdx.x;
+  __shared__ double red[kThreads];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += kThreads) acc += c.err_partial[(size_t)m * c.n_wg * 4 + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  Clock ck = c.clock[m];
+  if (ck.state) return;
+  if (ck.fin_next) { ck.state = 1; ck.accept = 0; c.clock[m] = ck; return; }
+  const double ratio = sqrt(red[0] / two_n_free);
+  ck.attempts++;
+  if (!(ratio == ratio)) { ck.state = 2; c.clock[m] = ck; return; }
+  const double h_new = dopri_next_step(ck.h, ratio);
+  ck.accept = ratio <= 1.0;
+  if (ck.accept) {
+    ck.t_last = ck.t; ck.h_acc = ck.h; ck.t = ck.t + ck.h; ck.accepted++;
+    ck.out_lo = ck.out_idx;
+    while (ck.out_idx < n_timepoints && c.ts_dev[ck.out_idx] <= ck.t) ck.out_idx++;
+    ck.out_hi = ck.out_idx;
+    if (ck.out_idx >= n_timepoints) ck.fin_next = 1;
+  }
+  ck.h = h_new;
+  if (!(h_new > 0.0)) ck.state = 3;
+  c.clock[m] = ck;
+}
+
+// elementwise: dense output for the outputs crossed by an accepted step, commit (y_n <- y1, k_1 <- k_7), and the
+// stage-1 record of the next attempt with the new step size.  cm / cma: mid-point weights (velocity / position form).
+struct DenseCoef { double cm[7], cma[7]; double a10; };
+
+__global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, int n_timepoints) {
+  const int m = blockIdx.y;
+  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
+  if (slot >= c.n_slots) return;
+  const Clock ck = c.clock[m];
+  if (ck.state) return;
+  const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
+  const size_t nd = (size_t)c.n_blocks * 3;
+  const int dof = b * 3 + kd;
+  double* POS0 = c.POS + ((size_t)m * (c.s + 1) + 0) * c.n_blocks * kPos + (size_t)b * kPos;
+  double* VEL0 = c.VEL + ((size_t)m * (c.s + 1) + 0) * nd;
+  const double* POS3 = c.POS + ((size_t)m * (c.s + 1) + 3) * c.n_blocks * kPos + (size_t)b * kPos;
+  const double* VEL3 = c.VEL + ((size_t)m * (c.s + 1) + 3) * nd;
+  double* Am = c.A + (size_t)m * (c.s + 1) * nd;
+  double qn = POS0[kd], vn = VEL0[dof], a0 = Am[dof];
+  const int sidx = c.block_special[b];
+  const bool constrained = sidx >= 0 && k < 3 && ((c.special[sidx].con_mask >> k) & 1);
+  if (ck.accept) {
+    const double q1 = POS3[kd], v1 = VEL3[dof], a6 = Am[(size_t)6 * nd + dof];
+    if (k < 3 && ck.out_hi > ck.out_lo) {
+      const double h = ck.h_acc;
+      double sm = dc.cm[0] * a0 + dc.cm[6] * a6, sma = dc.cma[0] * a0 + dc.cma[6] * a6;
+      for (int l = 1; l < 6; ++l) { const double al = Am[(size_t)l * nd + dof]; sm += dc.cm[l] * al; sma += dc.cma[l] * al; }
+      const double qmid = qn + h * (0.5 * vn + h * sma), vmid = vn + h * sm;
+      for (int kk = ck.out_lo; kk < ck.out_hi; ++kk) {
+        const double tk = c.ts_dev[kk];
+        const double r = (tk - ck.t_last) / (ck.t - ck.t_last);
+        double oq = dopri_dense(qn, q1, qmid, vn, v1, h, r), ov = dopri_dense(vn, v1, vmid, a0, a6, h, r);
+        if (constrained) { TimeVals tv = constrained_value(c, m, c.special[sidx], k, tk); oq = tv.g; ov = tv.gt; }
+        double* f = c.fields_dev + ((size_t)m * n_timepoints + kk) * c.n_blocks * 6;
+        f[dof] = oq;
+        f[nd + dof] = ov;
+      }
+    }
+    // commit
+    if (k < 3) {
+      *reinterpret_cast<double2*>(POS0 + 2 * k) = *reinterpret_cast<const double2*>(POS3 + 2 * k);
+      VEL0[dof] = v1;
+      Am[dof] = a6;
+    }
+    qn = q1; vn = v1; a0 = a6;
+  }
+  // stage-1 record of the next attempt: Q_1 = q_n + h a10 v_n, V_1 = v_n + h a10 A_0
+  double qnext = qn + ck.h * dc.a10 * vn, vnext = vn + ck.h * dc.a10 * a0;
+  if (constrained) { TimeVals tv = constrained_value(c, m, c.special[sidx], k, ck.t + dc.a10 * ck.h); qnext = tv.g; vnext = tv.gt; }
+  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
+  double sn, cs;
+  sincos(0.5 * th2, &sn, &cs);
+  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
+  if (k < 3) {
+    *reinterpret_cast<double2*>(c.POS + ((size_t)m * (c.s + 1) + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
+    c.VEL[((size_t)m * (c.s + 1) + 1) * nd + dof] = vnext;
+  }
+}
+
+// per-member time for k_init (initial-step probe): records of state `y` at time tm[m] into buffer buf
+__global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* state0, const double* tm, int buf) {
+  const int m = blockIdx.y;
+  const int tid = blockIdx.x * kThreads + threadIdx.x;
+  if (tid >= c.n_slots) return;
+  const int b = tid >> 2, d = tid & 3;
+  if (d == 3) return;
+  const size_t nd = (size_t)c.n_blocks * 3;
+  double q = state0[(size_t)m * 2 * nd + b * 3 + d], v = state0[(size_t)m * 2 * nd + nd + b * 3 + d];
+  const int sidx = c.block_special[b];
+  if (sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1)) {
+    TimeVals tv = constrained_value(c, m, c.special[sidx], d, tm[m]);
+    q = tv.g; v = tv.gt;
+  }
+  double* pr = c.POS + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * kPos + (size_t)b * kPos;
+  pr[d] = q;
+  c.VEL[((size_t)m * (c.s + 1) + buf) * nd + b * 3 + d] = v;
+  if (d == 2) {
+    double sn, cs;
+    sincos(0.5 * q, &sn, &cs);
+    pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
   }
 }
 
@@ -392,7 +556,7 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   const int pb = (L.info < 0 ? slot : (L.info >> 1)) >> 2;
   const double wpx = Win[(size_t)pb * 3], wpy = Win[(size_t)pb * 3 + 1], wpth = Win[(size_t)pb * 3 + 2];
   const double v_i = vel_in(c, m, in_buf, n)[dof];
-  const double a_i = c.A[(size_t)m * c.s * nd + (size_t)i * nd + dof];
+  const double a_i = c.A[(size_t)m * (c.s + 1) * nd + (size_t)i * nd + dof];
   const double kq_in = c.KQ[((size_t)m * 2 + win) * nd + dof];
   const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
   const int sidx = c.block_special[b];
@@ -636,6 +800,10 @@ struct dfx_handle {
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping;
   DevBuf<TimeFn> d_fns;
   DevBuf<Seg> d_segs, d_cur;
+  DevBuf<Clock> d_clock;
+  DevBuf<double> d_err_partial, d_ts;
+  double rtol = 0.0, atol = 0.0;
+  bool adaptive = false;
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
   DevBuf<double> d_traj, d_POS, d_VEL, d_A, d_state0, d_fields;
@@ -669,6 +837,9 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;
   c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.fns = h->d_fns.p;
   c.cur = h->d_cur.p;
+  c.clock = h->adaptive ? h->d_clock.p : nullptr;
+  c.err_partial = h->d_err_partial.p; c.ts_dev = h->d_ts.p; c.fields_dev = h->d_fields.p;
+  c.rtol = h->rtol; c.atol = h->atol;
   c.traj = h->have_traj ? h->d_traj.p : nullptr;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
@@ -797,7 +968,7 @@ static int ensure_work_buffers(dfx_handle* h) {
   const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s;
   HIP_OK(h->d_POS.ensure(B * (s + 1) * nb * kPos));
   HIP_OK(h->d_VEL.ensure(B * (s + 1) * nb * 3));
-  HIP_OK(h->d_A.ensure(B * s * nb * 3));
+  HIP_OK(h->d_A.ensure(B * (s + 1) * nb * 3));
   HIP_OK(h->d_state0.ensure(B * nb * 6));
   HIP_OK(h->d_cur.ensure(1));
   return 0;
@@ -921,7 +1092,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
-  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release();
+  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_g.release(); h->d_fn_g.release();
@@ -977,6 +1148,7 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
+  h->adaptive = false;
   if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kStep;
@@ -1037,6 +1209,174 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
     stats->launches = h->launches;
     stats->kernel_ms = ms;
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
+  }
+  return 0;
+}
+
+
+// ---- adaptive forward (reference odeint semantics) ------------------------------------------------
+int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                         double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->have_params) { h->err = "forward_adaptive: set_params first"; return 1; }
+  if (n_timepoints < 1) { h->err = "forward_adaptive: need >= 1 timepoint"; return 1; }
+  if (h->pl.tab.s != 6) { h->err = "forward_adaptive: the adaptive controller is defined for the dopri5 tableau"; return 1; }
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks, nd = nb * 3;
+  const int Tn = n_timepoints;
+  const Dopri D = make_dopri();
+  h->ts.assign(timepoints, timepoints + Tn);
+  h->spi = 0; h->n_total = 0;
+  h->have_traj = false; h->have_fields = false;
+  h->adaptive = true; h->rtol = rtol; h->atol = atol;
+  if (ensure_work_buffers(h)) return 2;
+  const int n_wg = (pl.n_slots + kThreads - 1) / kThreads;
+  const int n_partials = (pl.n_slots + 63) / 64;
+  HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
+  HIP_OK(h->d_clock.ensure(B));
+  HIP_OK(h->d_err_partial.ensure(B * n_wg * 4));
+  HIP_OK(h->d_ts.ensure(Tn));
+  HIP_OK(h->d_tmp.ensure(std::max<size_t>(B * nb * 6, B)));
+  HIP_OK(hipMemcpyAsync(h->d_ts.p, timepoints, sizeof(double) * Tn, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
+  // constrained flags and free-DOF count
+  std::vector<char> con(nd, 0);
+  size_t n_free = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    const int sidx = pl.block_special[b];
+    for (int d = 0; d < 3; ++d) { con[b * 3 + d] = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1); n_free += !con[b * 3 + d]; }
+  }
+  if (n_free == 0) { h->err = "forward_adaptive: no free DOF"; return 1; }
+  // clocks for the two probing evaluations: h = 0, t = t0
+  std::vector<Clock> clk(B);
+  for (auto& c0 : clk) { memset(&c0, 0, sizeof(Clock)); c0.t = timepoints[0]; c0.out_idx = 1; }
+  HIP_OK(hipMemcpyAsync(h->d_clock.p, clk.data(), sizeof(Clock) * B, hipMemcpyHostToDevice, h->stream));
+  DevCtx c = make_ctx(h);
+  h->launches = 0;
+  dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1);
+  launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
+  std::vector<double> A((size_t)B * 7 * nd), V0(B * 7 * nd);
+  HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  // initial step size (Hairer II.4 as restated by jax, order 4), per member
+  std::vector<double> y1(B * 2 * nd), tm(B), h0(B), d1v(B);
+  for (size_t m = 0; m < B; ++m) {
+    const double* q = state0 + m * 2 * nd; const double* v = q + nd; const double* a = A.data() + m * 7 * nd;
+    double d0 = 0, d1 = 0;
+    for (size_t i = 0; i < nd; ++i) if (!con[i]) {
+      const double sq = atol + fabs(q[i]) * rtol, sv = atol + fabs(v[i]) * rtol;
+      d0 += (q[i] / sq) * (q[i] / sq) + (v[i] / sv) * (v[i] / sv);
+      d1 += (v[i] / sq) * (v[i] / sq) + (a[i] / sv) * (a[i] / sv);
+    }
+    d0 = sqrt(d0); d1 = sqrt(d1);
+    h0[m] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    d1v[m] = d1;
+    for (size_t i = 0; i < nd; ++i) { y1[m * 2 * nd + i] = q[i] + h0[m] * (con[i] ? 0.0 : v[i]); y1[m * 2 * nd + nd + i] = v[i] + h0[m] * a[i]; }
+    tm[m] = timepoints[0] + h0[m];
+    clk[m].t = tm[m];
+  }
+  HIP_OK(hipMemcpyAsync(h->d_clock.p, clk.data(), sizeof(Clock) * B, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->d_tmp.p, y1.data(), sizeof(double) * y1.size(), hipMemcpyHostToDevice, h->stream));
+  DevBuf<double> d_tm;
+  HIP_OK(d_tm.ensure(B));
+  HIP_OK(hipMemcpyAsync(d_tm.p, tm.data(), sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_init_tm, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_tmp.p, (const double*)d_tm.p, 1);
+  launch_fwd(h, c, 1, 0, 1, -1, 0, 0);                      // A_1 = f(y0 + h0 f0, t0 + h0)
+  HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  d_tm.release();
+  for (size_t m = 0; m < B; ++m) {
+    const double* q = state0 + m * 2 * nd; const double* v = q + nd;
+    const double* a0 = A.data() + m * 7 * nd; const double* a1 = a0 + nd; const double* v1 = y1.data() + m * 2 * nd + nd;
+    double d2 = 0;
+    for (size_t i = 0; i < nd; ++i) if (!con[i]) {
+      const double sq = atol + fabs(q[i]) * rtol, sv = atol + fabs(v[i]) * rtol;
+      const double x = (v1[i] - v[i]) / sq, y = (a1[i] - a0[i]) / sv;
+      d2 += x * x + y * y;
+    }
+    d2 = sqrt(d2) / h0[m];
+    const double h1 = (d1v[m] <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0[m] * 1e-3) : pow(0.01 / (d1v[m] + d2), 1.0 / 5.0);
+    memset(&clk[m], 0, sizeof(Clock));
+    clk[m].t = timepoints[0]; clk[m].t_last = timepoints[0]; clk[m].h = std::min(100.0 * h0[m], h1); clk[m].out_idx = 1;
+    if (Tn == 1) clk[m].state = 1;
+  }
+  HIP_OK(hipMemcpyAsync(h->d_clock.p, clk.data(), sizeof(Clock) * B, hipMemcpyHostToDevice, h->stream));
+  // coefficients
+  DenseCoef dc;
+  for (int l = 0; l < 7; ++l) { dc.cm[l] = D.cm[l]; dc.cma[l] = D.cma[l]; }
+  dc.a10 = D.a[1][0];
+  StageCoef sc_err;
+  memset(&sc_err, 0, sizeof(sc_err));
+  for (int l = 0; l < 7; ++l) { sc_err.cv[l] = D.e[l]; sc_err.cq[l] = D.ee[l]; }
+  sc_err.c_i = 1.0; sc_err.c_next = 1.0;
+  auto enqueue_attempt = [&]() {
+    // evaluations at S_1..S_5, candidate y1 into buffer 3, then the FSAL evaluation with the error estimate
+    static const int inb[6] = {0, 1, 2, 1, 2, 1}, outb[6] = {0, 2, 1, 2, 1, 3};
+    for (int i = 1; i <= 5; ++i) launch_fwd(h, c, i, 0, inb[i], outb[i], 0, 0);
+    if (pl.model == kNonlinear) {
+      if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<kNonlinear, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
+      else hipLaunchKernelGGL((k_fwd_stage<kNonlinear, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
+    } else {
+      if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<kLinearized, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
+      else hipLaunchKernelGGL((k_fwd_stage<kLinearized, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
+    }
+    hipLaunchKernelGGL(k_control, dim3((unsigned)B), dim3(kThreads), 0, h->stream, c, n_partials, 2.0 * (double)n_free, Tn);
+    hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn);
+    h->launches += 3;
+  };
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  // stage-1 record of the first attempt (accept = 0: nothing to commit)
+  hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn);
+  const int kAttemptsPerGraph = 32;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (h->use_graph) {
+    const long long before = h->launches;
+    HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int a = 0; a < kAttemptsPerGraph; ++a) enqueue_attempt();
+    HIP_OK(hipStreamEndCapture(h->stream, &graph));
+    h->launches = before;
+    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+  }
+  long long attempts_issued = 0;
+  int rc = 0;
+  while (true) {
+    if (exec) { HIP_OK(hipGraphLaunch(exec, h->stream)); h->launches += 8LL * kAttemptsPerGraph; }
+    else for (int a = 0; a < kAttemptsPerGraph; ++a) enqueue_attempt();
+    attempts_issued += kAttemptsPerGraph;
+    HIP_OK(hipMemcpyAsync(clk.data(), h->d_clock.p, sizeof(Clock) * B, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    bool all_done = true;
+    for (size_t m = 0; m < B; ++m) {
+      if (clk[m].state == 2) { h->err = "forward_adaptive: non-finite error estimate (member " + std::to_string(m) + ")"; rc = 3; }
+      if (clk[m].state == 3) { h->err = "forward_adaptive: step size underflow (member " + std::to_string(m) + ")"; rc = 3; }
+      if (clk[m].state == 0) all_done = false;
+    }
+    if (rc || all_done) break;
+    if (attempts_issued >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; rc = 4; break; }
+  }
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (rc) { h->adaptive = false; return rc; }
+  if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipGetLastError());
+  h->have_fields = true;
+  h->adaptive = false;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    long long acc = 0, att = 0;
+    for (size_t m = 0; m < B; ++m) { acc = std::max(acc, clk[m].accepted); att = std::max(att, clk[m].attempts); }
+    stats->steps = acc;
+    stats->rhs_evals = 6 * att + 2;
+    stats->launches = h->launches;
+    stats->kernel_ms = ms;
+    stats->stage_kernel_us = att ? 1e3 * ms / (double)(att * 8) : 0.0;
   }
   return 0;
 }
@@ -1136,6 +1476,7 @@ static int hook_prepare(dfx_handle* h, const double* y, double t) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   if (!h->have_params) { h->err = "set_params first"; return 1; }
+  h->adaptive = false;
   if (ensure_work_buffers(h)) return 2;
   if (ensure_adjoint_buffers(h)) return 2;
   h->have_traj = false;
@@ -1158,7 +1499,7 @@ int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
   const size_t B = pl.batch, nb = pl.n_blocks;
   DevCtx c = make_ctx(h);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);
-  std::vector<double> A(B * pl.tab.s * nb * 3), S(B * (pl.tab.s + 1) * nb * 3);
+  std::vector<double> A(B * (pl.tab.s + 1) * nb * 3), S(B * (pl.tab.s + 1) * nb * 3);
   HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(S.data(), h->d_VEL.p, sizeof(double) * S.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -1169,7 +1510,7 @@ int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
         const int sidx = pl.block_special[b];
         const bool con = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1);
         dy[m * nb * 6 + b * 3 + d] = con ? 0.0 : S[m * (pl.tab.s + 1) * nb * 3 + b * 3 + d];
-        dy[m * nb * 6 + nb * 3 + b * 3 + d] = A[m * pl.tab.s * nb * 3 + b * 3 + d];
+        dy[m * nb * 6 + nb * 3 + b * 3 + d] = A[m * (pl.tab.s + 1) * nb * 3 + b * 3 + d];
       }
   return 0;
 }

@@ -372,4 +372,66 @@ inline Tableau tableau_rk4() {
   return make_tableau(4, c, a);
 }
 
+
+// Dormand-Prince 5(4) with embedded error and dense output, as used by jax.experimental.ode (7 rows incl. FSAL).
+struct Dopri {
+  double c[7];        // stage times of k_0..k_6 (k_6 is evaluated at the new state, t + h)
+  double a[7][7];     // a[i][j]: stage i uses k_j (row 6 = 5th-order solution weights)
+  double e[7];        // error weights
+  double cm[7];       // mid-point weights of the dense output
+  // acceleration form (k_j = (V_j, A_j), V_j = v_n + h sum_l a[j][l] A_l):
+  double aa[7][7];    // sum_j a[i][j] a[j][l]
+  double ee[7];       // sum_j e[j] a[j][l]      (position error = h^2 sum_l ee[l] A_l, since sum_j e[j] = 0)
+  double cma[7];      // sum_j cm[j] a[j][l]     (q_mid = q_n + h/2 v_n + h^2 sum_l cma[l] A_l)
+};
+
+inline Dopri make_dopri() {
+  Dopri d;
+  const double c[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+  const double a[7][7] = {
+      {0, 0, 0, 0, 0, 0, 0},
+      {1.0 / 5, 0, 0, 0, 0, 0, 0},
+      {3.0 / 40, 9.0 / 40, 0, 0, 0, 0, 0},
+      {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0, 0},
+      {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0, 0},
+      {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0, 0},
+      {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0}};
+  const double e[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                       -2187.0 / 6784 - -12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
+  const double cm[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
+                        -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
+                        -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+  for (int i = 0; i < 7; ++i) {
+    d.c[i] = c[i]; d.e[i] = e[i]; d.cm[i] = cm[i];
+    for (int j = 0; j < 7; ++j) d.a[i][j] = a[i][j];
+  }
+  for (int l = 0; l < 7; ++l) {
+    d.ee[l] = 0.0; d.cma[l] = 0.0;
+    for (int j = 0; j < 7; ++j) { d.ee[l] += e[j] * a[j][l]; d.cma[l] += cm[j] * a[j][l]; }
+    for (int i = 0; i < 7; ++i) {
+      d.aa[i][l] = 0.0;
+      for (int j = 0; j < 7; ++j) d.aa[i][l] += a[i][j] * a[j][l];
+    }
+  }
+  return d;
+}
+
+// step-size controller of jax.experimental.ode.optimal_step_size (safety 0.9, ifactor 10, dfactor 0.2, order 5)
+DFX_HD double dopri_next_step(double h, double ratio) {
+  if (ratio == 0.0) return h * 10.0;
+  const double dfac = ratio < 1.0 ? 1.0 : 0.2;
+  double f = 0.9 * pow(ratio, -0.2);
+  f = f > dfac ? f : dfac;
+  f = f < 10.0 ? f : 10.0;
+  return h * f;
+}
+
+// quartic through (y0, y1, y_mid, dy0, dy1) evaluated at relative time r in [0,1]  (jax: fit_4th_order_polynomial + polyval)
+DFX_HD double dopri_dense(double y0, double y1, double ymid, double dy0, double dy1, double dt, double r) {
+  const double a = -2.0 * dt * dy0 + 2.0 * dt * dy1 - 8.0 * y0 - 8.0 * y1 + 16.0 * ymid;
+  const double b = 5.0 * dt * dy0 - 3.0 * dt * dy1 + 18.0 * y0 + 14.0 * y1 - 32.0 * ymid;
+  const double c = -4.0 * dt * dy0 + dt * dy1 - 11.0 * y0 - 5.0 * y1 + 16.0 * ymid;
+  return (((a * r + b) * r + c) * r + dt * dy0) * r + y0;
+}
+
 }  // namespace dfx

@@ -4,9 +4,11 @@ engine.  The returned ``solve_dynamics(state0, timepoints, control_params)`` has
 ``jax.grad`` through the reference solver -- returning a ``ControlParams``-shaped gradient tree.
 
 Differences that are inherent to running inside hand-written kernels (all keyword-only, all with defaults):
-  * the integrator is the reference's Dormand-Prince tableau on a FIXED step grid, ``steps_per_interval`` steps
-    between consecutive ``timepoints`` (default: chosen from a stiffness bound so that h*omega_max <= 0.5);
-    ``rtol``/``atol`` are accepted for signature compatibility and ignored by the fixed grid;
+  * by default the forward solve is the reference's own scheme: adaptive Dormand-Prince 5(4) controlled by ``rtol`` /
+    ``atol`` with dense output at ``timepoints`` (jax.experimental.ode.odeint semantics, every member its own step).
+    With ``steps_per_interval=k`` (or ``keep_trajectory=True``, because the reverse sweep is the discrete adjoint of a
+    FIXED grid) the same tableau runs on k equal steps between consecutive ``timepoints``; when k is not given it is
+    chosen from a stiffness bound so that h*omega_max <= 0.5;
   * ``energy_fn``, ``loading_fn`` and ``constrained_DOFs_fn`` must come from ``difflexmm_amd.energy`` /
     ``difflexmm_amd.loading`` (declarative specs), otherwise ``TypeError`` at setup;
   * ``batch=B`` integrates B members (list of B ``ControlParams``) side by side.
@@ -140,14 +142,20 @@ class DynamicSolver:
         flats = [self._flatten(cp) for cp in cps]
         self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
         spi = steps_per_interval or self.steps_per_interval
-        if spi is None:
-            spi = max(self.estimate_steps_per_interval(f, timepoints) for f in flats)
         state0 = np.asarray(state0, dtype=float)
         if state0.ndim == 3:
             state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
+        if spi is None and not keep_trajectory:
+            # reference behaviour: adaptive Dormand-Prince controlled by rtol / atol (dynamics.py:166)
+            fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol)
+            self._last = None
+            self.stats = dict(stats, steps_per_interval=None, step_control="adaptive")
+            return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
+        if spi is None:   # the reverse sweep needs a fixed grid: choose it from the stiffness bound
+            spi = max(self.estimate_steps_per_interval(f, timepoints) for f in flats)
         fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory)
         self._last = (cps, flats, np.asarray(timepoints, dtype=float))
-        self.stats = dict(stats, steps_per_interval=spi)
+        self.stats = dict(stats, steps_per_interval=spi, step_control="fixed")
         return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
 
     # -- reverse mode ------------------------------------------------------------------------------------

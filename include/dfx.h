@@ -130,6 +130,15 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats);
 
+/* The reference's own integrator semantics (jax.experimental.ode.odeint 0.4.8 called at dynamics.py:166): adaptive
+ * Dormand-Prince 5(4), RMS error norm over the free (q, v) components with tolerance atol + rtol*max(|y0|,|y1|),
+ * step factor min(10, max(0.9 ratio^-1/5, 1 | 0.2)) applied on accept and reject, Hairer initial step, quartic dense
+ * output at `timepoints` (steps are not clipped to output times).  Every member controls its own step.  Forward only:
+ * the reverse sweep needs the fixed grid of dfx_forward.  stats->steps = accepted steps (max over members),
+ * stats->rhs_evals = RHS evaluations (max over members). */
+int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                         double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats);
+
 /* Reverse sweep over the checkpointed trajectory of the last dfx_forward(keep_trajectory=1).
  * fields_bar: (batch, T, 2, n_blocks, 3) cotangent of `fields`. */
 int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_stats* stats);

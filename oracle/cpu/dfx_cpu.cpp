@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -174,6 +175,153 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   }
   return 0;
 }
+
+}  // extern "C" (reopened below)
+
+// ---- adaptive Dormand-Prince with the semantics of jax.experimental.ode.odeint (see oracle/ref_ode.py) -----------
+namespace {
+struct AdaptiveMember {
+  const Tables& tb;
+  const Plan& pl;
+  std::vector<double> S, Abuf;
+  std::vector<char> con;   // constrained flag per DOF
+  AdaptiveMember(const Tables& t, const Plan& p) : tb(t), pl(p), S((size_t)p.n_blocks * kRec), Abuf((size_t)p.tab.s * p.n_blocks * 3), con((size_t)p.n_blocks * 3, 0) {
+    for (int b = 0; b < p.n_blocks; ++b) {
+      int sidx = p.block_special[b];
+      if (sidx >= 0) for (int d = 0; d < 3; ++d) con[b * 3 + d] = (p.special[sidx].con_mask >> d) & 1;
+    }
+  }
+  // k = f(y, t): kq = v (0 on constrained DOFs), kv = acceleration
+  void rhs(const double* q, const double* v, double t, double* kq, double* kv) {
+    const int nb = pl.n_blocks, nd = nb * 3;
+    std::vector<double> y(2 * (size_t)nd);
+    memcpy(y.data(), q, sizeof(double) * nd);
+    memcpy(y.data() + nd, v, sizeof(double) * nd);
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) init_dof(tb, y.data(), t, S.data(), b, d);
+    FwdStage st;
+    st.S_in = S.data(); st.S_out = nullptr; st.Y = S.data(); st.A = Abuf.data(); st.i = 0; st.h = 0.0; st.t_i = t; st.t_next = t;
+    fwd_stage(tb, pl.tab, st);
+    for (int i = 0; i < nd; ++i) { kq[i] = con[i] ? 0.0 : v[i]; kv[i] = Abuf[i]; }
+  }
+};
+}  // namespace
+
+extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                    double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats) {
+  if (!h->have_params) { h->err = "forward_adaptive: set_params first"; return 1; }
+  if (n_timepoints < 1) { h->err = "forward_adaptive: need >= 1 timepoint"; return 1; }
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks, nd = nb * 3, B = pl.batch, Tn = n_timepoints;
+  const Dopri D = make_dopri();
+  h->ts.assign(timepoints, timepoints + Tn);
+  h->have_traj = false;
+  h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
+  int64_t max_acc = 0, max_try = 0;
+  for (int m = 0; m < B; ++m) {
+    Tables tb = member_tables(h, m);
+    AdaptiveMember M(tb, pl);
+    std::vector<double> q(state0 + (size_t)m * 2 * nd, state0 + (size_t)m * 2 * nd + nd), v(state0 + (size_t)m * 2 * nd + nd, state0 + (size_t)(m + 1) * 2 * nd);
+    std::vector<double> kq(7 * (size_t)nd), kv(7 * (size_t)nd), yq(nd), yv(nd), q1(nd), v1(nd), qm(nd), vm(nd);
+    int n_free = 0;
+    for (int i = 0; i < nd; ++i) n_free += !M.con[i];
+    double* fm = h->fields.data() + (size_t)m * Tn * nb * 6;
+    auto write_out = [&](int k, const double* oq, const double* ov) {
+      // constrained DOFs follow c(t_k), c'(t_k) exactly (dynamics.py:132-134)
+      std::vector<double> y(2 * (size_t)nd), S((size_t)nb * kRec);
+      memcpy(y.data(), oq, sizeof(double) * nd); memcpy(y.data() + nd, ov, sizeof(double) * nd);
+      for (int b = 0; b < nb; ++b) for (int d = 0; d < 3; ++d) init_dof(tb, y.data(), timepoints[k], S.data(), b, d);
+      snapshot(S.data(), nb, fm + (size_t)k * nb * 6);
+    };
+    double t = timepoints[0];
+    M.rhs(q.data(), v.data(), t, kq.data(), kv.data());
+    write_out(0, q.data(), v.data());
+    // initial step (Hairer II.4 as restated by jax, order 4)
+    double d0 = 0, d1 = 0, d2 = 0;
+    for (int i = 0; i < nd; ++i) if (!M.con[i]) {
+      double sq = atol + fabs(q[i]) * rtol, sv = atol + fabs(v[i]) * rtol;
+      d0 += (q[i] / sq) * (q[i] / sq) + (v[i] / sv) * (v[i] / sv);
+      d1 += (kq[i] / sq) * (kq[i] / sq) + (kv[i] / sv) * (kv[i] / sv);
+    }
+    d0 = sqrt(d0); d1 = sqrt(d1);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    for (int i = 0; i < nd; ++i) { yq[i] = q[i] + h0 * kq[i]; yv[i] = v[i] + h0 * kv[i]; }
+    M.rhs(yq.data(), yv.data(), t + h0, kq.data() + nd, kv.data() + nd);
+    for (int i = 0; i < nd; ++i) if (!M.con[i]) {
+      double sq = atol + fabs(q[i]) * rtol, sv = atol + fabs(v[i]) * rtol;
+      double a = (kq[nd + i] - kq[i]) / sq, b = (kv[nd + i] - kv[i]) / sv;
+      d2 += a * a + b * b;
+    }
+    d2 = sqrt(d2) / h0;
+    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : pow(0.01 / (d1 + d2), 1.0 / 5.0);
+    double dt = std::min(100.0 * h0, h1);
+    int64_t n_try = 0, n_acc = 0;
+    double t_last = t;
+    std::vector<double> c_q0, c_v0;  // state at the start of the last accepted step (for dense output)
+    bool have_step = false;
+    double h_acc = 0.0;
+    std::vector<double> sq0(nd), sv0(nd), sq1(nd), sv1(nd), smq(nd), smv(nd), f0q(nd), f0v(nd), f1q(nd), f1v(nd);
+    for (int k = 1; k < Tn; ++k) {
+      const double target = timepoints[k];
+      while (t < target && dt > 0) {
+        if (n_try >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; return 4; }
+        for (int i = 1; i < 7; ++i) {
+          for (int x = 0; x < nd; ++x) {
+            double aq = 0, av = 0;
+            for (int j = 0; j < i; ++j) { aq += D.a[i][j] * kq[(size_t)j * nd + x]; av += D.a[i][j] * kv[(size_t)j * nd + x]; }
+            yq[x] = q[x] + dt * aq; yv[x] = v[x] + dt * av;
+          }
+          M.rhs(yq.data(), yv.data(), t + D.c[i] * dt, kq.data() + (size_t)i * nd, kv.data() + (size_t)i * nd);
+        }
+        // y1 = stage-6 state (a[6] = solution weights); error estimate
+        double r2 = 0.0;
+        for (int x = 0; x < nd; ++x) {
+          q1[x] = yq[x]; v1[x] = yv[x];
+          if (M.con[x]) continue;
+          double eq = 0, ev = 0;
+          for (int j = 0; j < 7; ++j) { eq += D.e[j] * kq[(size_t)j * nd + x]; ev += D.e[j] * kv[(size_t)j * nd + x]; }
+          eq *= dt; ev *= dt;
+          double tq = atol + rtol * std::max(fabs(q[x]), fabs(q1[x])), tv = atol + rtol * std::max(fabs(v[x]), fabs(v1[x]));
+          r2 += (eq / tq) * (eq / tq) + (ev / tv) * (ev / tv);
+        }
+        const double ratio = sqrt(r2 / (2.0 * n_free));
+        if (!(ratio == ratio)) { h->err = "forward_adaptive: non-finite error estimate"; return 3; }
+        ++n_try;
+        const double dt_new = dopri_next_step(dt, ratio);
+        if (ratio <= 1.0) {
+          for (int x = 0; x < nd; ++x) {
+            double mq = 0, mv = 0;
+            for (int j = 0; j < 7; ++j) { mq += D.cm[j] * kq[(size_t)j * nd + x]; mv += D.cm[j] * kv[(size_t)j * nd + x]; }
+            sq0[x] = q[x]; sv0[x] = v[x]; sq1[x] = q1[x]; sv1[x] = v1[x];
+            smq[x] = q[x] + dt * mq; smv[x] = v[x] + dt * mv;
+            f0q[x] = kq[x]; f0v[x] = kv[x]; f1q[x] = kq[(size_t)6 * nd + x]; f1v[x] = kv[(size_t)6 * nd + x];
+            q[x] = q1[x]; v[x] = v1[x];
+            kq[x] = f1q[x]; kv[x] = f1v[x];   // FSAL
+          }
+          t_last = t; h_acc = dt; t += dt; have_step = true;
+          ++n_acc;
+        }
+        dt = dt_new;
+      }
+      if (have_step) {
+        const double r = (target - t_last) / (t - t_last);
+        for (int x = 0; x < nd; ++x) {
+          yq[x] = dopri_dense(sq0[x], sq1[x], smq[x], f0q[x], f1q[x], h_acc, r);
+          yv[x] = dopri_dense(sv0[x], sv1[x], smv[x], f0v[x], f1v[x], h_acc, r);
+        }
+        write_out(k, yq.data(), yv.data());
+      } else {
+        write_out(k, q.data(), v.data());
+      }
+    }
+    max_acc = std::max(max_acc, n_acc); max_try = std::max(max_try, n_try);
+  }
+  if (fields) memcpy(fields, h->fields.data(), sizeof(double) * h->fields.size());
+  if (stats) { memset(stats, 0, sizeof(*stats)); stats->steps = max_acc; stats->rhs_evals = 6 * max_try + 2; }
+  return 0;
+}
+
+extern "C" {
 
 static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T*nb*6 [q(3) v(3)] per block */,
                        dfx_grads* grads, dfx_stats* stats) {

@@ -51,3 +51,34 @@ def test_tensile_known_answer(hip_lib, n1_cells, strain, nonlinear):
     """reference tests/test_difflexmm.py:35-146 through the HIP engine."""
     got, _ = tensile_solver(None, n1_cells, strain, nonlinear)
     assert abs(got - strain) / strain < 1e-4
+
+
+def test_adaptive_matches_reference_odeint_golden(hip_lib):
+    """Default call (no steps_per_interval): adaptive Dopri5 with the reference's controller on the device, against the
+    golden trajectory of the oracle's restatement of jax.experimental.ode.odeint (rtol = atol = 1e-8)."""
+    gold = np.load(os.path.join(GOLD, "adaptive_8x8.npz"))
+    c = Case("quads", 8, False, False, damping=False, seed=1, lib=None)
+    c.solver.rtol = c.solver.atol = 1e-8
+    cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=float(gold["loading_rate"]), input_delay=float(gold["input_delay"])))
+    f = c.solver(np.zeros((2, 64, 3)), gold["timepoints"], cp)
+    assert c.solver.stats["step_control"] == "adaptive"
+    # same controller, same tableau: the step sequences coincide unless an accept/reject decision sits within rounding of 1
+    assert abs(c.solver.stats["steps"] - int(gold["accepted"])) <= 2
+    assert relerr(f, gold["fields"]) < 1e-9
+
+
+def test_adaptive_members_control_their_own_step(hip_lib):
+    ts = np.linspace(0.0, 2e-3, 5)
+    singles, cps = [], []
+    for seed, rate in ((31, 900.0), (32, 2500.0)):
+        c = Case("quads", 5, True, True, seed=seed, lib=None, cutoff_deg=42.0)
+        cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=rate, input_delay=1e-5))
+        c.solver.rtol = c.solver.atol = 1e-9
+        singles.append((c.solver(np.zeros((2, 25, 3)), ts, cp), c.solver.stats["steps"]))
+        cps.append(cp)
+    cb = Case("quads", 5, True, True, seed=31, lib=None, cutoff_deg=42.0, batch=2)
+    cb.solver.rtol = cb.solver.atol = 1e-9
+    fb = cb.solver(np.zeros((2, 25, 3)), ts, cps)
+    assert singles[0][1] != singles[1][1]          # the two members really take different numbers of steps
+    for m in range(2):
+        assert np.array_equal(fb[m], singles[m][0])
