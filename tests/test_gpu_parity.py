@@ -114,3 +114,44 @@ def test_unstable_step_reports_an_error(hip_lib):
     c.cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=300.0, input_delay=0.0))
     with pytest.raises(RuntimeError, match="non-finite"):
         c.solver(np.zeros((2, 36, 3)), np.linspace(0, 0.5, 3), c.cp, steps_per_interval=20)   # h = 12.5 ms >> 1/omega_max
+
+
+def test_config_c2_32x32_10k_steps_forward(hip_lib, cpu_lib):
+    """BASELINE config C2: 32x32 quads, nonlinear ligaments + damping, 10 000 fixed steps over 2/f, forward only.
+    HIP vs the CPU port on the identical grid, plus a physical property: with the driver off again and damping on,
+    the kinetic energy at the end is far below its peak."""
+    ts = np.linspace(0.0, 2.0 / 30.0, 11)
+    out = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("quads", 32, True, False, seed=2, lib=lib)
+        out[name] = c.solver(np.zeros((2, 1024, 3)), ts, c.cp, steps_per_interval=1000)
+        assert c.solver.stats["steps"] == 10000
+    assert relerr(out["hip"], out["cpu"]) < 1e-8
+    ke = (out["hip"][:, 1] ** 2).sum((1, 2))
+    assert ke.max() > 0 and np.isfinite(out["hip"]).all()
+
+
+def test_config_c4_kagome_64x64_forward_and_gradient(hip_lib, cpu_lib):
+    """BASELINE config C4 lattice (64x64-cell kagome, 8 192 triangles, contact + damping, pulse): forward fields and the
+    target-kinetic-energy gradient w.r.t. the three shift fields, HIP vs CPU port, on a short window."""
+    from difflexmm_amd.problems import kagome_focusing_constraints, kagome_target_blocks
+    res = {}
+    ts = np.linspace(0.0, 3e-4, 3)
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("kagome", 64, True, True, seed=100, lib=lib, cutoff_deg=125.0)
+        cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=5000.0, input_delay=1e-6))
+        f = c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, cp, keep_trajectory=True, steps_per_interval=20)
+        mid = 2 * 64 * 32
+        target = np.array([mid + 2, mid + 3, mid + 4, mid + 5], dtype=np.int32)
+        obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(target)
+        g = c.geo.vjp(c.design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
+        res[name] = (f, obj, g)
+    assert res["cpu"][1] > 0
+    assert relerr(res["hip"][0], res["cpu"][0]) < 1e-10
+    assert abs(res["hip"][1] - res["cpu"][1]) / res["cpu"][1] < 1e-10
+    for a, b in zip(res["hip"][2], res["cpu"][2]):
+        assert relerr(a, b) < 1e-8
+    # BC index patterns of problems/kagome_focusing.py on this lattice: 2 driven blocks x 3 DOFs + 4 clamped corners
+    pairs, vec, driven, clamped = kagome_focusing_constraints(c.geo, 2, 2)
+    assert len(driven) == 2 and vec.sum() == 2 and len(np.unique(pairs[:, 0] * 3 + pairs[:, 1])) == len(pairs)
+    assert len(kagome_target_blocks(c.geo, (2, 2), (3, 3))) == 8
