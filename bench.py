@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 SPI = 250                     # steps between outputs: 50 000 steps / 200 output intervals
 FREQ = 30.0
 DT = (2.0 / FREQ) / 50000.0
-MEMBERS_FOR_TRAFFIC = 1
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md, chip-level parameters
 # algorithmic bytes per rigid unit per launch
 BYTES_FWD_STAGE = 272 + 72    # one RHS evaluation (quads + contact) + its share of the stage combine (432/6)
@@ -71,7 +70,7 @@ def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
     sd._last = (cps, flats, fw.timepoints)
     _, st_f = eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), fw.timepoints, spi, keep_trajectory=adjoint,
                           want_fields=False)
-    out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "objective": None, "adj_ms": 0.0, "adj_launches": 0}
+    out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "streams": max(1, int(st_f.get("streams", 1))), "objective": None, "adj_ms": 0.0, "adj_launches": 0}
     if adjoint:
         out["objective"] = eng.objective_kinetic(obj.target_blocks)
         grads, st_a = eng.adjoint_kinetic(obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
@@ -119,12 +118,13 @@ def cpu_baseline(size, seed, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=250)
     ap.add_argument("--members", type=int, default=4, help="independent designs per GPU integrated side by side (grid.y)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--streams", type=int, default=4, help="member groups advanced concurrently, one HIP stream each")
     ap.add_argument("--no-single", action="store_true", help="skip the extra 1-member reference measurement")
     args = ap.parse_args()
 
@@ -137,8 +137,7 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    global MEMBERS_FOR_TRAFFIC
-    MEMBERS_FOR_TRAFFIC = args.members
+    os.environ["DFX_STREAMS"] = str(args.streams)
     K = max(SPI, (args.steps // SPI) * SPI)
     W = 0 if args.warmup <= 0 else max(SPI, (args.warmup // SPI) * SPI)
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
@@ -169,7 +168,33 @@ def main():
     if rank == 0:
         n_units = args.size * args.size
         total_units_steps = K * n_units * args.members * world
-        fwd_us = 1e3 * res["fwd_ms"] / max(1, res["fwd_launches"])
+        streams = res["streams"]
+
+        def per_launch(r, n_streams):
+            """(fwd launch us, adj launch us): region device time / launches issued per stream."""
+            f_us = 1e3 * r["fwd_ms"] / max(1.0, r["fwd_launches"] / n_streams)
+            a_us = None
+            if r["adj_launches"]:
+                n_adj = r["adj_launches"] / 2.0 / n_streams          # half of the reverse launches are recomputed forward stages
+                a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * f_us) / n_adj)
+            return f_us, a_us
+
+        # (1) per-launch roofline of the dominant kernel: ONE stream, every launch integrates all `members` designs.
+        #     This is the regime rocprofv3 can observe (its kernel trace serialises queues):
+        #     `python bench.py --streams 1` under rocprofv3 --kernel-trace --stats reports the same average duration.
+        if streams > 1:
+            os.environ["DFX_STREAMS"] = "1"
+            fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
+            os.environ["DFX_STREAMS"] = str(args.streams)
+            Kr = min(K, 1000)
+            fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 1, keep_trajectory=not args.forward_only)
+            run_once(fwr, objr, desr, SPI, adjoint=not args.forward_only)
+            torch.cuda.synchronize()
+            rr = run_once(fwr, objr, desr, Kr, adjoint=not args.forward_only)
+            del fwr, objr
+        else:
+            rr = res
+        fwd_us, adj_us = per_launch(rr, 1)
         roof_bytes = BYTES_FWD_STAGE * n_units * args.members
         achieved = roof_bytes / (fwd_us * 1e-6) / 1e9
         line = {
@@ -180,22 +205,33 @@ def main():
             "config": {"workload": f"C3: {args.size}x{args.size} quads, nonlinear ligaments + damping + angle contact, "
                                    f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
                                    f"{'forward only' if args.forward_only else 'forward + adjoint wrt 66048 geometry params'}",
-                       "members_per_gpu": args.members, "integrator": "dopri5-fixed", "steps_per_output": SPI},
+                       "members_per_gpu": args.members, "concurrent_streams": streams, "integrator": "dopri5-fixed",
+                       "steps_per_output": SPI},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
             "launches": {"forward": res["fwd_launches"], "adjoint": res["adj_launches"]},
             "objective": [float(x) for x in np.atleast_1d(objective)][:8],
             "roofline": {"bound": "hbm", "kernel": "k_fwd_stage<nonlinear,contact>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
-                         "bytes_per_launch": roof_bytes, "launch_us": fwd_us},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(args.members),
+                         "bytes_per_launch": roof_bytes, "launch_us": fwd_us, "members_per_launch": args.members,
+                         "measured_with": "1 stream, HIP events around the forward region / launches"},
         }
-        if res["adj_launches"]:
-            s = 6
-            n_adj = res["adj_launches"] / 2.0
-            adj_us = max(1e-9, (1e3 * res["adj_ms"] - n_adj * fwd_us) / n_adj)
+        if adj_us:
             a2 = BYTES_ADJ_STAGE * n_units * args.members / (adj_us * 1e-6) / 1e9
             line["roofline_adjoint_kernel"] = {"kernel": "k_adj_stage<nonlinear,contact>", "achieved": a2, "peak": HBM_PEAK_GBS,
-                                               "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS, "launch_us": adj_us}
+                                               "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS, "launch_us": adj_us,
+                                               "bytes_per_launch": BYTES_ADJ_STAGE * n_units * args.members}
+        if streams > 1:
+            # (2) the timed job itself: `streams` member groups overlap on the chip; aggregate algorithmic bytes / region time
+            f_eff, a_eff = per_launch(res, streams)
+            agg = {"concurrent_streams": streams, "members_per_launch": args.members / streams,
+                   "fwd_stage_period_us": f_eff, "fwd_achieved": roof_bytes / (f_eff * 1e-6) / 1e9}
+            agg["fwd_frac"] = agg["fwd_achieved"] / HBM_PEAK_GBS
+            if a_eff:
+                agg["adj_stage_period_us"] = a_eff
+                agg["adj_achieved"] = BYTES_ADJ_STAGE * n_units * args.members / (a_eff * 1e-6) / 1e9
+                agg["adj_frac"] = agg["adj_achieved"] / HBM_PEAK_GBS
+            line["roofline_concurrent"] = agg
         if args.members > 1 and not args.forward_only and not args.no_single:
             # the same config with ONE design per GPU (latency-bound: one wave per SIMD), for reference
             fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
@@ -220,13 +256,14 @@ def main():
         dist.destroy_process_group()
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or null."""
+def load_pmc_traffic(members_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
+    bytes per member and launch, with the guide's x2 correction of FETCH_SIZE), or null."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
             d = json.load(open(p))
-            return d.get("k_fwd_stage_bytes_per_member_launch") * MEMBERS_FOR_TRAFFIC
+            return d.get("k_fwd_stage_bytes_per_member_launch") * members_per_launch
         except Exception:
             return None
     return None

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,6 +80,7 @@ struct AdjCoef {
 
 struct DevCtx {
   int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
+  int m0, pad1;           // first member of the group this launch integrates (one stream per group)
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
   const int32_t* slot_info;
@@ -173,7 +175,7 @@ __device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, co
 
 // records of a full (2, n_blocks, 3) state at time t0 -> stage buffer `buf`  (constrained DOFs follow c(t0), c'(t0))
 __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
 
 // fields[m, k] <- (disp, vel) of stage buffer 0
 __global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * 3) return;
   const int b = tid / 3, d = tid % 3;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields,
 
 // copy stage buffer 0 into checkpoint slot n (only for the initial state)
 __global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * kStep) return;
   double* t = c.traj + (size_t)m * c.traj_stride;
@@ -271,7 +273,7 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
 template <int MODEL, int CONTACT>
 __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int lwg = logical_wg(blockIdx.x, c.n_wg);
   int slot = lwg * kThreads + threadIdx.x;
   const int write_traj = mode & 1, err_mode = mode & 2;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, 
 struct DenseCoef { double cm[7], cma[7]; double a10; };
 
 __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, int n_timepoints) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
   const Clock ck = c.clock[m];
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
 
 // per-member time for k_init (initial-step probe): records of state `y` at time tm[m] into buffer buf
 __global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* state0, const double* tm, int buf) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* st
 
 template <int MODEL, int CONTACT>
 __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int slot = blockIdx.x * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
   LaneIn L;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
 template <int MODEL, int CONTACT>
 __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
   const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
 
 // start of the reverse sweep: lambda_N = G_last; kbar_{s-1} of the last step into buffer `buf`
 __global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last,
 
 // test hook: w = lam_v / m, kbar_q = lam_q  into buffer 0
 __global__ __launch_bounds__(kThreads) void k_seed_vjp(DevCtx c, const double* lam) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * 3) return;
   const int b = tid / 3, d = tid % 3;
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fi
 
 // explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_g
 __global__ void k_kinetic_mass_grad(DevCtx c, const double* fields, const int32_t* target, int n_target) {
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + c.m0;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_target * 3) return;
   const int b = target[r / 3], d = r % 3;
@@ -785,8 +787,32 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// pinned host staging area: pageable hipMemcpy runs at < 1 GB/s on this platform, pinned DMA at PCIe rate
+struct PinnedBuf {
+  char* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= n && p) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+    hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(bytes, 64), hipHostMallocDefault);
+    if (e == hipSuccess) n = std::max<size_t>(bytes, 64);
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
+struct Group {            // members [m0, m0+nm) advance on their own stream so launch bubbles of one group overlap work of another
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  int m0 = 0, nm = 0;
+};
+
 struct dfx_handle {
   Plan pl;
+  std::vector<Group> groups;
+  PinnedBuf stage;
+  hipEvent_t ev_fork = nullptr;
   PackedParams pp;
   std::string err;
   int device = 0;
@@ -849,6 +875,14 @@ static DevCtx make_ctx(dfx_handle* h) {
 }
 
 static dim3 slot_grid(const dfx_handle* h) { return dim3((h->pl.n_slots + kThreads - 1) / kThreads, h->pl.batch); }
+static dim3 slot_grid(const dfx_handle* h, const Group& g) { return dim3((h->pl.n_slots + kThreads - 1) / kThreads, g.nm); }
+// context of one group: same arrays, its own member range and its own segment cursor
+static DevCtx group_ctx(const dfx_handle* h, const DevCtx& c, int gi) {
+  DevCtx cg = c;
+  cg.m0 = h->groups[gi].m0;
+  cg.cur = h->d_cur.p + gi;
+  return cg;
+}
 
 static StageCoef stage_coef(const Tableau& T, int i) {
   StageCoef sc;
@@ -873,52 +907,59 @@ static AdjCoef adj_coef(const Tableau& T, int i) {
 }
 
 template <int MODEL, int CONTACT>
-static void launch_fwd_t(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int out_buf, int y_buf, int write_traj) {
-  hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT>), slot_grid(h), dim3(kThreads), 0, h->stream, c, stage_coef(h->pl.tab, i), i, j,
-                     in_buf, out_buf, y_buf, write_traj);
+static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
+  hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
 }
-static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int out_buf, int y_buf, int write_traj) {
+static void launch_fwd(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   const Plan& pl = h->pl;
-  if (pl.model == kNonlinear) { if (pl.contact) launch_fwd_t<kNonlinear, 1>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); else launch_fwd_t<kNonlinear, 0>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); }
-  else { if (pl.contact) launch_fwd_t<kLinearized, 1>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); else launch_fwd_t<kLinearized, 0>(h, c, i, j, in_buf, out_buf, y_buf, write_traj); }
+  if (pl.model == kNonlinear) { if (pl.contact) launch_fwd_t<kNonlinear, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<kNonlinear, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); }
+  else { if (pl.contact) launch_fwd_t<kLinearized, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<kLinearized, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); }
   h->launches++;
+}
+static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
+  launch_fwd(h, c, h->stream, slot_grid(h), i, j, in_buf, out_buf, y_buf, mode);
 }
 template <int MODEL, int CONTACT>
-static void launch_adj_t(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wbuf, int local_only) {
-  hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT>), slot_grid(h), dim3(kThreads), 0, h->stream, c, adj_coef(h->pl.tab, i), i, j, in_buf,
-                     wbuf, local_only);
+static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
+  hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only);
+}
+static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
+  const Plan& pl = h->pl;
+  if (pl.model == kNonlinear) { if (pl.contact) launch_adj_t<kNonlinear, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<kNonlinear, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); }
+  else { if (pl.contact) launch_adj_t<kLinearized, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<kLinearized, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); }
+  h->launches++;
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wbuf, int local_only) {
-  const Plan& pl = h->pl;
-  if (pl.model == kNonlinear) { if (pl.contact) launch_adj_t<kNonlinear, 1>(h, c, i, j, in_buf, wbuf, local_only); else launch_adj_t<kNonlinear, 0>(h, c, i, j, in_buf, wbuf, local_only); }
-  else { if (pl.contact) launch_adj_t<kLinearized, 1>(h, c, i, j, in_buf, wbuf, local_only); else launch_adj_t<kLinearized, 0>(h, c, i, j, in_buf, wbuf, local_only); }
-  h->launches++;
+  launch_adj(h, c, h->stream, slot_grid(h), i, j, in_buf, wbuf, local_only);
 }
 
 // forward: stage i reads buffer fin(i), writes fout(i); buffer 0 is the step state
 static int fin(int i) { return i == 0 ? 0 : 1 + ((i - 1) & 1); }
 static int fout(int i, int s) { return i == s - 1 ? 0 : 1 + (i & 1); }
 
-// enqueue one segment (kind 0: forward steps; kind 1: reverse steps) on h->stream
-static void enqueue_segment(dfx_handle* h, const DevCtx& c, int n_steps, int kind) {
+// enqueue one segment (kind 0: forward steps; kind 1: reverse steps) of group gi on that group's stream
+static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_steps, int kind) {
   const int s = h->pl.tab.s;
-  hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p, kind == 0 ? 1 : -1, h->d_cur.p);
+  const Group& g = h->groups[gi];
+  const DevCtx c = group_ctx(h, cbase, gi);
+  const dim3 grid = slot_grid(h, g);
+  hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, g.stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
   h->launches++;
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
-      for (int i = 0; i < s; ++i) launch_fwd(h, c, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
+      for (int i = 0; i < s; ++i) launch_fwd(h, c, g.stream, grid, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
   } else {
     for (int j = n_steps - 1; j >= 0; --j) {
       // recompute the stage records of step n from its checkpoint: stage i -> buffer i+1
-      for (int i = 0; i < s - 1; ++i) launch_fwd(h, c, i, j, i == 0 ? -1 : i, i + 1, -1, 0);
-      launch_fwd(h, c, s - 1, j, s - 1, -1, -1, 0);
-      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, i, j, i == 0 ? -1 : i, -1, 0);
+      for (int i = 0; i < s - 1; ++i) launch_fwd(h, c, g.stream, grid, i, j, i == 0 ? -1 : i, i + 1, -1, 0);
+      launch_fwd(h, c, g.stream, grid, s - 1, j, s - 1, -1, -1, 0);
+      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, i == 0 ? -1 : i, -1, 0);
     }
   }
 }
 
-static int run_segment(dfx_handle* h, const DevCtx& c, int n_steps, int kind) {
-  if (!h->use_graph) { enqueue_segment(h, c, n_steps, kind); return 0; }
+static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int kind) {
+  if (!h->use_graph) { enqueue_segment(h, c, gi, n_steps, kind); return 0; }
   DevCtx key_ctx = c;
   key_ctx.n_timepoints = 0;  // not read by the stage kernels
   if (!h->graph_ctx_valid || memcmp(&h->graph_ctx_snapshot, &key_ctx, sizeof(DevCtx)) != 0) {
@@ -926,24 +967,41 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int n_steps, int kind) {
     h->graph_ctx_snapshot = key_ctx;
     h->graph_ctx_valid = true;
   }
-  auto key = std::make_pair(n_steps, kind);
+  auto key = std::make_pair(n_steps, kind * 64 + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
   const long long per = 1 + (long long)n_steps * s * (kind == 0 ? 1 : 2);
+  hipStream_t st = h->groups[gi].stream;
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const long long before = h->launches;
-    HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_segment(h, c, n_steps, kind);
-    HIP_OK(hipStreamEndCapture(h->stream, &graph));
+    HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    enqueue_segment(h, c, gi, n_steps, kind);
+    HIP_OK(hipStreamEndCapture(st, &graph));
     h->launches = before;
     HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
     it = h->graphs.emplace(key, exec).first;
   }
-  HIP_OK(hipGraphLaunch(it->second, h->stream));
+  HIP_OK(hipGraphLaunch(it->second, st));
   h->launches += per;
+  return 0;
+}
+
+// the main stream has prepared the inputs: let every group stream start after it ...
+static int fork_groups(dfx_handle* h) {
+  HIP_OK(hipEventRecord(h->ev_fork, h->stream));
+  for (auto& g : h->groups) if (g.stream != h->stream) HIP_OK(hipStreamWaitEvent(g.stream, h->ev_fork, 0));
+  return 0;
+}
+// ... and the main stream continue after all of them
+static int join_groups(dfx_handle* h) {
+  for (auto& g : h->groups) {
+    if (g.stream == h->stream) continue;
+    HIP_OK(hipEventRecord(g.done, g.stream));
+    HIP_OK(hipStreamWaitEvent(h->stream, g.done, 0));
+  }
   return 0;
 }
 
@@ -970,7 +1028,7 @@ static int ensure_work_buffers(dfx_handle* h) {
   HIP_OK(h->d_VEL.ensure(B * (s + 1) * nb * 3));
   HIP_OK(h->d_A.ensure(B * (s + 1) * nb * 3));
   HIP_OK(h->d_state0.ensure(B * nb * 6));
-  HIP_OK(h->d_cur.ensure(1));
+  HIP_OK(h->d_cur.ensure(64));
   return 0;
 }
 
@@ -1007,24 +1065,32 @@ static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots;
   const size_t nsp = std::max(1, pl.n_special);
-  std::vector<double> g_r(B * NS * 2), g_phi(B * NS * 2), g_b(B * NS * 8, 0.0), blk_g(B * nb * 6), fn_g(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0),
-      lam(B * nb * 6);
-  HIP_OK(hipMemcpyAsync(g_r.data(), h->d_g_r.p, sizeof(double) * g_r.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(g_phi.data(), h->d_g_phi.p, sizeof(double) * g_phi.size(), hipMemcpyDeviceToHost, h->stream));
-  if (h->want_bond_grads) HIP_OK(hipMemcpyAsync(g_b.data(), h->d_g_b.p, sizeof(double) * g_b.size(), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(blk_g.data(), h->d_blk_g.p, sizeof(double) * blk_g.size(), hipMemcpyDeviceToHost, h->stream));
-  if (h->want_fn_grads) HIP_OK(hipMemcpyAsync(fn_g.data(), h->d_fn_g.p, sizeof(double) * fn_g.size(), hipMemcpyDeviceToHost, h->stream));
-  if (with_state0) HIP_OK(hipMemcpyAsync(lam.data(), h->d_LAM.p, sizeof(double) * lam.size(), hipMemcpyDeviceToHost, h->stream));
+  const size_t n_r = B * NS * 2, n_phi = B * NS * 2, n_b = B * NS * 8, n_blk = B * nb * 6, n_fn = B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, n_lam = B * nb * 6;
+  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_blk + n_fn + n_lam) * sizeof(double)));
+  double* g_r = reinterpret_cast<double*>(h->stage.p);
+  double* g_phi = g_r + n_r;
+  double* g_b = g_phi + n_phi;
+  double* blk_g_p = g_b + n_b;
+  double* fn_g_p = blk_g_p + n_blk;
+  double* lam = fn_g_p + n_fn;
+  HIP_OK(hipMemcpyAsync(g_r, h->d_g_r.p, sizeof(double) * n_r, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(g_phi, h->d_g_phi.p, sizeof(double) * n_phi, hipMemcpyDeviceToHost, h->stream));
+  if (h->want_bond_grads) HIP_OK(hipMemcpyAsync(g_b, h->d_g_b.p, sizeof(double) * n_b, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(blk_g_p, h->d_blk_g.p, sizeof(double) * n_blk, hipMemcpyDeviceToHost, h->stream));
+  if (h->want_fn_grads) HIP_OK(hipMemcpyAsync(fn_g_p, h->d_fn_g.p, sizeof(double) * n_fn, hipMemcpyDeviceToHost, h->stream));
+  else memset(fn_g_p, 0, sizeof(double) * n_fn);
+  if (with_state0) HIP_OK(hipMemcpyAsync(lam, h->d_LAM.p, sizeof(double) * n_lam, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
+  std::vector<double> blk_g(blk_g_p, blk_g_p + n_blk), fn_g(fn_g_p, fn_g_p + n_fn);
   if (!grads) return 0;
   std::vector<double> slot_g(B * NS * kSlotGrads, 0.0);
   for (size_t i = 0; i < B * NS; ++i) {
     double* q = slot_g.data() + i * kSlotGrads;
     q[0] = g_r[i * 2]; q[1] = g_r[i * 2 + 1];
-    for (int c = 0; c < 5; ++c) q[2 + c] = g_b[i * 8 + c];
+    if (h->want_bond_grads) for (int c = 0; c < 5; ++c) q[2 + c] = g_b[i * 8 + c];
     q[7] = g_phi[i * 2]; q[8] = g_phi[i * 2 + 1];
-    for (int c = 0; c < 3; ++c) q[9 + c] = g_b[i * 8 + 5 + c];
+    if (h->want_bond_grads) for (int c = 0; c < 3; ++c) q[9 + c] = g_b[i * 8 + 5 + c];
   }
   dfx_grads g = *grads;
   if (!with_state0) g.state0 = nullptr;
@@ -1071,10 +1137,26 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   (void)hipEventCreate(&h->ev1);
   const char* g = getenv("DFX_NO_GRAPH");
   h->use_graph = !(g && g[0] == '1');
+  {
+    const char* e = getenv("DFX_STREAMS");
+    int want = e ? atoi(e) : 4;
+    int ng = std::max(1, std::min(want, h->pl.batch));
+    (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    for (int gi = 0; gi < ng; ++gi) {
+      Group gr;
+      const int base = h->pl.batch / ng, rem = h->pl.batch % ng;
+      gr.m0 = gi * base + std::min(gi, rem);
+      gr.nm = base + (gi < rem ? 1 : 0);
+      if (gi == 0) gr.stream = h->stream;   // group 0 rides on the main stream (HIP multiplexes streams onto few hardware queues)
+      else if (hipStreamCreateWithFlags(&gr.stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(2); }
+      (void)hipEventCreateWithFlags(&gr.done, hipEventDisableTiming);
+      h->groups.push_back(gr);
+    }
+  }
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
-            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2) == hipSuccess &&
-            h->d_cur.ensure(1) == hipSuccess;
+            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2 + 64) == hipSuccess &&
+            h->d_cur.ensure(64) == hipSuccess;
   if (!ok) { h->err = "hipMalloc (static tables) failed"; return fail(2); }
   (void)hipMemcpy(h->d_slot_info.p, pl.slot_info.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
   (void)hipMemcpy(h->d_block_special.p, pl.block_special.data(), sizeof(int32_t) * pl.n_blocks, hipMemcpyHostToDevice);
@@ -1096,7 +1178,9 @@ int dfx_destroy(dfx_handle* h) {
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_g.release(); h->d_fn_g.release();
-  h->d_tmp.release(); h->d_obj.release(); h->d_target.release();
+  h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release();
+  for (auto& gr : h->groups) { if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1106,19 +1190,35 @@ int dfx_destroy(dfx_handle* h) {
 
 int dfx_set_params(dfx_handle* h, const dfx_params* params) {
   HIP_OK(hipSetDevice(h->device));
+  const bool timing = getenv("DFX_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
   if (pack_params(h->pl, params, h->pp, h->err)) return 1;
+  auto t1 = std::chrono::steady_clock::now();
   const PackedParams& pp = h->pp;
-  auto up = [&](DevBuf<double>& d, const std::vector<double>& v) -> int {
-    HIP_OK(d.ensure(v.size()));
-    if (!v.empty()) HIP_OK(hipMemcpyAsync(d.p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, h->stream));
-    return 0;
-  };
-  if (up(h->d_p_r, pp.p_r) || up(h->d_p_l, pp.p_l) || (!pp.k_uniform && up(h->d_p_k, pp.p_k)) || up(h->d_p_phi, pp.p_phi) || up(h->d_cst, pp.cst) ||
-      up(h->d_inv_m, pp.inv_m) || up(h->d_damping, pp.damping))
-    return 2;
+  {
+    const std::vector<double>* src[7] = {&pp.p_r, &pp.p_l, pp.k_uniform ? nullptr : &pp.p_k, &pp.p_phi, &pp.cst, &pp.inv_m, &pp.damping};
+    DevBuf<double>* dst[7] = {&h->d_p_r, &h->d_p_l, &h->d_p_k, &h->d_p_phi, &h->d_cst, &h->d_inv_m, &h->d_damping};
+    size_t total = 0;
+    for (int i = 0; i < 7; ++i) if (src[i]) total += src[i]->size() * sizeof(double);
+    HIP_OK(h->stage.ensure(total));
+    size_t off = 0;
+    for (int i = 0; i < 7; ++i) {
+      if (!src[i] || src[i]->empty()) continue;
+      const size_t bytes = src[i]->size() * sizeof(double);
+      HIP_OK(dst[i]->ensure(src[i]->size()));
+      memcpy(h->stage.p + off, src[i]->data(), bytes);
+      HIP_OK(hipMemcpyAsync(dst[i]->p, h->stage.p + off, bytes, hipMemcpyHostToDevice, h->stream));
+      off += bytes;
+    }
+  }
   HIP_OK(h->d_fns.ensure(pp.fns.size()));
   HIP_OK(hipMemcpyAsync(h->d_fns.p, pp.fns.data(), sizeof(TimeFn) * pp.fns.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
+  if (timing) {
+    auto t2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dfx] set_params: pack %.2f ms, upload %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(t2 - t1).count());
+  }
   h->have_params = true;
   h->have_traj = false;
   h->have_fields = false;
@@ -1171,8 +1271,9 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
-  const int minus1[2] = {-1, 0};   // segment cursor, non-finite flag
-  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, minus1, 2 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> cursors(2 + 64, -1);   // [0] unused, [1] non-finite flag, [2+g] segment cursor of group g
+  cursors[1] = 0;
+  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
   h->launches = 0;
@@ -1182,12 +1283,19 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
+  if (fork_groups(h)) return 2;
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
-    if (int rc = run_segment(h, c, sg.n_steps, 0)) return rc;
-    if (sg.j0 + sg.n_steps == h->spi)   // buffer 0 holds the state at the end of the interval
-      hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, sg.interval + 1, h->d_seg_idx.p + 1);
+    for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
+      if (int rc = run_segment(h, c, gi, sg.n_steps, 0)) return rc;
+      if (sg.j0 + sg.n_steps == h->spi) {   // buffer 0 holds the state at the end of the interval
+        const Group& gr = h->groups[gi];
+        hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
+                           h->d_seg_idx.p + 1);
+      }
+    }
   }
+  if (join_groups(h)) return 2;
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
   int bad = 0;
@@ -1208,6 +1316,7 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
     stats->rhs_evals = h->n_total * pl.tab.s;
     stats->launches = h->launches;
     stats->kernel_ms = ms;
+    stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
   }
   return 0;
@@ -1376,6 +1485,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     stats->rhs_evals = 6 * att + 2;
     stats->launches = h->launches;
     stats->kernel_ms = ms;
+    stats->streams = 1;
     stats->stage_kernel_us = att ? 1e3 * ms / (double)(att * 8) : 0.0;
   }
   return 0;
@@ -1391,13 +1501,17 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
   h->launches = 0;
   if (zero_grad_accumulators(h)) return 2;
   const int nseg = (int)h->segs.size();
-  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, &nseg, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> cursors(64, nseg);
+  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p + 2, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   const double h_last = Tn > 1 ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spi : 0.0;
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   const int wb = (int)((h->n_total * pl.tab.s - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb);
+  if (fork_groups(h)) return 2;
   for (int si = nseg - 1; si >= 0; --si)
-    if (int rc = run_segment(h, c, h->segs[si].n_steps, 1)) return rc;
+    for (int gi = 0; gi < (int)h->groups.size(); ++gi)
+      if (int rc = run_segment(h, c, gi, h->segs[si].n_steps, 1)) return rc;
+  if (join_groups(h)) return 2;
   if (kinetic) {
     dim3 g((unsigned)((n_target * 3 + 63) / 64), (unsigned)B);
     hipLaunchKernelGGL(k_kinetic_mass_grad, g, dim3(64), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_target.p, n_target);
@@ -1412,6 +1526,7 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
     stats->rhs_evals = h->n_total * pl.tab.s;
     stats->launches = h->launches;
     stats->kernel_ms = ms;
+    stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
   }
   return 0;

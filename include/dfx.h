@@ -108,6 +108,7 @@ typedef struct dfx_stats {
   int64_t launches;                       /* kernel launches issued                              */
   double kernel_ms;                       /* device time of the integration loop (HIP events)    */
   double stage_kernel_us;                 /* mean duration of one stage-kernel launch incl. gap  */
+  int64_t streams;                        /* member groups integrated concurrently (one HIP stream each) */
 } dfx_stats;
 
 typedef struct dfx_handle dfx_handle;
