@@ -145,11 +145,10 @@ class QuadsFocusingForward:
         self.is_setup = True
 
     def control_params(self, design):
-        hs, vs = design
         g = self.geometry
         return ControlParams(
-            geometrical_params=GeometricalParams(block_centroids=g.block_centroids(hs, vs),
-                                                 centroid_node_vectors=g.centroid_node_vectors(hs, vs)),
+            geometrical_params=GeometricalParams(block_centroids=g.block_centroids(*design),
+                                                 centroid_node_vectors=g.centroid_node_vectors(*design)),
             mechanical_params=MechanicalParams(
                 bond_params=LigamentParams(self.k_stretch, self.k_shear, self.k_rot, self.reference_bond_vectors),
                 density=self.density, damping=self.damping,
@@ -169,15 +168,76 @@ class QuadsFocusingForward:
                             self.bond_connectivity, self.timepoints, fields)
 
 
+@dataclass
+class KagomeFocusingForward:
+    """NumPy counterpart of ``problems/kagome_focusing.py:ForwardProblem`` (fields with the same names; left-loaded)."""
+    n1_cells: int
+    n2_cells: int
+    cell_size: Any
+    bond_length: Any
+    k_stretch: Any
+    k_shear: Any
+    k_rot: Any
+    density: Any
+    damping: Any
+    amplitude: Any
+    loading_rate: Any
+    input_delay: Any
+    n_excited_blocks: int
+    simulation_time: Any
+    n_timepoints: int
+    loaded_side: str = "left"
+    cell_angle: Any = np.pi / 3
+    linearized_strains: bool = False
+    use_contact: bool = True
+    k_contact: Any = 1.
+    min_angle: Any = 0. * np.pi / 180
+    cutoff_angle: Any = 5. * np.pi / 180
+    n_blocks_clamped_corner: int = 2
+    steps_per_interval: Optional[int] = None
+    integrator: str = "dopri5"
+    batch: int = 1
+    device: int = 0
+    name: str = "kagome_focusing"
+    _lib: Any = None
+
+    def setup(self):
+        if self.loaded_side != "left":
+            raise ValueError(f"Unknown loaded_side: {self.loaded_side}. Only 'left' is implemented.")   # kagome_focusing.py:107-109
+        basis = self.cell_size * np.array([[1.0, 0.0], [np.cos(self.cell_angle), np.sin(self.cell_angle)]])
+        g = self.geometry = KagomeGeometry(self.n1_cells, self.n2_cells, basis, self.bond_length)
+        self.bond_connectivity = g.bond_connectivity()
+        self.reference_bond_vectors = g.reference_bond_vectors()
+        pairs, vec, self.driven_blocks_ids, self.clamped_blocks_ids = kagome_focusing_constraints(
+            g, self.n_excited_blocks, self.n_blocks_clamped_corner)
+        self.constrained_block_DOF_pairs = pairs
+        self.moving_blocks_ids = np.setdiff1d(np.arange(g.n_blocks), self.clamped_blocks_ids)
+        strain = E.build_strain_energy(self.bond_connectivity,
+                                       E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
+        energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
+        self.solve_dynamics = setup_dynamic_solver(
+            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=L.Pulse(vec),
+            damped_blocks=np.arange(g.n_blocks), integrator=self.integrator,
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, _lib=self._lib)
+        self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
+        self.state0 = np.zeros((2, g.n_blocks, 3))
+        self.signed_amplitude = self.amplitude
+        self.is_setup = True
+
+    control_params = QuadsFocusingForward.control_params
+    solve = QuadsFocusingForward.solve
+
+
 class TargetKineticEnergy:
     """objective(design) = sum_t sum_{b in target} m v^2/2 and its gradient w.r.t. the design
-    (problems/quads_focusing.py:432-471 + jit(value_and_grad(.)) at :565)."""
+    (problems/quads_focusing.py:432-471 + jit(value_and_grad(.)) at :565; kagome_focusing.py:388-424)."""
 
     def __init__(self, forward, target_size, target_shift):
         self.forward = forward
         if not getattr(forward, "is_setup", False):
             forward.setup()
-        self.target_blocks = quads_target_blocks(forward.geometry, target_size, target_shift)
+        pick = kagome_target_blocks if isinstance(forward.geometry, KagomeGeometry) else quads_target_blocks
+        self.target_blocks = pick(forward.geometry, target_size, target_shift)
 
     def value(self, design):
         sol = self.forward.solve(design)
@@ -196,3 +256,107 @@ class TargetKineticEnergy:
         grads = [fw.geometry.vjp(d, t.geometrical_params.centroid_node_vectors, t.geometrical_params.block_centroids)
                  for d, t in zip(designs, trees)]
         return (obj, grads) if many else (obj, grads[0])
+
+
+class MultiInputTargetKineticEnergy:
+    """weights @ [target kinetic energy of every forward problem], all sharing one design
+    (problems/quads_focusing_multi_input.py:43-86).  The forward problems differ in their boundary conditions
+    (loaded side / input shift), so each owns a solver; the design gradient is the weighted sum."""
+
+    def __init__(self, forward_problems, target_size, target_shift, weights):
+        self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
+        self.weights = np.asarray(weights, dtype=float)
+        self.target_blocks = self.objectives[0].target_blocks
+        self.forward = forward_problems[0]
+
+    def individual(self, design):
+        return np.array([o.value(design) for o in self.objectives])
+
+    def value(self, design):
+        return float(self.weights @ self.individual(design))
+
+    def value_and_grad(self, design):
+        vals, total = [], None
+        for w, o in zip(self.weights, self.objectives):
+            v, g = o.value_and_grad(design)
+            vals.append(float(v))
+            total = [w * gi for gi in g] if total is None else [t + w * gi for t, gi in zip(total, g)]
+        self.last_individual = np.array(vals)
+        return float(self.weights @ self.last_individual), tuple(total)
+
+
+# -- geometric constraints of the optimisation (problems/quads_focusing.py:473-544) ------------------------------------
+
+def angle_constraints(geometry, design, min_void_angle=0., min_block_angle=0.):
+    """<= 0 when satisfied: -(angle mod 2pi - min) for the two void and the two block angles of every bond."""
+    from .geometry import compute_edge_angles
+    a = np.mod(np.stack(compute_edge_angles(geometry.centroid_node_vectors(*design), geometry.bond_connectivity())), 2 * np.pi)
+    return np.concatenate([-(a[0] - min_void_angle), -(a[1] - min_void_angle), -(a[2] - min_block_angle), -(a[3] - min_block_angle)])
+
+
+def edge_length_constraints(geometry, design, min_edge_length):
+    """<= 0 when satisfied (problems/quads_focusing.py:535-544)."""
+    from .geometry import compute_edge_lengths
+    return -(compute_edge_lengths(geometry.centroid_node_vectors(*design)).reshape(-1) - min_edge_length)
+
+
+@dataclass
+class OptimizationProblem:
+    """Inverse design loop with the bookkeeping of the reference's ``OptimizationProblem``
+    (problems/quads_focusing.py:408-690: objective_values, design_values, constraints_violation, to_dict).
+    NLopt is not available on the target image, so ``run_optimization`` is a bound-projected gradient ASCENT with
+    back-tracking that only accepts feasible designs (angle / edge-length constraints) -- the reference maximises the
+    same objective with NLopt's LD_MMA."""
+    objective: Any
+    objective_values: Optional[list] = None
+    design_values: Optional[list] = None
+    constraints_violation: Optional[dict] = None
+    name: str = "quads_focusing"
+
+    def __post_init__(self):
+        self.objective_values = [] if self.objective_values is None else self.objective_values
+        self.design_values = [] if self.design_values is None else self.design_values
+        self.constraints_violation = {"angles": [], "edge_lengths": []} if self.constraints_violation is None else self.constraints_violation
+
+    def violation(self, design, min_void_angle, min_block_angle, min_edge_length):
+        g = self.objective.forward.geometry
+        va = angle_constraints(g, design, min_void_angle, min_block_angle).max() if min_void_angle is not None and min_block_angle is not None else -np.inf
+        ve = edge_length_constraints(g, design, min_edge_length).max() if min_edge_length is not None else -np.inf
+        return va, ve
+
+    def run_optimization(self, initial_guess, n_iterations, lower_bound=None, upper_bound=None, min_void_angle=None,
+                         min_block_angle=None, min_edge_length=None, initial_step=None, verbose=True):
+        x = tuple(np.array(a, dtype=float) for a in initial_guess)
+        clip = (lambda d: tuple(np.clip(a, lower_bound, upper_bound) for a in d)) if (lower_bound is not None or upper_bound is not None) else (lambda d: d)
+        v, g = self.objective.value_and_grad(x)
+        scale = max(np.abs(a).max() for a in g) or 1.0
+        step = initial_step if initial_step is not None else 0.01 * getattr(self.objective.forward.geometry, "spacing", 1.0)
+        for it in range(n_iterations):
+            self.objective_values.append(float(v))
+            self.design_values.append(x)
+            va, ve = self.violation(x, min_void_angle, min_block_angle, min_edge_length)
+            self.constraints_violation["angles"].append(va)
+            self.constraints_violation["edge_lengths"].append(ve)
+            if verbose:
+                print(f"Iteration: {len(self.objective_values)}\nObjective = {self.objective_values[-1]}")
+            accepted = False
+            for _ in range(12):
+                trial = clip(tuple(a + step * ga / scale for a, ga in zip(x, g)))
+                va, ve = self.violation(trial, min_void_angle, min_block_angle, min_edge_length)
+                if max(va, ve) <= 1e-8:
+                    vt, gt = self.objective.value_and_grad(trial)
+                    if vt > v:
+                        x, v, g, accepted = trial, vt, gt, True
+                        scale = max(np.abs(a).max() for a in g) or 1.0
+                        step *= 1.5
+                        break
+                step *= 0.5
+            if not accepted:
+                break
+        self.objective_values.append(float(v))
+        self.design_values.append(x)
+        return x
+
+    def to_dict(self):
+        return dict(name=self.name, objective_values=list(self.objective_values), design_values=list(self.design_values),
+                    constraints_violation=dict(self.constraints_violation))

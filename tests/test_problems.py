@@ -1,0 +1,93 @@
+"""Problem layer: BC index patterns, objectives, multi-input weighting, constraints,
+the optimisation loop -- exercised through the CPU port (host logic; the same code drives the HIP engine)."""
+import math
+
+import numpy as np
+import pytest
+
+from difflexmm_amd import problems as P
+from difflexmm_amd.geometry import KagomeGeometry, QuadGeometry
+
+
+def _quads(lib, side="left", shift=0, n=6):
+    fw = P.QuadsFocusingForward(
+        n1_blocks=n, n2_blocks=n, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5,
+        density=6.18e-9, damping=1e-4 * np.ones((n * n, 3)), amplitude=7.5, loading_rate=3000.0, input_delay=1e-5,
+        n_excited_blocks=2, loaded_side=side, input_shift=shift, simulation_time=4e-4, n_timepoints=5,
+        use_contact=True, k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180,
+        steps_per_interval=10, _lib=lib)
+    fw.setup()
+    return fw
+
+
+def _design(fw, seed=0, amp=0.2):
+    rng = np.random.default_rng(seed)
+    base = fw.geometry.get_design_from_rotated_square(25 * math.pi / 180)
+    return tuple(b + rng.uniform(-amp, amp, b.shape) for b in base)
+
+
+def test_quads_bc_patterns_match_reference_counts():
+    """24x16 paper lattice: 6 driven + 36 clamped = 42 constrained DOFs, ordering as in
+    problems/quads_focusing.py:104-197 (driven pairs first, first n_excited entries carry the pulse)."""
+    g = QuadGeometry(24, 16, 15.0, 2.25)
+    pairs, vec, driven, clamped = P.quads_focusing_constraints(g, 2, "left", 0, 2)
+    assert len(pairs) == 42 and vec.sum() == 2 and np.all(vec[:2] == 1)
+    assert list(driven) == [7 * 24, 8 * 24] and len(clamped) == 12
+    assert list(pairs[:6, 1]) == [0, 0, 1, 1, 2, 2]
+    pb, _, drb, _ = P.quads_focusing_constraints(g, 2, "bottom", -2, 2)
+    assert list(drb) == [9, 10] and list(pb[:6, 1]) == [1, 1, 0, 0, 2, 2]
+    with pytest.raises(ValueError):
+        P.quads_focusing_constraints(g, 2, "diagonal")
+    assert list(P.quads_target_blocks(g, (2, 2), (4, 3))) == [10 * 24 + 15, 11 * 24 + 15, 10 * 24 + 16, 11 * 24 + 16]
+
+
+def test_kagome_bc_patterns():
+    g = KagomeGeometry(20, 12, 20.0 * np.array([[1.0, 0.0], [0.5, math.sqrt(3) / 2]]), 2.25)
+    pairs, vec, driven, clamped = P.kagome_focusing_constraints(g, 2, 2)
+    assert len(np.unique(pairs[:, 0] * 3 + pairs[:, 1])) == len(pairs) == 6 + 3 * (3 + 4 + 3 + 4)
+    assert list(driven) == [2 * 20 * 5, 2 * 20 * 6]
+
+
+def test_kagome_forward_problem_runs(cpu_lib):
+    fw = P.KagomeFocusingForward(n1_cells=5, n2_cells=4, cell_size=20.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19,
+                                 k_rot=1.5, density=6.18e-9, damping=1e-4 * np.ones((40, 3)), amplitude=5.0, loading_rate=3000.0,
+                                 input_delay=1e-5, n_excited_blocks=2, simulation_time=4e-4, n_timepoints=5, use_contact=True,
+                                 k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180,
+                                 steps_per_interval=10, _lib=cpu_lib)
+    obj = P.TargetKineticEnergy(fw, (2, 2), (1, 0))
+    design = tuple(np.zeros(s) for s in fw.geometry.design_shapes())
+    v, g = obj.value_and_grad(design)
+    assert v > 0 and all(np.isfinite(a).all() for a in g) and len(g) == 3
+    assert abs(obj.value(design) - v) / v < 1e-12
+
+
+def test_multi_input_objective_is_weighted_sum_and_gradient_matches_fd(cpu_lib):
+    fws = [_quads(cpu_lib, "left", 0), _quads(cpu_lib, "bottom", -1)]
+    mi = P.MultiInputTargetKineticEnergy(fws, (2, 2), (1, 1), weights=(1.0, 0.5))
+    d = _design(fws[0])
+    v, g = mi.value_and_grad(d)
+    ind = mi.individual(d)
+    assert abs(v - (ind[0] + 0.5 * ind[1])) / v < 1e-12 and np.all(ind > 0)
+    rng = np.random.default_rng(1)
+    dirn = tuple(rng.normal(size=a.shape) for a in d)
+    eps = 1e-5
+    vp = mi.value(tuple(a + eps * b for a, b in zip(d, dirn)))
+    vm = mi.value(tuple(a - eps * b for a, b in zip(d, dirn)))
+    fd = (vp - vm) / (2 * eps)
+    an = sum((a * b).sum() for a, b in zip(g, dirn))
+    assert abs(fd - an) / abs(fd) < 1e-6
+
+
+def test_optimisation_loop_increases_objective_and_stays_feasible(cpu_lib):
+    fw = _quads(cpu_lib)
+    obj = P.TargetKineticEnergy(fw, (2, 2), (1, 1))
+    opt = P.OptimizationProblem(obj)
+    x0 = _design(fw, amp=0.05)
+    x = opt.run_optimization(x0, 3, lower_bound=-3.0, upper_bound=3.0, min_void_angle=5 * math.pi / 180,
+                             min_block_angle=5 * math.pi / 180, min_edge_length=1.0, verbose=False)
+    assert opt.objective_values[-1] > opt.objective_values[0]
+    assert all(b > a for a, b in zip(opt.objective_values, opt.objective_values[1:]))
+    assert P.angle_constraints(fw.geometry, x, 5 * math.pi / 180, 5 * math.pi / 180).max() <= 1e-8
+    assert P.edge_length_constraints(fw.geometry, x, 1.0).max() <= 1e-8
+    d = opt.to_dict()
+    assert len(d["design_values"]) == len(d["objective_values"])
