@@ -175,8 +175,8 @@ def main():
             f_us = 1e3 * r["fwd_ms"] / max(1.0, r["fwd_launches"] / n_streams)
             a_us = None
             if r["adj_launches"]:
-                n_adj = r["adj_launches"] / 2.0 / n_streams          # half of the reverse launches are recomputed forward stages
-                a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * f_us) / n_adj)
+                n_adj = r["adj_launches"] * 6.0 / 11.0 / n_streams   # per reverse step: 5 recomputed forward stages + 6 reverse stages
+                a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * (5.0 / 6.0) * f_us) / n_adj)
             return f_us, a_us
 
         # (1) per-launch roofline of the dominant kernel: ONE stream, every launch integrates all `members` designs.

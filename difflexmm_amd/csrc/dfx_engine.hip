@@ -80,7 +80,7 @@ struct AdjCoef {
 
 struct DevCtx {
   int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
-  int m0, pad1;           // first member of the group this launch integrates (one stream per group)
+  int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
   const int32_t* slot_info;
@@ -143,11 +143,11 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 }
 
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.POS + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * kPos;
+  if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * c.n_blocks * kPos;
   return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep;
 }
 __device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.VEL + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * 3;
+  if (buf >= 0) return c.VEL + ((size_t)m * c.nbuf + buf) * c.n_blocks * 3;
   return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep + (size_t)c.n_blocks * kPos;
 }
 
@@ -187,9 +187,9 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
     TimeVals tv = constrained_value(c, m, c.special[sidx], d, t0);
     q = tv.g; v = tv.gt;
   }
-  double* pr = c.POS + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * kPos + (size_t)b * kPos;
+  double* pr = c.POS + ((size_t)m * c.nbuf + buf) * c.n_blocks * kPos + (size_t)b * kPos;
   pr[d] = q;
-  c.VEL[((size_t)m * (c.s + 1) + buf) * nd + b * 3 + d] = v;
+  c.VEL[((size_t)m * c.nbuf + buf) * nd + b * 3 + d] = v;
   if (d == 2) {
     double sn, cs;
     sincos(0.5 * q, &sn, &cs);
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields,
   if (tid >= c.n_blocks * 3) return;
   const int b = tid / 3, d = tid % 3;
   double* f = fields + ((size_t)m * c.n_timepoints + k) * c.n_blocks * 6;
-  const double q = c.POS[(size_t)m * (c.s + 1) * c.n_blocks * kPos + (size_t)b * kPos + d];
-  const double v = c.VEL[(size_t)m * (c.s + 1) * c.n_blocks * 3 + tid];
+  const double q = c.POS[(size_t)m * c.nbuf * c.n_blocks * kPos + (size_t)b * kPos + d];
+  const double v = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + tid];
   f[tid] = q;
   f[(size_t)c.n_blocks * 3 + tid] = v;
   if (!isfinite(q) || !isfinite(v)) *bad = k + 1;   // any writer wins: only "some output row is not finite" matters
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * kStep) return;
   double* t = c.traj + (size_t)m * c.traj_stride;
-  if (tid < c.n_blocks * kPos) t[tid] = c.POS[(size_t)m * (c.s + 1) * c.n_blocks * kPos + tid];
-  else t[tid] = c.VEL[(size_t)m * (c.s + 1) * c.n_blocks * 3 + (tid - c.n_blocks * kPos)];
+  if (tid < c.n_blocks * kPos) t[tid] = c.POS[(size_t)m * c.nbuf * c.n_blocks * kPos + tid];
+  else t[tid] = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + (tid - c.n_blocks * kPos)];
 }
 
 struct LaneIn {
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
   sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3 && !(c.ablate & 2)) {
-    *reinterpret_cast<double2*>(c.POS + ((size_t)m * (c.s + 1) + out_buf) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
-    c.VEL[((size_t)m * (c.s + 1) + out_buf) * nd + dof] = vnext;
+    *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + out_buf) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
+    c.VEL[((size_t)m * c.nbuf + out_buf) * nd + dof] = vnext;
     if (write_traj) {
       double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)(n + 1) * c.n_blocks * kStep;
       *reinterpret_cast<double2*>(tr + (size_t)b * kPos + 2 * k) = chunk;
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
   const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
   const size_t nd = (size_t)c.n_blocks * 3;
   const int dof = b * 3 + kd;
-  double* POS0 = c.POS + ((size_t)m * (c.s + 1) + 0) * c.n_blocks * kPos + (size_t)b * kPos;
-  double* VEL0 = c.VEL + ((size_t)m * (c.s + 1) + 0) * nd;
-  const double* POS3 = c.POS + ((size_t)m * (c.s + 1) + 3) * c.n_blocks * kPos + (size_t)b * kPos;
-  const double* VEL3 = c.VEL + ((size_t)m * (c.s + 1) + 3) * nd;
+  double* POS0 = c.POS + ((size_t)m * c.nbuf + 0) * c.n_blocks * kPos + (size_t)b * kPos;
+  double* VEL0 = c.VEL + ((size_t)m * c.nbuf + 0) * nd;
+  const double* POS3 = c.POS + ((size_t)m * c.nbuf + 3) * c.n_blocks * kPos + (size_t)b * kPos;
+  const double* VEL3 = c.VEL + ((size_t)m * c.nbuf + 3) * nd;
   double* Am = c.A + (size_t)m * (c.s + 1) * nd;
   double qn = POS0[kd], vn = VEL0[dof], a0 = Am[dof];
   const int sidx = c.block_special[b];
@@ -483,8 +483,8 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
   sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3) {
-    *reinterpret_cast<double2*>(c.POS + ((size_t)m * (c.s + 1) + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
-    c.VEL[((size_t)m * (c.s + 1) + 1) * nd + dof] = vnext;
+    *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
+    c.VEL[((size_t)m * c.nbuf + 1) * nd + dof] = vnext;
   }
 }
 
@@ -502,9 +502,9 @@ __global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* st
     TimeVals tv = constrained_value(c, m, c.special[sidx], d, tm[m]);
     q = tv.g; v = tv.gt;
   }
-  double* pr = c.POS + ((size_t)m * (c.s + 1) + buf) * c.n_blocks * kPos + (size_t)b * kPos;
+  double* pr = c.POS + ((size_t)m * c.nbuf + buf) * c.n_blocks * kPos + (size_t)b * kPos;
   pr[d] = q;
-  c.VEL[((size_t)m * (c.s + 1) + buf) * nd + b * 3 + d] = v;
+  c.VEL[((size_t)m * c.nbuf + buf) * nd + b * 3 + d] = v;
   if (d == 2) {
     double sn, cs;
     sincos(0.5 * q, &sn, &cs);
@@ -558,7 +558,6 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   const int pb = (L.info < 0 ? slot : (L.info >> 1)) >> 2;
   const double wpx = Win[(size_t)pb * 3], wpy = Win[(size_t)pb * 3 + 1], wpth = Win[(size_t)pb * 3 + 2];
   const double v_i = vel_in(c, m, in_buf, n)[dof];
-  const double a_i = c.A[(size_t)m * (c.s + 1) * nd + (size_t)i * nd + dof];
   const double kq_in = c.KQ[((size_t)m * 2 + win) * nd + dof];
   const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
   const int sidx = c.block_special[b];
@@ -577,6 +576,7 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
+  double ex = 0.0, ey = 0.0, eth = 0.0;   // dE/du of this slot (value parts): gives the stage acceleration without re-reading it
   if (L.info >= 0) {
     BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
     BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);
@@ -584,10 +584,12 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
     bond_grad<MODEL, Dual>(o, p, Dual(L.rox), Dual(L.roy), Dual(L.rpx), Dual(L.rpy), Dual(L.lx), Dual(L.ly), L.l0, L.il0,
                            Dual(L.ks), Dual(L.ksh), Dual(L.kr), L.sgn, g);
     hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
+    ex = g.fx.v; ey = g.fy.v; eth = g.fth.v;
     ContactGrad<Dual> cg;
     if (CONTACT) {
       contact_grad<Dual>(L.sgn * (o.th - p.th), Dual(L.phi1), Dual(L.phi2), Dual(L.am), Dual(L.ac), Dual(L.kc), cg);
       hth += L.sgn * cg.dkap.e;
+      eth += L.sgn * cg.dkap.v;
     }
     // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
     const size_t gs = (size_t)m * c.n_slots + slot;
@@ -612,28 +614,36 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   hx = quad_sum(hx);
   hy = quad_sum(hy);
   hth = quad_sum(hth);
+  ex = quad_sum(ex);
+  ey = quad_sum(ey);
+  eth = quad_sum(eth);
   // ---- DOF epilogue
   const double h = sg.h;
   if (k < 3) {
     const double hw = k == 0 ? hx : (k == 1 ? hy : hth);
+    const double dE = k == 0 ? ex : (k == 1 ? ey : eth);
     bool constrained = false;
+    double fload = 0.0;
     if (sidx >= 0) {
       const dfx_special& sp = c.special[sidx];
       constrained = (sp.con_mask >> k) & 1;
-      if (c.fn_g) {
-        const double t_i = sg.t_interval + (sg.j0 + j) * h + ac.c_i * h;
-        double gp[kMaxFnParams];
-        for (int f = 0; f < c.n_fns; ++f) {
-          const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
-          if (coef != 0.0) {
-            double g, gt;
-            eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
+      const double t_i = sg.t_interval + (sg.j0 + j) * h + ac.c_i * h;
+      double gp[kMaxFnParams];
+      for (int f = 0; f < c.n_fns; ++f) {
+        const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
+        const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
+        if ((coef != 0.0 && c.fn_g) || loaded) {
+          double g, gt;
+          eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
+          if (loaded) fload += sp.load_coef[k][f] * g;
+          if (coef != 0.0 && c.fn_g) {
             double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
             for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) q[kk] += coef * gp[kk];
           }
         }
       }
     }
+    const double a_i = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
     double ybq = 0.0, ybv = 0.0;
     if (!constrained) {
       ybq = -hw;
@@ -804,13 +814,17 @@ struct PinnedBuf {
 
 struct Group {            // members [m0, m0+nm) advance on their own stream so launch bubbles of one group overlap work of another
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // reverse sweep: recompute of step n-1 runs here while `stream` does the reverse stages of step n
   hipEvent_t done = nullptr;
+  std::vector<hipEvent_t> ev_a, ev_b;  // per step of a segment: records ready / reverse stages done
   int m0 = 0, nm = 0;
 };
 
 struct dfx_handle {
   Plan pl;
   std::vector<Group> groups;
+  bool dual_chain = true;
+  hipEvent_t ev_fork2 = nullptr;
   PinnedBuf stage;
   hipEvent_t ev_fork = nullptr;
   PackedParams pp;
@@ -857,6 +871,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.n_blocks = pl.n_blocks; c.n_slots = pl.n_slots; c.n_fns = pl.n_fns; c.batch = pl.batch; c.s = pl.tab.s;
   { const char* a = getenv("DFX_ABLATE"); c.ablate = a ? atoi(a) : 0; }
   c.n_wg = (pl.n_slots + kThreads - 1) / kThreads;
+  c.nbuf = 2 * pl.tab.s;
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
   c.traj_stride = pl.batch ? (long long)(h->d_traj.n / pl.batch) : 0;
   c.slot_info = h->d_slot_info.p; c.block_special = h->d_block_special.p; c.special = h->d_special.p;
@@ -948,13 +963,36 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
       for (int i = 0; i < s; ++i) launch_fwd(h, c, g.stream, grid, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
-  } else {
+  } else if (!h->dual_chain) {
     for (int j = n_steps - 1; j >= 0; --j) {
       // recompute the stage records of step n from its checkpoint: stage i -> buffer i+1
+      // (the acceleration of the last stage is re-derived inside its reverse launch, so s-1 recompute launches suffice)
       for (int i = 0; i < s - 1; ++i) launch_fwd(h, c, g.stream, grid, i, j, i == 0 ? -1 : i, i + 1, -1, 0);
-      launch_fwd(h, c, g.stream, grid, s - 1, j, s - 1, -1, -1, 0);
       for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, i == 0 ? -1 : i, -1, 0);
     }
+  } else {
+    // Two chains: A(j) = recompute the stage records of step j (stream2), B(j) = its reverse stages (stream).
+    // B(j) needs A(j); A(j-1) only needs the checkpoint, so it overlaps B(j).  Stage records are double-buffered by
+    // step parity (set p: stage i in buffer 1 + p*(s-1) + i-1), hence A(j-1) must wait for B(j+1), the last reader of its set.
+    Group& gm = h->groups[gi];
+    while ((int)gm.ev_a.size() < n_steps) {
+      hipEvent_t a = nullptr, b = nullptr;
+      (void)hipEventCreateWithFlags(&a, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&b, hipEventDisableTiming);
+      gm.ev_a.push_back(a); gm.ev_b.push_back(b);
+    }
+    auto buf = [&](int j, int i) { return 1 + (j & 1) * (s - 1) + (i - 1); };
+    (void)hipEventRecord(h->ev_fork2, g.stream);                 // stream2 joins the capture / the sequence
+    (void)hipStreamWaitEvent(g.stream2, h->ev_fork2, 0);
+    for (int j = n_steps - 1; j >= 0; --j) {
+      if (j + 2 <= n_steps - 1) (void)hipStreamWaitEvent(g.stream2, gm.ev_b[j + 2], 0);
+      for (int i = 0; i < s - 1; ++i) launch_fwd(h, c, g.stream2, grid, i, j, i == 0 ? -1 : buf(j, i), buf(j, i + 1), -1, 0);
+      (void)hipEventRecord(gm.ev_a[j], g.stream2);
+      (void)hipStreamWaitEvent(g.stream, gm.ev_a[j], 0);
+      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, i == 0 ? -1 : buf(j, i), -1, 0);
+      (void)hipEventRecord(gm.ev_b[j], g.stream);
+    }
+    // every stream2 operation is an ancestor of the last ev_a, which `stream` already waited for: the chains are joined
   }
 }
 
@@ -970,7 +1008,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
   auto key = std::make_pair(n_steps, kind * 64 + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
-  const long long per = 1 + (long long)n_steps * s * (kind == 0 ? 1 : 2);
+  const long long per = 1 + (long long)n_steps * (kind == 0 ? s : 2 * s - 1);
   hipStream_t st = h->groups[gi].stream;
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1024,8 +1062,8 @@ static void build_segments(dfx_handle* h) {
 static int ensure_work_buffers(dfx_handle* h) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s;
-  HIP_OK(h->d_POS.ensure(B * (s + 1) * nb * kPos));
-  HIP_OK(h->d_VEL.ensure(B * (s + 1) * nb * 3));
+  HIP_OK(h->d_POS.ensure(B * (2 * s) * nb * kPos));
+  HIP_OK(h->d_VEL.ensure(B * (2 * s) * nb * 3));
   HIP_OK(h->d_A.ensure(B * (s + 1) * nb * 3));
   HIP_OK(h->d_state0.ensure(B * nb * 6));
   HIP_OK(h->d_cur.ensure(64));
@@ -1142,6 +1180,10 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     int want = e ? atoi(e) : 4;
     int ng = std::max(1, std::min(want, h->pl.batch));
     (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming);
+    // the recompute/reverse overlap pays when the chip is otherwise idle (one system: measured -20 % reverse time for one
+    // 128x128 system) and hurts once member groups already fill the 4 hardware queues (measured +50 % with 4 members)
+    { const char* d = getenv("DFX_DUAL_CHAIN"); h->dual_chain = d ? d[0] != '0' : h->pl.batch == 1; }
     for (int gi = 0; gi < ng; ++gi) {
       Group gr;
       const int base = h->pl.batch / ng, rem = h->pl.batch % ng;
@@ -1150,6 +1192,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
       if (gi == 0) gr.stream = h->stream;   // group 0 rides on the main stream (HIP multiplexes streams onto few hardware queues)
       else if (hipStreamCreateWithFlags(&gr.stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(2); }
       (void)hipEventCreateWithFlags(&gr.done, hipEventDisableTiming);
+      if (hipStreamCreateWithFlags(&gr.stream2, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(2); }
       h->groups.push_back(gr);
     }
   }
@@ -1179,8 +1222,9 @@ int dfx_destroy(dfx_handle* h) {
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_g.release(); h->d_fn_g.release();
   h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release();
-  for (auto& gr : h->groups) { if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
+  for (auto& gr : h->groups) { for (auto e : gr.ev_a) (void)hipEventDestroy(e); for (auto e : gr.ev_b) (void)hipEventDestroy(e); if (gr.stream2) (void)hipStreamDestroy(gr.stream2); if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1614,7 +1658,7 @@ int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
   const size_t B = pl.batch, nb = pl.n_blocks;
   DevCtx c = make_ctx(h);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);
-  std::vector<double> A(B * (pl.tab.s + 1) * nb * 3), S(B * (pl.tab.s + 1) * nb * 3);
+  std::vector<double> A(B * (pl.tab.s + 1) * nb * 3), S(B * (2 * pl.tab.s) * nb * 3);
   HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(S.data(), h->d_VEL.p, sizeof(double) * S.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -1624,7 +1668,7 @@ int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
       for (int d = 0; d < 3; ++d) {
         const int sidx = pl.block_special[b];
         const bool con = sidx >= 0 && ((pl.special[sidx].con_mask >> d) & 1);
-        dy[m * nb * 6 + b * 3 + d] = con ? 0.0 : S[m * (pl.tab.s + 1) * nb * 3 + b * 3 + d];
+        dy[m * nb * 6 + b * 3 + d] = con ? 0.0 : S[m * (2 * pl.tab.s) * nb * 3 + b * 3 + d];
         dy[m * nb * 6 + nb * 3 + b * 3 + d] = A[m * (pl.tab.s + 1) * nb * 3 + b * 3 + d];
       }
   return 0;
@@ -1664,10 +1708,10 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
   if (!h->have_params) { h->err = "energy: set_params first"; return 1; }
   // records straight from u (no constraint override: the energy of the configuration as given)
   if (ensure_work_buffers(h)) return 2;
-  std::vector<double> S(B * (pl.tab.s + 1) * nb * kPos, 0.0);
+  std::vector<double> S(B * (2 * pl.tab.s) * nb * kPos, 0.0);
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b) {
-      double* r = S.data() + m * (pl.tab.s + 1) * nb * kPos + b * kPos;
+      double* r = S.data() + m * (2 * pl.tab.s) * nb * kPos + b * kPos;
       for (int d = 0; d < 3; ++d) r[d] = u[m * nb * 3 + b * 3 + d];
       r[3] = cos(0.5 * r[2]); r[4] = sin(0.5 * r[2]);
     }
