@@ -91,7 +91,10 @@ struct DevCtx {
   const double* p_l;      // n_slots*2   reference vector of the slot's ligament
   const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
   const double* p_phi;    // n_slots*2   undeformed void angles
-  const double* cst;      // 8           min_angle cutoff_angle k_contact | uniform k_stretch k_shear k_rot
+  const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
+  const double* l_dict;   // 256*2
+  int l_dict_on, damping_uniform;
+  const double* cst;      // 16           min_angle cutoff_angle k_contact | uniform k_stretch k_shear k_rot
   const double* inv_m;    // n_blocks*3
   const double* damping;  // n_blocks*3
   const TimeFn* fns;
@@ -238,8 +241,9 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   const size_t ps = (size_t)m * c.n_slots;
   const double2 pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (size_t)b * kPos + 2 * k) : make_double2(0.0, 0.0);
   const double2 ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
-  const double2 lv = *reinterpret_cast<const double2*>(c.p_l + (ps + slot) * 2);
-  const double* cst = c.cst + (size_t)m * 8;
+  const double2 lv = c.l_dict_on ? *reinterpret_cast<const double2*>(c.l_dict + (size_t)m * 512 + 2 * (int)c.p_lidx[ps + slot])
+                                 : *reinterpret_cast<const double2*>(c.p_l + (ps + slot) * 2);
+  const double* cst = c.cst + (size_t)m * 16;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { const double* pk = c.p_k + (ps + slot) * 4; L.ks = pk[0]; L.ksh = pk[1]; L.kr = pk[2]; }
   if (CONTACT) {
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
   const double vn = vel_in(c, m, y_buf, n)[dof];
   const double v_i = vel_in(c, m, in_buf, n)[dof];
   double* Am = c.A + (size_t)m * (c.s + 1) * nd;
-  const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
+  const double damp = c.damping_uniform ? c.cst[(size_t)m * 16 + 6 + kd] : c.damping[(size_t)m * nd + dof];
+  const double invm = c.inv_m[(size_t)m * nd + dof];
   const int sidx = c.block_special[b];
   double sv = 0.0, sq = 0.0;
   for (int l = 0; l < i; ++l) {
@@ -559,7 +564,8 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   const double wpx = Win[(size_t)pb * 3], wpy = Win[(size_t)pb * 3 + 1], wpth = Win[(size_t)pb * 3 + 2];
   const double v_i = vel_in(c, m, in_buf, n)[dof];
   const double kq_in = c.KQ[((size_t)m * 2 + win) * nd + dof];
-  const double damp = c.damping[(size_t)m * nd + dof], invm = c.inv_m[(size_t)m * nd + dof];
+  const double damp = c.damping_uniform ? c.cst[(size_t)m * 16 + 6 + kd] : c.damping[(size_t)m * nd + dof];
+  const double invm = c.inv_m[(size_t)m * nd + dof];
   const int sidx = c.block_special[b];
   double* YBm = c.YB + (size_t)m * c.s * nd6;
   double* LAMm = c.LAM + (size_t)m * nd6;
@@ -837,7 +843,8 @@ struct dfx_handle {
   bool want_bond_grads = true, want_fn_grads = true;
   DevBuf<int32_t> d_slot_info, d_block_special;
   DevBuf<dfx_special> d_special;
-  DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping;
+  DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict;
+  DevBuf<uint8_t> d_l_idx;
   DevBuf<TimeFn> d_fns;
   DevBuf<Seg> d_segs, d_cur;
   DevBuf<Clock> d_clock;
@@ -875,6 +882,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
   c.traj_stride = pl.batch ? (long long)(h->d_traj.n / pl.batch) : 0;
   c.slot_info = h->d_slot_info.p; c.block_special = h->d_block_special.p; c.special = h->d_special.p;
+  c.p_lidx = h->d_l_idx.p; c.l_dict = h->d_l_dict.p; c.l_dict_on = h->pp.l_dict_ok ? 1 : 0; c.damping_uniform = h->pp.damping_uniform ? 1 : 0;
   c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;
   c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.fns = h->d_fns.p;
   c.cur = h->d_cur.p;
@@ -1215,7 +1223,7 @@ int dfx_destroy(dfx_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release();
-  h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release();
+  h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
@@ -1240,13 +1248,21 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
   auto t1 = std::chrono::steady_clock::now();
   const PackedParams& pp = h->pp;
   {
-    const std::vector<double>* src[7] = {&pp.p_r, &pp.p_l, pp.k_uniform ? nullptr : &pp.p_k, &pp.p_phi, &pp.cst, &pp.inv_m, &pp.damping};
-    DevBuf<double>* dst[7] = {&h->d_p_r, &h->d_p_l, &h->d_p_k, &h->d_p_phi, &h->d_cst, &h->d_inv_m, &h->d_damping};
-    size_t total = 0;
-    for (int i = 0; i < 7; ++i) if (src[i]) total += src[i]->size() * sizeof(double);
-    HIP_OK(h->stage.ensure(total));
+    constexpr int NA = 8;
+    const std::vector<double>* src[NA] = {&pp.p_r, pp.l_dict_ok ? nullptr : &pp.p_l, pp.k_uniform ? nullptr : &pp.p_k, &pp.p_phi, &pp.cst, &pp.inv_m,
+                                          pp.damping_uniform ? nullptr : &pp.damping, pp.l_dict_ok ? &pp.l_dict : nullptr};
+    DevBuf<double>* dst[NA] = {&h->d_p_r, &h->d_p_l, &h->d_p_k, &h->d_p_phi, &h->d_cst, &h->d_inv_m, &h->d_damping, &h->d_l_dict};
+    size_t total = pp.l_idx.size();
+    for (int i = 0; i < NA; ++i) if (src[i]) total += src[i]->size() * sizeof(double);
+    HIP_OK(h->stage.ensure(total + 64));
     size_t off = 0;
-    for (int i = 0; i < 7; ++i) {
+    if (pp.l_dict_ok) {
+      HIP_OK(h->d_l_idx.ensure(pp.l_idx.size()));
+      memcpy(h->stage.p, pp.l_idx.data(), pp.l_idx.size());
+      HIP_OK(hipMemcpyAsync(h->d_l_idx.p, h->stage.p, pp.l_idx.size(), hipMemcpyHostToDevice, h->stream));
+      off = (pp.l_idx.size() + 63) & ~(size_t)63;
+    }
+    for (int i = 0; i < NA; ++i) {
       if (!src[i] || src[i]->empty()) continue;
       const size_t bytes = src[i]->size() * sizeof(double);
       HIP_OK(dst[i]->ensure(src[i]->size()));

@@ -86,8 +86,13 @@ struct PackedParams {
   std::vector<double> p_l;      // batch * n_slots * 2 : reference vector (oriented node1 -> node2)
   std::vector<double> p_k;      // batch * n_slots * 4 : k_stretch, k_shear, k_rot, 0
   std::vector<double> p_phi;    // batch * n_slots * 2 : undeformed void angles
-  std::vector<double> cst;      // batch * 8 : min_angle, cutoff_angle, k_contact, k_stretch, k_shear, k_rot (if uniform), 0, 0
+  std::vector<double> cst;      // batch * 16 (first 9 used) : min_angle, cutoff_angle, k_contact, k_stretch, k_shear, k_rot (if uniform), 0, 0
   bool k_uniform = true;        // every ligament of a member has the same three stiffnesses
+  // dictionary compression of per-slot constants that take few distinct values (lattices have 2-3 reference vectors):
+  std::vector<uint8_t> l_idx;   // batch * n_slots : index into l_dict
+  std::vector<double> l_dict;   // batch * 256 * 2
+  bool l_dict_ok = true;        // <= 256 distinct reference vectors in every member
+  bool damping_uniform = true;  // the three per-DOF damping coefficients are the same for every block of a member (cst[6..8])
 };
 
 inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, std::string& err, bool gpu_image = true) {
@@ -137,8 +142,10 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     if (m == 0) {
       out.p_r.assign((size_t)B * NS * 2, 0.0); out.p_l.assign((size_t)B * NS * 2, 0.0);
       out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
-      out.cst.assign((size_t)B * 8, 0.0);
+      out.cst.assign((size_t)B * 16, 0.0);
       out.k_uniform = true;
+      out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 512, 0.0);
+      out.l_dict_ok = true; out.damping_uniform = true;
     }
     for (int s_ = 0; s_ < NS; ++s_) {
       const double* s = sp + (size_t)s_ * kSlotParams;
@@ -156,8 +163,28 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
         if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) out.k_uniform = false;
       }
     }
-    if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 8 + i] = q->contact[m * 3 + i];
-    if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 8 + 3 + i] = kb[i];
+    if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + i] = q->contact[m * 3 + i];
+    if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + 3 + i] = kb[i];
+    {  // dictionary of reference vectors
+      int n_dict = 0;
+      double* dict = out.l_dict.data() + (size_t)m * 512;
+      for (int s_ = 0; s_ < NS && out.l_dict_ok; ++s_) {
+        if (pl.slot_info[s_] < 0) continue;
+        const double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
+        int hit = -1;
+        for (int d = 0; d < n_dict; ++d) if (dict[2 * d] == l[0] && dict[2 * d + 1] == l[1]) { hit = d; break; }
+        if (hit < 0) {
+          if (n_dict == 256) { out.l_dict_ok = false; break; }
+          hit = n_dict++; dict[2 * hit] = l[0]; dict[2 * hit + 1] = l[1];
+        }
+        out.l_idx[(size_t)m * NS + s_] = (uint8_t)hit;
+      }
+    }
+    for (int d = 0; d < 3; ++d) {
+      const double d0 = out.damping[(size_t)m * NB * 3 + d];
+      out.cst[(size_t)m * 16 + 6 + d] = d0;
+      for (int b = 1; b < NB && out.damping_uniform; ++b) if (out.damping[(size_t)m * NB * 3 + b * 3 + d] != d0) out.damping_uniform = false;
+    }
   }
   return 0;
 }

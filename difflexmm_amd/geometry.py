@@ -25,19 +25,37 @@ def rotation_matrix(angle):
 def polygon_props(v):
     """area, centroid, polar moment about the centroid of CCW polygons v (..., n, 2).
     Works for complex input (used by the complex-step Jacobians): |S| is sign(Re S) * S."""
-    v1 = np.roll(v, 1, axis=-2)
-    cr = v1[..., 0] * v[..., 1] - v1[..., 1] * v[..., 0]
+    x, y = v[..., 0], v[..., 1]
+    x1, y1 = np.roll(x, 1, axis=-1), np.roll(y, 1, axis=-1)
+    cr = x1 * y - y1 * x
     S = cr.sum(-1)
     area = np.where(S.real < 0, -1.0, 1.0) * S / 2                      # geometry.py:84
-    s = v1 + v
-    cen = np.stack([(s[..., 0] * cr).sum(-1), (s[..., 1] * cr).sum(-1)], -1) / (6 * area)[..., None]  # :103-106
-    a = v1 - cen[..., None, :]
-    b = v - cen[..., None, :]
-    crc = a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
-    q = a[..., 0] ** 2 + a[..., 0] * b[..., 0] + b[..., 0] ** 2 + a[..., 1] ** 2 + a[..., 1] * b[..., 1] + b[..., 1] ** 2
-    M = (crc * q).sum(-1) / 12
+    cx = ((x1 + x) * cr).sum(-1) / (6 * area)                           # geometry.py:103-106
+    cy = ((y1 + y) * cr).sum(-1) / (6 * area)
+    ax, ay, bx, by = x1 - cx[..., None], y1 - cy[..., None], x - cx[..., None], y - cy[..., None]
+    q = ax * ax + ax * bx + bx * bx + ay * ay + ay * by + by * by
+    M = ((ax * by - ay * bx) * q).sum(-1) / 12
     ip = np.where(M.real < 0, -1.0, 1.0) * M                              # geometry.py:123-127
-    return area, cen, ip
+    return area, np.stack([cx, cy], -1), ip
+
+
+# (area, polar moment) of centred node vectors produced by a lattice class in this process, keyed by the identity of the
+# (read-only) array: compute_inertia on exactly that array then costs nothing (one polygon pass per design instead of three).
+_PROPS_CACHE = {}
+
+
+def _remember_props(cnv, area, ip):
+    import weakref
+    cnv.flags.writeable = False
+    key = id(cnv)
+    _PROPS_CACHE[key] = (weakref.ref(cnv, lambda _r, k=key: _PROPS_CACHE.pop(k, None)), area, ip)
+
+
+def _recall_props(v):
+    hit = _PROPS_CACHE.get(id(v))
+    if hit is not None and hit[0]() is v:
+        return hit[1], hit[2]
+    return None
 
 
 def polygon_area(v):
@@ -71,7 +89,11 @@ def polygon_props_jac(v):
 
 def compute_inertia(vertices, density):
     """geometry.py:144-160 -> (n_blocks, 3) = [rho A, rho A, rho I_p]."""
-    area, _, ip = polygon_props(np.asarray(vertices, dtype=float))
+    hit = _recall_props(vertices)
+    if hit is None:
+        area, _, ip = polygon_props(np.asarray(vertices, dtype=float))
+    else:
+        area, ip = hit
     m = density * area
     return np.column_stack((m, m, density * ip))
 
@@ -176,8 +198,15 @@ class Geometry:
 
     # centred node vectors / centroids from the un-centred reference node vectors
     def _centre(self, ref):
-        cen = polygon_props(ref)[1]
-        return ref - cen[:, None, :], cen
+        area, cen, ip = polygon_props(ref)
+        cnv = ref - cen[:, None, :]
+        _remember_props(cnv, area, ip)      # the polar moment is about the centroid: translation-invariant
+        return cnv, cen
+
+    def geometry_from_design(self, *design):
+        """(block_centroids, centroid_node_vectors) from one polygon pass (the two reference callables each do their own)."""
+        cnv, cen = self._centre(self.reference_node_vectors(*design))
+        return self.reference_points() + cen, cnv
 
     def _centre_vjp(self, ref, cnv_bar, centroid_bar):
         _, dC, _ = polygon_props_jac(ref)

@@ -145,10 +145,9 @@ class QuadsFocusingForward:
         self.is_setup = True
 
     def control_params(self, design):
-        g = self.geometry
+        centroids, cnv = self.geometry.geometry_from_design(*design)
         return ControlParams(
-            geometrical_params=GeometricalParams(block_centroids=g.block_centroids(*design),
-                                                 centroid_node_vectors=g.centroid_node_vectors(*design)),
+            geometrical_params=GeometricalParams(block_centroids=centroids, centroid_node_vectors=cnv),
             mechanical_params=MechanicalParams(
                 bond_params=LigamentParams(self.k_stretch, self.k_shear, self.k_rot, self.reference_bond_vectors),
                 density=self.density, damping=self.damping,

@@ -1,7 +1,7 @@
 import time, numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-fw, obj, des = bench.c3_problem(128, 3, 4)
+fw, obj, des = bench.c3_problem(128, 3, int(os.environ.get("M", "8")))
 eng = fw.solve_dynamics.engine
 eng.reserve(2500, 11, True)
 bench.run_once(fw, obj, des, 250)
