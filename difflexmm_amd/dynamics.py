@@ -169,7 +169,31 @@ class DynamicSolver:
             fb = fb[None]
         grads, stats = self.engine.adjoint(fb)
         self.adjoint_stats = stats
-        return self._unflatten_grads(grads, fb)
+        trees, s0 = self._unflatten_grads(grads, fb)
+        # cotangents on the OUTPUTS of prescribed DOFs feed the constraint parameters directly:
+        # fields[k, 0, dof] = c_dof(t_k; p), fields[k, 1, dof] = dc_dof/dt(t_k; p)   (dynamics.py:132-134, 169-182)
+        if len(self.constrained_pairs) and self.con_terms:
+            cps, flats, ts = self._last
+            tl = trees if isinstance(trees, list) else [trees]
+            n_con = len(self.constrained_pairs)
+            dofs = self.constrained_pairs[:, 0] * 3 + self.constrained_pairs[:, 1]
+            for m, (cp, tree) in enumerate(zip(cps, tl)):
+                fbm = fb[m].reshape(len(ts), 2, -1)
+                for term in self.con_terms:
+                    vec = _bcast(term.vector, n_con)
+                    wq = fbm[:, 0, dofs] @ vec          # (T,) weights of g(t_k)
+                    wv = fbm[:, 1, dofs] @ vec          # (T,) weights of g'(t_k)
+                    if not (np.any(wq) or np.any(wv)):
+                        continue
+                    p = term.resolve(cp.constraint_params)
+                    g5 = np.zeros(_b.DFX_FN_PARAMS)
+                    for k, t in enumerate(ts):
+                        if wq[k]:
+                            g5 += wq[k] * term.param_partials(float(t), p, "value")
+                        if wv[k]:
+                            g5 += wv[k] * term.param_partials(float(t), p, "rate")
+                    term.scatter_grad(g5, tree.constraint_params)
+        return trees, s0
 
     def kinetic_energy_value_and_vjp(self, target_blocks):
         """objective = sum_t sum_{b in target} m v^2/2 (energy.py:494-499 over problems/quads_focusing.py:461-467),

@@ -50,6 +50,23 @@ class TimeFunction:
     def value(self, t, p):
         return 0.0
 
+    def rate(self, t, p, eps=1e-7):
+        """d value / dt (central difference in the scale of t; the kernels use the analytic form)."""
+        h = eps * max(1.0, abs(t))
+        return (self.value(t + h, p) - self.value(t - h, p)) / (2 * h)
+
+    def param_partials(self, t, p, of="value"):
+        """d value/dp or d rate/dp (5 numbers) by central differences -- only used on the host for the cotangents of
+        prescribed-DOF OUTPUTS, a handful of numbers per solve."""
+        f = self.value if of == "value" else self.rate
+        out = np.zeros(DFX_FN_PARAMS)
+        for i in range(len(self.param_names)):
+            h = 1e-6 * max(1.0, abs(p[i]))
+            pp, pm = p.copy(), p.copy()
+            pp[i] += h; pm[i] -= h
+            out[i] = (f(t, pp) - f(t, pm)) / (2 * h)
+        return out
+
     def _eval(self, t, kwargs):
         return self.vector * self.value(float(t), self.resolve(kwargs))
 
