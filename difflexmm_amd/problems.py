@@ -167,6 +167,25 @@ class QuadsFocusingForward:
                             self.bond_connectivity, self.timepoints, fields)
 
 
+def _compute_response_data(self, solution_data):
+    """Strain-energy and kinetic-energy histories of a solution (problems/quads_focusing.py:319-372): the fields of
+    SolutionData plus strain_energy_{stretch,shear,bending} (T, n_bonds) and kinetic_energy (T, n_blocks)."""
+    if type(solution_data) is not SolutionData:
+        raise ValueError("Solution data is not of type SolutionData!")
+    out = solution_data._asdict()
+    axial, shear, bending = E.compute_ligament_strains_history(solution_data.fields[:, 0], solution_data.centroid_node_vectors,
+                                                               solution_data.bond_connectivity, self.reference_bond_vectors)
+    out["strain_energy_stretch"] = 0.5 * self.k_stretch * (axial * self.bond_length) ** 2
+    out["strain_energy_shear"] = 0.5 * self.k_shear * (shear * self.bond_length) ** 2
+    out["strain_energy_bending"] = 0.5 * self.k_rot * bending ** 2
+    inertia = compute_inertia(solution_data.centroid_node_vectors, self.density)
+    out["kinetic_energy"] = np.sum(0.5 * solution_data.fields[:, 1] ** 2 * inertia, axis=-1)
+    return out
+
+
+QuadsFocusingForward.compute_response_data = _compute_response_data
+
+
 @dataclass
 class KagomeFocusingForward:
     """NumPy counterpart of ``problems/kagome_focusing.py:ForwardProblem`` (fields with the same names; left-loaded)."""
@@ -225,6 +244,7 @@ class KagomeFocusingForward:
 
     control_params = QuadsFocusingForward.control_params
     solve = QuadsFocusingForward.solve
+    compute_response_data = _compute_response_data
 
 
 class TargetKineticEnergy:

@@ -20,4 +20,16 @@ def load():
     if _LIB is None:
         from difflexmm_amd._binding import declare
         _LIB = declare(ctypes.CDLL(build()))
+        # hosts report hundreds of logical CPUs but may grant only a few: a spinning 256-thread OpenMP team on small
+        # lattices is pathologically slow, so cap the team unless the user asked for something else
+        if "OMP_NUM_THREADS" not in os.environ:
+            set_threads(min(os.cpu_count() or 1, 8))
     return _LIB
+
+
+def set_threads(n):
+    """Number of OpenMP threads of the CPU port (libgomp)."""
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass

@@ -91,3 +91,19 @@ def test_optimisation_loop_increases_objective_and_stays_feasible(cpu_lib):
     assert P.edge_length_constraints(fw.geometry, x, 1.0).max() <= 1e-8
     d = opt.to_dict()
     assert len(d["design_values"]) == len(d["objective_values"])
+
+
+def test_response_data_energies(cpu_lib):
+    """problems/quads_focusing.py:319-372: per-bond strain energies and per-block kinetic energy histories; the summed
+    strain energy equals the engine's potential energy (no contact active here)."""
+    fw = _quads(cpu_lib)
+    sol = fw.solve(_design(fw))
+    r = fw.compute_response_data(sol)
+    T, nb = len(fw.timepoints), fw.geometry.n_blocks
+    assert r["strain_energy_stretch"].shape == (T, len(fw.bond_connectivity)) and r["kinetic_energy"].shape == (T, nb)
+    cp = fw.control_params(_design(fw))
+    flat = fw.solve_dynamics._flatten(cp)
+    fw.solve_dynamics.engine.set_params(**{k: v[None] for k, v in flat.items()})
+    e = fw.solve_dynamics.engine.energy(sol.fields[-1, 0][None])[0]
+    tot = (r["strain_energy_stretch"] + r["strain_energy_shear"] + r["strain_energy_bending"])[-1].sum()
+    assert abs(e - tot) / tot < 1e-10
