@@ -226,6 +226,8 @@ class Engine:
 
     def adjoint(self, fields_bar, which=ALL_GRADS):
         B, nb = self.batch, self.n_blocks
+        if self.n_timepoints is None:
+            raise RuntimeError("dfx_adjoint failed: run forward with keep_trajectory=1 first")
         fb = _f64(fields_bar, (B, self.n_timepoints, 2, nb, 3))
         g, out = self._grads(which)
         st = dfx_stats()
