@@ -105,7 +105,7 @@ class Case:
     def oracle_cp(self, leaves=None):
         """Oracle ControlParams; ``leaves`` (dict name -> torch tensor) overrides entries so autograd can track them."""
         def T(x):
-            return torch.as_tensor(np.asarray(x, dtype=np.float64))
+            return torch.as_tensor(np.array(x, dtype=np.float64))
         lv = dict(cnv=T(self.cnv), cen=T(self.cen), refv=T(self.refv),
                   ks=T(self.ks), ksh=T(self.ksh), kr=T(self.kr),
                   density=T(DENSITY), damping=T(self.dval),
