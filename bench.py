@@ -85,8 +85,18 @@ def execute(fw, obj, adjoint=True, spi=SPI):
     return out
 
 
+def spin_up(fw, n_steps=500, spi=SPI):
+    """Untimed burst on the resident inputs right before a timed region: the host-side preparation leaves the GPU idle
+    for tens of milliseconds and the first launches after an idle period run at a lower clock."""
+    eng = fw.solve_dynamics.engine
+    ts = np.arange(n_steps // spi + 1) * (spi * DT)
+    eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), ts, spi, keep_trajectory=False, want_fields=False)
+
+
 def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
     prepare(fw, designs, n_steps, spi)
+    if fw.solve_dynamics.engine.lib.dfx_device_count() > 0:
+        spin_up(fw, spi=spi) if spi == SPI else None
     return execute(fw, obj, adjoint, spi)
 
 
@@ -173,6 +183,7 @@ def main():
         torch.cuda.synchronize()
 
     prepare(fw, designs, K)                    # inputs resident in HBM before the timed region
+    spin_up(fw)
     barrier()
     t0 = time.perf_counter()
     res = execute(fw, obj, adjoint=not args.forward_only)
@@ -263,6 +274,7 @@ def main():
             fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 1, keep_trajectory=True)
             run_once(fw1, obj1, des1, SPI)
             prepare(fw1, des1, K1)
+            spin_up(fw1)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             r1 = execute(fw1, obj1)

@@ -92,7 +92,7 @@ struct DevCtx {
   const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
   const double* p_phi;    // n_slots*2   undeformed void angles
   const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
-  const double* l_dict;   // 256*2
+  const double* l_dict;   // 256*4   lx ly |l0| 1/|l0|
   int l_dict_on, damping_uniform;
   const double* cst;      // 16           min_angle cutoff_angle k_contact | uniform k_stretch k_shear k_rot
   const double* inv_m;    // n_blocks*3
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
   c.VEL[((size_t)m * c.nbuf + buf) * nd + b * 3 + d] = v;
   if (d == 2) {
     double sn, cs;
-    sincos(0.5 * q, &sn, &cs);
+    fast_sincos(0.5 * q, &sn, &cs);
     pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
   }
 }
@@ -241,8 +241,13 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   const size_t ps = (size_t)m * c.n_slots;
   const double2 pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (size_t)b * kPos + 2 * k) : make_double2(0.0, 0.0);
   const double2 ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
-  const double2 lv = c.l_dict_on ? *reinterpret_cast<const double2*>(c.l_dict + (size_t)m * 512 + 2 * (int)c.p_lidx[ps + slot])
-                                 : *reinterpret_cast<const double2*>(c.p_l + (ps + slot) * 2);
+  double2 lv, ln = make_double2(0.0, 0.0);
+  if (c.l_dict_on) {
+    const double2* e = reinterpret_cast<const double2*>(c.l_dict + (size_t)m * 1024 + 4 * (int)c.p_lidx[ps + slot]);
+    lv = e[0]; ln = e[1];
+  } else {
+    lv = *reinterpret_cast<const double2*>(c.p_l + (ps + slot) * 2);
+  }
   const double* cst = c.cst + (size_t)m * 16;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { const double* pk = c.p_k + (ps + slot) * 4; L.ks = pk[0]; L.ksh = pk[1]; L.kr = pk[2]; }
@@ -263,9 +268,11 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   L.p.x = b0.x; L.p.y = b0.y; L.p.th = b1.x; L.p.ch = b1.y; L.p.sh = b2;
   L.rox = ro.x; L.roy = ro.y; L.rpx = rp.x; L.rpy = rp.y;
   L.lx = lv.x; L.ly = lv.y;
-  const double l02 = lv.x * lv.x + lv.y * lv.y;
-  L.il0 = info < 0 ? 1.0 : rsqrt(l02);
-  L.l0 = l02 * L.il0;
+  if (c.l_dict_on) { L.l0 = ln.x; L.il0 = ln.y; }
+  else {
+    L.l0 = info < 0 ? 1.0 : sqrt(lv.x * lv.x + lv.y * lv.y);
+    L.il0 = 1.0 / L.l0;
+  }
   L.sgn = (info & 1) ? 1.0 : -1.0;
 }
 
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
   // ---- publish the next stage record: lanes 0..2 each store one aligned 16-byte chunk (x,y) (th,ch) (sh,0)
   const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
   double sn, cs;
-  sincos(0.5 * th2, &sn, &cs);
+  fast_sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3 && !(c.ablate & 2)) {
     *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + out_buf) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
   if (constrained) { TimeVals tv = constrained_value(c, m, c.special[sidx], k, ck.t + dc.a10 * ck.h); qnext = tv.g; vnext = tv.gt; }
   const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
   double sn, cs;
-  sincos(0.5 * th2, &sn, &cs);
+  fast_sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3) {
     *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* st
   c.VEL[((size_t)m * c.nbuf + buf) * nd + b * 3 + d] = v;
   if (d == 2) {
     double sn, cs;
-    sincos(0.5 * q, &sn, &cs);
+    fast_sincos(0.5 * q, &sn, &cs);
     pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
   }
 }

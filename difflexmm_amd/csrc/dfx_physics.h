@@ -94,9 +94,62 @@ DFX_HD Dual tsqrt(Dual a) {
   double s = sqrt(a.v);
   return Dual(s, 0.5 * a.e / s);
 }
-DFX_HD double tatan2(double y, double x) { return atan2(y, x); }
+// 1/sqrt: one transcendental instead of sqrt + reciprocal (v_rsq_f64 + Newton on the device)
+DFX_HD double trsqrt(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(a);
+#else
+  return 1.0 / sqrt(a);
+#endif
+}
+DFX_HD Dual trsqrt(Dual a) {
+  double r = trsqrt(a.v);
+  return Dual(r, -0.5 * a.e * r * r * r);
+}
+// atan2 with a short path for small angles in the right half plane: the shear angle of a ligament is almost always a
+// few degrees, and the general fp64 atan2 is ~120 instructions.  |y| <= x/8: the alternating series through r^17
+// truncates below 3e-18 relative.
+DFX_HD double fast_atan2(double y, double x) {
+  if (x > 0.0 && fabs(y) <= 0.125 * x) {
+    const double r = y * trcp(x), z = r * r;
+    double p = -1.0 / 17.0;
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, -1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, -1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, -1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    return fma(-(r * z), p, r);
+  }
+  return atan2(y, x);
+}
+DFX_HD double tatan2(double y, double x) { return fast_atan2(y, x); }
 DFX_HD Dual tatan2(Dual y, Dual x) {
-  return Dual(atan2(y.v, x.v), (x.v * y.e - y.v * x.e) / (x.v * x.v + y.v * y.v));
+  return Dual(fast_atan2(y.v, x.v), (x.v * y.e - y.v * x.e) * trcp(x.v * x.v + y.v * y.v));
+}
+// sin and cos for |x| <= pi/4 by the fdlibm kernel polynomials (< 1 ulp), library sincos otherwise: the half rotation
+// angle of a block is small except in extreme configurations, and the general fp64 sincos is ~190 instructions.
+DFX_HD void fast_sincos(double x, double* sn, double* cs) {
+  if (fabs(x) <= 0.78539816339744830962) {
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    *sn = fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    *cs = 1.0 - (0.5 * z - z * (z * pc));
+  } else {
+    sincos(x, sn, cs);
+  }
 }
 // wrap an angle into [-pi, pi] (value only; derivative 1)
 DFX_HD double twrap(double a) { return a - kTwoPi * rint(a * (1.0 / kTwoPi)); }
@@ -159,12 +212,12 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, T rox, T roy, 
     T cb = o.ch * p.ch - o.sh * p.sh, sb = o.sh * p.ch + o.ch * p.sh;  // cos/sin of (th_o+th_p)/2
     T bx = dUx + lx, by = dUy + ly;
     T L2 = bx * bx + by * by;
-    T Lb = tsqrt(L2);
+    T Lb = tsqrt(L2);          // correctly rounded: a lattice at rest has Lb == l0 bit for bit, hence exactly zero force
+    T iLb = trcp(Lb);
+    T iL2 = iLb * iLb;
     T px = cb * lx - sb * ly, py = sb * lx + cb * ly;
     T gam = tatan2(px * by - py * bx, px * bx + py * by);
     T es = Lb - l0;
-    T iL2 = trcp(L2);
-    T iLb = Lb * iL2;
     T kse = ks * es, kshg = ksh * gam;
     T shear = kshg * l02;  // dE/dgamma
     g.e = 0.5 * (kse * es) + 0.5 * (shear * gam) + 0.5 * (kr * kap * kap);

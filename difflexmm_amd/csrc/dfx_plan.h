@@ -90,7 +90,7 @@ struct PackedParams {
   bool k_uniform = true;        // every ligament of a member has the same three stiffnesses
   // dictionary compression of per-slot constants that take few distinct values (lattices have 2-3 reference vectors):
   std::vector<uint8_t> l_idx;   // batch * n_slots : index into l_dict
-  std::vector<double> l_dict;   // batch * 256 * 2
+  std::vector<double> l_dict;   // batch * 256 * 4 : lx, ly, |l0|, 1/|l0|
   bool l_dict_ok = true;        // <= 256 distinct reference vectors in every member
   bool damping_uniform = true;  // the three per-DOF damping coefficients are the same for every block of a member (cst[6..8])
 };
@@ -144,7 +144,7 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
       out.cst.assign((size_t)B * 16, 0.0);
       out.k_uniform = true;
-      out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 512, 0.0);
+      out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 1024, 0.0);
       out.l_dict_ok = true; out.damping_uniform = true;
     }
     for (int s_ = 0; s_ < NS; ++s_) {
@@ -167,15 +167,16 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + 3 + i] = kb[i];
     {  // dictionary of reference vectors
       int n_dict = 0;
-      double* dict = out.l_dict.data() + (size_t)m * 512;
+      double* dict = out.l_dict.data() + (size_t)m * 1024;
       for (int s_ = 0; s_ < NS && out.l_dict_ok; ++s_) {
         if (pl.slot_info[s_] < 0) continue;
         const double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
         int hit = -1;
-        for (int d = 0; d < n_dict; ++d) if (dict[2 * d] == l[0] && dict[2 * d + 1] == l[1]) { hit = d; break; }
+        for (int d = 0; d < n_dict; ++d) if (dict[4 * d] == l[0] && dict[4 * d + 1] == l[1]) { hit = d; break; }
         if (hit < 0) {
           if (n_dict == 256) { out.l_dict_ok = false; break; }
-          hit = n_dict++; dict[2 * hit] = l[0]; dict[2 * hit + 1] = l[1];
+          hit = n_dict++; dict[4 * hit] = l[0]; dict[4 * hit + 1] = l[1];
+          dict[4 * hit + 2] = sqrt(l[0] * l[0] + l[1] * l[1]); dict[4 * hit + 3] = 1.0 / dict[4 * hit + 2];
         }
         out.l_idx[(size_t)m * NS + s_] = (uint8_t)hit;
       }

@@ -125,7 +125,7 @@ DFX_HD void fwd_dof(const Tables& tb, const Tableau& T, const FwdStage& st, int 
   ro[5 + d] = vnext;
   if (d == 2) {
     double s, c;
-    sincos(0.5 * qnext, &s, &c);
+    fast_sincos(0.5 * qnext, &s, &c);
     ro[3] = c;
     ro[4] = s;
   }
@@ -151,7 +151,7 @@ DFX_HD void init_dof(const Tables& tb, const double* state0 /* (2, n_blocks, 3) 
   r[5 + d] = v;
   if (d == 2) {
     double s, c;
-    sincos(0.5 * q, &s, &c);
+    fast_sincos(0.5 * q, &s, &c);
     r[3] = c;
     r[4] = s;
   }
