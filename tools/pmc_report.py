@@ -1,0 +1,14 @@
+"""Summarise rocprofv3 --pmc counter_collection.csv files per stage kernel (mean per dispatch)."""
+import csv, glob, sys, collections, json
+import numpy as np
+out = {}
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = "fwd" if "k_fwd_stage" in r["Kernel_Name"] else "adj" if "k_adj_stage" in r["Kernel_Name"] else None
+            if k:
+                acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            out.setdefault(k, {})[c] = float(np.mean(v))
+print(json.dumps(out, indent=1))
