@@ -143,11 +143,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=250)
-    ap.add_argument("--members", type=int, default=4, help="independent designs per GPU integrated side by side (grid.y)")
+    ap.add_argument("--members", type=int, default=16,
+                    help="independent designs per GPU integrated side by side (grid.y); capped so that the per-step "
+                         "checkpoint of all members (72 B x units x steps each) fits the free HBM")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="member groups advanced concurrently, one HIP stream each")
+    ap.add_argument("--streams", type=int, default=2, help="member groups advanced concurrently, one HIP stream each")
     ap.add_argument("--no-single", action="store_true", help="skip the extra 1-member reference measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
@@ -171,6 +173,19 @@ def main():
     os.environ["DFX_STREAMS"] = str(args.streams)
     K = max(SPI, (args.steps // SPI) * SPI)
     W = 0 if args.warmup <= 0 else max(SPI, (args.warmup // SPI) * SPI)
+    requested_members = args.members
+    if not args.forward_only and args.backend == "nccl":
+        # the reverse sweep reads a checkpoint of every step: 72 B per unit per step per member
+        free_b, _ = torch.cuda.mem_get_info(local_rank)
+        per_member = 72.0 * args.size * args.size * (max(K, W) + 1) + 64e6
+        args.members = max(1, min(args.members, int(0.85 * free_b / per_member)))
+        if dist is not None:                    # same work on every rank (weak scaling): take the smallest cap
+            tm = torch.tensor([args.members], device=dev, dtype=torch.int64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MIN)
+            args.members = int(tm.item())
+        if args.members < args.streams:
+            args.streams = args.members
+            os.environ["DFX_STREAMS"] = str(args.streams)
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
     fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 1, keep_trajectory=not args.forward_only)
     if W:
@@ -240,7 +255,7 @@ def main():
             "config": {"workload": f"C3: {args.size}x{args.size} quads, nonlinear ligaments + damping + angle contact, "
                                    f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
                                    f"{'forward only' if args.forward_only else 'forward + adjoint wrt 66048 geometry params'}",
-                       "members_per_gpu": args.members, "concurrent_streams": streams, "integrator": "dopri5-fixed",
+                       "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams, "integrator": "dopri5-fixed",
                        "steps_per_output": SPI},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},

@@ -90,7 +90,7 @@ struct DevCtx {
   const double* p_r;      // n_slots*2   own centroid->node vector
   const double* p_l;      // n_slots*2   reference vector of the slot's ligament
   const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
-  const double* p_phi;    // n_slots*2   undeformed void angles
+  const double* p_phi;    // n_slots     undeformed void angle: phi1 on end-0 slots, phi2 on end-1 slots (the other one is gathered from the partner slot)
   const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
   const double* l_dict;   // 256*4   lx ly |l0| 1/|l0|
   int l_dict_on, damping_uniform;
@@ -116,9 +116,10 @@ struct DevCtx {
   double* KQ;             // batch * 2 * n_blocks*3
   const double* G;        // T * batch * n_blocks*6 (time-major)
   double* g_r;            // batch * n_slots*2     d/d(own node vector)
-  double* g_phi;          // batch * n_slots*2     d/d(void angles)       (end-1 slots)
+  double* g_phi;          // batch * n_slots       d/d(void angle): phi1 on the end-0 slot of a ligament, phi2 on its end-1 slot
   double* g_b;            // batch * n_slots*8     d/d(l0(2), k(3), contact(3)) (end-1 slots) or null
-  double* blk_g;          // batch * n_blocks*6
+  double* blk_m;          // batch * n_blocks*3    d/d(inertia)
+  double* blk_c;          // batch * n_blocks*3    d/d(damping) or null
   double* fn_g;           // batch * n_special*MAX_FNS*FN_PARAMS or null
 };
 
@@ -252,8 +253,7 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { const double* pk = c.p_k + (ps + slot) * 4; L.ks = pk[0]; L.ksh = pk[1]; L.kr = pk[2]; }
   if (CONTACT) {
-    const double2 ph = *reinterpret_cast<const double2*>(c.p_phi + (ps + slot) * 2);
-    L.phi1 = ph.x; L.phi2 = ph.y;
+    L.phi1 = c.p_phi[ps + slot];
     L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2];
   }
   // partner (dependent on info)
@@ -262,6 +262,11 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   const double2 b0 = reinterpret_cast<const double2*>(pp)[0], b1 = reinterpret_cast<const double2*>(pp)[1];
   const double b2 = pp[4];
   const double2 rp = *reinterpret_cast<const double2*>(c.p_r + (ps + pslot) * 2);
+  if (CONTACT) {
+    const double own = L.phi1, other = c.p_phi[ps + pslot];
+    L.phi1 = (info & 1) ? other : own;
+    L.phi2 = (info & 1) ? own : other;
+  }
   L.o.x = quad_bcast<0>(pc.x); L.o.y = quad_bcast<0>(pc.y);
   L.o.th = quad_bcast<1>(pc.x); L.o.ch = quad_bcast<1>(pc.y);
   L.o.sh = quad_bcast<2>(pc.x);
@@ -610,13 +615,9 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
     double2 r = *gr;
     r.x -= g.rx.e; r.y -= g.ry.e;
     *gr = r;
+    // both ends hold the same contact dual: each accumulates one of the two void-angle derivatives (8 B per lane)
+    if (CONTACT) c.g_phi[gs] -= (L.info & 1) ? cg.p2.e : cg.p1.e;
     if (!(L.info & 1)) {
-      if (CONTACT) {
-        double2* gp = reinterpret_cast<double2*>(c.g_phi + gs * 2);
-        double2 q = *gp;
-        q.x -= cg.p1.e; q.y -= cg.p2.e;
-        *gp = q;
-      }
       if (c.g_b) {
         double* q = c.g_b + gs * 8;
         q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
@@ -661,9 +662,8 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
-      double* q = c.blk_g + ((size_t)m * c.n_blocks + b) * 6;
-      q[k] -= w_d * a_i;
-      q[3 + k] -= w_d * v_i;
+      c.blk_m[(size_t)m * nd + dof] -= w_d * a_i;
+      if (c.blk_c) c.blk_c[(size_t)m * nd + dof] -= w_d * v_i;
     }
     YBm[(size_t)i * nd6 + b * 6 + k] = ybq;
     YBm[(size_t)i * nd6 + b * 6 + 3 + k] = ybv;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fi
   if (threadIdx.x == 0 && objective) objective[m] = red[0];
 }
 
-// explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_g
+// explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_m
 __global__ void k_kinetic_mass_grad(DevCtx c, const double* fields, const int32_t* target, int n_target) {
   const int m = blockIdx.y + c.m0;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,7 +776,7 @@ __global__ void k_kinetic_mass_grad(DevCtx c, const double* fields, const int32_
     const double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
     acc += 0.5 * v * v;
   }
-  c.blk_g[((size_t)m * c.n_blocks + b) * 6 + d] += acc;
+  c.blk_m[((size_t)m * c.n_blocks + b) * 3 + d] += acc;
 }
 
 }  // namespace
@@ -847,7 +847,7 @@ struct dfx_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_params = false, have_traj = false, have_fields = false;
   bool use_graph = true;
-  bool want_bond_grads = true, want_fn_grads = true;
+  bool want_bond_grads = true, want_fn_grads = true, want_damping_grads = true;
   DevBuf<int32_t> d_slot_info, d_block_special;
   DevBuf<dfx_special> d_special;
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict;
@@ -861,7 +861,7 @@ struct dfx_handle {
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
   DevBuf<double> d_traj, d_POS, d_VEL, d_A, d_state0, d_fields;
-  DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_g, d_fn_g, d_tmp, d_obj;
+  DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_m, d_blk_c, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
   int spi = 0;
@@ -900,7 +900,8 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
   c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
-  c.blk_g = h->d_blk_g.p; c.fn_g = h->want_fn_grads ? h->d_fn_g.p : nullptr;
+  c.blk_m = h->d_blk_m.p; c.blk_c = h->want_damping_grads ? h->d_blk_c.p : nullptr;
+  c.fn_g = h->want_fn_grads ? h->d_fn_g.p : nullptr;
   return c;
 }
 
@@ -1094,9 +1095,10 @@ static int ensure_adjoint_buffers(dfx_handle* h) {
   HIP_OK(h->d_W.ensure(B * 2 * nb * 3));
   HIP_OK(h->d_KQ.ensure(B * 2 * nb * 3));
   HIP_OK(h->d_g_r.ensure(B * pl.n_slots * 2));
-  HIP_OK(h->d_g_phi.ensure(B * pl.n_slots * 2));
+  HIP_OK(h->d_g_phi.ensure(B * pl.n_slots));
   HIP_OK(h->d_g_b.ensure(B * pl.n_slots * 8));
-  HIP_OK(h->d_blk_g.ensure(B * nb * 6));
+  HIP_OK(h->d_blk_m.ensure(B * nb * 3));
+  HIP_OK(h->d_blk_c.ensure(B * nb * 3));
   HIP_OK(h->d_fn_g.ensure(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS));
   return 0;
 }
@@ -1106,9 +1108,10 @@ static int zero_grad_accumulators(dfx_handle* h) {
   const size_t B = pl.batch, nb = pl.n_blocks;
   const size_t nsp = std::max(1, pl.n_special);
   HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots, h->stream));
   if (h->want_bond_grads) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_blk_g.p, 0, sizeof(double) * B * nb * 6, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_blk_m.p, 0, sizeof(double) * B * nb * 3, h->stream));
+  if (h->want_damping_grads) HIP_OK(hipMemsetAsync(h->d_blk_c.p, 0, sizeof(double) * B * nb * 3, h->stream));
   HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
   return 0;
 }
@@ -1118,7 +1121,7 @@ static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots;
   const size_t nsp = std::max(1, pl.n_special);
-  const size_t n_r = B * NS * 2, n_phi = B * NS * 2, n_b = B * NS * 8, n_blk = B * nb * 6, n_fn = B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, n_lam = B * nb * 6;
+  const size_t n_r = B * NS * 2, n_phi = B * NS, n_b = B * NS * 8, n_blk = B * nb * 6, n_fn = B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, n_lam = B * nb * 6;
   HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_blk + n_fn + n_lam) * sizeof(double)));
   double* g_r = reinterpret_cast<double*>(h->stage.p);
   double* g_phi = g_r + n_r;
@@ -1129,20 +1132,25 @@ static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
   HIP_OK(hipMemcpyAsync(g_r, h->d_g_r.p, sizeof(double) * n_r, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(g_phi, h->d_g_phi.p, sizeof(double) * n_phi, hipMemcpyDeviceToHost, h->stream));
   if (h->want_bond_grads) HIP_OK(hipMemcpyAsync(g_b, h->d_g_b.p, sizeof(double) * n_b, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(blk_g_p, h->d_blk_g.p, sizeof(double) * n_blk, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(blk_g_p, h->d_blk_m.p, sizeof(double) * n_blk / 2, hipMemcpyDeviceToHost, h->stream));
+  if (h->want_damping_grads) HIP_OK(hipMemcpyAsync(blk_g_p + n_blk / 2, h->d_blk_c.p, sizeof(double) * n_blk / 2, hipMemcpyDeviceToHost, h->stream));
+  else memset(blk_g_p + n_blk / 2, 0, sizeof(double) * n_blk / 2);
   if (h->want_fn_grads) HIP_OK(hipMemcpyAsync(fn_g_p, h->d_fn_g.p, sizeof(double) * n_fn, hipMemcpyDeviceToHost, h->stream));
   else memset(fn_g_p, 0, sizeof(double) * n_fn);
   if (with_state0) HIP_OK(hipMemcpyAsync(lam, h->d_LAM.p, sizeof(double) * n_lam, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
-  std::vector<double> blk_g(blk_g_p, blk_g_p + n_blk), fn_g(fn_g_p, fn_g_p + n_fn);
+  std::vector<double> blk_g(n_blk), fn_g(fn_g_p, fn_g_p + n_fn);
+  for (size_t i = 0; i < B * nb; ++i)
+    for (int d = 0; d < 3; ++d) { blk_g[i * 6 + d] = blk_g_p[i * 3 + d]; blk_g[i * 6 + 3 + d] = blk_g_p[n_blk / 2 + i * 3 + d]; }
   if (!grads) return 0;
   std::vector<double> slot_g(B * NS * kSlotGrads, 0.0);
   for (size_t i = 0; i < B * NS; ++i) {
     double* q = slot_g.data() + i * kSlotGrads;
     q[0] = g_r[i * 2]; q[1] = g_r[i * 2 + 1];
     if (h->want_bond_grads) for (int c = 0; c < 5; ++c) q[2 + c] = g_b[i * 8 + c];
-    q[7] = g_phi[i * 2]; q[8] = g_phi[i * 2 + 1];
+    const int info = pl.slot_info[i % NS];
+    if (info >= 0 && !(info & 1)) { q[7] = g_phi[i]; q[8] = g_phi[i - i % NS + (size_t)(info >> 1)]; }
     if (h->want_bond_grads) for (int c = 0; c < 3; ++c) q[9 + c] = g_b[i * 8 + 5 + c];
   }
   dfx_grads g = *grads;
@@ -1161,6 +1169,7 @@ static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
 static void set_grad_wishes(dfx_handle* h, const dfx_grads* g) {
   h->want_bond_grads = !g || g->reference_vector || g->k_bond || g->contact;
   h->want_fn_grads = !g || g->fn_params;
+  h->want_damping_grads = !g || g->damping;
 }
 
 extern "C" {
@@ -1235,7 +1244,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
-  h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_g.release(); h->d_fn_g.release();
+  h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
   h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release();
   for (auto& gr : h->groups) { for (auto e : gr.ev_a) (void)hipEventDestroy(e); for (auto e : gr.ev_b) (void)hipEventDestroy(e); if (gr.stream2) (void)hipStreamDestroy(gr.stream2); if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

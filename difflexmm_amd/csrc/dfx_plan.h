@@ -85,7 +85,7 @@ struct PackedParams {
   std::vector<double> p_r;      // batch * n_slots * 2 : own node vector
   std::vector<double> p_l;      // batch * n_slots * 2 : reference vector (oriented node1 -> node2)
   std::vector<double> p_k;      // batch * n_slots * 4 : k_stretch, k_shear, k_rot, 0
-  std::vector<double> p_phi;    // batch * n_slots * 2 : undeformed void angles
+  std::vector<double> p_phi;    // batch * n_slots : undeformed void angle, phi1 on the end-0 slot of a ligament, phi2 on its end-1 slot
   std::vector<double> cst;      // batch * 16 (first 9 used) : min_angle, cutoff_angle, k_contact, k_stretch, k_shear, k_rot (if uniform), 0, 0
   bool k_uniform = true;        // every ligament of a member has the same three stiffnesses
   // dictionary compression of per-slot constants that take few distinct values (lattices have 2-3 reference vectors):
@@ -141,7 +141,7 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     if (!gpu_image) continue;
     if (m == 0) {
       out.p_r.assign((size_t)B * NS * 2, 0.0); out.p_l.assign((size_t)B * NS * 2, 0.0);
-      out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
+      out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS, 0.0);
       out.cst.assign((size_t)B * 16, 0.0);
       out.k_uniform = true;
       out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 1024, 0.0);
@@ -152,14 +152,14 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       double* r = out.p_r.data() + ((size_t)m * NS + s_) * 2;
       double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
       double* k = out.p_k.data() + ((size_t)m * NS + s_) * 4;
-      double* ph = out.p_phi.data() + ((size_t)m * NS + s_) * 2;
+      double* ph = out.p_phi.data() + ((size_t)m * NS + s_);
       r[0] = s[0]; r[1] = s[1];
       int info = pl.slot_info[s_];
       if (info >= 0) {
         if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { err = "set_params: zero-length reference vector"; return 1; }
         l[0] = s[2]; l[1] = s[3];
         k[0] = s[4]; k[1] = s[5]; k[2] = s[6];
-        ph[0] = s[7]; ph[1] = s[8];
+        ph[0] = (info & 1) ? s[8] : s[7];
         if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) out.k_uniform = false;
       }
     }
