@@ -35,6 +35,14 @@
 
 using namespace dfx;
 
+// occupancy hints for the two stage kernels (waves per SIMD the register allocator must leave room for)
+#ifndef DFX_FWD_OCC
+#define DFX_FWD_OCC
+#endif
+#ifndef DFX_ADJ_OCC
+#define DFX_ADJ_OCC
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -81,6 +89,7 @@ struct AdjCoef {
 struct DevCtx {
   int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
+  int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
   const int32_t* slot_info;
@@ -228,50 +237,84 @@ __global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
 struct LaneIn {
   BlockRec<double> o, p;
   double rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, phi1, phi2, am, ac, kc, sgn;
-  int info;
+  int info, pslot, guess;
 };
 
-// Everything a lane needs for its ligament.  Own data: one coalesced 16-byte chunk per lane, spread over the
-// quad by DPP.  Partner data: gathered through slot_info from the same arrays (lines shared with the lanes
-// that own them, i.e. served by the XCD's L2).
+struct Partner {
+  double2 b0, b1, rp;
+  double b2, phi;
+};
+
 template <int CONTACT>
-__device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneIn& L) {
+__device__ __forceinline__ void load_partner(const DevCtx& c, size_t ps, int pslot, const double* POSin, Partner& P) {
+  const double* pp = POSin + (size_t)(pslot >> 2) * kPos;
+  P.b0 = reinterpret_cast<const double2*>(pp)[0];
+  P.b1 = reinterpret_cast<const double2*>(pp)[1];
+  P.b2 = pp[4];
+  P.rp = *reinterpret_cast<const double2*>(c.p_r + (ps + pslot) * 2);
+  P.phi = CONTACT ? c.p_phi[ps + pslot] : 0.0;
+}
+
+// Everything a lane needs for its ligament, in two phases so that every load that does not depend on another
+// load is in flight before the first wait:
+//   issue_lane   own data (one coalesced 16-byte chunk per lane, spread over the quad by DPP later), slot_info, and
+//                the partner's data from a GUESSED slot (own slot + the lattice's usual offset for this node slot);
+//                the kernels then issue their own epilogue operands;
+//   resolve_lane what depends on loaded values: the dictionary entry of the reference vector, and a second gather
+//                only for lanes whose real partner is not the guessed one (irregular connectivity).
+// Partner data comes from the same arrays the owners read (lines served by the XCD's L2).
+struct LaneRaw {
+  Partner P;
+  double2 pc, ro, lv;
+  double ks, ksh, kr, phi;
+  int info, guess, lidx;
+};
+
+template <int CONTACT>
+__device__ __forceinline__ void issue_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneRaw& R) {
   const int b = slot >> 2, k = slot & 3;
-  const int info = c.slot_info[slot];
-  L.info = info;
   const size_t ps = (size_t)m * c.n_slots;
-  const double2 pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (size_t)b * kPos + 2 * k) : make_double2(0.0, 0.0);
-  const double2 ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
-  double2 lv, ln = make_double2(0.0, 0.0);
+  R.info = c.slot_info[slot];
+  R.pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (size_t)b * kPos + 2 * k) : make_double2(0.0, 0.0);
+  R.ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
+  // branch-free (a branch here would end the batch of loads): the unused one of the two reads one shared valid address
+  const double* cst = c.cst + (size_t)m * 16;
+  R.lidx = (int)*(c.l_dict_on ? c.p_lidx + (ps + slot) : reinterpret_cast<const uint8_t*>(cst));
+  R.lv = *reinterpret_cast<const double2*>(c.l_dict_on ? cst : c.p_l + (ps + slot) * 2);
+  R.ks = R.ksh = R.kr = 0.0;
+  if (!c.k_uniform) { const double* pk = c.p_k + (ps + slot) * 4; R.ks = pk[0]; R.ksh = pk[1]; R.kr = pk[2]; }
+  R.phi = CONTACT ? c.p_phi[ps + slot] : 0.0;
+  const int delta = k == 0 ? c.pred[0] : (k == 1 ? c.pred[1] : (k == 2 ? c.pred[2] : c.pred[3]));   // selects: a dynamic index would be a memory load
+  R.guess = min(max(slot + delta, 0), c.n_slots - 1);
+  load_partner<CONTACT>(c, ps, R.guess, POSin, R.P);
+}
+
+template <int CONTACT>
+__device__ __forceinline__ void resolve_lane(const DevCtx& c, int m, const double* POSin, LaneRaw& R, LaneIn& L) {
+  const size_t ps = (size_t)m * c.n_slots;
+  const int info = R.info;
+  L.info = info;
+  double2 lv = R.lv, ln = make_double2(0.0, 0.0);
   if (c.l_dict_on) {
-    const double2* e = reinterpret_cast<const double2*>(c.l_dict + (size_t)m * 1024 + 4 * (int)c.p_lidx[ps + slot]);
+    const double2* e = reinterpret_cast<const double2*>(c.l_dict + (size_t)m * 1024 + 4 * R.lidx);
     lv = e[0]; ln = e[1];
-  } else {
-    lv = *reinterpret_cast<const double2*>(c.p_l + (ps + slot) * 2);
   }
+  const int pslot = info < 0 ? R.guess : (info >> 1);
+  L.pslot = pslot; L.guess = R.guess;
+  if (pslot != R.guess) load_partner<CONTACT>(c, ps, pslot, POSin, R.P);
   const double* cst = c.cst + (size_t)m * 16;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
-  else { const double* pk = c.p_k + (ps + slot) * 4; L.ks = pk[0]; L.ksh = pk[1]; L.kr = pk[2]; }
+  else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
   if (CONTACT) {
-    L.phi1 = c.p_phi[ps + slot];
+    L.phi1 = (info & 1) ? R.P.phi : R.phi;
+    L.phi2 = (info & 1) ? R.phi : R.P.phi;
     L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2];
   }
-  // partner (dependent on info)
-  const int pslot = info < 0 ? slot : (info >> 1);
-  const double* pp = POSin + (size_t)(pslot >> 2) * kPos;
-  const double2 b0 = reinterpret_cast<const double2*>(pp)[0], b1 = reinterpret_cast<const double2*>(pp)[1];
-  const double b2 = pp[4];
-  const double2 rp = *reinterpret_cast<const double2*>(c.p_r + (ps + pslot) * 2);
-  if (CONTACT) {
-    const double own = L.phi1, other = c.p_phi[ps + pslot];
-    L.phi1 = (info & 1) ? other : own;
-    L.phi2 = (info & 1) ? own : other;
-  }
-  L.o.x = quad_bcast<0>(pc.x); L.o.y = quad_bcast<0>(pc.y);
-  L.o.th = quad_bcast<1>(pc.x); L.o.ch = quad_bcast<1>(pc.y);
-  L.o.sh = quad_bcast<2>(pc.x);
-  L.p.x = b0.x; L.p.y = b0.y; L.p.th = b1.x; L.p.ch = b1.y; L.p.sh = b2;
-  L.rox = ro.x; L.roy = ro.y; L.rpx = rp.x; L.rpy = rp.y;
+  L.o.x = quad_bcast<0>(R.pc.x); L.o.y = quad_bcast<0>(R.pc.y);
+  L.o.th = quad_bcast<1>(R.pc.x); L.o.ch = quad_bcast<1>(R.pc.y);
+  L.o.sh = quad_bcast<2>(R.pc.x);
+  L.p.x = R.P.b0.x; L.p.y = R.P.b0.y; L.p.th = R.P.b1.x; L.p.ch = R.P.b1.y; L.p.sh = R.P.b2;
+  L.rox = R.ro.x; L.roy = R.ro.y; L.rpx = R.P.rp.x; L.rpy = R.P.rp.y;
   L.lx = lv.x; L.ly = lv.y;
   if (c.l_dict_on) { L.l0 = ln.x; L.il0 = ln.y; }
   else {
@@ -281,13 +324,20 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   L.sgn = (info & 1) ? 1.0 : -1.0;
 }
 
+template <int CONTACT>
+__device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneIn& L) {
+  LaneRaw R;
+  issue_lane<CONTACT>(c, m, slot, POSin, R);
+  resolve_lane<CONTACT>(c, m, POSin, R, L);
+}
+
 // ---- forward stage ---------------------------------------------------------------------------
 //   in_buf  : stage buffer holding this stage's records, or -1: the checkpoint of step n (reverse recompute, i == 0)
 //   out_buf : buffer for the next stage's records (-1: none)
 //   y_buf   : 0: step base state (q_n, v_n) in buffer 0;  -1: in the checkpoint of step n
 //   write_traj: also store the new record into the checkpoint of step n+1 (last stage, keep_trajectory)
 template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
+__global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   const int m = blockIdx.y + c.m0;
   const int lwg = logical_wg(blockIdx.x, c.n_wg);
@@ -310,8 +360,8 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
   const size_t nd = (size_t)c.n_blocks * 3;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
-  LaneIn L;
-  load_lane<CONTACT>(c, m, slot, POSin, L);
+  LaneRaw R;
+  issue_lane<CONTACT>(c, m, slot, POSin, R);
   const int dof = b * 3 + kd;
   const double qn = pos_in(c, m, y_buf, n)[(size_t)b * kPos + kd];
   const double vn = vel_in(c, m, y_buf, n)[dof];
@@ -320,11 +370,17 @@ __global__ __launch_bounds__(kThreads) void k_fwd_stage(DevCtx c, StageCoef sc, 
   const double damp = c.damping_uniform ? c.cst[(size_t)m * 16 + 6 + kd] : c.damping[(size_t)m * nd + dof];
   const double invm = c.inv_m[(size_t)m * nd + dof];
   const int sidx = c.block_special[b];
+  // earlier stage accelerations: all loads issued together (a rolled loop waits for each one in turn)
+  double al[kMaxStages - 1];
+#pragma unroll
+  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? Am[(size_t)l * nd + dof] : 0.0;
+  LaneIn L;
+  resolve_lane<CONTACT>(c, m, POSin, R, L);
   double sv = 0.0, sq = 0.0;
-  for (int l = 0; l < i; ++l) {
-    const double al = Am[(size_t)l * nd + dof];
-    sv += sc.cv[l] * al;
-    sq += sc.cq[l] * al;
+#pragma unroll
+  for (int l = 0; l < kMaxStages - 1; ++l) {
+    sv += sc.cv[l] * al[l];
+    sq += sc.cq[l] * al[l];
   }
   // ---- ligament + contact of this slot
   double fx = 0.0, fy = 0.0, fth = 0.0;
@@ -554,7 +610,7 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
 //   in_buf: stage buffer with the stage records (recomputed), or -1: the checkpoint of step n (i == 0)
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
+__global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only) {
   const int m = blockIdx.y + c.m0;
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
@@ -567,13 +623,14 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   const size_t nd = (size_t)c.n_blocks * 3, nd6 = (size_t)c.n_blocks * 6;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
-  LaneIn L;
-  load_lane<CONTACT>(c, m, slot, POSin, L);
+  LaneRaw R;
+  issue_lane<CONTACT>(c, m, slot, POSin, R);
   const int dof = b * 3 + kd;
   const double* Win = c.W + ((size_t)m * 2 + win) * nd;
   const double w_d = Win[dof];
-  const int pb = (L.info < 0 ? slot : (L.info >> 1)) >> 2;
-  const double wpx = Win[(size_t)pb * 3], wpy = Win[(size_t)pb * 3 + 1], wpth = Win[(size_t)pb * 3 + 2];
+  // partner's w from the guessed slot (same batch as everything else)
+  double wpx, wpy, wpth;
+  { const size_t gb = (size_t)(R.guess >> 2) * 3; wpx = Win[gb]; wpy = Win[gb + 1]; wpth = Win[gb + 2]; }
   const double v_i = vel_in(c, m, in_buf, n)[dof];
   const double kq_in = c.KQ[((size_t)m * 2 + win) * nd + dof];
   const double damp = c.damping_uniform ? c.cst[(size_t)m * 16 + 6 + kd] : c.damping[(size_t)m * nd + dof];
@@ -584,13 +641,23 @@ __global__ __launch_bounds__(kThreads) void k_adj_stage(DevCtx c, AdjCoef ac, in
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
   if (!local_only) {
     lq = LAMm[b * 6 + kd]; lv = LAMm[b * 6 + 3 + kd];
-    for (int jj = i + 1; jj < c.s; ++jj) {
-      const double yq = YBm[(size_t)jj * nd6 + b * 6 + kd], yv = YBm[(size_t)jj * nd6 + b * 6 + 3 + kd];
+    double yq[kMaxStages], yv[kMaxStages];
+#pragma unroll
+    for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
+      const bool on = jj > i && jj < c.s;
+      yq[jj] = on ? YBm[(size_t)jj * nd6 + b * 6 + kd] : 0.0;
+      yv[jj] = on ? YBm[(size_t)jj * nd6 + b * 6 + 3 + kd] : 0.0;
+    }
+#pragma unroll
+    for (int jj = 1; jj < kMaxStages; ++jj) {
       const double cf = i > 0 ? ac.col[jj] : 1.0;
-      sq += cf * yq;
-      sv += cf * yv;
+      sq += cf * yq[jj];
+      sv += cf * yv[jj];
     }
   }
+  LaneIn L;
+  resolve_lane<CONTACT>(c, m, POSin, R, L);
+  if (L.pslot != L.guess) { const size_t pb = (size_t)(L.pslot >> 2) * 3; wpx = Win[pb]; wpy = Win[pb + 1]; wpth = Win[pb + 2]; }
   const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
@@ -885,6 +952,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.n_blocks = pl.n_blocks; c.n_slots = pl.n_slots; c.n_fns = pl.n_fns; c.batch = pl.batch; c.s = pl.tab.s;
   { const char* a = getenv("DFX_ABLATE"); c.ablate = a ? atoi(a) : 0; }
   c.n_wg = (pl.n_slots + kThreads - 1) / kThreads;
+  for (int k = 0; k < 4; ++k) c.pred[k] = pl.pred_delta[k];
   c.nbuf = 2 * pl.tab.s;
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
   c.traj_stride = pl.batch ? (long long)(h->d_traj.n / pl.batch) : 0;

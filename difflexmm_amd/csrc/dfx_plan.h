@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/dfx.h"
@@ -31,6 +32,8 @@ struct Plan {
   Tableau tab;
   std::vector<int32_t> slot_info;      // n_slots
   std::vector<int32_t> slot_bond;      // n_slots, bond id or -1
+  int pred_delta[4] = {0, 0, 0, 0};    // most frequent (partner slot - own slot) per node slot: the kernels gather from the guess
+                                       // while slot_info is still in flight (regular lattices: right everywhere but the rim)
   std::vector<int32_t> block_special;  // n_blocks, index into special or -1
   std::vector<dfx_special> special;
 };
@@ -62,6 +65,14 @@ inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
     pl.slot_info[s2] = 2 * s1 + 1;
     pl.slot_bond[s1] = b;
     pl.slot_bond[s2] = b;
+  }
+  for (int k = 0; k < kSlots; ++k) {
+    std::map<int, int> votes;
+    for (int s = k; s < pl.n_slots; s += kSlots)
+      if (pl.slot_info[s] >= 0) ++votes[(pl.slot_info[s] >> 1) - s];
+    int best = 0, n_best = 0;
+    for (auto& kv : votes) if (kv.second > n_best) { best = kv.first; n_best = kv.second; }
+    pl.pred_delta[k] = best;
   }
   pl.block_special.assign(p->n_blocks, -1);
   pl.special.assign(p->special, p->special + p->n_special);
