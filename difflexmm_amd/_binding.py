@@ -49,7 +49,8 @@ class dfx_stats(C.Structure):
                 ("kernel_ms", C.c_double), ("stage_kernel_us", C.c_double), ("streams", C.c_int64)]
 
 
-EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_adaptive", "dfx_adjoint",
+EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid",
+           "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
 
@@ -64,6 +65,9 @@ def declare(lib):
     lib.dfx_set_params.argtypes = [H, C.POINTER(dfx_params)]
     lib.dfx_reserve.argtypes = [H, C.c_int64, C.c_int32, C.c_int32]
     lib.dfx_forward.argtypes = [H, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_forward_grid.argtypes = [H, _dp, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_adaptive_step_counts.argtypes = [H, _ip]
+    lib.dfx_adaptive_step_times.argtypes = [H, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]
     lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
@@ -184,17 +188,38 @@ class Engine:
         self._check(self.lib.dfx_reserve(self._h, int(max_steps), int(max_timepoints), int(bool(keep_trajectory))), "dfx_reserve")
 
     # -- solves -------------------------------------------------------------------------------
-    def forward(self, state0, timepoints, steps_per_interval, keep_trajectory=False, want_fields=True):
+    def forward(self, state0, timepoints, steps_per_interval, keep_trajectory=False, want_fields=True, step_times=None):
         B, nb = self.batch, self.n_blocks
         state0 = _f64(state0, (B, 2, nb, 3))
         ts = _f64(timepoints)
         T = len(ts)
         fields = np.empty((B, T, 2, nb, 3)) if want_fields else None
         st = dfx_stats()
-        self._check(self.lib.dfx_forward(self._h, _ptr(state0), _ptr(ts), T, int(steps_per_interval),
-                                         int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward")
+        if np.ndim(steps_per_interval) == 0 and step_times is None:
+            self._check(self.lib.dfx_forward(self._h, _ptr(state0), _ptr(ts), T, int(steps_per_interval),
+                                             int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward")
+        else:   # its own number of equal steps in every output interval
+            spis = np.ascontiguousarray(np.broadcast_to(steps_per_interval, (max(T - 1, 0),)), dtype=np.int32)
+            if step_times is not None:      # caller-chosen step boundaries (every timepoint must be one of them)
+                step_times = _f64(step_times, (int(spis.sum()) + 1,))
+            self._check(self.lib.dfx_forward_grid(self._h, _ptr(state0), _ptr(ts), T, spis.ctypes.data_as(_ip), _ptr(step_times),
+                                                  int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward_grid")
         self.n_timepoints = T
         return fields, _stats(st)
+
+    def adaptive_step_counts(self):
+        """(batch, T-1) accepted steps of the last forward_adaptive per member and output interval."""
+        out = np.zeros((self.batch, max(self.n_timepoints - 1, 0)), dtype=np.int32)
+        self._check(self.lib.dfx_adaptive_step_counts(self._h, out.ctypes.data_as(_ip)), "dfx_adaptive_step_counts")
+        return out
+
+    def adaptive_step_times(self, member=0):
+        """End times of the steps one member accepted in the last forward_adaptive."""
+        n = C.c_int64(0)
+        self._check(self.lib.dfx_adaptive_step_times(self._h, int(member), None, 0, C.byref(n)), "dfx_adaptive_step_times")
+        out = np.empty(n.value)
+        self._check(self.lib.dfx_adaptive_step_times(self._h, int(member), _ptr(out), n.value, C.byref(n)), "dfx_adaptive_step_times")
+        return out
 
     def forward_adaptive(self, state0, timepoints, rtol, atol, max_attempts=10_000_000):
         """Adaptive Dormand-Prince with the reference's odeint semantics (forward only)."""

@@ -46,6 +46,7 @@ using namespace dfx;
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kAccCap = 1 << 20;   // accepted step times recorded per member (adaptive)
 constexpr int kMaxGraphSteps = 256;
 constexpr int kPos = 6;   // doubles per unit position record: x y th cos(th/2) sin(th/2) pad   (three 16-byte chunks)
 constexpr int kStep = 9;  // doubles per unit in a trajectory checkpoint: position record + velocity (3)
@@ -110,6 +111,10 @@ struct DevCtx {
   const Seg* cur;         // the segment being replayed
   Clock* clock;           // per-member clocks (adaptive mode) or null
   double* err_partial;    // batch * n_wg*4 per-wave partial sums of the squared error ratio
+  int* step_counts;       // batch * (n_timepoints-1) accepted steps per output interval (adaptive)
+  double* acc_times;      // batch * acc_cap end times of the accepted steps (adaptive)
+  int acc_cap;
+  const double* t_steps;  // n_total+1 step boundaries of a caller-chosen grid, or null: equal steps (Seg.h)
   const double* ts_dev;   // output times (adaptive mode)
   double* fields_dev;     // batch * T * n_blocks*6 (adaptive mode writes its dense output here)
   double rtol, atol;
@@ -401,8 +406,8 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   fy = quad_sum(fy);
   fth = quad_sum(fth);
   // ---- DOF epilogue on lanes 0..2
-  const double h = sg.h;
-  const double t = sg.t_interval + (sg.j0 + j) * h;
+  double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
+  if (c.t_steps && !c.clock) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
   double qnext = 0.0, vnext = 0.0;
   if (k < 3) {
     const double dE = k == 0 ? fx : (k == 1 ? fy : fth);
@@ -493,6 +498,8 @@ __global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, 
   if (ck.accept) {
     ck.t_last = ck.t; ck.h_acc = ck.h; ck.t = ck.t + ck.h; ck.accepted++;
     ck.out_lo = ck.out_idx;
+    if (c.acc_times && ck.accepted <= c.acc_cap) c.acc_times[(size_t)m * c.acc_cap + ck.accepted - 1] = ck.t;
+    if (c.step_counts && n_timepoints > 1) c.step_counts[(size_t)m * (n_timepoints - 1) + min(max(ck.out_idx - 1, 0), n_timepoints - 2)]++;
     while (ck.out_idx < n_timepoints && c.ts_dev[ck.out_idx] <= ck.t) ck.out_idx++;
     ck.out_hi = ck.out_idx;
     if (ck.out_idx >= n_timepoints) ck.fin_next = 1;
@@ -699,7 +706,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   ey = quad_sum(ey);
   eth = quad_sum(eth);
   // ---- DOF epilogue
-  const double h = sg.h;
+  double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
+  if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
   if (k < 3) {
     const double hw = k == 0 ? hx : (k == 1 ? hy : hth);
     const double dE = k == 0 ? ex : (k == 1 ? ey : eth);
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     if (sidx >= 0) {
       const dfx_special& sp = c.special[sidx];
       constrained = (sp.con_mask >> k) & 1;
-      const double t_i = sg.t_interval + (sg.j0 + j) * h + ac.c_i * h;
+      const double t_i = t_n + ac.c_i * h;
       double gp[kMaxFnParams];
       for (int f = 0; f < c.n_fns; ++f) {
         const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
@@ -750,9 +758,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
         if (constrained) { lq = 0.0; lv = 0.0; }
         LAMm[b * 6 + k] = lq;
         LAMm[b * 6 + 3 + k] = lv;
-        const double hp = first ? sg.h_prev : h;
-        kq = hp * ac.col[c.s] * lq;
-        kv = hp * ac.col[c.s] * lv;
+        kq = h_before * ac.col[c.s] * lq;
+        kv = h_before * ac.col[c.s] * lv;
       }
       c.KQ[((size_t)m * 2 + (win ^ 1)) * nd + dof] = kq;
       c.W[((size_t)m * 2 + (win ^ 1)) * nd + dof] = constrained ? 0.0 : kv * invm;
@@ -931,7 +938,14 @@ struct dfx_handle {
   DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_m, d_blk_c, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
-  int spi = 0;
+  std::vector<int> spis;           // RK steps in each output interval (fixed grid)
+  std::vector<long long> step0;    // first step ordinal of each interval
+  DevBuf<int> d_step_counts;
+  int n_counts = 0;
+  DevBuf<double> d_acc_times, d_tsteps;
+  std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps)
+  std::vector<long long> accepted_per_member;
+  bool have_adaptive_record = false;
   long long n_total = 0;
   std::map<std::pair<int, int>, hipGraphExec_t> graphs;
   DevCtx graph_ctx_snapshot;
@@ -963,6 +977,9 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.cur = h->d_cur.p;
   c.clock = h->adaptive ? h->d_clock.p : nullptr;
   c.err_partial = h->d_err_partial.p; c.ts_dev = h->d_ts.p; c.fields_dev = h->d_fields.p;
+  c.step_counts = h->adaptive ? h->d_step_counts.p : nullptr;
+  c.acc_times = h->adaptive ? h->d_acc_times.p : nullptr; c.acc_cap = kAccCap;
+  c.t_steps = (!h->adaptive && !h->t_steps.empty()) ? h->d_tsteps.p : nullptr;
   c.rtol = h->rtol; c.atol = h->atol;
   c.traj = h->have_traj ? h->d_traj.p : nullptr;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
@@ -1127,18 +1144,27 @@ static int join_groups(dfx_handle* h) {
   return 0;
 }
 
+// One segment = one graph replay of n_steps steps inside one output interval.  A uniform grid is cut into chunks of
+// kMaxGraphSteps; a grid with its own count per interval is cut into power-of-two chunks so that the number of distinct
+// graphs stays <= log2(kMaxGraphSteps)+1 whatever the counts are.
 static void build_segments(dfx_handle* h) {
   h->segs.clear();
   const int Tn = (int)h->ts.size();
+  bool uniform = true;
+  for (int k = 1; k + 1 < Tn; ++k) uniform = uniform && h->spis[k] == h->spis[0];
   for (int k = 0; k + 1 < Tn; ++k) {
-    const double hh = (h->ts[k + 1] - h->ts[k]) / h->spi;
-    const double hp = k > 0 ? (h->ts[k] - h->ts[k - 1]) / h->spi : 0.0;
-    for (int j0 = 0; j0 < h->spi; j0 += kMaxGraphSteps) {
+    const int spi = h->spis[k];
+    const double hh = (h->ts[k + 1] - h->ts[k]) / spi;
+    const double hp = k > 0 ? (h->ts[k] - h->ts[k - 1]) / h->spis[k - 1] : 0.0;
+    for (int j0 = 0; j0 < spi;) {
+      int n = std::min(kMaxGraphSteps, spi - j0);
+      if (!uniform) { int p2 = 1; while (p2 * 2 <= n) p2 *= 2; n = p2; }
       Seg sg;
       sg.t_interval = h->ts[k]; sg.h = hh; sg.h_prev = hp;
-      sg.base_step = (long long)k * h->spi + j0; sg.j0 = j0; sg.interval = k;
-      sg.n_steps = std::min(kMaxGraphSteps, h->spi - j0); sg.pad = 0;
+      sg.base_step = h->step0[k] + j0; sg.j0 = j0; sg.interval = k;
+      sg.n_steps = n; sg.pad = 0;
       h->segs.push_back(sg);
+      j0 += n;
     }
   }
 }
@@ -1309,7 +1335,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
-  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release();
+  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
@@ -1390,16 +1416,39 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
 
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
+  if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+  std::vector<int32_t> spis((size_t)std::max(0, n_timepoints - 1), steps_per_interval);
+  return dfx_forward_grid(h, state0, timepoints, n_timepoints, spis.data(), nullptr, keep_trajectory, fields, stats);
+}
+
+int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                     const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                     double* fields, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
   h->adaptive = false;
-  if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+  if (n_timepoints < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kStep;
   const int Tn = n_timepoints;
   h->ts.assign(timepoints, timepoints + Tn);
-  h->spi = steps_per_interval;
-  h->n_total = (long long)(Tn - 1) * steps_per_interval;
+  h->spis.assign(steps_per_interval, steps_per_interval + (Tn - 1));
+  h->step0.assign(Tn, 0);
+  for (int k = 0; k + 1 < Tn; ++k) {
+    if (h->spis[k] < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+    h->step0[k + 1] = h->step0[k] + h->spis[k];
+  }
+  h->n_total = h->step0[Tn - 1];
+  h->t_steps.clear();
+  if (step_times) {
+    h->t_steps.assign(step_times, step_times + h->n_total + 1);
+    for (long long n = 0; n < h->n_total; ++n)
+      if (!(h->t_steps[n + 1] > h->t_steps[n])) { h->err = "forward: step_times must be strictly increasing"; return 1; }
+    for (int k = 0; k < Tn; ++k)
+      if (h->t_steps[h->step0[k]] != timepoints[k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
+    HIP_OK(h->d_tsteps.ensure(h->t_steps.size()));
+    HIP_OK(hipMemcpyAsync(h->d_tsteps.p, h->t_steps.data(), sizeof(double) * h->t_steps.size(), hipMemcpyHostToDevice, h->stream));
+  }
   if (ensure_work_buffers(h)) return 2;
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
   h->have_traj = false;
@@ -1432,7 +1481,7 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
     const Seg& sg = h->segs[si];
     for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
       if (int rc = run_segment(h, c, gi, sg.n_steps, 0)) return rc;
-      if (sg.j0 + sg.n_steps == h->spi) {   // buffer 0 holds the state at the end of the interval
+      if (sg.j0 + sg.n_steps == h->spis[sg.interval]) {   // buffer 0 holds the state at the end of the interval
         const Group& gr = h->groups[gi];
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
                            h->d_seg_idx.p + 1);
@@ -1479,15 +1528,20 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   const int Tn = n_timepoints;
   const Dopri D = make_dopri();
   h->ts.assign(timepoints, timepoints + Tn);
-  h->spi = 0; h->n_total = 0;
+  h->spis.clear(); h->n_total = 0;
   h->have_traj = false; h->have_fields = false;
   h->adaptive = true; h->rtol = rtol; h->atol = atol;
+  h->have_adaptive_record = false;
   if (ensure_work_buffers(h)) return 2;
   const int n_wg = (pl.n_slots + kThreads - 1) / kThreads;
   const int n_partials = (pl.n_slots + 63) / 64;
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
   HIP_OK(h->d_clock.ensure(B));
   HIP_OK(h->d_err_partial.ensure(B * n_wg * 4));
+  h->n_counts = std::max(0, Tn - 1);
+  HIP_OK(h->d_step_counts.ensure(std::max<size_t>(1, B * h->n_counts)));
+  HIP_OK(hipMemsetAsync(h->d_step_counts.p, 0, sizeof(int) * std::max<size_t>(1, B * h->n_counts), h->stream));
+  HIP_OK(h->d_acc_times.ensure(B * (size_t)kAccCap));
   HIP_OK(h->d_ts.ensure(Tn));
   HIP_OK(h->d_tmp.ensure(std::max<size_t>(B * nb * 6, B)));
   HIP_OK(hipMemcpyAsync(h->d_ts.p, timepoints, sizeof(double) * Tn, hipMemcpyHostToDevice, h->stream));
@@ -1619,6 +1673,9 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   HIP_OK(hipGetLastError());
   h->have_fields = true;
   h->adaptive = false;
+  h->have_adaptive_record = true;
+  h->accepted_per_member.assign(B, 0);
+  for (size_t m = 0; m < B; ++m) h->accepted_per_member[m] = clk[m].accepted;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;
@@ -1647,7 +1704,8 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
   const int nseg = (int)h->segs.size();
   std::vector<int> cursors(64, nseg);
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p + 2, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  const double h_last = Tn > 1 ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spi : 0.0;
+  const double h_last = Tn > 1 ? (h->t_steps.empty() ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]
+                                                     : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   const int wb = (int)((h->n_total * pl.tab.s - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb);
@@ -1672,6 +1730,31 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
     stats->kernel_ms = ms;
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
+  }
+  return 0;
+}
+
+int dfx_adaptive_step_counts(dfx_handle* h, int32_t* counts) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->have_adaptive_record) { h->err = "adaptive_step_counts: run forward_adaptive first"; return 1; }
+  if (h->n_counts > 0) {
+    HIP_OK(hipMemcpyAsync(counts, h->d_step_counts.p, sizeof(int) * (size_t)h->pl.batch * h->n_counts, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int dfx_adaptive_step_times(dfx_handle* h, int32_t member, double* times, int64_t capacity, int64_t* n) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->have_adaptive_record) { h->err = "adaptive_step_times: run forward_adaptive first"; return 1; }
+  if (member < 0 || member >= h->pl.batch) { h->err = "adaptive_step_times: no such member"; return 1; }
+  const long long acc = h->accepted_per_member[member];
+  if (acc > kAccCap) { h->err = "adaptive_step_times: more than 2^20 accepted steps, times were not recorded"; return 1; }
+  *n = acc;
+  const long long cnt = std::min<long long>(acc, capacity);
+  if (cnt > 0) {
+    HIP_OK(hipMemcpyAsync(times, h->d_acc_times.p + (size_t)member * kAccCap, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
   }
   return 0;
 }
@@ -1742,6 +1825,7 @@ static int hook_prepare(dfx_handle* h, const double* y, double t) {
   h->have_fields = false;
   h->ts.assign(1, t);
   h->n_total = 1;
+  h->t_steps.clear();
   Seg sg;
   sg.t_interval = t; sg.h = 0.0; sg.h_prev = 0.0; sg.base_step = 0; sg.j0 = 0; sg.interval = 0; sg.n_steps = 1; sg.pad = 0;
   HIP_OK(hipMemcpyAsync(h->d_cur.p, &sg, sizeof(Seg), hipMemcpyHostToDevice, h->stream));

@@ -6,9 +6,11 @@ engine.  The returned ``solve_dynamics(state0, timepoints, control_params)`` has
 Differences that are inherent to running inside hand-written kernels (all keyword-only, all with defaults):
   * by default the forward solve is the reference's own scheme: adaptive Dormand-Prince 5(4) controlled by ``rtol`` /
     ``atol`` with dense output at ``timepoints`` (jax.experimental.ode.odeint semantics, every member its own step).
-    With ``steps_per_interval=k`` (or ``keep_trajectory=True``, because the reverse sweep is the discrete adjoint of a
-    FIXED grid) the same tableau runs on k equal steps between consecutive ``timepoints``; when k is not given it is
-    chosen from a stiffness bound so that h*omega_max <= 0.5;
+    With ``steps_per_interval=k`` (an int, or one int per output interval) the same tableau runs on k equal steps
+    between consecutive ``timepoints`` (``step_times=`` gives the step boundaries explicitly).  ``keep_trajectory=True`` (needed by ``vjp``: the reverse sweep is the exact
+    discrete adjoint of a FIXED grid) without a grid first runs the adaptive controller and then freezes ITS grid: the
+    step boundaries it accepted (for the member that needed the most steps) plus the output times, so the
+    differentiated solve has the accuracy rtol / atol ask for;
   * ``energy_fn``, ``loading_fn`` and ``constrained_DOFs_fn`` must come from ``difflexmm_amd.energy`` /
     ``difflexmm_amd.loading`` (declarative specs), otherwise ``TypeError`` at setup;
   * ``batch=B`` integrates B members (list of B ``ControlParams``) side by side.
@@ -136,12 +138,33 @@ class DynamicSolver:
         span = np.diff(np.asarray(timepoints, dtype=float)).max() if len(timepoints) > 1 else 0.0
         return max(1, int(np.ceil(span / dt)))
 
+    def adaptive_grid(self, state0, timepoints, flats):
+        """(steps per output interval, step boundaries) frozen from a forward-only adaptive solve of the same problem
+        (parameters already on the device): the step boundaries the controller accepted for the member that needed
+        the most steps, merged with the output times (the controller steps across them and interpolates; a fixed grid
+        has to land on them).  Accepted boundaries closer to an output time than 1 % of the neighbouring step are dropped."""
+        ts = np.asarray(timepoints, dtype=float)
+        if len(ts) < 2:
+            return np.zeros(0, dtype=np.int32), None
+        _, st = self.engine.forward_adaptive(state0, ts, self.rtol, self.atol)
+        self.adaptive_stats = st
+        counts = self.engine.adaptive_step_counts()
+        acc = self.engine.adaptive_step_times(int(counts.sum(1).argmax()))
+        acc = acc[(acc > ts[0]) & (acc < ts[-1])]
+        if len(acc):
+            step = np.diff(np.concatenate([[ts[0]], acc]))
+            near = np.abs(acc[:, None] - ts[None, :]).min(1)
+            acc = acc[near > 0.01 * step]
+        grid = np.union1d(ts, acc)
+        spis = np.array([np.count_nonzero((grid >= a) & (grid < b)) for a, b in zip(ts[:-1], ts[1:])], dtype=np.int32)
+        return spis, grid
+
     # -- solve -----------------------------------------------------------------------------------------
-    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None):
+    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None, step_times=None):
         cps = self._members(control_params)
         flats = [self._flatten(cp) for cp in cps]
         self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
-        spi = steps_per_interval or self.steps_per_interval
+        spi = steps_per_interval if steps_per_interval is not None else self.steps_per_interval
         state0 = np.asarray(state0, dtype=float)
         if state0.ndim == 3:
             state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
@@ -151,11 +174,13 @@ class DynamicSolver:
             self._last = None
             self.stats = dict(stats, steps_per_interval=None, step_control="adaptive")
             return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
-        if spi is None:   # the reverse sweep needs a fixed grid: choose it from the stiffness bound
-            spi = max(self.estimate_steps_per_interval(f, timepoints) for f in flats)
-        fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory)
+        control = "fixed"
+        if spi is None:   # the reverse sweep needs a fixed grid: freeze the one the adaptive controller chooses
+            spi, step_times = self.adaptive_grid(state0, timepoints, flats)
+            control = "adaptive-grid"
+        fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times)
         self._last = (cps, flats, np.asarray(timepoints, dtype=float))
-        self.stats = dict(stats, steps_per_interval=spi, step_control="fixed")
+        self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control=control)
         return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
 
     # -- reverse mode ------------------------------------------------------------------------------------

@@ -131,6 +131,15 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats);
 
+/* Same on a caller-chosen grid: steps_per_interval[k] steps between timepoints[k] and timepoints[k+1]
+ * (n_timepoints - 1 entries); step_times == NULL: equal steps inside every interval; otherwise step_times holds the
+ * sum(steps_per_interval) + 1 step boundaries, strictly increasing, with the boundary that starts interval k equal to
+ * timepoints[k].  This is how the grid chosen by the adaptive controller (dfx_adaptive_step_counts /
+ * dfx_adaptive_step_times) is made differentiable: dfx_adjoint is the exact reverse of this solve. */
+int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                     const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                     double* fields, dfx_stats* stats);
+
 /* The reference's own integrator semantics (jax.experimental.ode.odeint 0.4.8 called at dynamics.py:166): adaptive
  * Dormand-Prince 5(4), RMS error norm over the free (q, v) components with tolerance atol + rtol*max(|y0|,|y1|),
  * step factor min(10, max(0.9 ratio^-1/5, 1 | 0.2)) applied on accept and reject, Hairer initial step, quartic dense
@@ -139,6 +148,14 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
  * stats->rhs_evals = RHS evaluations (max over members). */
 int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                          double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats);
+
+/* Accepted steps of the last dfx_forward_adaptive per member and output interval: counts (batch, n_timepoints - 1);
+ * a step is counted in the interval that contains its start. */
+int dfx_adaptive_step_counts(dfx_handle* h, int32_t* counts);
+
+/* End times of the steps member `member` accepted in the last dfx_forward_adaptive: writes min(*n, capacity) values
+ * into times and the number of accepted steps into *n (at most 2^20 steps per member are recorded). */
+int dfx_adaptive_step_times(dfx_handle* h, int32_t member, double* times, int64_t capacity, int64_t* n);
 
 /* Reverse sweep over the checkpointed trajectory of the last dfx_forward(keep_trajectory=1).
  * fields_bar: (batch, T, 2, n_blocks, 3) cotangent of `fields`. */

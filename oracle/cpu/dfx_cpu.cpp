@@ -33,7 +33,11 @@ struct dfx_handle {
   std::vector<double> traj;       // batch * (N+1) * n_blocks * kRec   (when kept)
   std::vector<double> fields;     // batch * T * 2 * n_blocks * 3
   std::vector<double> ts;
-  int spi = 0;
+  std::vector<int> spis;          // steps per output interval
+  std::vector<int64_t> step0;     // first step ordinal of every interval
+  std::vector<int32_t> step_counts;  // accepted steps per member and interval (adaptive)
+  std::vector<std::vector<double>> acc_times;  // end times of the accepted steps per member (adaptive)
+  std::vector<double> t_steps;       // caller-chosen step boundaries (empty: equal steps)
   bool have_traj = false;
 };
 
@@ -124,18 +128,44 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
 
 int dfx_reserve(dfx_handle*, int64_t, int32_t, int32_t) { return 0; }
 
+int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                     const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                     double* fields, dfx_stats* stats);
+
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
-  if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
   if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+  std::vector<int32_t> spis((size_t)std::max(0, n_timepoints - 1), steps_per_interval);
+  return dfx_forward_grid(h, state0, timepoints, n_timepoints, spis.data(), nullptr, keep_trajectory, fields, stats);
+}
+
+int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                     const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                     double* fields, dfx_stats* stats) {
+  if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
+  if (n_timepoints < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
   const Plan& pl = h->pl;
   const Tableau& T = pl.tab;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = n_timepoints, spi = steps_per_interval;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = n_timepoints;
   const size_t rec = (size_t)nb * kRec;
-  const int64_t N = (int64_t)(Tn - 1) * spi;
+  h->spis.assign(steps_per_interval, steps_per_interval + (Tn - 1));
+  h->step0.assign(Tn, 0);
+  for (int k = 0; k + 1 < Tn; ++k) {
+    if (h->spis[k] < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+    h->step0[k + 1] = h->step0[k] + h->spis[k];
+  }
+  const int64_t N = h->step0[Tn - 1];
+  h->t_steps.clear();
+  if (step_times) {
+    h->t_steps.assign(step_times, step_times + N + 1);
+    for (int64_t n = 0; n < N; ++n)
+      if (!(h->t_steps[n + 1] > h->t_steps[n])) { h->err = "forward: step_times must be strictly increasing"; return 1; }
+    for (int k = 0; k < Tn; ++k)
+      if (h->t_steps[h->step0[k]] != timepoints[k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
+  }
+  const bool own_grid = !h->t_steps.empty();
   auto t_begin = std::chrono::steady_clock::now();
   h->ts.assign(timepoints, timepoints + Tn);
-  h->spi = spi;
   h->have_traj = keep_trajectory != 0;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
   if (keep_trajectory) h->traj.assign((size_t)B * (N + 1) * rec, 0.0);
@@ -150,9 +180,11 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
     snapshot(Y, nb, fm);
     int64_t n = 0;
     for (int k = 0; k + 1 < Tn; ++k) {
-      const double hh = (timepoints[k + 1] - timepoints[k]) / spi;
+      const int spi = h->spis[k];
+      const double heq = (timepoints[k + 1] - timepoints[k]) / spi;
       for (int j = 0; j < spi; ++j, ++n) {
-        const double t = timepoints[k] + j * hh;
+        const double t = own_grid ? h->t_steps[n] : timepoints[k] + j * heq;
+        const double hh = own_grid ? h->t_steps[n + 1] - t : heq;
         double* Ynext = tr ? tr + (size_t)(n + 1) * rec : (Y == Ybuf.data() ? Ybuf.data() + rec : Ybuf.data());
         for (int i = 0; i < T.s; ++i) {
           FwdStage st;
@@ -217,6 +249,8 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
   h->ts.assign(timepoints, timepoints + Tn);
   h->have_traj = false;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
+  h->step_counts.assign((size_t)B * std::max(0, Tn - 1), 0);
+  h->acc_times.assign(B, {});
   int64_t max_acc = 0, max_try = 0;
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
@@ -300,6 +334,8 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
           }
           t_last = t; h_acc = dt; t += dt; have_step = true;
           ++n_acc;
+          ++h->step_counts[(size_t)m * (Tn - 1) + (k - 1)];   // the interval that contains the start of the step
+          h->acc_times[m].push_back(t);
         }
         dt = dt_new;
       }
@@ -328,9 +364,9 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
   if (!h->have_traj) { h->err = "adjoint: run forward with keep_trajectory=1 first"; return 1; }
   const Plan& pl = h->pl;
   const Tableau& T = pl.tab;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size(), spi = h->spi;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
   const size_t rec = (size_t)nb * kRec;
-  const int64_t N = (int64_t)(Tn - 1) * spi;
+  const int64_t N = h->step0[Tn - 1];
   auto t_begin = std::chrono::steady_clock::now();
   const int nsp = pl.n_special > 0 ? pl.n_special : 1;
   std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
@@ -344,15 +380,18 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
     const double* tr = h->traj.data() + (size_t)m * (N + 1) * rec;
     const double* G = Gall.data() + (size_t)m * Tn * nb * 6;
     int cur = 0;
-    const double h_last = Tn > 1 ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / spi : 0.0;
+    const bool own_grid = !h->t_steps.empty();
+    const double h_last = Tn > 1 ? (own_grid ? h->t_steps[N] - h->t_steps[N - 1] : (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]) : 0.0;
     for (int b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d)
         adj_begin_dof(tb, T, G + (size_t)(Tn - 1) * nb * 6, h_last, LAM.data(), W.data() + (size_t)cur * nb * 3, KQ.data() + (size_t)cur * nb * 3, b, d);
     for (int k = Tn - 2; k >= 0; --k) {
-      const double hh = (h->ts[k + 1] - h->ts[k]) / spi;
+      const int spi = h->spis[k];
+      const double heq = (h->ts[k + 1] - h->ts[k]) / spi;
       for (int j = spi - 1; j >= 0; --j) {
-        const int64_t n = (int64_t)k * spi + j;
-        const double t = h->ts[k] + j * hh;
+        const int64_t n = h->step0[k] + j;
+        const double t = own_grid ? h->t_steps[n] : h->ts[k] + j * heq;
+        const double hh = own_grid ? h->t_steps[n + 1] - t : heq;
         const double* Y = tr + (size_t)n * rec;
         // recompute the stage records of step n
         for (int i = 0; i < T.s; ++i) {
@@ -372,7 +411,8 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
           st.YB = YB.data(); st.LAM = LAM.data();
           st.G = (i == 0 && j == 0) ? G + (size_t)k * nb * 6 : nullptr;
           st.i = i; st.local_only = 0; st.t_i = t + T.c[i] * hh; st.h = hh;
-          st.h_prev = j > 0 ? hh : (k > 0 ? (h->ts[k] - h->ts[k - 1]) / spi : 0.0);
+          st.h_prev = own_grid ? (n > 0 ? t - h->t_steps[n - 1] : 0.0)
+                               : (j > 0 ? hh : (k > 0 ? (h->ts[k] - h->ts[k - 1]) / h->spis[k - 1] : 0.0));
           adj_stage(tb, T, st, acc);
           cur = 1 - cur;
         }
@@ -394,6 +434,20 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
     stats->steps = N; stats->rhs_evals = N * T.s;
     stats->kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
+  return 0;
+}
+
+int dfx_adaptive_step_counts(dfx_handle* h, int32_t* counts) {
+  if (h->step_counts.empty() && h->ts.size() > 1) { h->err = "adaptive_step_counts: run forward_adaptive first"; return 1; }
+  if (!h->step_counts.empty()) memcpy(counts, h->step_counts.data(), sizeof(int32_t) * h->step_counts.size());
+  return 0;
+}
+
+int dfx_adaptive_step_times(dfx_handle* h, int32_t member, double* times, int64_t capacity, int64_t* n) {
+  if (member < 0 || member >= (int)h->acc_times.size()) { h->err = "adaptive_step_times: run forward_adaptive first"; return 1; }
+  const std::vector<double>& a = h->acc_times[member];
+  *n = (int64_t)a.size();
+  for (int64_t i = 0; i < std::min<int64_t>(capacity, (int64_t)a.size()); ++i) times[i] = a[i];
   return 0;
 }
 

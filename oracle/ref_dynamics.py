@@ -85,7 +85,7 @@ def build_RHS(energy_fn, loading_fn):
 def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loading_fn=None,
                          constrained_block_DOF_pairs=(), constrained_DOFs_fn=lambda t, **kw: 0.0,
                          damped_blocks=None, rtol=1e-8, atol=1e-8,
-                         integrator="adaptive", steps_per_interval=None, tableau="dopri5"):
+                         integrator="adaptive", steps_per_interval=None, tableau="dopri5", step_times=None):
     """dynamics.py:60-186.  ``integrator='adaptive'`` is the reference behaviour (odeint);
     ``'fixed'`` runs the same tableau on the engine's fixed grid.
     The returned solver has the reference signature and result layout (T, 2, n_blocks, 3);
@@ -146,7 +146,8 @@ def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loadi
         if integrator == "adaptive":
             sol = ref_ode.odeint(f, y0.detach().numpy().reshape(-1), ts, rtol=rtol, atol=atol, stats=stats)
         else:
-            sol = ref_ode.odeint_fixed(f, y0.detach().numpy().reshape(-1), ts, steps_per_interval, tableau, stats=stats)
+            sol = ref_ode.odeint_fixed(f, y0.detach().numpy().reshape(-1), ts, steps_per_interval, tableau, stats=stats,
+                                       step_times=step_times)
         sol = torch.as_tensor(sol).reshape(len(ts), 2, n_free)
         # dynamics.py:169-182: scatter free DOFs, constrained DOFs follow c(t) and dc/dt
         out = torch.zeros(len(ts), 2, geometry.n_blocks * 3, dtype=F64)
@@ -167,7 +168,7 @@ def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loadi
 
 
 def solve_fixed_differentiable(solver, geometry, state0, timepoints, control_params, steps_per_interval,
-                               tableau="dopri5"):
+                               tableau="dopri5", step_times=None):
     """Fixed-step solve kept on the autograd tape (small lattices only): the oracle's stand-in for
     ``jax.grad`` through ``solve_dynamics`` (problems/quads_focusing.py:565).  Returns the free-DOF
     history (T, 2, n_free) as a differentiable tensor plus the reduced inertia."""
@@ -182,10 +183,16 @@ def solve_fixed_differentiable(solver, geometry, state0, timepoints, control_par
         return solver.rhs(s, t, control_params, inertia, create_graph=True)
 
     k1 = f(y, float(ts[0])) if tableau == "dopri5" else None
-    for a, b in zip(ts[:-1], ts[1:]):
-        h = (b - a) / steps_per_interval
-        for s in range(steps_per_interval):
-            t = a + s * h
+    spis = np.broadcast_to(np.asarray(steps_per_interval, dtype=np.int64), (max(len(ts) - 1, 0),))
+    n = 0
+    for a, b, spi in zip(ts[:-1], ts[1:], spis):
+        for s in range(int(spi)):
+            if step_times is None:
+                h = (b - a) / int(spi)
+                t = a + s * h
+            else:
+                t, h = float(step_times[n]), float(step_times[n + 1] - step_times[n])
+            n += 1
             if tableau == "dopri5":
                 ks = [k1]
                 for i in range(1, 7):

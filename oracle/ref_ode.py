@@ -112,9 +112,9 @@ def odeint(func, y0, ts, rtol=1.4e-8, atol=1.4e-8, mxstep=np.inf, hmax=np.inf, s
     return np.stack(out)
 
 
-def odeint_fixed(func, y0, ts, steps_per_interval, tableau="dopri5", stats=None):
+def odeint_fixed(func, y0, ts, steps_per_interval, tableau="dopri5", stats=None, step_times=None):
     """Fixed-step explicit RK on the grid the MI355X engine uses: every output interval
-    [ts[i], ts[i+1]] is split into ``steps_per_interval`` equal steps; outputs are step ends.
+    [ts[i], ts[i+1]] is split into ``steps_per_interval`` (one int, or one per interval) equal steps; outputs are step ends.
     ``dopri5``: 5th-order solution weights, 6 RHS evaluations per step with FSAL reuse.
     ``rk4``: classical 4-stage method."""
     y = np.asarray(y0, dtype=np.float64).ravel().copy()
@@ -122,10 +122,14 @@ def odeint_fixed(func, y0, ts, steps_per_interval, tableau="dopri5", stats=None)
     out = [y.copy()]
     n = 0
     f = func(y, ts[0]) if tableau == "dopri5" else None
-    for a, b in zip(ts[:-1], ts[1:]):
-        h = (b - a) / steps_per_interval
-        for s in range(steps_per_interval):
-            t = a + s * h
+    spis = np.broadcast_to(np.asarray(steps_per_interval, dtype=np.int64), (max(len(ts) - 1, 0),))   # one count, or one per interval
+    for a, b, spi in zip(ts[:-1], ts[1:], spis):
+        for s in range(int(spi)):
+            if step_times is None:
+                h = (b - a) / int(spi)
+                t = a + s * h
+            else:       # caller-chosen step boundaries
+                t, h = step_times[n], step_times[n + 1] - step_times[n]
             if tableau == "dopri5":
                 y, f, _, _ = runge_kutta_step(func, y, f, t, h)
             else:

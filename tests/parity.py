@@ -67,7 +67,8 @@ def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=Tr
     return errs
 
 
-def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, contact=True, seed=5, spi=6, n_out=5, batch=1):
+def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, contact=True, seed=5, spi=6, n_out=5, batch=1,
+                                 own_step_times=False):
     cut = (125.0 if lattice == "kagome" else 42.0)
     c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, integrator=integrator)
     fast = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)   # a full pulse inside the short window
@@ -75,13 +76,18 @@ def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, co
     ts = np.linspace(0, 3e-4, n_out)
     s = c.solver
     y0 = c.random_state(0.05, 0.02, 5.0)
-    fields = s(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=spi)
-    osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi, tableau=integrator)
+    step_times = None
+    if own_step_times:      # unequal steps inside every interval
+        counts = np.broadcast_to(spi, (n_out - 1,))
+        step_times = np.concatenate([a + (b - a) * np.linspace(0, 1, int(k) + 1)[:-1] ** 1.7 for a, b, k in zip(ts[:-1], ts[1:], counts)]
+                                    + [ts[-1:]])
+    fields = s(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=spi, step_times=step_times)
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi, tableau=integrator, step_times=step_times)
     lv = dict(loading_rate=T64(3000.0), input_delay=T64(1e-5))
     of = osol(y0, ts, c.oracle_cp(lv)).numpy()
     e_fwd = relerr(fields, of)
     assert e_fwd < RTOL_TRAJ, ("forward", lattice, integrator, e_fwd)
-    assert s.stats["steps"] == (n_out - 1) * spi
+    assert s.stats["steps"] == int(np.sum(np.broadcast_to(spi, (n_out - 1,))))
     fb = c.rng.normal(size=fields.shape)
     # the oracle's differentiable history holds the free DOFs only: keep the cotangent off the prescribed DOFs here
     # (their direct contribution is covered by test_cotangents_on_prescribed_dof_outputs_reach_constraint_params)
@@ -93,7 +99,7 @@ def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, co
     amp, y0t = T64(7.5, True), T64(y0, True)
     free = osol.free_DOF_ids
     hist, _ = OD.solve_fixed_differentiable(osol, c.ogeo, y0t, ts, c.oracle_cp(dict(cnv=cnv, cen=cen, amplitude=amp, **lv)),
-                                            spi, integrator)
+                                            spi, integrator, step_times=step_times)
     L = (hist * T64(fb.reshape(len(ts), 2, -1)[:, :, free])).sum()
     gr = torch.autograd.grad(L, design + [amp, y0t])
     mine = c.geo.vjp(c.design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)

@@ -153,3 +153,47 @@ def test_config_c4_kagome_64x64_forward_and_gradient(hip_lib, cpu_lib):
     pairs, vec, driven, clamped = kagome_focusing_constraints(c.geo, 2, 2)
     assert len(driven) == 2 and vec.sum() == 2 and len(np.unique(pairs[:, 0] * 3 + pairs[:, 1])) == len(pairs)
     assert len(kagome_target_blocks(c.geo, (2, 2), (3, 3))) == 8
+
+
+def test_grid_with_its_own_step_count_per_interval(hip_lib):
+    """dfx_forward_grid: a different number of steps in every output interval (power-of-two graph chunks)."""
+    parity.check_trajectory_and_adjoint(None, "quads", 4, "dopri5", spi=np.array([3, 7, 1, 5]))
+
+
+@pytest.mark.parametrize("lattice,n,integrator", [("quads", 4, "dopri5"), ("kagome", 3, "rk4")])
+def test_grid_with_caller_chosen_step_boundaries(hip_lib, lattice, n, integrator):
+    """dfx_forward_grid(step_times=...): unequal steps inside the intervals, forward and reverse."""
+    parity.check_trajectory_and_adjoint(None, lattice, n, integrator, spi=np.array([3, 7, 2, 5]), own_step_times=True)
+
+
+def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib):
+    """keep_trajectory=True without a grid: freeze the adaptive controller's accepted step boundaries, then forward +
+    reverse on that grid.  The frozen solve stays within the tolerance of the adaptive one; on the SAME grid the CPU port
+    gives the same fields and gradient; the CPU port's own controller picks the same grid up to the rounding
+    sensitivity of the error norm (the step factor is the -1/5 power of an O(1e-8) quantity)."""
+    def case(lib):
+        c = Case("quads", 6, True, True, seed=9, lib=lib, cutoff_deg=42.0, batch=2)
+        cps = [c.cp._replace(constraint_params=dict(amplitude=a, loading_rate=3000.0, input_delay=1e-5)) for a in (7.5, 3.0)]
+        return c, cps, c.random_state(0.05, 0.02, 5.0)
+
+    ts = np.array([0.0, 0.5e-4, 1.0e-4, 2.5e-4, 3.0e-4])
+    c, cps, y0 = case(None)
+    s = c.solver
+    adaptive = s(y0, ts, cps)
+    frozen = s(y0, ts, cps, keep_trajectory=True)
+    assert s.stats["step_control"] == "adaptive-grid"
+    assert np.abs(frozen - adaptive).max() < 1e-6 * np.abs(adaptive).max()
+    grid, spis = s.stats["step_times"], s.stats["steps_per_interval"]
+    fb = np.random.default_rng(1).normal(size=frozen.shape)
+    trees, s0 = s.vjp(fb)
+    g_hip = np.stack([t.geometrical_params.centroid_node_vectors for t in trees])
+
+    cc, cps_c, _ = case(cpu_lib)
+    sc = cc.solver
+    f_cpu = sc(y0, ts, cps_c, keep_trajectory=True, steps_per_interval=spis, step_times=grid)
+    trees_c, s0_c = sc.vjp(fb)
+    g_cpu = np.stack([t.geometrical_params.centroid_node_vectors for t in trees_c])
+    assert relerr(frozen, f_cpu) < 1e-9
+    assert relerr(g_hip, g_cpu) < 1e-8 and relerr(s0, s0_c) < 1e-8
+    sc(y0, ts, cps_c, keep_trajectory=True)
+    assert len(sc.stats["step_times"]) == len(grid) and relerr(sc.stats["step_times"], grid) < 1e-6
