@@ -45,6 +45,11 @@ using namespace dfx;
 
 namespace {
 
+// Index arithmetic inside the stage kernels is 32-bit (one s_mul / v_mad instead of a 64-bit multiply chain per array);
+// dfx_create refuses ensembles whose largest per-handle array would not fit (check_index_range).  The trajectory
+// checkpoint and the cotangent table keep 64-bit offsets.
+typedef unsigned u32;
+
 constexpr int kThreads = 256;
 constexpr int kAccCap = 1 << 20;   // accepted step times recorded per member (adaptive)
 constexpr int kMaxGraphSteps = 256;
@@ -161,11 +166,11 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 }
 
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * c.n_blocks * kPos;
+  if (buf >= 0) return c.POS + (((u32)m * c.nbuf + buf) * (u32)c.n_blocks) * kPos;
   return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep;
 }
 __device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.VEL + ((size_t)m * c.nbuf + buf) * c.n_blocks * 3;
+  if (buf >= 0) return c.VEL + (((u32)m * c.nbuf + buf) * (u32)c.n_blocks) * 3;
   return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep + (size_t)c.n_blocks * kPos;
 }
 
@@ -251,8 +256,8 @@ struct Partner {
 };
 
 template <int CONTACT>
-__device__ __forceinline__ void load_partner(const DevCtx& c, size_t ps, int pslot, const double* POSin, Partner& P) {
-  const double* pp = POSin + (size_t)(pslot >> 2) * kPos;
+__device__ __forceinline__ void load_partner(const DevCtx& c, u32 ps, int pslot, const double* POSin, Partner& P) {
+  const double* pp = POSin + (u32)(pslot >> 2) * kPos;
   P.b0 = reinterpret_cast<const double2*>(pp)[0];
   P.b1 = reinterpret_cast<const double2*>(pp)[1];
   P.b2 = pp[4];
@@ -278,12 +283,12 @@ struct LaneRaw {
 template <int CONTACT>
 __device__ __forceinline__ void issue_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneRaw& R) {
   const int b = slot >> 2, k = slot & 3;
-  const size_t ps = (size_t)m * c.n_slots;
+  const u32 ps = (u32)m * (u32)c.n_slots;
   R.info = c.slot_info[slot];
-  R.pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (size_t)b * kPos + 2 * k) : make_double2(0.0, 0.0);
+  R.pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (u32)b * kPos + 2 * k) : make_double2(0.0, 0.0);
   R.ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
   // branch-free (a branch here would end the batch of loads): the unused one of the two reads one shared valid address
-  const double* cst = c.cst + (size_t)m * 16;
+  const double* cst = c.cst + (u32)m * 16;
   R.lidx = (int)*(c.l_dict_on ? c.p_lidx + (ps + slot) : reinterpret_cast<const uint8_t*>(cst));
   R.lv = *reinterpret_cast<const double2*>(c.l_dict_on ? cst : c.p_l + (ps + slot) * 2);
   R.ks = R.ksh = R.kr = 0.0;
@@ -296,18 +301,18 @@ __device__ __forceinline__ void issue_lane(const DevCtx& c, int m, int slot, con
 
 template <int CONTACT>
 __device__ __forceinline__ void resolve_lane(const DevCtx& c, int m, const double* POSin, LaneRaw& R, LaneIn& L) {
-  const size_t ps = (size_t)m * c.n_slots;
+  const u32 ps = (u32)m * (u32)c.n_slots;
   const int info = R.info;
   L.info = info;
   double2 lv = R.lv, ln = make_double2(0.0, 0.0);
   if (c.l_dict_on) {
-    const double2* e = reinterpret_cast<const double2*>(c.l_dict + (size_t)m * 1024 + 4 * R.lidx);
+    const double2* e = reinterpret_cast<const double2*>(c.l_dict + ((u32)m * 1024 + 4 * R.lidx));
     lv = e[0]; ln = e[1];
   }
   const int pslot = info < 0 ? R.guess : (info >> 1);
   L.pslot = pslot; L.guess = R.guess;
   if (pslot != R.guess) load_partner<CONTACT>(c, ps, pslot, POSin, R.P);
-  const double* cst = c.cst + (size_t)m * 16;
+  const double* cst = c.cst + (u32)m * 16;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
   if (CONTACT) {
@@ -362,23 +367,23 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
     sg.t_interval = ck.t; sg.h = ck.h; sg.j0 = 0; sg.base_step = 0; j = 0;
   }
   const long long n = sg.base_step + j;
-  const size_t nd = (size_t)c.n_blocks * 3;
+  const u32 nd = (u32)c.n_blocks * 3;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
   LaneRaw R;
   issue_lane<CONTACT>(c, m, slot, POSin, R);
   const int dof = b * 3 + kd;
-  const double qn = pos_in(c, m, y_buf, n)[(size_t)b * kPos + kd];
+  const double qn = pos_in(c, m, y_buf, n)[(u32)b * kPos + kd];
   const double vn = vel_in(c, m, y_buf, n)[dof];
   const double v_i = vel_in(c, m, in_buf, n)[dof];
-  double* Am = c.A + (size_t)m * (c.s + 1) * nd;
-  const double damp = c.damping_uniform ? c.cst[(size_t)m * 16 + 6 + kd] : c.damping[(size_t)m * nd + dof];
-  const double invm = c.inv_m[(size_t)m * nd + dof];
+  double* Am = c.A + (u32)m * (u32)(c.s + 1) * nd;
+  const double damp = c.damping_uniform ? c.cst[(u32)m * 16 + 6 + kd] : c.damping[(u32)m * nd + dof];
+  const double invm = c.inv_m[(u32)m * nd + dof];
   const int sidx = c.block_special[b];
   // earlier stage accelerations: all loads issued together (a rolled loop waits for each one in turn)
   double al[kMaxStages - 1];
 #pragma unroll
-  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? Am[(size_t)l * nd + dof] : 0.0;
+  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? Am[(u32)l * nd + dof] : 0.0;
   LaneIn L;
   resolve_lane<CONTACT>(c, m, POSin, R, L);
   double sv = 0.0, sq = 0.0;
@@ -421,13 +426,13 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
         for (int f = 0; f < c.n_fns; ++f)
           if (sp.load_coef[k][f] != 0.0) {
             double g, gt;
-            eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t + sc.c_i * h, g, gt, gp);
+            eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + sc.c_i * h, g, gt, gp);
             fload += sp.load_coef[k][f] * g;
           }
       }
     }
     const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-    Am[(size_t)i * nd + dof] = a;
+    Am[(u32)i * nd + dof] = a;
     sv += sc.cv[i] * a;
     sq += sc.cq[i] * a;
     qnext = qn + h * (sc.c_next * vn + h * sq);
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       // i == 6 evaluated at the candidate y1: with (cv, cq) = (e, ee) the sums are the embedded error estimate
       double r2 = 0.0;
       if (!constrained) {
-        const double q1 = POSin[(size_t)b * kPos + k];
+        const double q1 = POSin[(u32)b * kPos + k];
         const double eq = h * h * sq, ev = h * sv;
         const double tq = c.atol + c.rtol * fmax(fabs(qn), fabs(q1)), tv = c.atol + c.rtol * fmax(fabs(vn), fabs(v_i));
         r2 = (eq / tq) * (eq / tq) + (ev / tv) * (ev / tv);
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
     // per-wave sum of the squared error ratios (fixed order -> deterministic); lane 0 of each wave stores it
     double r2 = (k < 3 && valid) ? qnext : 0.0;
     for (int off = 32; off > 0; off >>= 1) r2 += __shfl_down(r2, off, 64);
-    if ((threadIdx.x & 63) == 0) c.err_partial[((size_t)m * c.n_wg + lwg) * 4 + (threadIdx.x >> 6)] = r2;
+    if ((threadIdx.x & 63) == 0) c.err_partial[((u32)m * c.n_wg + lwg) * 4 + (threadIdx.x >> 6)] = r2;
     return;
   }
   if (out_buf < 0) return;
@@ -462,12 +467,12 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   fast_sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3 && !(c.ablate & 2)) {
-    *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + out_buf) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
-    c.VEL[((size_t)m * c.nbuf + out_buf) * nd + dof] = vnext;
+    *reinterpret_cast<double2*>(c.POS + ((((u32)m * c.nbuf + out_buf) * (u32)c.n_blocks + b) * kPos + 2 * k)) = chunk;
+    c.VEL[((u32)m * c.nbuf + out_buf) * nd + dof] = vnext;
     if (write_traj) {
       double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)(n + 1) * c.n_blocks * kStep;
-      *reinterpret_cast<double2*>(tr + (size_t)b * kPos + 2 * k) = chunk;
-      tr[(size_t)c.n_blocks * kPos + dof] = vnext;
+      *reinterpret_cast<double2*>(tr + ((u32)b * kPos + 2 * k)) = chunk;
+      tr[(u32)c.n_blocks * kPos + dof] = vnext;
     }
   }
 }
@@ -627,24 +632,24 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   const long long n = sg.base_step + j;
   // the reverse sweep visits forward ordinals n*s+i in decreasing order, so the buffer parity alternates
   const int win = wbuf_static >= 0 ? wbuf_static : (int)((n * c.s + i) & 1);
-  const size_t nd = (size_t)c.n_blocks * 3, nd6 = (size_t)c.n_blocks * 6;
+  const u32 nd = (u32)c.n_blocks * 3, nd6 = (u32)c.n_blocks * 6;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
   LaneRaw R;
   issue_lane<CONTACT>(c, m, slot, POSin, R);
   const int dof = b * 3 + kd;
-  const double* Win = c.W + ((size_t)m * 2 + win) * nd;
+  const double* Win = c.W + ((u32)m * 2 + win) * nd;
   const double w_d = Win[dof];
   // partner's w from the guessed slot (same batch as everything else)
   double wpx, wpy, wpth;
-  { const size_t gb = (size_t)(R.guess >> 2) * 3; wpx = Win[gb]; wpy = Win[gb + 1]; wpth = Win[gb + 2]; }
+  { const u32 gb = (u32)(R.guess >> 2) * 3; wpx = Win[gb]; wpy = Win[gb + 1]; wpth = Win[gb + 2]; }
   const double v_i = vel_in(c, m, in_buf, n)[dof];
-  const double kq_in = c.KQ[((size_t)m * 2 + win) * nd + dof];
-  const double damp = c.damping_uniform ? c.cst[(size_t)m * 16 + 6 + kd] : c.damping[(size_t)m * nd + dof];
-  const double invm = c.inv_m[(size_t)m * nd + dof];
+  const double kq_in = c.KQ[((u32)m * 2 + win) * nd + dof];
+  const double damp = c.damping_uniform ? c.cst[(u32)m * 16 + 6 + kd] : c.damping[(u32)m * nd + dof];
+  const double invm = c.inv_m[(u32)m * nd + dof];
   const int sidx = c.block_special[b];
-  double* YBm = c.YB + (size_t)m * c.s * nd6;
-  double* LAMm = c.LAM + (size_t)m * nd6;
+  double* YBm = c.YB + (u32)m * (u32)c.s * nd6;
+  double* LAMm = c.LAM + (u32)m * nd6;
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
   if (!local_only) {
     lq = LAMm[b * 6 + kd]; lv = LAMm[b * 6 + 3 + kd];
@@ -652,8 +657,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
 #pragma unroll
     for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
       const bool on = jj > i && jj < c.s;
-      yq[jj] = on ? YBm[(size_t)jj * nd6 + b * 6 + kd] : 0.0;
-      yv[jj] = on ? YBm[(size_t)jj * nd6 + b * 6 + 3 + kd] : 0.0;
+      yq[jj] = on ? YBm[(u32)jj * nd6 + b * 6 + kd] : 0.0;
+      yv[jj] = on ? YBm[(u32)jj * nd6 + b * 6 + 3 + kd] : 0.0;
     }
 #pragma unroll
     for (int jj = 1; jj < kMaxStages; ++jj) {
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   }
   LaneIn L;
   resolve_lane<CONTACT>(c, m, POSin, R, L);
-  if (L.pslot != L.guess) { const size_t pb = (size_t)(L.pslot >> 2) * 3; wpx = Win[pb]; wpy = Win[pb + 1]; wpth = Win[pb + 2]; }
+  if (L.pslot != L.guess) { const u32 pb = (u32)(L.pslot >> 2) * 3; wpx = Win[pb]; wpy = Win[pb + 1]; wpth = Win[pb + 2]; }
   const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
       eth += L.sgn * cg.dkap.v;
     }
     // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
-    const size_t gs = (size_t)m * c.n_slots + slot;
+    const u32 gs = (u32)m * (u32)c.n_slots + slot;
     double2* gr = reinterpret_cast<double2*>(c.g_r + gs * 2);
     double2 r = *gr;
     r.x -= g.rx.e; r.y -= g.ry.e;
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
         const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
         if ((coef != 0.0 && c.fn_g) || loaded) {
           double g, gt;
-          eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
+          eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
           if (loaded) fload += sp.load_coef[k][f] * g;
           if (coef != 0.0 && c.fn_g) {
             double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
@@ -737,11 +742,11 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
-      c.blk_m[(size_t)m * nd + dof] -= w_d * a_i;
-      if (c.blk_c) c.blk_c[(size_t)m * nd + dof] -= w_d * v_i;
+      c.blk_m[(u32)m * nd + dof] -= w_d * a_i;
+      if (c.blk_c) c.blk_c[(u32)m * nd + dof] -= w_d * v_i;
     }
-    YBm[(size_t)i * nd6 + b * 6 + k] = ybq;
-    YBm[(size_t)i * nd6 + b * 6 + 3 + k] = ybv;
+    YBm[(u32)i * nd6 + b * 6 + k] = ybq;
+    YBm[(u32)i * nd6 + b * 6 + 3 + k] = ybv;
     if (!local_only) {
       double kq, kv;
       if (i > 0) {
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
         lv += ybv + sv;
         const bool first = (sg.j0 + j) == 0;
         if (first && c.G && !constrained) {
-          const double* G = c.G + ((size_t)sg.interval * c.batch + m) * nd6;
+          const double* G = c.G + ((size_t)sg.interval * c.batch + m) * (size_t)nd6;
           lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
         }
         if (constrained) { lq = 0.0; lv = 0.0; }
@@ -761,8 +766,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
         kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
-      c.KQ[((size_t)m * 2 + (win ^ 1)) * nd + dof] = kq;
-      c.W[((size_t)m * 2 + (win ^ 1)) * nd + dof] = constrained ? 0.0 : kv * invm;
+      c.KQ[((u32)m * 2 + (win ^ 1)) * nd + dof] = kq;
+      c.W[((u32)m * 2 + (win ^ 1)) * nd + dof] = constrained ? 0.0 : kv * invm;
     }
   }
 }
@@ -1282,6 +1287,15 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   dfx_handle* h = new dfx_handle();
   auto fail = [&](int rc) { g_create_error = h->err; delete h; return rc; };
   if (build_plan(problem, h->pl, h->err)) return fail(1);
+  {  // the stage kernels index per-handle arrays with 32 bits
+    const Plan& pl = h->pl;
+    const double B = pl.batch, nb = pl.n_blocks, st = pl.tab.s;
+    const double largest = std::max({B * 2 * st * nb * kPos, B * pl.n_slots * 8.0, B * (st + 1) * nb * 6.0});
+    if (largest >= 2147483648.0) {
+      h->err = "create: batch x lattice too large for one handle (an array would exceed 2^31 elements); split the ensemble over several handles";
+      return fail(1);
+    }
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) { h->err = "no HIP device available (libdfx has no CPU fallback)"; return fail(2); }
