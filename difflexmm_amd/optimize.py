@@ -1,0 +1,171 @@
+"""Method of moving asymptotes for the design loop.
+
+The reference maximises its objectives with NLopt's ``LD_MMA`` (``problems/quads_focusing.py:546-652``:
+``nlopt.opt(nlopt.LD_MMA, n)``, ``add_inequality_mconstraint``, ``set_max_objective``, bounds, ``maxeval``).  NLopt is a
+third-party dependency (2.7.1, ``poetry.lock``) that is not on the target image; this is a NumPy restatement of the
+algorithm it documents: Svanberg's globally convergent MMA / CCSA (K. Svanberg, SIAM J. Optim. 12(2), 2002) in the form
+NLopt uses it --
+
+  * every function (objective and each constraint) is replaced around the current point x by the separable convex
+    approximation  g(x + d) = f(x) + sum_j [ f'_j s_j^2 d_j + (|f'_j| s_j + rho s_j^2 / 2) d_j^2 ] / (s_j^2 - d_j^2),
+    with moving asymptote widths s_j and a conservativeness parameter rho per function;
+  * the approximate problem is solved through its dual (one multiplier per constraint; the inner minimisation over d is
+    separable and closed-form), here with bound-constrained L-BFGS on the concave dual;
+  * the candidate is accepted when every approximation is conservative at it (g >= f), otherwise the rho of the
+    offending functions grow and the sub-problem is solved again (inner iterations);
+  * after an accepted step rho shrinks and s_j shrinks for oscillating coordinates / grows for monotone ones.
+
+Constraint Jacobians may be ``scipy.sparse`` matrices (the geometric constraints of the lattices are local).
+Host code (a few thousand variables, once per design iteration), not part of the kernel path.
+"""
+import numpy as np
+import scipy.optimize
+import scipy.sparse as sp
+
+
+class MMAResult(dict):
+    __getattr__ = dict.get
+
+
+def _abs(J):
+    return abs(J) if sp.issparse(J) else np.abs(J)
+
+
+def mma_minimize(fun, x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=0.0, xtol_rel=0.0,
+                 callback=None, verbose=False):
+    """minimise fun(x) -> (value, gradient) subject to lower <= x <= upper and c(x) <= 0 for every
+    ``(c, jac)`` pair in ``constraints`` (c(x) -> (m,), jac(x) -> (m, n) dense or sparse).
+    ``maxeval`` counts objective evaluations like NLopt's ``set_maxeval``."""
+    x = np.array(x0, dtype=float).ravel()
+    n = x.size
+    lb = np.full(n, -np.inf) if lower is None else np.broadcast_to(np.asarray(lower, dtype=float), (n,)).copy()
+    ub = np.full(n, np.inf) if upper is None else np.broadcast_to(np.asarray(upper, dtype=float), (n,)).copy()
+    x = np.clip(x, lb, ub)
+    finite = np.isfinite(lb) & np.isfinite(ub)
+    sigma = np.where(finite, 0.5 * (ub - lb), 1.0)
+    sig_min = np.where(finite, 1e-8 * (ub - lb), 1e-8)
+    sig_max = np.where(finite, 10.0 * (ub - lb), np.inf)
+
+    def eval_constraints(z):
+        if not constraints:
+            return np.zeros(0), sp.csr_matrix((0, n))
+        vals, jacs = [], []
+        for c, jac in constraints:
+            vals.append(np.asarray(c(z), dtype=float).ravel())
+            jacs.append(sp.csr_matrix(jac(z)))
+        return np.concatenate(vals), sp.vstack(jacs).tocsr()
+
+    def eval_constraint_values(z):
+        return np.concatenate([np.asarray(c(z), dtype=float).ravel() for c, _ in constraints]) if constraints else np.zeros(0)
+
+    f, g = fun(x)
+    g = np.asarray(g, dtype=float).ravel()
+    n_eval = 1
+    fc, J = eval_constraints(x)
+    m = fc.size
+    rho, rhoc = 1.0, np.ones(m)
+    feasible = bool(np.all(fc <= 0))
+    infeasibility = fc.max() if m else 0.0
+    x_prev = x_prev2 = x.copy()
+    best = (f, x.copy()) if feasible else (np.inf, x.copy())
+    y = np.zeros(m)
+    history = [f]
+    k = 0
+    status = "maxeval"
+    while n_eval < maxeval:
+        k += 1
+        s2 = sigma * sigma
+        Jabs = _abs(J)
+        lo = np.maximum(lb - x, -0.9 * sigma)
+        hi = np.minimum(ub - x, 0.9 * sigma)
+        accepted = False
+        for inner in range(60):
+            # ---- dual of the separable approximation
+            def primal(yv):
+                u = s2 * (g + (J.T @ yv if m else 0.0))
+                v = sigma * (np.abs(g) + (Jabs.T @ yv if m else 0.0)) + 0.5 * s2 * (rho + (rhoc @ yv if m else 0.0))
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    d = np.where(np.abs(u) < 1e-3 * (v + 1e-300), -0.5 * u / np.maximum(v, 1e-300) * 1.0,
+                                 (s2 / u) * (-v + np.sqrt(np.maximum(v * v - u * u / s2, 0.0))))
+                d = np.where(np.isfinite(d), d, 0.0)
+                return np.clip(d, lo, hi)
+
+            def approx(d, grad, r):
+                """g(x+d) - f(x) for one function with gradient grad and conservativeness r."""
+                return np.sum((grad * s2 * d + (np.abs(grad) * sigma + 0.5 * r * s2) * d * d) / (s2 - d * d))
+
+            def approx_constraints(d):
+                w = d / (s2 - d * d)
+                w2 = d * d / (s2 - d * d)
+                return fc + J @ (s2 * w) + Jabs @ (sigma * w2) + 0.5 * rhoc * np.sum(s2 * w2)
+
+            if m:
+                def neg_dual(yv):
+                    d = primal(yv)
+                    gc = approx_constraints(d)
+                    val = f + approx(d, g, rho) + yv @ gc
+                    return -val, -gc
+                res = scipy.optimize.minimize(neg_dual, y, jac=True, method="L-BFGS-B", bounds=[(0.0, None)] * m,
+                                              options=dict(maxiter=200, ftol=1e-14, gtol=1e-10))
+                y = np.maximum(res.x, 0.0)
+            d = primal(y)
+            x_new = x + d
+            f_new, g_new = fun(x_new)
+            n_eval += 1
+            fc_new = eval_constraint_values(x_new)
+            g0 = f + approx(d, g, rho)
+            gc = approx_constraints(d) if m else np.zeros(0)
+            feas_new = bool(np.all(fc_new <= 0))
+            infeas_new = fc_new.max() if m else 0.0
+            # NLopt's acceptance of a new best point: feasible and better, or less infeasible while none is feasible yet
+            if (feas_new and (f_new < best[0] or not feasible)) or (not feasible and infeas_new < infeasibility):
+                best = (f_new if feas_new else np.inf, x_new.copy())
+                feasible = feasible or feas_new
+                infeasibility = min(infeasibility, infeas_new)
+            conservative = g0 >= f_new - 1e-12 * max(1.0, abs(f_new)) and (not m or np.all(gc >= fc_new - 1e-12))
+            if conservative or n_eval >= maxeval:
+                accepted = True
+                break
+            w = 0.5 * np.sum(d * d / (s2 - d * d))
+            if w <= 0:
+                accepted = True
+                break
+            if g0 < f_new:
+                rho = min(10.0 * rho, 1.1 * (rho + (f_new - g0) / w))
+            if m:
+                bad = gc < fc_new
+                rhoc[bad] = np.minimum(10.0 * rhoc[bad], 1.1 * (rhoc[bad] + (fc_new[bad] - gc[bad]) / w))
+        if not accepted:
+            status = "inner iterations exhausted"
+            break
+        # ---- outer update
+        x_prev2, x_prev = x_prev, x
+        x, f_old, f, g = x_new, f, f_new, np.asarray(g_new, dtype=float).ravel()
+        fc, J = eval_constraints(x)
+        history.append(f)
+        if callback is not None:
+            callback(x, f, fc)
+        if verbose:
+            print(f"mma {k}: f = {f:.6e}  max constraint = {fc.max() if m else 0.0:.3e}  evals = {n_eval}")
+        rho = max(0.1 * rho, 1e-5)
+        rhoc = np.maximum(0.1 * rhoc, 1e-5)
+        if k > 1:
+            osc = (x - x_prev) * (x_prev - x_prev2)
+            sigma = np.clip(sigma * np.where(osc < 0, 0.7, np.where(osc > 0, 1.2, 1.0)), sig_min, sig_max)
+        if ftol_rel > 0 and abs(f - f_old) <= ftol_rel * max(abs(f), abs(f_old)):
+            status = "ftol"
+            break
+        if xtol_rel > 0 and np.all(np.abs(x - x_prev) <= xtol_rel * np.maximum(np.abs(x), 1e-300)):
+            status = "xtol"
+            break
+    x_best = best[1] if np.isfinite(best[0]) else x
+    f_best = best[0] if np.isfinite(best[0]) else f
+    return MMAResult(x=x_best, fun=f_best, n_eval=n_eval, n_iter=k, status=status, feasible=feasible, history=history)
+
+
+def mma_maximize(fun, x0, **kw):
+    """maximise: fun(x) -> (value, gradient); same options as :func:`mma_minimize` (``opt.set_max_objective``)."""
+    res = mma_minimize(lambda z: tuple(-np.asarray(a) for a in fun(z)), x0, **kw)
+    res["fun"] = -res["fun"]
+    res["history"] = [-h for h in res["history"]]
+    return res

@@ -277,6 +277,63 @@ class TargetKineticEnergy:
         return (obj, grads) if many else (obj, grads[0])
 
 
+class TargetAngularMomentum:
+    """objective(design) = sum_t sum_{b in target} [ (c_b + u_b - p) x (m v_b) + J omega_b ]: angular momentum of the
+    target blocks about ``spin_center`` summed over the output times (problems/quads_spin.py:380-430 with
+    energy.py:502-519).  Evaluated on the host from the fields; its cotangent goes through ``solve_dynamics.vjp`` (any
+    objective that is a function of the fields can be written like this), the explicit dependence on the design through
+    block centroids and inertia is added here.  ``spin_center``: a point, or "center" = mean centroid of the target
+    blocks in the design the objective was set up with (quads_spin.py:400-402)."""
+
+    def __init__(self, forward, target_size, target_shift, spin_center="center", reference_design=None):
+        self.forward = forward
+        if not getattr(forward, "is_setup", False):
+            forward.setup()
+        pick = kagome_target_blocks if isinstance(forward.geometry, KagomeGeometry) else quads_target_blocks
+        self.target_blocks = pick(forward.geometry, target_size, target_shift)
+        if isinstance(spin_center, str):
+            if reference_design is None:
+                raise ValueError("spin_center='center' needs the reference design")
+            spin_center = forward.geometry.block_centroids(*reference_design)[self.target_blocks].mean(0)
+        self.spin_center = np.asarray(spin_center, dtype=float)
+
+    def _value(self, sol):
+        from .geometry import compute_inertia
+        tb = self.target_blocks
+        inertia = compute_inertia(sol.centroid_node_vectors, self.forward.density)[tb]
+        pos = sol.block_centroids[tb][None] + sol.fields[:, 0, tb, :2] - self.spin_center    # (T, nt, 2)
+        vel = sol.fields[:, 1, tb, :]
+        lin = pos[..., 0] * vel[..., 1] * inertia[:, 1] - pos[..., 1] * vel[..., 0] * inertia[:, 0]
+        return float(np.sum(lin + vel[..., 2] * inertia[:, 2])), inertia, pos, vel
+
+    def value(self, design):
+        return self._value(self.forward.solve(design))[0]
+
+    def value_and_grad(self, design):
+        from .geometry import compute_inertia_vjp
+        fw, tb = self.forward, self.target_blocks
+        sol = fw.solve(design, keep_trajectory=True)
+        val, inertia, pos, vel = self._value(sol)
+        fb = np.zeros_like(sol.fields)
+        fb[:, 0, tb, 0] = vel[..., 1] * inertia[:, 1]
+        fb[:, 0, tb, 1] = -vel[..., 0] * inertia[:, 0]
+        fb[:, 1, tb, 0] = -pos[..., 1] * inertia[:, 0]
+        fb[:, 1, tb, 1] = pos[..., 0] * inertia[:, 1]
+        fb[:, 1, tb, 2] = inertia[:, 2]
+        tree, _ = fw.solve_dynamics.vjp(fb)
+        cnv_bar = tree.geometrical_params.centroid_node_vectors.copy()
+        cen_bar = np.array(tree.geometrical_params.block_centroids, dtype=float, copy=True)
+        # explicit terms: positions contain the block centroids; the inertia of the target blocks
+        cen_bar[tb, 0] += (vel[..., 1] * inertia[:, 1]).sum(0)
+        cen_bar[tb, 1] += (-vel[..., 0] * inertia[:, 0]).sum(0)
+        ib = np.zeros((fw.geometry.n_blocks, 3))
+        ib[tb, 0] = (-pos[..., 1] * vel[..., 0]).sum(0)
+        ib[tb, 1] = (pos[..., 0] * vel[..., 1]).sum(0)
+        ib[tb, 2] = vel[..., 2].sum(0)
+        cnv_bar += compute_inertia_vjp(sol.centroid_node_vectors, fw.density, ib)[0]
+        return val, fw.geometry.vjp(design, cnv_bar, cen_bar)
+
+
 class MultiInputTargetKineticEnergy:
     """weights @ [target kinetic energy of every forward problem], all sharing one design
     (problems/quads_focusing_multi_input.py:43-86).  The forward problems differ in their boundary conditions
@@ -317,6 +374,83 @@ def edge_length_constraints(geometry, design, min_edge_length):
     """<= 0 when satisfied (problems/quads_focusing.py:535-544)."""
     from .geometry import compute_edge_lengths
     return -(compute_edge_lengths(geometry.centroid_node_vectors(*design)).reshape(-1) - min_edge_length)
+
+
+def design_index_map(geometry):
+    """(n_blocks, n_npb, 2) int: which entry of the flattened design tuple every reference node coordinate adds.
+    The lattices place every node at ``constant + one design shift`` (geometry.py:607-952), so the map is read off by
+    pushing the entry numbers through ``reference_node_vectors``."""
+    shapes = geometry.design_shapes()
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    ids = np.split(np.arange(sum(sizes), dtype=float), np.cumsum(sizes)[:-1])
+    zeros = [np.zeros(sh) for sh in shapes]
+    ref = geometry.reference_node_vectors(*[i.reshape(sh) for i, sh in zip(ids, shapes)]) - geometry.reference_node_vectors(*zeros)
+    return np.rint(ref).astype(np.int64)
+
+
+def _flatten_design(design):
+    return np.concatenate([np.asarray(a, dtype=float).ravel() for a in design])
+
+
+def _unflatten_design(geometry, x):
+    shapes = geometry.design_shapes()
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    return tuple(p.reshape(sh) for p, sh in zip(np.split(np.asarray(x, dtype=float), np.cumsum(sizes)[:-1]), shapes))
+
+
+def _angle_rows(rows, cols, vals, row0, imap, bu, iu, lu, u, bw, iw, lw, w, sign):
+    """Append the triplets of d angle(u, w) / d design for angles numbered row0.., u = r[bu, iu] - r[bu, lu] etc.
+    angle = atan2(u x w, u . w): d/du = -perp(u)/|u|^2, d/dw = perp(w)/|w|^2, perp(a) = (-a_y, a_x)."""
+    n = len(u)
+    r = row0 + np.arange(n)
+    du = -np.stack([-u[:, 1], u[:, 0]], 1) / (u ** 2).sum(1)[:, None] * sign
+    dw = np.stack([-w[:, 1], w[:, 0]], 1) / (w ** 2).sum(1)[:, None] * sign
+    for blk, node, d in ((bu, iu, du), (bu, lu, -du), (bw, iw, dw), (bw, lw, -dw)):
+        for c in range(2):
+            rows.append(r); cols.append(imap[blk, node, c]); vals.append(d[:, c])
+
+
+def angle_constraints_jac(geometry, design):
+    """Sparse Jacobian (4 n_bonds, n_design) of :func:`angle_constraints` (the reference takes ``jax.jacobian`` of it,
+    problems/quads_focusing.py:586-587).  Edge vectors are differences of node vectors of one block, so the centroid
+    shift cancels and the reference node vectors can be differentiated directly."""
+    import scipy.sparse as sp
+    ref = geometry.reference_node_vectors(*design)
+    bonds = np.asarray(geometry.bond_connectivity(), dtype=np.int64)
+    n = geometry.n_npb
+    b1, l1 = bonds[:, 0] // n, bonds[:, 0] % n
+    b2, l2 = bonds[:, 1] // n, bonds[:, 1] % n
+    n1, p1, n2, p2 = (l1 + 1) % n, (l1 - 1) % n, (l2 + 1) % n, (l2 - 1) % n
+    e1p, e1m = ref[b1, n1] - ref[b1, l1], ref[b1, p1] - ref[b1, l1]
+    e2p, e2m = ref[b2, n2] - ref[b2, l2], ref[b2, p2] - ref[b2, l2]
+    imap = design_index_map(geometry)
+    nb = len(bonds)
+    rows, cols, vals = [], [], []
+    # rows: void_1 = angle(e2m, e1p), void_2 = angle(e1m, e2p), block_1 = angle(e1p, e1m), block_2 = angle(e2p, e2m); constraint = -(angle - min)
+    _angle_rows(rows, cols, vals, 0 * nb, imap, b2, p2, l2, e2m, b1, n1, l1, e1p, -1.0)
+    _angle_rows(rows, cols, vals, 1 * nb, imap, b1, p1, l1, e1m, b2, n2, l2, e2p, -1.0)
+    _angle_rows(rows, cols, vals, 2 * nb, imap, b1, n1, l1, e1p, b1, p1, l1, e1m, -1.0)
+    _angle_rows(rows, cols, vals, 3 * nb, imap, b2, n2, l2, e2p, b2, p2, l2, e2m, -1.0)
+    n_design = int(sum(np.prod(sh) for sh in geometry.design_shapes()))
+    return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(4 * nb, n_design)).tocsr()
+
+
+def edge_length_constraints_jac(geometry, design):
+    """Sparse Jacobian (n_nodes, n_design) of :func:`edge_length_constraints`."""
+    import scipy.sparse as sp
+    ref = geometry.reference_node_vectors(*design)
+    e = np.roll(ref, 1, axis=1) - ref                       # edge k = r[k-1] - r[k]
+    unit = e / np.linalg.norm(e, axis=2, keepdims=True)
+    imap = design_index_map(geometry)
+    nbk, npb = ref.shape[:2]
+    r = np.arange(nbk * npb).reshape(nbk, npb)
+    rows, cols, vals = [], [], []
+    for c in range(2):
+        rows += [r.ravel(), r.ravel()]
+        cols += [np.roll(imap, 1, axis=1)[:, :, c].ravel(), imap[:, :, c].ravel()]
+        vals += [-unit[:, :, c].ravel(), unit[:, :, c].ravel()]   # constraint = -(length - min)
+    n_design = int(sum(np.prod(sh) for sh in geometry.design_shapes()))
+    return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nbk * npb, n_design)).tocsr()
 
 
 @dataclass
@@ -375,6 +509,52 @@ class OptimizationProblem:
         self.objective_values.append(float(v))
         self.design_values.append(x)
         return x
+
+    def run_optimization_nlopt(self, initial_guess, n_iterations, max_time=None, lower_bound=None, upper_bound=None,
+                               min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=True):
+        """The reference's loop (problems/quads_focusing.py:546-652) with the same arguments and bookkeeping: maximise the
+        objective with the method of moving asymptotes (``difflexmm_amd.optimize``, standing in for ``nlopt.LD_MMA``)
+        under the angle and edge-length inequality constraints, ``n_iterations`` objective evaluations at most."""
+        import time
+        from .optimize import mma_maximize
+        g = self.objective.forward.geometry
+        t0 = time.perf_counter()
+
+        class _TimeUp(Exception):
+            pass
+
+        def fun(x):
+            if max_time is not None and self.objective_values and time.perf_counter() - t0 > max_time:
+                raise _TimeUp
+            design = _unflatten_design(g, x)
+            v, grad = self.objective.value_and_grad(design)
+            self.objective_values.append(float(v))
+            self.design_values.append(design)
+            if verbose:
+                print(f"Iteration: {len(self.objective_values)}\nObjective = {self.objective_values[-1]}")
+            return float(v), _flatten_design(grad)
+
+        constraints = []
+        if min_void_angle is not None and min_block_angle is not None:
+            def ca(x):
+                r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
+                self.constraints_violation["angles"].append(float(r.max()))
+                return r - 1e-8                                  # nlopt tolerance of the reference: 1e-8 per constraint
+            constraints.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
+        if min_edge_length is not None:
+            def ce(x):
+                r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
+                self.constraints_violation["edge_lengths"].append(float(r.max()))
+                return r - 1e-8
+            constraints.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
+        try:
+            res = mma_maximize(fun, _flatten_design(initial_guess), lower=lower_bound, upper=upper_bound,
+                               constraints=constraints, maxeval=n_iterations)
+            self.mma_result = res
+            best = _unflatten_design(g, res.x)
+        except _TimeUp:
+            best = self.design_values[int(np.argmax(self.objective_values))]
+        return best
 
     def to_dict(self):
         return dict(name=self.name, objective_values=list(self.objective_values), design_values=list(self.design_values),
