@@ -12,6 +12,9 @@ import numpy as np
 
 
 def _dist():
+    import sys
+    if "torch.distributed" not in sys.modules:      # nobody initialised a process group: single process, no torch import
+        return None
     import torch.distributed as dist
     return dist if dist.is_available() and dist.is_initialized() else None
 

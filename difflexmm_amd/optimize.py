@@ -31,11 +31,11 @@ def _abs(J):
     return abs(J) if sp.issparse(J) else np.abs(J)
 
 
-def mma_minimize(fun, x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=0.0, xtol_rel=0.0,
-                 callback=None, verbose=False):
-    """minimise fun(x) -> (value, gradient) subject to lower <= x <= upper and c(x) <= 0 for every
-    ``(c, jac)`` pair in ``constraints`` (c(x) -> (m,), jac(x) -> (m, n) dense or sparse).
-    ``maxeval`` counts objective evaluations like NLopt's ``set_maxeval``."""
+def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=0.0, xtol_rel=0.0,
+              callback=None, verbose=False):
+    """The algorithm as a coroutine: ``yield x`` asks the driver for ``(value, gradient)`` of the objective at x
+    (``generator.send((f, g))``); the generator returns the :class:`MMAResult`.  Lets many optimisations advance in
+    lock-step with their objective evaluations batched into one engine call (:func:`mma_minimize_ensemble`)."""
     x = np.array(x0, dtype=float).ravel()
     n = x.size
     lb = np.full(n, -np.inf) if lower is None else np.broadcast_to(np.asarray(lower, dtype=float), (n,)).copy()
@@ -58,7 +58,7 @@ def mma_minimize(fun, x0, lower=None, upper=None, constraints=(), maxeval=100, f
     def eval_constraint_values(z):
         return np.concatenate([np.asarray(c(z), dtype=float).ravel() for c, _ in constraints]) if constraints else np.zeros(0)
 
-    f, g = fun(x)
+    f, g = yield x
     g = np.asarray(g, dtype=float).ravel()
     n_eval = 1
     fc, J = eval_constraints(x)
@@ -110,7 +110,7 @@ def mma_minimize(fun, x0, lower=None, upper=None, constraints=(), maxeval=100, f
                 y = np.maximum(res.x, 0.0)
             d = primal(y)
             x_new = x + d
-            f_new, g_new = fun(x_new)
+            f_new, g_new = yield x_new
             n_eval += 1
             fc_new = eval_constraint_values(x_new)
             g0 = f + approx(d, g, rho)
@@ -161,6 +161,51 @@ def mma_minimize(fun, x0, lower=None, upper=None, constraints=(), maxeval=100, f
     x_best = best[1] if np.isfinite(best[0]) else x
     f_best = best[0] if np.isfinite(best[0]) else f
     return MMAResult(x=x_best, fun=f_best, n_eval=n_eval, n_iter=k, status=status, feasible=feasible, history=history)
+
+
+def _drive(gen, fun):
+    try:
+        x = next(gen)
+        while True:
+            x = gen.send(fun(x))
+    except StopIteration as stop:
+        return stop.value
+
+
+def mma_minimize(fun, x0, **kw):
+    """minimise fun(x) -> (value, gradient) subject to lower <= x <= upper and c(x) <= 0 for every
+    ``(c, jac)`` pair in ``constraints`` (c(x) -> (m,), jac(x) -> (m, n) dense or sparse).
+    ``maxeval`` counts objective evaluations like NLopt's ``set_maxeval``."""
+    return _drive(mma_steps(x0, **kw), fun)
+
+
+def mma_minimize_ensemble(batch_fun, x0s, per_member_kw=None, **kw):
+    """Independent minimisations advancing in lock-step: ``batch_fun(list of x) -> list of (value, gradient)`` is called
+    once per round with the pending point of EVERY member (members that have finished resubmit their last point so the
+    batch keeps its size: the engine integrates a fixed number of members side by side).  Each member's sequence of
+    iterates is exactly what :func:`mma_minimize` would produce for it alone."""
+    n = len(x0s)
+    gens = [mma_steps(x0, **dict(kw, **(per_member_kw[i] if per_member_kw else {}))) for i, x0 in enumerate(x0s)]
+    pending = [next(g) for g in gens]
+    results = [None] * n
+    while any(r is None for r in results):
+        values = batch_fun(pending)
+        for i, g in enumerate(gens):
+            if results[i] is not None:
+                continue
+            try:
+                pending[i] = g.send(values[i])
+            except StopIteration as stop:
+                results[i] = stop.value
+    return results
+
+
+def mma_maximize_ensemble(batch_fun, x0s, **kw):
+    res = mma_minimize_ensemble(lambda xs: [tuple(-np.asarray(a) for a in vg) for vg in batch_fun(xs)], x0s, **kw)
+    for r in res:
+        r["fun"] = -r["fun"]
+        r["history"] = [-h for h in r["history"]]
+    return res
 
 
 def mma_maximize(fun, x0, **kw):

@@ -269,6 +269,8 @@ class TargetKineticEnergy:
         fw = self.forward
         fw.solve(design, keep_trajectory=True)
         obj, trees, _ = fw.solve_dynamics.kinetic_energy_value_and_vjp(self.target_blocks)
+        # device time of this evaluation (forward + reverse sweep), for throughput reports
+        self.device_ms = getattr(self, "device_ms", 0.0) + fw.solve_dynamics.stats["kernel_ms"] + fw.solve_dynamics.adjoint_stats["kernel_ms"]
         many = isinstance(design, list)
         designs = design if many else [design]
         trees = trees if many else [trees]
@@ -352,13 +354,68 @@ class MultiInputTargetKineticEnergy:
         return float(self.weights @ self.individual(design))
 
     def value_and_grad(self, design):
+        """design: one design tuple, or a list of them (one per ensemble member of the batched forward problems)."""
+        many = isinstance(design, list)
         vals, total = [], None
         for w, o in zip(self.weights, self.objectives):
             v, g = o.value_and_grad(design)
-            vals.append(float(v))
-            total = [w * gi for gi in g] if total is None else [t + w * gi for t, gi in zip(total, g)]
-        self.last_individual = np.array(vals)
-        return float(self.weights @ self.last_individual), tuple(total)
+            vals.append(np.asarray(v, dtype=float))
+            gl = g if many else [g]
+            total = [[w * gi for gi in gm] for gm in gl] if total is None else \
+                [[t + w * gi for t, gi in zip(tm, gm)] for tm, gm in zip(total, gl)]
+        self.last_individual = np.array(vals)                      # (n_inputs,) or (n_inputs, n_members)
+        value = self.weights @ self.last_individual
+        if many:
+            return list(value), [tuple(t) for t in total]
+        return float(value), tuple(total[0])
+
+
+def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bound=None, upper_bound=None,
+                              min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=False):
+    """``len(initial_guesses)`` independent design optimisations (BASELINE config 5: an ensemble of multi-input focusing
+    designs) advancing in lock-step: every round the pending design of EVERY member is evaluated in one batched call of
+    the objective (``objective.value_and_grad(list of designs)`` -- the forward problems were built with
+    ``batch=len(initial_guesses)``), i.e. one forward + reverse sweep of the engine integrates all members side by side.
+    Each member runs the reference's loop (method of moving asymptotes under the angle / edge-length constraints,
+    problems/quads_focusing.py:546-652) exactly as it would alone.
+    Returns (best designs, list of per-member dicts with objective_values / constraints_violation / mma result)."""
+    from .optimize import mma_maximize_ensemble
+    g = objective.forward.geometry
+    n = len(initial_guesses)
+    logs = [dict(objective_values=[], constraints_violation={"angles": [], "edge_lengths": []}) for _ in range(n)]
+    finished = [False] * n
+
+    def batch_fun(xs):
+        designs = [_unflatten_design(g, x) for x in xs]
+        vals, grads = objective.value_and_grad(designs)
+        for i, v in enumerate(vals):
+            if len(logs[i]["objective_values"]) < n_iterations:
+                logs[i]["objective_values"].append(float(v))
+        if verbose:
+            print(f"round: objectives = {np.array2string(np.asarray(vals), precision=4)}")
+        return [(float(v), _flatten_design(gr)) for v, gr in zip(vals, grads)]
+
+    per_member = []
+    for i in range(n):
+        cons = []
+        if min_void_angle is not None and min_block_angle is not None:
+            def ca(x, i=i):
+                r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
+                logs[i]["constraints_violation"]["angles"].append(float(r.max()))
+                return r - 1e-8
+            cons.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
+        if min_edge_length is not None:
+            def ce(x, i=i):
+                r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
+                logs[i]["constraints_violation"]["edge_lengths"].append(float(r.max()))
+                return r - 1e-8
+            cons.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
+        per_member.append(dict(constraints=cons))
+    res = mma_maximize_ensemble(batch_fun, [_flatten_design(d) for d in initial_guesses], per_member_kw=per_member,
+                                lower=lower_bound, upper=upper_bound, maxeval=n_iterations)
+    for log, r in zip(logs, res):
+        log["mma"] = r
+    return [_unflatten_design(g, r.x) for r in res], logs
 
 
 # -- geometric constraints of the optimisation (problems/quads_focusing.py:473-544) ------------------------------------

@@ -178,3 +178,35 @@ def test_angular_momentum_objective_gradient_matches_fd(cpu_lib):
     fd = (vp - vm) / (2 * eps)
     an = sum((a * b).sum() for a, b in zip(g, d))
     assert abs(v) > 0 and abs(an - fd) < 2e-5 * abs(fd), (an, fd)
+
+
+def test_ensemble_optimisation_in_lock_step_equals_members_alone(cpu_lib):
+    """BASELINE config 5 in small: an ensemble of multi-input focusing designs optimised side by side (one batched
+    forward + reverse sweep per round) goes through exactly the iterates each member would visit alone."""
+    amin = 5 * math.pi / 180
+    kw = dict(lower_bound=-3.0, upper_bound=3.0, min_void_angle=amin, min_block_angle=amin, min_edge_length=1.0)
+
+    def objective(batch):
+        fws = []
+        for side, shift in (("left", 0), ("bottom", -1)):
+            fw = P.QuadsFocusingForward(
+                n1_blocks=5, n2_blocks=5, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5,
+                density=6.18e-9, damping=1e-4 * np.ones((25, 3)), amplitude=7.5, loading_rate=3000.0, input_delay=1e-5,
+                n_excited_blocks=1, loaded_side=side, input_shift=shift, simulation_time=3e-4, n_timepoints=4,
+                use_contact=True, k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180,
+                steps_per_interval=8, batch=batch, _lib=cpu_lib)
+            fw.setup()
+            fws.append(fw)
+        return P.MultiInputTargetKineticEnergy(fws, (1, 1), (1, 1), weights=[1.0, 0.5]), fws[0]
+
+    obj3, fw = objective(3)
+    x0s = [_design(fw, seed=s, amp=0.05) for s in (0, 1, 2)]
+    best, logs = P.run_ensemble_optimization(obj3, x0s, 5, **kw)
+    assert all(len(l["objective_values"]) == 5 for l in logs)
+    obj1, _ = objective(1)
+    for m in (0, 2):
+        opt = P.OptimizationProblem(obj1)
+        x = opt.run_optimization_nlopt(x0s[m], 5, verbose=False, **kw)
+        assert np.allclose(opt.objective_values, logs[m]["objective_values"], rtol=1e-9)
+        assert all(np.allclose(a, b, rtol=0, atol=1e-10) for a, b in zip(x, best[m]))
+    assert all(l["mma"].fun >= l["objective_values"][0] for l in logs)
