@@ -625,7 +625,9 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
 // ---- reverse stage ---------------------------------------------------------------------------
 //   in_buf: stage buffer with the stage records (recomputed), or -1: the checkpoint of step n (i == 0)
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
-template <int MODEL, int CONTACT>
+//   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
+//   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
+template <int MODEL, int CONTACT, int BOND_GRADS>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only) {
   const int m = blockIdx.y + c.m0;
@@ -682,13 +684,12 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
     BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);
     BondGrad<Dual> g;
-    bond_grad<MODEL, Dual>(o, p, Dual(L.rox), Dual(L.roy), Dual(L.rpx), Dual(L.rpy), Dual(L.lx), Dual(L.ly), L.l0, L.il0,
-                           Dual(L.ks), Dual(L.ksh), Dual(L.kr), L.sgn, g);
+    bond_grad<MODEL, Dual>(o, p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
     hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
     ex = g.fx.v; ey = g.fy.v; eth = g.fth.v;
     ContactGrad<Dual> cg;
     if (CONTACT) {
-      contact_grad<Dual>(L.sgn * (o.th - p.th), Dual(L.phi1), Dual(L.phi2), Dual(L.am), Dual(L.ac), Dual(L.kc), cg);
+      contact_grad<Dual>(L.sgn * (o.th - p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
       hth += L.sgn * cg.dkap.e;
       eth += L.sgn * cg.dkap.v;
     }
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     // both ends hold the same contact dual: each accumulates one of the two void-angle derivatives (8 B per lane)
     if (CONTACT) c.g_phi[gs] -= (L.info & 1) ? cg.p2.e : cg.p1.e;
     if (!(L.info & 1)) {
-      if (c.g_b) {
+      if (BOND_GRADS) {
         double* q = c.g_b + gs * 8;
         q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
         if (CONTACT) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
@@ -1046,7 +1047,8 @@ static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf,
 }
 template <int MODEL, int CONTACT>
 static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
-  hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only);
+  if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only);
+  else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only);
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
   const Plan& pl = h->pl;

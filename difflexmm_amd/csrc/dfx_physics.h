@@ -189,9 +189,12 @@ struct BondGrad {
 // sgn = +1 when the own block holds node2 (end B), -1 when it holds node1 (end A).
 // (ro) / (rp) are the centroid->node vectors of the two bonded nodes, (lx,ly) the
 // reference vector oriented node1 -> node2.
-template <int MODEL, class T>
-DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, T rox, T roy, T rpx, T rpy,
-                      T lx, T ly, double l0v, double il0v, T ks, T ksh, T kr, double sgn, BondGrad<T>& g) {
+// T: type of the kinematic state (double, or Dual in the reverse sweep); P: type of the parameters -- double in every
+// kernel: a parameter carries no epsilon part, and typing it as a Dual with a zero epsilon would cost an extra multiply-add
+// per product (x * 0.0 cannot be folded away under IEEE semantics).
+template <int MODEL, class T, class P>
+DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, P rox, P roy, P rpx, P rpy,
+                      P lx, P ly, double l0v, double il0v, P ks, P ksh, P kr, double sgn, BondGrad<T>& g) {
   // rotation of own / partner block from the half angles
   T co = o.ch * o.ch - o.sh * o.sh, so = 2.0 * (o.sh * o.ch);
   T cp = p.ch * p.ch - p.sh * p.sh, sp = 2.0 * (p.sh * p.ch);
@@ -203,9 +206,8 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, T rox, T roy, 
   T kap = sgn * (o.th - p.th);  // theta_2 - theta_1
   // l0 = |(lx, ly)| and 1/l0 are per-solve constants (the reference vector is a parameter: it carries no
   // epsilon part, and every derivative w.r.t. it below is written in closed form)
-  T l02 = lx * lx + ly * ly;
-  T l0 = T(l0v);
-  T il0 = T(il0v);
+  P l02 = lx * lx + ly * ly;
+  const double l0 = l0v, il0 = il0v;
   T gbx, gby, gtb;  // dE/d(dU), dE/d(mean rotation)
   if (MODEL == kNonlinear) {
     // energy.py:139-155,172-176
@@ -220,14 +222,14 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, T rox, T roy, 
     T es = Lb - l0;
     T kse = ks * es, kshg = ksh * gam;
     T shear = kshg * l02;  // dE/dgamma
-    g.e = 0.5 * (kse * es) + 0.5 * (shear * gam) + 0.5 * (kr * kap * kap);
+    g.e = 0.5 * (kse * es) + 0.5 * (shear * gam) + 0.5 * (kr * (kap * kap));
     gbx = kse * bx * iLb - shear * by * iL2;
     gby = kse * by * iLb + shear * bx * iL2;
     gtb = -shear;
-    g.lx = gbx - kse * lx * il0 + kshg * gam * lx + kshg * ly;
-    g.ly = gby - kse * ly * il0 + kshg * gam * ly - kshg * lx;
+    g.lx = gbx - kse * (lx * il0) + kshg * gam * lx + kshg * ly;
+    g.ly = gby - kse * (ly * il0) + kshg * gam * ly - kshg * lx;
     g.ks = 0.5 * (es * es);
-    g.ksh = 0.5 * (l02 * gam * gam);
+    g.ksh = 0.5 * (l02 * (gam * gam));
   } else {
     // energy.py:88-96,113-117
     T tb = 0.5 * (o.th + p.th);
@@ -236,14 +238,14 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, T rox, T roy, 
     T es = dot * il0;
     T esh = crs * il0 - tb * l0;
     T kse = ks * es, kshe = ksh * esh;
-    g.e = 0.5 * (kse * es) + 0.5 * (kshe * esh) + 0.5 * (kr * kap * kap);
+    g.e = 0.5 * (kse * es) + 0.5 * (kshe * esh) + 0.5 * (kr * (kap * kap));
     gbx = (kse * lx - kshe * ly) * il0;
     gby = (kse * ly + kshe * lx) * il0;
     gtb = -(kshe * l0);
-    T il02 = il0 * il0;
-    T c3 = crs * il0 * il02;
-    g.lx = kse * (dUx * il0 - es * lx * il02) + kshe * (dUy * il0 - c3 * lx - tb * lx * il0);
-    g.ly = kse * (dUy * il0 - es * ly * il02) + kshe * (-(dUx * il0) - c3 * ly - tb * ly * il0);
+    const double il02 = il0 * il0;
+    T c3 = crs * (il0 * il02);
+    g.lx = kse * (dUx * il0 - es * (lx * il02)) + kshe * (dUy * il0 - c3 * lx - tb * (lx * il0));
+    g.ly = kse * (dUy * il0 - es * (ly * il02)) + kshe * (-(dUx * il0) - c3 * ly - tb * (ly * il0));
     g.ks = 0.5 * (es * es);
     g.ksh = 0.5 * (esh * esh);
   }
@@ -266,28 +268,28 @@ struct ContactGrad {
   T e;
 };
 
-template <class T>
-DFX_HD void contact_one(T a, T am, T ac, T kc, T& e, T& da, T& dam, T& dac, T& dkc) {
+template <class T, class P>
+DFX_HD void contact_one(T a, P am, P ac, P kc, T& e, T& da, T& dam, T& dac, T& dkc) {
   a = twrap(a);
   if (val(a) >= val(am) && val(a) < val(ac)) {
-    T D = ac - am;
+    P D = ac - am;
     T x = (a - ac) * trcp(D);
     T ip = trcp(x + 1.0), im = trcp(x - 1.0);
     T h = ip - im - 2.0;
     T hp = im * im - ip * ip;
-    T qD = 0.25 * (kc * D);
+    P qD = 0.25 * (kc * D);
     e = qD * D * h;
     da = qD * hp;
     dac = qD * (2.0 * h - (1.0 + x) * hp);
     dam = qD * (x * hp - 2.0 * h);
-    dkc = 0.25 * (D * D * h);
+    dkc = 0.25 * ((D * D) * h);
   } else {
     e = T(0.0); da = T(0.0); dam = T(0.0); dac = T(0.0); dkc = T(0.0);
   }
 }
 
-template <class T>
-DFX_HD void contact_grad(T kap, T phi1, T phi2, T am, T ac, T kc, ContactGrad<T>& g) {
+template <class T, class P>
+DFX_HD void contact_grad(T kap, P phi1, P phi2, P am, P ac, P kc, ContactGrad<T>& g) {
   T e1, d1, m1, c1, k1, e2, d2, m2, c2, k2;
   contact_one(phi1 - kap, am, ac, kc, e1, d1, m1, c1, k1);
   contact_one(phi2 + kap, am, ac, kc, e2, d2, m2, c2, k2);

@@ -181,13 +181,12 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
   BlockRec<Dual> p = seed_rec(rp, W[bp * 3], W[bp * 3 + 1], W[bp * 3 + 2]);
   BondGrad<Dual> g;
   const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
-  bond_grad<MODEL, Dual>(o, p, Dual(sp[0]), Dual(sp[1]), Dual(pp[0]), Dual(pp[1]), Dual(sp[2]), Dual(sp[3]), l0, 1.0 / l0,
-                         Dual(sp[4]), Dual(sp[5]), Dual(sp[6]), sgn, g);
+  bond_grad<MODEL, Dual>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], sgn, g);
   hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
   ContactGrad<Dual> c;
   if (CONTACT) {
     Dual kap = sgn * (o.th - p.th);
-    contact_grad<Dual>(kap, Dual(sp[7]), Dual(sp[8]), Dual(tb.contact_p[0]), Dual(tb.contact_p[1]), Dual(tb.contact_p[2]), c);
+    contact_grad<Dual>(kap, sp[7], sp[8], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
     hth += sgn * c.dkap.e;
   }
   if (acc.slot_g) {
