@@ -285,7 +285,7 @@ def main():
                 agg["adj_achieved"] = BYTES_ADJ_STAGE * n_units * args.members / (a_eff * 1e-6) / 1e9
                 agg["adj_frac"] = agg["adj_achieved"] / HBM_PEAK_GBS
             line["roofline_concurrent"] = agg
-        if args.members > 1 and not args.forward_only and not args.no_single:
+        if args.members > 1 and not args.forward_only and not args.no_single and world == 1:
             # the same config with ONE design per GPU (latency-bound: one wave per SIMD), for reference
             fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
             K1 = min(K, 2500)
@@ -304,7 +304,7 @@ def main():
                                      "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
             fw1.solve_dynamics.engine.close()
             del fw1, obj1
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.size, 3)
         print(json.dumps(line), flush=True)
     if dist is not None:
