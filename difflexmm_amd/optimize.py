@@ -69,6 +69,7 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
     x_prev = x_prev2 = x.copy()
     best = (f, x.copy()) if feasible else (np.inf, x.copy())
     y = np.zeros(m)
+    dual_bounds = scipy.optimize.Bounds(np.zeros(m), np.full(m, np.inf)) if m else None
     history = [f]
     k = 0
     status = "maxeval"
@@ -105,8 +106,8 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
                     gc = approx_constraints(d)
                     val = f + approx(d, g, rho) + yv @ gc
                     return -val, -gc
-                res = scipy.optimize.minimize(neg_dual, y, jac=True, method="L-BFGS-B", bounds=[(0.0, None)] * m,
-                                              options=dict(maxiter=200, ftol=1e-14, gtol=1e-10))
+                res = scipy.optimize.minimize(neg_dual, y, jac=True, method="L-BFGS-B", bounds=dual_bounds,
+                                              options=dict(maxiter=100, ftol=1e-12, gtol=1e-8))
                 y = np.maximum(res.x, 0.0)
             d = primal(y)
             x_new = x + d

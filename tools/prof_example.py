@@ -1,0 +1,6 @@
+import cProfile, pstats, sys
+sys.argv=['x','--members','32','--iterations','4']
+sys.path.insert(0,'examples')
+import multi_input_ensemble as M
+cProfile.run('M.main()','/tmp/prof.out')
+p=pstats.Stats('/tmp/prof.out'); p.sort_stats('tottime').print_stats(25)
