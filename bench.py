@@ -186,6 +186,23 @@ def main():
         if args.members < args.streams:
             args.streams = args.members
             os.environ["DFX_STREAMS"] = str(args.streams)
+    # (1) per-launch roofline of the dominant kernel: ONE stream, every launch integrates all `members` designs.
+    #     This is the regime rocprofv3 can observe (its kernel trace serialises queues): `python bench.py --streams 1` under
+    #     rocprofv3 --kernel-trace --stats reports the same average duration.  Measured on rank 0 BEFORE the timed job, on
+    #     its own engine (closed again: HIP multiplexes streams onto few hardware queues, and the big checkpoint of the
+    #     timed job is allocated afterwards).
+    rr = None
+    if rank == 0 and args.streams > 1:
+        os.environ["DFX_STREAMS"] = "1"
+        fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
+        os.environ["DFX_STREAMS"] = str(args.streams)
+        Kr = min(K, 1000)
+        fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 1, keep_trajectory=not args.forward_only)
+        run_once(fwr, objr, desr, SPI, adjoint=not args.forward_only)
+        torch.cuda.synchronize()
+        rr = run_once(fwr, objr, desr, Kr, adjoint=not args.forward_only)
+        fwr.solve_dynamics.engine.close()
+        del fwr, objr
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
     fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 1, keep_trajectory=not args.forward_only)
     if W:
@@ -229,22 +246,8 @@ def main():
                 a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * (5.0 / 6.0) * f_us) / n_adj)
             return f_us, a_us
 
-        # (1) per-launch roofline of the dominant kernel: ONE stream, every launch integrates all `members` designs.
-        #     This is the regime rocprofv3 can observe (its kernel trace serialises queues):
-        #     `python bench.py --streams 1` under rocprofv3 --kernel-trace --stats reports the same average duration.
-        fw.solve_dynamics.engine.close()       # free its streams: HIP multiplexes streams onto few hardware queues
-        if streams > 1:
-            os.environ["DFX_STREAMS"] = "1"
-            fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
-            os.environ["DFX_STREAMS"] = str(args.streams)
-            Kr = min(K, 1000)
-            fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 1, keep_trajectory=not args.forward_only)
-            run_once(fwr, objr, desr, SPI, adjoint=not args.forward_only)
-            torch.cuda.synchronize()
-            rr = run_once(fwr, objr, desr, Kr, adjoint=not args.forward_only)
-            fwr.solve_dynamics.engine.close()
-            del fwr, objr
-        else:
+        fw.solve_dynamics.engine.close()
+        if rr is None:
             rr = res
         fwd_us, adj_us = per_launch(rr, 1)
         roof_bytes = BYTES_FWD_STAGE * n_units * args.members
