@@ -25,5 +25,8 @@ itself.  It is pinned by everything the reference's own tests hold for this path
 
 all reproduced in ``tests/test_oracle_kat.py``.  Contact energy, displacement driving, velocity
 reconstruction and every gradient are "parity unpinned" by the reference's tests; for those the
-oracle is a line-by-line restatement cross-checked by finite differences and SciPy.
+oracle is a line-by-line restatement cross-checked by finite differences and SciPy.  The
+Dormand-Prince constants recalled from jax.experimental.ode are pinned against SciPy's RK45
+(same published tableau: exact match of nodes, stage coefficients, weights and mid-point
+interpolation; the embedded error weights are Shampine's variant, -2/3 of SciPy's).
 """
