@@ -14,7 +14,7 @@ DFX_FN_PARAMS = 5
 BOND_LINEARIZED, BOND_NONLINEAR = 0, 1
 CONTACT_NONE, CONTACT_ANGLE = 0, 1
 TABLEAU = {"dopri5": 0, "rk4": 1}
-FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_PULSE = range(7)
+FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_PULSE, FN_TABLE = range(8)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -29,7 +29,8 @@ class dfx_problem(C.Structure):
     _fields_ = [("n_blocks", C.c_int32), ("n_npb", C.c_int32), ("n_bonds", C.c_int32), ("bonds", _ip),
                 ("bond_model", C.c_int32), ("contact", C.c_int32), ("n_special", C.c_int32),
                 ("special", C.POINTER(dfx_special)), ("n_fns", C.c_int32), ("fn_type", C.c_int32 * DFX_MAX_FNS),
-                ("batch", C.c_int32), ("tableau", C.c_int32), ("device", C.c_int32)]
+                ("batch", C.c_int32), ("tableau", C.c_int32), ("device", C.c_int32),
+                ("fn_table_n", C.c_int32 * DFX_MAX_FNS), ("fn_table", _dp * DFX_MAX_FNS)]
 
 
 _PARAM_FIELDS = ["centroid_node_vectors", "reference_vector", "k_bond", "inertia", "damping", "void_angle0",
@@ -118,7 +119,7 @@ class Engine:
     """One ``dfx_handle``: a lattice + boundary-condition pattern, ``batch`` members wide."""
 
     def __init__(self, n_blocks, n_npb, bonds, bond_model, contact, special, fn_types, batch=1,
-                 tableau="dopri5", device=0, lib=None):
+                 tableau="dopri5", device=0, lib=None, fn_tables=None):
         self.lib = lib if lib is not None else load_library()
         self.n_blocks, self.n_npb, self.batch = int(n_blocks), int(n_npb), int(batch)
         self.bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
@@ -142,6 +143,15 @@ class Engine:
         for f in range(DFX_MAX_FNS):
             prob.fn_type[f] = int(self.fn_types[f]) if f < self.n_fns else 0
         prob.batch, prob.tableau, prob.device = self.batch, TABLEAU[tableau], int(device)
+        tables = []                                   # (times, values) of FN_TABLE functions: static data, copied by dfx_create
+        for f in range(DFX_MAX_FNS):
+            tab = fn_tables[f] if fn_tables is not None and f < len(fn_tables) else None
+            if tab is not None:
+                tv = np.ascontiguousarray(np.concatenate([np.asarray(tab[0], dtype=float), np.asarray(tab[1], dtype=float)]))
+                tables.append(tv)
+                prob.fn_table_n[f], prob.fn_table[f] = len(tv) // 2, tv.ctypes.data_as(_dp)
+            else:
+                prob.fn_table_n[f], prob.fn_table[f] = 0, None
         self._h = C.c_void_p()
         rc = self.lib.dfx_create(C.byref(prob), C.byref(self._h))
         if rc != 0:

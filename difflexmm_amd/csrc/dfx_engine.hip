@@ -937,6 +937,7 @@ struct dfx_handle {
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict;
   DevBuf<uint8_t> d_l_idx;
   DevBuf<TimeFn> d_fns;
+  DevBuf<double> d_fn_table[DFX_MAX_FNS];
   DevBuf<Seg> d_segs, d_cur;
   DevBuf<Clock> d_clock;
   DevBuf<double> d_err_partial, d_ts;
@@ -1309,6 +1310,14 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   h->device = problem->device;
   if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(2); }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(2); }
+  for (int f = 0; f < DFX_MAX_FNS; ++f) {     // recorded input signals: static data, read by the few lanes that own driven DOFs
+    if (h->pl.fn_table[f].empty()) continue;
+    if (h->d_fn_table[f].ensure(h->pl.fn_table[f].size()) != hipSuccess ||
+        hipMemcpy(h->d_fn_table[f].p, h->pl.fn_table[f].data(), sizeof(double) * h->pl.fn_table[f].size(), hipMemcpyHostToDevice) != hipSuccess) {
+      h->err = "create: cannot upload the table of a time function"; return fail(2);
+    }
+    h->pl.fn_table_ptr[f] = h->d_fn_table[f].p;
+  }
   (void)hipEventCreate(&h->ev0);
   (void)hipEventCreate(&h->ev1);
   const char* g = getenv("DFX_NO_GRAPH");
@@ -1359,6 +1368,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
+  for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();

@@ -312,14 +312,16 @@ enum TimeFnType {
   kFnRamp = 3,        // p = (A, r):       A * (t r  if t < 1/r else 1)
   kFnSech2Tanh = 4,   // p = (A, s):       2A/s^2 sech^2(t/s - 3) tanh(3 - t/s)
   kFnConstant = 5,    // p = (A)
-  kFnRampPulse = 6    // p = (A, f, t_d, S, r): S*min(t r,1) + pulse(t - t_d; A, f)   (static tuning)
+  kFnRampPulse = 6,   // p = (A, f, t_d, S, r): S*min(t r,1) + pulse(t - t_d; A, f)   (static tuning)
+  kFnTable = 7        // p = (A, t_d): A * piecewise-linear table(t - t_d), end values held
 };
 constexpr int kMaxFnParams = 5;
 
 struct TimeFn {
   int type;
-  int pad;
+  int n_tab;            // kFnTable: breakpoints
   double p[kMaxFnParams];
+  const double* tab;    // kFnTable: n_tab times then n_tab values (device memory in the HIP engine)
 };
 
 // g = value, gt = dg/dt, gp[i] = dg/dp[i]
@@ -368,6 +370,22 @@ DFX_HD void eval_time_fn(const TimeFn& f, double t, double& g, double& gt, doubl
       g = f.p[0];
       gp[0] = 1.0;
       break;
+    case kFnTable: {
+      const double A = f.p[0], tau = t - f.p[1];
+      const double* T = f.tab;
+      const double* Y = f.tab + f.n_tab;
+      double y, dy = 0.0;
+      if (tau <= T[0]) y = Y[0];
+      else if (tau >= T[f.n_tab - 1]) y = Y[f.n_tab - 1];
+      else {
+        int lo = 0, hi = f.n_tab - 1;            // T[lo] <= tau < T[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T[mid] <= tau) lo = mid; else hi = mid; }
+        dy = (Y[hi] - Y[lo]) / (T[hi] - T[lo]);
+        y = Y[lo] + dy * (tau - T[lo]);
+      }
+      g = A * y; gt = A * dy;
+      gp[0] = y; gp[1] = -gt;
+    } break;
     default:
       break;
   }

@@ -29,6 +29,8 @@ struct Plan {
   int n_blocks = 0, n_npb = 0, n_bonds = 0, batch = 1, n_slots = 0;
   int model = 0, contact = 0, n_fns = 0, n_special = 0;
   int fn_type[DFX_MAX_FNS] = {0, 0};
+  std::vector<double> fn_table[DFX_MAX_FNS];        // DFX_FN_TABLE: times then values
+  const double* fn_table_ptr[DFX_MAX_FNS] = {nullptr, nullptr};   // where the kernels read it (device copy in the HIP engine)
   Tableau tab;
   std::vector<int32_t> slot_info;      // n_slots
   std::vector<int32_t> slot_bond;      // n_slots, bond id or -1
@@ -48,6 +50,16 @@ inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
   pl.n_slots = p->n_blocks * kSlots;
   pl.model = p->bond_model; pl.contact = p->contact; pl.n_fns = p->n_fns; pl.n_special = p->n_special;
   for (int i = 0; i < DFX_MAX_FNS; ++i) pl.fn_type[i] = i < p->n_fns ? p->fn_type[i] : 0;
+  for (int i = 0; i < p->n_fns; ++i) {
+    pl.fn_table[i].clear();
+    if (pl.fn_type[i] != DFX_FN_TABLE) continue;
+    const int n = p->fn_table_n[i];
+    if (n < 2 || !p->fn_table[i]) { err = "create: a table time function needs >= 2 breakpoints"; return 1; }
+    pl.fn_table[i].assign(p->fn_table[i], p->fn_table[i] + 2 * n);
+    for (int k = 0; k + 1 < n; ++k)
+      if (!(pl.fn_table[i][k + 1] > pl.fn_table[i][k])) { err = "create: table times must be strictly increasing"; return 1; }
+    pl.fn_table_ptr[i] = pl.fn_table[i].data();
+  }
   if (p->tableau == DFX_TABLEAU_DOPRI5) pl.tab = tableau_dopri5();
   else if (p->tableau == DFX_TABLEAU_RK4) pl.tab = tableau_rk4();
   else { err = "invalid tableau"; return 1; }
@@ -146,6 +158,8 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     for (int f = 0; f < pl.n_fns; ++f) {
       TimeFn& tf = out.fns[(size_t)m * DFX_MAX_FNS + f];
       tf.type = pl.fn_type[f];
+      tf.n_tab = (int)(pl.fn_table[f].size() / 2);
+      tf.tab = pl.fn_table_ptr[f];
       for (int i = 0; i < DFX_FN_PARAMS; ++i) tf.p[i] = q->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i];
     }
     // ---- GPU structure-of-arrays image

@@ -81,7 +81,8 @@ class DynamicSolver:
         self._special = [(blk, e[0], e[1], e[2]) for blk, e in sorted(special.items())]
         self.engine = _b.Engine(self.n_blocks, self.n_npb, self.bonds, self.spec.bond_model,
                                 _b.CONTACT_ANGLE if self.spec.contact else _b.CONTACT_NONE, self._special, fn_types,
-                                batch=self.batch, tableau=integrator, device=device, lib=lib)
+                                batch=self.batch, tableau=integrator, device=device, lib=lib,
+                                fn_tables=[getattr(f, "table", None) for f in self.con_terms + self.load_terms])
         self._last = None
 
     # -- ControlParams -> engine arrays -------------------------------------------------------------

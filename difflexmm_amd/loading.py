@@ -12,7 +12,7 @@ Every parameter is either a number (a constant baked into the solver) or a strin
 import numpy as np
 
 from ._binding import (DFX_FN_PARAMS, FN_CONSTANT, FN_HARMONIC, FN_PULSE, FN_RAMP, FN_RAMP_PULSE,
-                       FN_SECH2TANH, FN_ZERO)
+                       FN_SECH2TANH, FN_TABLE, FN_ZERO)
 
 
 class TimeFunction:
@@ -160,6 +160,24 @@ class RampPulse(TimeFunction):
         return pulse + p[3] * (t * p[4] if t * p[4] < 1 else 1.0)
 
 
+class Table(TimeFunction):
+    """amplitude * interp(t - delay; times, values): a recorded input signal, piecewise linear, end values held
+    (``jnp.interp`` semantics; the reference resamples its experimental signals with it, problems/hinge_characterization.py:546-551).
+    The table is static data of the solver; ``amplitude`` and ``delay`` are parameters."""
+    type_id = FN_TABLE
+    param_names = ("amplitude", "delay")
+
+    def __init__(self, times, values, vector=1.0, amplitude=1.0, delay=0.0):
+        super().__init__(vector, amplitude=amplitude, delay=delay)
+        self.times, self.values = np.asarray(times, dtype=float), np.asarray(values, dtype=float)
+        if self.times.ndim != 1 or self.times.shape != self.values.shape or len(self.times) < 2 or np.any(np.diff(self.times) <= 0):
+            raise ValueError("Table: times must be 1-D, strictly increasing, as long as values, with >= 2 entries")
+        self.table = (self.times, self.values)
+
+    def value(self, t, p):
+        return p[0] * float(np.interp(t - p[1], self.times, self.values))
+
+
 zero = Zero()
 
 
@@ -170,5 +188,5 @@ def as_time_function(fn, what):
     if isinstance(fn, TimeFunction):
         return fn
     raise TypeError(
-        f"{what} must be built from difflexmm_amd.loading (Pulse, Harmonic, Ramp, Sech2Tanh, Constant, RampPulse, "
+        f"{what} must be built from difflexmm_amd.loading (Pulse, Harmonic, Ramp, Sech2Tanh, Constant, RampPulse, Table, "
         f"zero, or a sum of them): an arbitrary Python callable cannot be evaluated inside a HIP kernel")

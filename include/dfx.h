@@ -47,7 +47,9 @@ enum {
   DFX_FN_RAMP = 3,         /* (A, r)        tests/test_difflexmm.py:85-86                        */
   DFX_FN_SECH2TANH = 4,    /* (A, s)        scripts/pulse_RS.py:49-50                            */
   DFX_FN_CONSTANT = 5,     /* (A)                                                                 */
-  DFX_FN_RAMP_PULSE = 6    /* (A, f, t_d, S, r) problems/quads_kinetic_energy_static_tuning.py:176-196 */
+  DFX_FN_RAMP_PULSE = 6,   /* (A, f, t_d, S, r) problems/quads_kinetic_energy_static_tuning.py:176-196 */
+  DFX_FN_TABLE = 7         /* (A, t_d): A * interp(t - t_d; table), piecewise linear, end values held (jnp.interp semantics):
+                              a recorded input signal; the table itself is static data of dfx_problem             */
 };
 
 /* A block that has constrained and/or force-loaded DOFs.  u[dof] = sum_m con_coef[d][m] * g_m(t)
@@ -74,6 +76,8 @@ typedef struct dfx_problem {
   int32_t batch;                          /* ensemble members integrated together                */
   int32_t tableau;                        /* DFX_TABLEAU_*                                       */
   int32_t device;                         /* HIP device ordinal (ignored by the CPU port)        */
+  int32_t fn_table_n[DFX_MAX_FNS];        /* DFX_FN_TABLE: number of breakpoints (>= 2), else 0   */
+  const double* fn_table[DFX_MAX_FNS];    /* DFX_FN_TABLE: fn_table_n increasing times, then fn_table_n values */
 } dfx_problem;
 
 /* ControlParams, flattened (utils.py:48-163).  Leading axis of every array = batch. */

@@ -111,3 +111,64 @@ def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, co
     for k, v in errs.items():
         assert v < RTOL_GRAD, (lattice, integrator, k, v)
     return errs
+
+
+def torch_table(times, values, vector):
+    """Oracle twin of loading.Table: amplitude * interp(t - input_delay; times, values) (jnp.interp semantics)."""
+    T, Y = np.asarray(times, dtype=float), np.asarray(values, dtype=float)
+    vt = torch.as_tensor(np.asarray(vector, dtype=float))
+
+    def fn(t, amplitude, loading_rate=None, input_delay=0.0):
+        tau = torch.as_tensor(t, dtype=torch.float64) - input_delay
+        tf = float(tau.detach())
+        if tf <= T[0]:
+            y = Y[0] + 0.0 * tau
+        elif tf >= T[-1]:
+            y = Y[-1] + 0.0 * tau
+        else:
+            lo = int(np.searchsorted(T, tf, side="right")) - 1
+            y = Y[lo] + (Y[lo + 1] - Y[lo]) / (T[lo + 1] - T[lo]) * (tau - T[lo])
+        return amplitude * y * vt
+    return fn
+
+
+def check_table_drive(lib, spi=6, n_out=5):
+    """Prescribed displacement from a recorded signal (DFX_FN_TABLE): trajectory and gradients (design, amplitude, delay)
+    against the oracle driven by the same piecewise-linear function."""
+    import difflexmm_amd.loading as ld
+    from difflexmm_amd.dynamics import setup_dynamic_solver
+    import difflexmm_amd.energy as en_mod
+    c = Case("quads", 4, True, True, seed=7, lib=lib, cutoff_deg=42.0)
+    rng = np.random.default_rng(11)
+    times = np.concatenate([[0.0], np.sort(rng.uniform(0.1e-4, 2.9e-4, 9)), [3.2e-4]])
+    values = np.concatenate([[0.0], rng.normal(size=9), [0.3]])
+    energy = en_mod.combine_block_energies(en_mod.build_strain_energy(c.bonds, en_mod.ligament_energy), en_mod.build_contact_energy(c.bonds))
+    s = setup_dynamic_solver(c.geo, energy, constrained_block_DOF_pairs=c.con,
+                             constrained_DOFs_fn=ld.Table(times, values, c.vec, amplitude="amplitude", delay="input_delay"),
+                             damped_blocks=c.damped, _lib=lib)
+    c.osolver_args["constrained_DOFs_fn"] = torch_table(times, values, c.vec)
+    cp = c.cp._replace(constraint_params=dict(amplitude=2.5, input_delay=2e-5))
+    ts = np.linspace(0, 3e-4, n_out)
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    fields = s(y0, ts, cp, keep_trajectory=True, steps_per_interval=spi)
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi, tableau="dopri5")
+    of = osol(y0, ts, c.oracle_cp(dict(amplitude=T64(2.5), input_delay=T64(2e-5)))).numpy()
+    e_fwd = relerr(fields, of)
+    assert e_fwd < RTOL_TRAJ, ("table forward", e_fwd)
+    fb = c.rng.normal(size=fields.shape)
+    fb.reshape(len(ts), 2, -1)[:, :, s.constrained_DOF_ids] = 0.0
+    tree, _ = s.vjp(fb)
+    design = [T64(d, True) for d in c.design]
+    cnv, cen = c.ogeo.centroid_node_vectors(*design), c.ogeo.block_centroids(*design)
+    amp, dly = T64(2.5, True), T64(2e-5, True)
+    hist, _ = OD.solve_fixed_differentiable(osol, c.ogeo, T64(y0), ts, c.oracle_cp(dict(cnv=cnv, cen=cen, amplitude=amp, input_delay=dly)),
+                                            spi, "dopri5")
+    L = (hist * T64(fb.reshape(len(ts), 2, -1)[:, :, osol.free_DOF_ids])).sum()
+    gr = torch.autograd.grad(L, design + [amp, dly])
+    mine = c.geo.vjp(c.design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
+    errs = {f"design{i}": relerr(a, b.numpy()) for i, (a, b) in enumerate(zip(mine, gr))}
+    errs["amplitude"] = abs(tree.constraint_params["amplitude"] - gr[-2].item()) / abs(gr[-2].item())
+    errs["delay"] = abs(tree.constraint_params["input_delay"] - gr[-1].item()) / abs(gr[-1].item())
+    for k, v in errs.items():
+        assert v < RTOL_GRAD, ("table", k, v)
+    return errs

@@ -97,3 +97,7 @@ def test_adaptive_grid_makes_the_default_solve_differentiable(cpu_lib):
     lm = (fb * s(y0, ts, cp._replace(constraint_params=dict(cp.constraint_params, amplitude=7.5 - eps)), **kw)).sum()
     fd = (lp - lm) / (2 * eps)
     assert abs(g - fd) < 2e-6 * abs(fd), (g, fd)
+
+
+def test_recorded_signal_as_prescribed_displacement(cpu_lib):
+    parity.check_table_drive(cpu_lib)

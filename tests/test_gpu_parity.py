@@ -197,3 +197,8 @@ def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib):
     assert relerr(g_hip, g_cpu) < 1e-8 and relerr(s0, s0_c) < 1e-8
     sc(y0, ts, cps_c, keep_trajectory=True)
     assert len(sc.stats["step_times"]) == len(grid) and relerr(sc.stats["step_times"], grid) < 1e-6
+
+
+def test_recorded_signal_as_prescribed_displacement(hip_lib):
+    """DFX_FN_TABLE: the table lives in device memory, read by the lanes that own driven DOFs."""
+    parity.check_table_drive(None)
