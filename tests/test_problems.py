@@ -210,3 +210,19 @@ def test_ensemble_optimisation_in_lock_step_equals_members_alone(cpu_lib):
         assert np.allclose(opt.objective_values, logs[m]["objective_values"], rtol=1e-9)
         assert all(np.allclose(a, b, rtol=0, atol=1e-10) for a, b in zip(x, best[m]))
     assert all(l["mma"].fun >= l["objective_values"][0] for l in logs)
+
+
+def test_bench_host_path_on_cpu_port(cpu_lib):
+    """bench.py's workload builder and its prepare / execute split (the timed region) through the CPU port on a small
+    lattice: same code path as on the GPU box up to the library behind the C ABI."""
+    import bench
+    fw, obj, designs = bench.c3_problem(8, 3, 2, lib=cpu_lib)
+    assert len(designs) == 2 and fw.solve_dynamics.engine.batch == 2
+    bench.prepare(fw, designs, 4, spi=2)
+    res = bench.execute(fw, obj, spi=2)
+    # (a few microseconds of simulated time: the pulse has not reached the target blocks yet, objective and gradient are 0)
+    assert res["objective"].shape == (2,) and np.all(np.isfinite(res["objective"])) and np.isfinite(res["grad_norm"])
+    assert res["fwd_launches"] == 0 and res["streams"] >= 1                          # the CPU port launches no kernels
+    line = bench.cpu_baseline(8, 3, budget_s=1.0)
+    assert line["kind"] == "port" and line["value"] > 0 and line["cores"] >= 1
+    assert bench.load_pmc_traffic(16) > 16 * bench.BYTES_FWD_STAGE * 128 * 128     # PMC traffic >= algorithmic bytes
