@@ -158,6 +158,10 @@ __device__ __forceinline__ double quad_sum(double v) {
   v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
   return v;
 }
+// accumulate into an array that several lanes of one launch may hit (time-function parameter gradients of a block whose
+// DOFs share a function): hardware fp64 atomic add performed in L2, result not returned
+__device__ __forceinline__ void acc_add(double* p, double v) { (void)unsafeAtomicAdd(p, v); }
+
 template <int J>
 __device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<J | (J << 2) | (J << 4) | (J << 6)>(v); }
 
@@ -694,6 +698,9 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
       eth += L.sgn * cg.dkap.v;
     }
     // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
+    // Every accumulator address has exactly one writer per launch: plain load-add-store.  (Fire-and-forget L2 atomics,
+    // global_atomic_add_f64 without return, would spare the round trip for the old value but were measured 10-25 %
+    // slower per launch: four fp64 atomics per lane saturate the L2 atomic units.)
     const u32 gs = (u32)m * (u32)c.n_slots + slot;
     double2* gr = reinterpret_cast<double2*>(c.g_r + gs * 2);
     double2 r = *gr;
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
           if (loaded) fload += sp.load_coef[k][f] * g;
           if (coef != 0.0 && c.fn_g) {
             double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
-            for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) q[kk] += coef * gp[kk];
+            for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * gp[kk]);   // up to 3 DOF lanes of a block share q
           }
         }
       }

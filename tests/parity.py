@@ -172,3 +172,36 @@ def check_table_drive(lib, spi=6, n_out=5):
     for k, v in errs.items():
         assert v < RTOL_GRAD, ("table", k, v)
     return errs
+
+
+def check_several_dofs_of_one_block_share_a_time_function(lib, spi=6, n_out=5):
+    """x, y and theta of the driven block all follow the same pulse with different coefficients: their contributions to
+    the time-function parameter gradients land on the same accumulator entries (three lanes of one quad in the kernel)."""
+    import difflexmm_amd.loading as ld
+    from difflexmm_amd.dynamics import setup_dynamic_solver
+    import difflexmm_amd.energy as en_mod
+    from .common import torch_pulse
+    c = Case("quads", 4, True, False, seed=8, lib=lib)
+    vec = np.array([1.0, 0.5, -0.02, 0, 0, 0, 0])
+    energy = en_mod.build_strain_energy(c.bonds, en_mod.ligament_energy)
+    s = setup_dynamic_solver(c.geo, energy, constrained_block_DOF_pairs=c.con, constrained_DOFs_fn=ld.Pulse(vec),
+                             damped_blocks=c.damped, _lib=lib)
+    c.osolver_args["constrained_DOFs_fn"] = torch_pulse(vec)
+    fast = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)
+    cp = c.cp._replace(constraint_params=fast)
+    ts = np.linspace(0, 3e-4, n_out)
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    fields = s(y0, ts, cp, keep_trajectory=True, steps_per_interval=spi)
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi, tableau="dopri5")
+    fb = c.rng.normal(size=fields.shape)
+    fb.reshape(len(ts), 2, -1)[:, :, s.constrained_DOF_ids] = 0.0
+    tree, _ = s.vjp(fb)
+    amp, rate, dly = T64(7.5, True), T64(3000.0, True), T64(1e-5, True)
+    hist, _ = OD.solve_fixed_differentiable(osol, c.ogeo, T64(y0), ts, c.oracle_cp(dict(amplitude=amp, loading_rate=rate, input_delay=dly)),
+                                            spi, "dopri5")
+    assert relerr(fields.reshape(len(ts), 2, -1)[:, :, osol.free_DOF_ids], hist.detach().numpy()) < RTOL_TRAJ
+    L = (hist * T64(fb.reshape(len(ts), 2, -1)[:, :, osol.free_DOF_ids])).sum()
+    gr = torch.autograd.grad(L, [amp, rate, dly])
+    for name, g in zip(("amplitude", "loading_rate", "input_delay"), gr):
+        e = abs(tree.constraint_params[name] - g.item()) / abs(g.item())
+        assert e < RTOL_GRAD, (name, e)

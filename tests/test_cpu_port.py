@@ -101,3 +101,7 @@ def test_adaptive_grid_makes_the_default_solve_differentiable(cpu_lib):
 
 def test_recorded_signal_as_prescribed_displacement(cpu_lib):
     parity.check_table_drive(cpu_lib)
+
+
+def test_several_dofs_of_one_block_share_a_time_function(cpu_lib):
+    parity.check_several_dofs_of_one_block_share_a_time_function(cpu_lib)

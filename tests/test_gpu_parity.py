@@ -202,3 +202,8 @@ def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib):
 def test_recorded_signal_as_prescribed_displacement(hip_lib):
     """DFX_FN_TABLE: the table lives in device memory, read by the lanes that own driven DOFs."""
     parity.check_table_drive(None)
+
+
+def test_several_dofs_of_one_block_share_a_time_function(hip_lib):
+    """The three DOF lanes of the driven block add into the same parameter-gradient entries (atomic adds in the kernel)."""
+    parity.check_several_dofs_of_one_block_share_a_time_function(None)
