@@ -173,11 +173,11 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 }
 
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.POS + (((u32)m * c.nbuf + buf) * (u32)c.n_blocks) * kPos;
+  if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
   return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep;
 }
 __device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.VEL + (((u32)m * c.nbuf + buf) * (u32)c.n_blocks) * 3;
+  if (buf >= 0) return c.VEL + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * 3;
   return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep + (size_t)c.n_blocks * kPos;
 }
 
@@ -251,6 +251,32 @@ __global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
   else t[tid] = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + (tid - c.n_blocks * kPos)];
 }
 
+// Addressing: every array access in the stage kernels is  uniform base (SGPR pair: kernel argument + member / buffer
+// offsets, scalar arithmetic)  +  32-bit per-lane byte offset (one VGPR, shared by all arrays that are indexed the same
+// way).  Written this way the compiler emits the `global_load v, v_off, s[base:base+1]` form: no 64-bit vector address
+// arithmetic and no VGPR pair per array.
+template <class T>
+__device__ __forceinline__ T ldg(const void* base, u32 byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void stg(void* base, u32 byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// uniform bases of member m's parameter arrays
+struct MemberBases {
+  const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict;
+  const uint8_t* p_lidx;
+};
+__device__ __forceinline__ MemberBases member_bases(const DevCtx& c, int m) {
+  MemberBases B;
+  const size_t ps = (size_t)m * (u32)c.n_slots;
+  B.p_r = c.p_r + ps * 2; B.p_phi = c.p_phi + ps; B.p_l = c.p_l + ps * 2; B.p_k = c.p_k + ps * 4;
+  B.cst = c.cst + (size_t)m * 16; B.l_dict = c.l_dict + (size_t)m * 1024; B.p_lidx = c.p_lidx + ps;
+  return B;
+}
+
 struct LaneIn {
   BlockRec<double> o, p;
   double rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, phi1, phi2, am, ac, kc, sgn;
@@ -263,13 +289,13 @@ struct Partner {
 };
 
 template <int CONTACT>
-__device__ __forceinline__ void load_partner(const DevCtx& c, u32 ps, int pslot, const double* POSin, Partner& P) {
-  const double* pp = POSin + (u32)(pslot >> 2) * kPos;
-  P.b0 = reinterpret_cast<const double2*>(pp)[0];
-  P.b1 = reinterpret_cast<const double2*>(pp)[1];
-  P.b2 = pp[4];
-  P.rp = *reinterpret_cast<const double2*>(c.p_r + (ps + pslot) * 2);
-  P.phi = CONTACT ? c.p_phi[ps + pslot] : 0.0;
+__device__ __forceinline__ void load_partner(const MemberBases& B, int pslot, const double* POSin, Partner& P) {
+  const u32 rec = (u32)(pslot >> 2) * (kPos * 8);
+  P.b0 = ldg<double2>(POSin, rec);
+  P.b1 = ldg<double2>(POSin, rec + 16);
+  P.b2 = ldg<double>(POSin, rec + 32);
+  P.rp = ldg<double2>(B.p_r, (u32)pslot * 16);
+  P.phi = CONTACT ? ldg<double>(B.p_phi, (u32)pslot * 8) : 0.0;
 }
 
 // Everything a lane needs for its ligament, in two phases so that every load that does not depend on another
@@ -288,38 +314,35 @@ struct LaneRaw {
 };
 
 template <int CONTACT>
-__device__ __forceinline__ void issue_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneRaw& R) {
+__device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B, int slot, const double* POSin, LaneRaw& R) {
   const int b = slot >> 2, k = slot & 3;
-  const u32 ps = (u32)m * (u32)c.n_slots;
-  R.info = c.slot_info[slot];
-  R.pc = k < 3 ? *reinterpret_cast<const double2*>(POSin + (u32)b * kPos + 2 * k) : make_double2(0.0, 0.0);
-  R.ro = *reinterpret_cast<const double2*>(c.p_r + (ps + slot) * 2);
+  R.info = ldg<int>(c.slot_info, (u32)slot * 4);
+  R.pc = k < 3 ? ldg<double2>(POSin, ((u32)b * kPos + 2 * k) * 8) : make_double2(0.0, 0.0);
+  R.ro = ldg<double2>(B.p_r, (u32)slot * 16);
   // branch-free (a branch here would end the batch of loads): the unused one of the two reads one shared valid address
-  const double* cst = c.cst + (u32)m * 16;
-  R.lidx = (int)*(c.l_dict_on ? c.p_lidx + (ps + slot) : reinterpret_cast<const uint8_t*>(cst));
-  R.lv = *reinterpret_cast<const double2*>(c.l_dict_on ? cst : c.p_l + (ps + slot) * 2);
+  R.lidx = (int)ldg<uint8_t>(c.l_dict_on ? (const void*)B.p_lidx : (const void*)B.cst, c.l_dict_on ? (u32)slot : 0u);
+  R.lv = ldg<double2>(c.l_dict_on ? B.cst : B.p_l, c.l_dict_on ? 0u : (u32)slot * 16);
   R.ks = R.ksh = R.kr = 0.0;
-  if (!c.k_uniform) { const double* pk = c.p_k + (ps + slot) * 4; R.ks = pk[0]; R.ksh = pk[1]; R.kr = pk[2]; }
-  R.phi = CONTACT ? c.p_phi[ps + slot] : 0.0;
+  if (!c.k_uniform) { R.ks = ldg<double>(B.p_k, (u32)slot * 32); R.ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); R.kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
+  R.phi = CONTACT ? ldg<double>(B.p_phi, (u32)slot * 8) : 0.0;
   const int delta = k == 0 ? c.pred[0] : (k == 1 ? c.pred[1] : (k == 2 ? c.pred[2] : c.pred[3]));   // selects: a dynamic index would be a memory load
   R.guess = min(max(slot + delta, 0), c.n_slots - 1);
-  load_partner<CONTACT>(c, ps, R.guess, POSin, R.P);
+  load_partner<CONTACT>(B, R.guess, POSin, R.P);
 }
 
 template <int CONTACT>
-__device__ __forceinline__ void resolve_lane(const DevCtx& c, int m, const double* POSin, LaneRaw& R, LaneIn& L) {
-  const u32 ps = (u32)m * (u32)c.n_slots;
+__device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases& B, const double* POSin, LaneRaw& R, LaneIn& L) {
   const int info = R.info;
   L.info = info;
   double2 lv = R.lv, ln = make_double2(0.0, 0.0);
   if (c.l_dict_on) {
-    const double2* e = reinterpret_cast<const double2*>(c.l_dict + ((u32)m * 1024 + 4 * R.lidx));
-    lv = e[0]; ln = e[1];
+    lv = ldg<double2>(B.l_dict, (u32)R.lidx * 32);
+    ln = ldg<double2>(B.l_dict, (u32)R.lidx * 32 + 16);
   }
   const int pslot = info < 0 ? R.guess : (info >> 1);
   L.pslot = pslot; L.guess = R.guess;
-  if (pslot != R.guess) load_partner<CONTACT>(c, ps, pslot, POSin, R.P);
-  const double* cst = c.cst + (u32)m * 16;
+  if (pslot != R.guess) load_partner<CONTACT>(B, pslot, POSin, R.P);
+  const double* cst = B.cst;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
   if (CONTACT) {
@@ -343,9 +366,10 @@ __device__ __forceinline__ void resolve_lane(const DevCtx& c, int m, const doubl
 
 template <int CONTACT>
 __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneIn& L) {
+  const MemberBases B = member_bases(c, m);
   LaneRaw R;
-  issue_lane<CONTACT>(c, m, slot, POSin, R);
-  resolve_lane<CONTACT>(c, m, POSin, R, L);
+  issue_lane<CONTACT>(c, B, slot, POSin, R);
+  resolve_lane<CONTACT>(c, B, POSin, R, L);
 }
 
 // ---- forward stage ---------------------------------------------------------------------------
@@ -377,22 +401,24 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   const u32 nd = (u32)c.n_blocks * 3;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
+  const MemberBases B = member_bases(c, m);
   LaneRaw R;
-  issue_lane<CONTACT>(c, m, slot, POSin, R);
+  issue_lane<CONTACT>(c, B, slot, POSin, R);
   const int dof = b * 3 + kd;
-  const double qn = pos_in(c, m, y_buf, n)[(u32)b * kPos + kd];
-  const double vn = vel_in(c, m, y_buf, n)[dof];
-  const double v_i = vel_in(c, m, in_buf, n)[dof];
-  double* Am = c.A + (u32)m * (u32)(c.s + 1) * nd;
-  const double damp = c.damping_uniform ? c.cst[(u32)m * 16 + 6 + kd] : c.damping[(u32)m * nd + dof];
-  const double invm = c.inv_m[(u32)m * nd + dof];
-  const int sidx = c.block_special[b];
+  const u32 o_dof = (u32)dof * 8, o_rec = ((u32)b * kPos + kd) * 8;      // per-lane byte offsets shared by all per-DOF arrays
+  const double qn = ldg<double>(pos_in(c, m, y_buf, n), o_rec);
+  const double vn = ldg<double>(vel_in(c, m, y_buf, n), o_dof);
+  const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
+  double* Am = c.A + (size_t)m * (u32)(c.s + 1) * nd;
+  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
+  const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
+  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
   // earlier stage accelerations: all loads issued together (a rolled loop waits for each one in turn)
   double al[kMaxStages - 1];
 #pragma unroll
-  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? Am[(u32)l * nd + dof] : 0.0;
+  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? ldg<double>(Am + (size_t)l * nd, o_dof) : 0.0;
   LaneIn L;
-  resolve_lane<CONTACT>(c, m, POSin, R, L);
+  resolve_lane<CONTACT>(c, B, POSin, R, L);
   double sv = 0.0, sq = 0.0;
 #pragma unroll
   for (int l = 0; l < kMaxStages - 1; ++l) {
@@ -439,7 +465,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       }
     }
     const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-    Am[(u32)i * nd + dof] = a;
+    stg<double>(Am + (size_t)i * nd, o_dof, a);
     sv += sc.cv[i] * a;
     sq += sc.cq[i] * a;
     qnext = qn + h * (sc.c_next * vn + h * sq);
@@ -448,7 +474,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       // i == 6 evaluated at the candidate y1: with (cv, cq) = (e, ee) the sums are the embedded error estimate
       double r2 = 0.0;
       if (!constrained) {
-        const double q1 = POSin[(u32)b * kPos + k];
+        const double q1 = ldg<double>(POSin, o_rec);
         const double eq = h * h * sq, ev = h * sv;
         const double tq = c.atol + c.rtol * fmax(fabs(qn), fabs(q1)), tv = c.atol + c.rtol * fmax(fabs(vn), fabs(v_i));
         r2 = (eq / tq) * (eq / tq) + (ev / tv) * (ev / tv);
@@ -474,12 +500,13 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   fast_sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3 && !(c.ablate & 2)) {
-    *reinterpret_cast<double2*>(c.POS + ((((u32)m * c.nbuf + out_buf) * (u32)c.n_blocks + b) * kPos + 2 * k)) = chunk;
-    c.VEL[((u32)m * c.nbuf + out_buf) * nd + dof] = vnext;
+    const u32 o_chunk = ((u32)b * kPos + 2 * k) * 8;
+    stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
+    stg<double>(c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
     if (write_traj) {
       double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)(n + 1) * c.n_blocks * kStep;
-      *reinterpret_cast<double2*>(tr + ((u32)b * kPos + 2 * k)) = chunk;
-      tr[(u32)c.n_blocks * kPos + dof] = vnext;
+      stg<double2>(tr, o_chunk, chunk);
+      stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
     }
   }
 }
@@ -645,30 +672,32 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   const u32 nd = (u32)c.n_blocks * 3, nd6 = (u32)c.n_blocks * 6;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
+  const MemberBases B = member_bases(c, m);
   LaneRaw R;
-  issue_lane<CONTACT>(c, m, slot, POSin, R);
+  issue_lane<CONTACT>(c, B, slot, POSin, R);
   const int dof = b * 3 + kd;
-  const double* Win = c.W + ((u32)m * 2 + win) * nd;
-  const double w_d = Win[dof];
+  const u32 o_dof = (u32)dof * 8, o_b6 = ((u32)b * 6 + kd) * 8;          // per-lane byte offsets shared by the per-DOF arrays
+  const double* Win = c.W + ((size_t)m * 2 + win) * nd;
+  const double w_d = ldg<double>(Win, o_dof);
   // partner's w from the guessed slot (same batch as everything else)
   double wpx, wpy, wpth;
-  { const u32 gb = (u32)(R.guess >> 2) * 3; wpx = Win[gb]; wpy = Win[gb + 1]; wpth = Win[gb + 2]; }
-  const double v_i = vel_in(c, m, in_buf, n)[dof];
-  const double kq_in = c.KQ[((u32)m * 2 + win) * nd + dof];
-  const double damp = c.damping_uniform ? c.cst[(u32)m * 16 + 6 + kd] : c.damping[(u32)m * nd + dof];
-  const double invm = c.inv_m[(u32)m * nd + dof];
-  const int sidx = c.block_special[b];
-  double* YBm = c.YB + (u32)m * (u32)c.s * nd6;
-  double* LAMm = c.LAM + (u32)m * nd6;
+  { const u32 gb = (u32)(R.guess >> 2) * 24; wpx = ldg<double>(Win, gb); wpy = ldg<double>(Win, gb + 8); wpth = ldg<double>(Win, gb + 16); }
+  const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
+  const double kq_in = ldg<double>(c.KQ + ((size_t)m * 2 + win) * nd, o_dof);
+  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
+  const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
+  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
+  double* YBm = c.YB + (size_t)m * (u32)c.s * nd6;
+  double* LAMm = c.LAM + (size_t)m * nd6;
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
   if (!local_only) {
-    lq = LAMm[b * 6 + kd]; lv = LAMm[b * 6 + 3 + kd];
+    lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24);
     double yq[kMaxStages], yv[kMaxStages];
 #pragma unroll
     for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
       const bool on = jj > i && jj < c.s;
-      yq[jj] = on ? YBm[(u32)jj * nd6 + b * 6 + kd] : 0.0;
-      yv[jj] = on ? YBm[(u32)jj * nd6 + b * 6 + 3 + kd] : 0.0;
+      yq[jj] = on ? ldg<double>(YBm + (size_t)jj * nd6, o_b6) : 0.0;
+      yv[jj] = on ? ldg<double>(YBm + (size_t)jj * nd6, o_b6 + 24) : 0.0;
     }
 #pragma unroll
     for (int jj = 1; jj < kMaxStages; ++jj) {
@@ -678,8 +707,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     }
   }
   LaneIn L;
-  resolve_lane<CONTACT>(c, m, POSin, R, L);
-  if (L.pslot != L.guess) { const u32 pb = (u32)(L.pslot >> 2) * 3; wpx = Win[pb]; wpy = Win[pb + 1]; wpth = Win[pb + 2]; }
+  resolve_lane<CONTACT>(c, B, POSin, R, L);
+  if (L.pslot != L.guess) { const u32 pb = (u32)(L.pslot >> 2) * 24; wpx = ldg<double>(Win, pb); wpy = ldg<double>(Win, pb + 8); wpth = ldg<double>(Win, pb + 16); }
   const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
@@ -701,16 +730,16 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     // Every accumulator address has exactly one writer per launch: plain load-add-store.  (Fire-and-forget L2 atomics,
     // global_atomic_add_f64 without return, would spare the round trip for the old value but were measured 10-25 %
     // slower per launch: four fp64 atomics per lane saturate the L2 atomic units.)
-    const u32 gs = (u32)m * (u32)c.n_slots + slot;
-    double2* gr = reinterpret_cast<double2*>(c.g_r + gs * 2);
-    double2 r = *gr;
+    const size_t ms = (size_t)m * (u32)c.n_slots;
+    double* grm = c.g_r + ms * 2;
+    double2 r = ldg<double2>(grm, (u32)slot * 16);
     r.x -= g.rx.e; r.y -= g.ry.e;
-    *gr = r;
+    stg<double2>(grm, (u32)slot * 16, r);
     // both ends hold the same contact dual: each accumulates one of the two void-angle derivatives (8 B per lane)
-    if (CONTACT) c.g_phi[gs] -= (L.info & 1) ? cg.p2.e : cg.p1.e;
+    if (CONTACT) stg<double>(c.g_phi + ms, (u32)slot * 8, ldg<double>(c.g_phi + ms, (u32)slot * 8) - ((L.info & 1) ? cg.p2.e : cg.p1.e));
     if (!(L.info & 1)) {
       if (BOND_GRADS) {
-        double* q = c.g_b + gs * 8;
+        double* q = c.g_b + (ms + slot) * 8;
         q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
         if (CONTACT) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
       }
@@ -754,11 +783,12 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
-      c.blk_m[(u32)m * nd + dof] -= w_d * a_i;
-      if (c.blk_c) c.blk_c[(u32)m * nd + dof] -= w_d * v_i;
+      double* bm = c.blk_m + (size_t)m * nd;
+      stg<double>(bm, o_dof, ldg<double>(bm, o_dof) - w_d * a_i);
+      if (c.blk_c) { double* bc = c.blk_c + (size_t)m * nd; stg<double>(bc, o_dof, ldg<double>(bc, o_dof) - w_d * v_i); }
     }
-    YBm[(u32)i * nd6 + b * 6 + k] = ybq;
-    YBm[(u32)i * nd6 + b * 6 + 3 + k] = ybv;
+    stg<double>(YBm + (size_t)i * nd6, o_b6, ybq);
+    stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv);
     if (!local_only) {
       double kq, kv;
       if (i > 0) {
@@ -773,13 +803,13 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
           lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
         }
         if (constrained) { lq = 0.0; lv = 0.0; }
-        LAMm[b * 6 + k] = lq;
-        LAMm[b * 6 + 3 + k] = lv;
+        stg<double>(LAMm, o_b6, lq);
+        stg<double>(LAMm, o_b6 + 24, lv);
         kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
-      c.KQ[((u32)m * 2 + (win ^ 1)) * nd + dof] = kq;
-      c.W[((u32)m * 2 + (win ^ 1)) * nd + dof] = constrained ? 0.0 : kv * invm;
+      stg<double>(c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
+      stg<double>(c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
     }
   }
 }
