@@ -6,7 +6,10 @@ ligaments + viscous damping + angle-based contact, raised-cosine displacement pu
 clamped corners, Dormand-Prince tableau on a fixed grid with dt = (2/f)/50 000, one output every 250 steps,
 objective = kinetic energy of the 2x2 target blocks, gradient w.r.t. the 66 048 geometry parameters.
 One "step" = one RK step (6 RHS evaluations) of one member, forward AND reverse.  `--steps K` times exactly K
-steps (K is rounded to a multiple of 250); the full config is K = 50 000.
+steps (output intervals of 250 steps and, if K is not a multiple of 250, one shorter last interval); the full config is
+K = 50 000.  Default: K = 5 000 with 16 independent designs per GPU, the largest member count whose state checkpoint AND
+stage checkpoint (72 + 120 B per unit and step: the reverse sweep then needs no recompute launches) fit the 288 GB;
+longer runs fall back to the state checkpoint alone (K = 10 000) and then to fewer members (K = 50 000: 4).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--members M] [--size 128]
 
@@ -58,11 +61,19 @@ def c3_problem(size, seed, members, lib=None, device=0):
     return fw, obj, designs
 
 
+def step_grid(n_steps, spi=SPI):
+    """EXACTLY n_steps RK steps of size DT: full output intervals of `spi` steps and, when n_steps is not a multiple of
+    spi, one shorter last interval.  Returns (timepoints, steps per interval)."""
+    full, rest = divmod(int(n_steps), spi)
+    counts = [spi] * full + ([rest] if rest else [])
+    ts = np.concatenate([[0.0], np.cumsum(counts) * DT])
+    return ts, (spi if not rest else np.array(counts, dtype=np.int32))
+
+
 def prepare(fw, designs, n_steps, spi=SPI):
     """Host side of a solve: design -> ControlParams -> flattened arrays -> device (dfx_set_params).  After this call the
     inputs are resident in HBM; it is NOT part of the timed region."""
-    T = n_steps // spi + 1
-    fw.timepoints = np.arange(T) * (spi * DT)
+    fw.timepoints, fw.step_counts = step_grid(n_steps, spi)
     sd = fw.solve_dynamics
     cps = [fw.control_params(d) for d in designs]
     flats = [sd._flatten(cp) for cp in cps]
@@ -73,7 +84,7 @@ def prepare(fw, designs, n_steps, spi=SPI):
 def execute(fw, obj, adjoint=True, spi=SPI):
     """The hot path on resident inputs: forward (+ objective + reverse sweep); returns device milliseconds + stats."""
     eng = fw.solve_dynamics.engine
-    _, st_f = eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), fw.timepoints, spi, keep_trajectory=adjoint,
+    _, st_f = eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), fw.timepoints, fw.step_counts, keep_trajectory=adjoint,
                           want_fields=False)
     out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "streams": max(1, int(st_f.get("streams", 1))),
            "objective": None, "adj_ms": 0.0, "adj_launches": 0}
@@ -81,6 +92,7 @@ def execute(fw, obj, adjoint=True, spi=SPI):
         out["objective"] = eng.objective_kinetic(obj.target_blocks)
         grads, st_a = eng.adjoint_kinetic(obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
+        out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
         out["grad_norm"] = float(np.linalg.norm(grads["centroid_node_vectors"]))
     return out
 
@@ -141,7 +153,7 @@ def cpu_baseline(size, seed, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=250)
     ap.add_argument("--members", type=int, default=16,
                     help="independent designs per GPU integrated side by side (grid.y); capped so that the per-step "
@@ -171,8 +183,8 @@ def main():
             dist.init_process_group(args.backend)
     dev = "cuda" if args.backend == "nccl" else "cpu"
     os.environ["DFX_STREAMS"] = str(args.streams)
-    K = max(SPI, (args.steps // SPI) * SPI)
-    W = 0 if args.warmup <= 0 else max(SPI, (args.warmup // SPI) * SPI)
+    K = max(1, args.steps)                      # EXACTLY K steps are timed
+    W = max(0, args.warmup)
     requested_members = args.members
     if not args.forward_only and args.backend == "nccl":
         # the reverse sweep reads a checkpoint of every step: 72 B per unit per step per member
@@ -186,6 +198,13 @@ def main():
         if args.members < args.streams:
             args.streams = args.members
             os.environ["DFX_STREAMS"] = str(args.streams)
+        # Stage checkpoint (+120 B per unit and step: the reverse sweep then needs no recompute launches): the engine takes
+        # it whenever it fits; decide here, by the same rule, so that the roofline leg below and the timed job run the
+        # same kernels.
+        if "DFX_STAGE_CHECKPOINT" not in os.environ:
+            free_b, total_b = torch.cuda.mem_get_info(local_rank)
+            need = (72.0 * (max(K, W) + 1) + 120.0 * max(K, W)) * args.size * args.size * args.members
+            os.environ["DFX_STAGE_CHECKPOINT"] = "1" if need + 0.05 * total_b + 2e9 < free_b else "0"
     # (1) per-launch roofline of the dominant kernel: ONE stream, every launch integrates all `members` designs.
     #     This is the regime rocprofv3 can observe (its kernel trace serialises queues): `python bench.py --streams 1` under
     #     rocprofv3 --kernel-trace --stats reports the same average duration.  Measured on rank 0 BEFORE the timed job, on
@@ -197,16 +216,20 @@ def main():
         fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
         os.environ["DFX_STREAMS"] = str(args.streams)
         Kr = min(K, 1000)
-        fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 1, keep_trajectory=not args.forward_only)
+        fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 2, keep_trajectory=not args.forward_only)
         run_once(fwr, objr, desr, SPI, adjoint=not args.forward_only)
+        if Kr % SPI:
+            run_once(fwr, objr, desr, Kr % SPI, adjoint=not args.forward_only)
         torch.cuda.synchronize()
         rr = run_once(fwr, objr, desr, Kr, adjoint=not args.forward_only)
         fwr.solve_dynamics.engine.close()
         del fwr, objr
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
-    fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 1, keep_trajectory=not args.forward_only)
+    fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=not args.forward_only)
     if W:
         run_once(fw, obj, designs, W, adjoint=not args.forward_only)
+    if K % SPI:      # the graphs of the shorter last interval are instantiated here, not inside the timed region
+        run_once(fw, obj, designs, K % SPI, adjoint=not args.forward_only)
 
     def barrier():
         torch.cuda.synchronize()
@@ -241,7 +264,9 @@ def main():
             """(fwd launch us, adj launch us): region device time / launches issued per stream."""
             f_us = 1e3 * r["fwd_ms"] / max(1.0, r["fwd_launches"] / n_streams)
             a_us = None
-            if r["adj_launches"]:
+            if r["adj_launches"] and r.get("stage_checkpoint"):
+                a_us = 1e3 * r["adj_ms"] / (r["adj_launches"] / n_streams)     # reverse stages only (stage checkpoint kept)
+            elif r["adj_launches"]:
                 n_adj = r["adj_launches"] * 6.0 / 11.0 / n_streams   # per reverse step: 5 recomputed forward stages + 6 reverse stages
                 a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * (5.0 / 6.0) * f_us) / n_adj)
             return f_us, a_us
@@ -260,7 +285,8 @@ def main():
             "config": {"workload": f"C3: {args.size}x{args.size} quads, nonlinear ligaments + damping + angle contact, "
                                    f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
                                    f"{'forward only' if args.forward_only else 'forward + adjoint wrt 66048 geometry params'}",
-                       "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams, "integrator": "dopri5-fixed",
+                       "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams,
+                       "stage_checkpoint": bool(res.get("stage_checkpoint", False)), "integrator": "dopri5-fixed",
                        "steps_per_output": SPI},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
@@ -292,7 +318,7 @@ def main():
             # the same config with ONE design per GPU (latency-bound: one wave per SIMD), for reference
             fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
             K1 = min(K, 2500)
-            fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 1, keep_trajectory=True)
+            fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 2, keep_trajectory=True)
             run_once(fw1, obj1, des1, SPI)
             prepare(fw1, des1, K1)
             spin_up(fw1)

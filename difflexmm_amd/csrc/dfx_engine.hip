@@ -123,6 +123,8 @@ struct DevCtx {
   double* acc_times;      // batch * acc_cap end times of the accepted steps (adaptive)
   int acc_cap;
   const double* t_steps;  // n_total+1 step boundaries of a caller-chosen grid, or null: equal steps (Seg.h)
+  double* AD;             // stage checkpoint: batch * (N * s * n_dof) stage accelerations of EVERY step, or null
+  long long ad_stride;    // elements between members in AD
   const double* ts_dev;   // output times (adaptive mode)
   double* fields_dev;     // batch * T * n_blocks*6 (adaptive mode writes its dense output here)
   double rtol, atol;
@@ -409,7 +411,10 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   const double qn = ldg<double>(pos_in(c, m, y_buf, n), o_rec);
   const double vn = ldg<double>(vel_in(c, m, y_buf, n), o_dof);
   const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
-  double* Am = c.A + (size_t)m * (u32)(c.s + 1) * nd;
+  // stage accelerations: the per-member scratch set, or (stage checkpoint) this step's own slot, kept for the reverse sweep
+  // (the last stage's acceleration is not kept: no stage record depends on it)
+  const bool keep_stages = c.AD && !c.clock;
+  double* Am = keep_stages ? c.AD + (size_t)m * c.ad_stride + (size_t)n * ((u32)(c.s - 1) * nd) : c.A + (size_t)m * (u32)(c.s + 1) * nd;
   const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
   const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       }
     }
     const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-    stg<double>(Am + (size_t)i * nd, o_dof, a);
+    if (!(keep_stages && i == c.s - 1)) stg<double>(Am + (size_t)i * nd, o_dof, a);
     sv += sc.cv[i] * a;
     sq += sc.cq[i] * a;
     qnext = qn + h * (sc.c_next * vn + h * sq);
@@ -653,14 +658,62 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
   e_slot[(size_t)m * c.n_slots + slot] = e;
 }
 
+// ---- stage checkpoint: rebuild a stage record in the reverse sweep --------------------------------------------------
+// Record r (1 <= r < s) of step nr from what the forward pass kept: (q, v) of the step in the trajectory checkpoint and
+// the stage accelerations A_0 .. A_{r-1} of that step in AD.  The stage state of a DOF depends on its own history only,
+// so this is elementwise; it is the forward epilogue run again.  All four lanes of a quad must call it (DPP).
+//   rc: stage_coef(tableau, r - 1)  (row r of the tableau; c_next = c_r),  h, t: size and start time of step nr
+__device__ __forceinline__ void rebuild_record(const DevCtx& c, int m, int b, int k, const StageCoef& rc, int r, long long nr,
+                                               double h, double t) {
+  const int kd = k < 3 ? k : 2;
+  const u32 nd = (u32)c.n_blocks * 3;
+  const u32 o_dof = ((u32)b * 3 + kd) * 8;
+  const double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)nr * c.n_blocks * kStep;
+  const double qn = ldg<double>(tr, ((u32)b * kPos + kd) * 8);
+  const double vn = ldg<double>(tr + (size_t)c.n_blocks * kPos, o_dof);
+  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
+  const double* Ad = c.AD + (size_t)m * c.ad_stride + (size_t)nr * ((u32)(c.s - 1) * nd);
+  double al[kMaxStages - 1];
+#pragma unroll
+  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < r ? ldg<double>(Ad + (size_t)l * nd, o_dof) : 0.0;
+  double sv = 0.0, sq = 0.0;
+#pragma unroll
+  for (int l = 0; l < kMaxStages - 1; ++l) { sv += rc.cv[l] * al[l]; sq += rc.cq[l] * al[l]; }
+  double qnext = qn + h * (rc.c_next * vn + h * sq);
+  double vnext = vn + h * sv;
+  if (k < 3 && sidx >= 0 && ((c.special[sidx].con_mask >> k) & 1)) {
+    const TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + rc.c_next * h);
+    qnext = tv.g; vnext = tv.gt;
+  }
+  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
+  double sn, cs;
+  fast_sincos(0.5 * th2, &sn, &cs);
+  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
+  if (k < 3) {
+    stg<double2>(c.POS + ((size_t)m * c.nbuf + r) * (u32)c.n_blocks * kPos, ((u32)b * kPos + 2 * k) * 8, chunk);
+    stg<double>(c.VEL + ((size_t)m * c.nbuf + r) * nd, o_dof, vnext);
+  }
+}
+
+// record s-1 of the LAST step, before the reverse sweep starts (every later record is rebuilt by the reverse launch
+// that precedes its reader)
+__global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef rc, int r, long long nr, double h, double t) {
+  const int m = blockIdx.y + c.m0;
+  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
+  if (slot >= c.n_slots) return;
+  rebuild_record(c, m, slot >> 2, slot & 3, rc, r, nr, h, t);
+}
+
 // ---- reverse stage ---------------------------------------------------------------------------
 //   in_buf: stage buffer with the stage records (recomputed), or -1: the checkpoint of step n (i == 0)
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
 template <int MODEL, int CONTACT, int BOND_GRADS>
+//   rb > 0 (stage checkpoint): after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
+//   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
-                                                        int local_only) {
+                                                        int local_only, StageCoef rc, int rb) {
   const int m = blockIdx.y + c.m0;
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
@@ -811,6 +864,10 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
       stg<double>(c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
       stg<double>(c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
     }
+  }
+  if (rb > 0) {
+    if (i > 0) rebuild_record(c, m, b, k, rc, rb, n, h, t_n);
+    else if (n > 0) rebuild_record(c, m, b, k, rc, rb, n - 1, h_before, c.t_steps ? c.t_steps[n - 1] : t_n - h_before);
   }
 }
 
@@ -991,6 +1048,8 @@ struct dfx_handle {
   DevBuf<int> d_step_counts;
   int n_counts = 0;
   DevBuf<double> d_acc_times, d_tsteps;
+  DevBuf<double> d_AD;             // stage checkpoint (stage accelerations of every step)
+  bool dense = false;              // the last fixed-grid forward kept the stage checkpoint
   std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps)
   std::vector<long long> accepted_per_member;
   bool have_adaptive_record = false;
@@ -1030,6 +1089,8 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.t_steps = (!h->adaptive && !h->t_steps.empty()) ? h->d_tsteps.p : nullptr;
   c.rtol = h->rtol; c.atol = h->atol;
   c.traj = h->have_traj ? h->d_traj.p : nullptr;
+  c.AD = (h->have_traj && h->dense) ? h->d_AD.p : nullptr;
+  c.ad_stride = pl.batch ? (long long)(h->d_AD.n / pl.batch) : 0;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
   c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
@@ -1085,8 +1146,12 @@ static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf,
 }
 template <int MODEL, int CONTACT>
 static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
-  if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only);
-  else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only);
+  // stage checkpoint: which record this launch rebuilds for the launch after it (0: none)
+  const int s = h->pl.tab.s;
+  const int rb = (c.AD && !local_only) ? (i >= 2 ? i - 1 : (i == 0 ? s - 1 : 0)) : 0;
+  const StageCoef rc = stage_coef(h->pl.tab, rb > 0 ? rb - 1 : 0);
+  if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
   const Plan& pl = h->pl;
@@ -1113,6 +1178,10 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
       for (int i = 0; i < s; ++i) launch_fwd(h, c, g.stream, grid, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
+  } else if (c.AD) {
+    // stage checkpoint: no recompute launches; every reverse launch also rebuilds the record its successor reads
+    for (int j = n_steps - 1; j >= 0; --j)
+      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, i == 0 ? -1 : i, -1, 0);
   } else if (!h->dual_chain) {
     for (int j = n_steps - 1; j >= 0; --j) {
       // recompute the stage records of step n from its checkpoint: stage i -> buffer i+1
@@ -1158,7 +1227,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
   auto key = std::make_pair(n_steps, kind * 64 + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
-  const long long per = 1 + (long long)n_steps * (kind == 0 ? s : 2 * s - 1);
+  const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD) ? s : 2 * s - 1);   // launches in the graph
   hipStream_t st = h->groups[gi].stream;
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1193,21 +1262,41 @@ static int join_groups(dfx_handle* h) {
   return 0;
 }
 
-// One segment = one graph replay of n_steps steps inside one output interval.  A uniform grid is cut into chunks of
-// kMaxGraphSteps; a grid with its own count per interval is cut into power-of-two chunks so that the number of distinct
-// graphs stays <= log2(kMaxGraphSteps)+1 whatever the counts are.
+// One segment = one graph replay of n_steps steps inside one output interval.  Intervals with the most frequent step
+// count are cut into chunks of kMaxGraphSteps; the others into power-of-two chunks, so that the number of distinct
+// graphs stays <= log2(kMaxGraphSteps) + 3 whatever the counts are.
+// Stage checkpoint: also keep the first s-1 stage accelerations of every step (+24 (s-1) B per unit and step on top of
+// the 72 B of the state checkpoint) whenever that fits beside it: the reverse sweep then needs no recompute launches (s instead of
+// 2s - 1 launches per step).  DFX_STAGE_CHECKPOINT=0/1 overrides the choice.  Returns whether the buffer is there.
+static bool ensure_stage_checkpoint(dfx_handle* h, long long n_steps) {
+  const Plan& pl = h->pl;
+  const char* e = getenv("DFX_STAGE_CHECKPOINT");
+  const size_t want = (size_t)pl.batch * (size_t)std::max<long long>(n_steps, 1) * (pl.tab.s - 1) * pl.n_blocks * 3;
+  bool use = e ? e[0] != '0' : true;
+  if (use && h->d_AD.n < want) {
+    size_t free_b = 0, total_b = 0;
+    // leave room: at most what is free minus 5 % of the device
+    if (!e && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (want - h->d_AD.n) * sizeof(double) + total_b / 20 > free_b)) use = false;
+    if (use && h->d_AD.ensure(want) != hipSuccess) { (void)hipGetLastError(); use = false; }
+  }
+  return use;
+}
+
 static void build_segments(dfx_handle* h) {
   h->segs.clear();
   const int Tn = (int)h->ts.size();
-  bool uniform = true;
-  for (int k = 1; k + 1 < Tn; ++k) uniform = uniform && h->spis[k] == h->spis[0];
+  // the most frequent count keeps whole-interval graphs (a run of K steps = many equal intervals + one shorter one)
+  std::map<int, int> votes;
+  for (int k = 0; k + 1 < Tn; ++k) ++votes[h->spis[k]];
+  int common = 0, n_common = 0;
+  for (auto& kv : votes) if (kv.second > n_common) { common = kv.first; n_common = kv.second; }
   for (int k = 0; k + 1 < Tn; ++k) {
     const int spi = h->spis[k];
     const double hh = (h->ts[k + 1] - h->ts[k]) / spi;
     const double hp = k > 0 ? (h->ts[k] - h->ts[k - 1]) / h->spis[k - 1] : 0.0;
     for (int j0 = 0; j0 < spi;) {
       int n = std::min(kMaxGraphSteps, spi - j0);
-      if (!uniform) { int p2 = 1; while (p2 * 2 <= n) p2 *= 2; n = p2; }
+      if (spi != common) { int p2 = 1; while (p2 * 2 <= n) p2 *= 2; n = p2; }
       Seg sg;
       sg.t_interval = h->ts[k]; sg.h = hh; sg.h_prev = hp;
       sg.base_step = h->step0[k] + j0; sg.j0 = j0; sg.interval = k;
@@ -1261,45 +1350,79 @@ static int zero_grad_accumulators(dfx_handle* h) {
 
 // download the accumulators and scatter them into dfx_grads
 static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
+  // Only what the caller asked for crosses PCIe, and it is scattered straight from the pinned staging area into the
+  // caller's arrays (a solve of a few steps is otherwise dominated by this function).
   const Plan& pl = h->pl;
-  const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots;
+  const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots, nbd = pl.n_bonds;
   const size_t nsp = std::max(1, pl.n_special);
-  const size_t n_r = B * NS * 2, n_phi = B * NS, n_b = B * NS * 8, n_blk = B * nb * 6, n_fn = B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, n_lam = B * nb * 6;
-  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_blk + n_fn + n_lam) * sizeof(double)));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipGetLastError());
+  if (!grads) return 0;
+  const bool w_r = grads->centroid_node_vectors, w_phi = grads->void_angle0 && pl.contact;
+  const bool w_b = h->want_bond_grads && (grads->reference_vector || grads->k_bond || grads->contact);
+  const bool w_m = grads->inertia, w_c = grads->damping && h->want_damping_grads, w_fn = grads->fn_params && h->want_fn_grads;
+  const bool w_lam = with_state0 && grads->state0;
+  const size_t n_r = w_r ? B * NS * 2 : 0, n_phi = w_phi ? B * NS : 0, n_b = w_b ? B * NS * 8 : 0, n_m = w_m ? B * nb * 3 : 0,
+               n_c = w_c ? B * nb * 3 : 0, n_fn = w_fn ? B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS : 0, n_lam = w_lam ? B * nb * 6 : 0;
+  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_m + n_c + n_fn + n_lam + 8) * sizeof(double)));
   double* g_r = reinterpret_cast<double*>(h->stage.p);
   double* g_phi = g_r + n_r;
   double* g_b = g_phi + n_phi;
-  double* blk_g_p = g_b + n_b;
-  double* fn_g_p = blk_g_p + n_blk;
-  double* lam = fn_g_p + n_fn;
-  HIP_OK(hipMemcpyAsync(g_r, h->d_g_r.p, sizeof(double) * n_r, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(g_phi, h->d_g_phi.p, sizeof(double) * n_phi, hipMemcpyDeviceToHost, h->stream));
-  if (h->want_bond_grads) HIP_OK(hipMemcpyAsync(g_b, h->d_g_b.p, sizeof(double) * n_b, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(blk_g_p, h->d_blk_m.p, sizeof(double) * n_blk / 2, hipMemcpyDeviceToHost, h->stream));
-  if (h->want_damping_grads) HIP_OK(hipMemcpyAsync(blk_g_p + n_blk / 2, h->d_blk_c.p, sizeof(double) * n_blk / 2, hipMemcpyDeviceToHost, h->stream));
-  else memset(blk_g_p + n_blk / 2, 0, sizeof(double) * n_blk / 2);
-  if (h->want_fn_grads) HIP_OK(hipMemcpyAsync(fn_g_p, h->d_fn_g.p, sizeof(double) * n_fn, hipMemcpyDeviceToHost, h->stream));
-  else memset(fn_g_p, 0, sizeof(double) * n_fn);
-  if (with_state0) HIP_OK(hipMemcpyAsync(lam, h->d_LAM.p, sizeof(double) * n_lam, hipMemcpyDeviceToHost, h->stream));
+  double* g_m = g_b + n_b;
+  double* g_c = g_m + n_m;
+  double* fn_g = g_c + n_c;
+  double* lam = fn_g + n_fn;
+  auto pull = [&](double* dst, const double* src, size_t n) {
+    return n ? hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+  };
+  HIP_OK(pull(g_r, h->d_g_r.p, n_r));
+  HIP_OK(pull(g_phi, h->d_g_phi.p, n_phi));
+  HIP_OK(pull(g_b, h->d_g_b.p, n_b));
+  HIP_OK(pull(g_m, h->d_blk_m.p, n_m));
+  HIP_OK(pull(g_c, h->d_blk_c.p, n_c));
+  HIP_OK(pull(fn_g, h->d_fn_g.p, n_fn));
+  HIP_OK(pull(lam, h->d_LAM.p, n_lam));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
-  std::vector<double> blk_g(n_blk), fn_g(fn_g_p, fn_g_p + n_fn);
-  for (size_t i = 0; i < B * nb; ++i)
-    for (int d = 0; d < 3; ++d) { blk_g[i * 6 + d] = blk_g_p[i * 3 + d]; blk_g[i * 6 + 3 + d] = blk_g_p[n_blk / 2 + i * 3 + d]; }
-  if (!grads) return 0;
-  std::vector<double> slot_g(B * NS * kSlotGrads, 0.0);
-  for (size_t i = 0; i < B * NS; ++i) {
-    double* q = slot_g.data() + i * kSlotGrads;
-    q[0] = g_r[i * 2]; q[1] = g_r[i * 2 + 1];
-    if (h->want_bond_grads) for (int c = 0; c < 5; ++c) q[2 + c] = g_b[i * 8 + c];
-    const int info = pl.slot_info[i % NS];
-    if (info >= 0 && !(info & 1)) { q[7] = g_phi[i]; q[8] = g_phi[i - i % NS + (size_t)(info >> 1)]; }
-    if (h->want_bond_grads) for (int c = 0; c < 3; ++c) q[9 + c] = g_b[i * 8 + 5 + c];
+  const int npb = pl.n_npb;
+  if (w_r)
+    for (size_t m = 0; m < B; ++m)
+      for (size_t b = 0; b < nb; ++b)
+        memcpy(grads->centroid_node_vectors + ((m * nb + b) * npb) * 2, g_r + (m * NS + b * kSlots) * 2, sizeof(double) * 2 * npb);
+  if (grads->void_angle0) memset(grads->void_angle0, 0, sizeof(double) * B * nbd * 2);
+  if (grads->reference_vector) memset(grads->reference_vector, 0, sizeof(double) * B * nbd * 2);
+  if (grads->k_bond) memset(grads->k_bond, 0, sizeof(double) * B * nbd * 3);
+  if (grads->contact) memset(grads->contact, 0, sizeof(double) * B * 3);
+  if (w_phi || w_b)
+    for (size_t m = 0; m < B; ++m)
+      for (size_t sl = 0; sl < NS; ++sl) {
+        const int info = pl.slot_info[sl];
+        if (info < 0 || (info & 1)) continue;            // one entry per ligament: its end-0 slot
+        const size_t bond = (size_t)pl.slot_bond[sl], i = m * NS + sl;
+        if (w_phi) {
+          grads->void_angle0[(m * nbd + bond) * 2] = g_phi[i];
+          grads->void_angle0[(m * nbd + bond) * 2 + 1] = g_phi[m * NS + (size_t)(info >> 1)];
+        }
+        if (w_b) {
+          const double* q = g_b + i * 8;
+          if (grads->reference_vector) { grads->reference_vector[(m * nbd + bond) * 2] = q[0]; grads->reference_vector[(m * nbd + bond) * 2 + 1] = q[1]; }
+          if (grads->k_bond) for (int c = 0; c < 3; ++c) grads->k_bond[(m * nbd + bond) * 3 + c] = q[2 + c];
+          if (grads->contact) for (int c = 0; c < 3; ++c) grads->contact[m * 3 + c] += q[5 + c];
+        }
+      }
+  if (grads->inertia) memcpy(grads->inertia, g_m, sizeof(double) * B * nb * 3);
+  if (grads->damping) { if (w_c) memcpy(grads->damping, g_c, sizeof(double) * B * nb * 3); else memset(grads->damping, 0, sizeof(double) * B * nb * 3); }
+  if (grads->fn_params) {
+    const int W = DFX_MAX_FNS * DFX_FN_PARAMS;
+    for (size_t m = 0; m < B; ++m)
+      for (int f = 0; f < pl.n_fns; ++f)
+        for (int i = 0; i < DFX_FN_PARAMS; ++i) {
+          double acc = 0.0;
+          if (w_fn) for (int sidx = 0; sidx < pl.n_special; ++sidx) acc += fn_g[(m * pl.n_special + sidx) * W + f * DFX_FN_PARAMS + i];
+          grads->fn_params[(m * pl.n_fns + f) * DFX_FN_PARAMS + i] = acc;
+        }
   }
-  dfx_grads g = *grads;
-  if (!with_state0) g.state0 = nullptr;
-  unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g);
-  if (with_state0 && grads->state0)
+  if (w_lam)
     for (size_t m = 0; m < B; ++m)
       for (size_t b = 0; b < nb; ++b)
         for (int d = 0; d < 3; ++d) {
@@ -1406,7 +1529,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
-  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release();
+  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release(); h->d_AD.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
@@ -1481,6 +1604,7 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
   if (keep_trajectory) {
     hipError_t e = h->d_traj.ensure(B * (size_t)(max_steps + 1) * rec);
     if (e != hipSuccess) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
+    (void)ensure_stage_checkpoint(h, max_steps);
   }
   return 0;
 }
@@ -1530,6 +1654,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
       return 2;
     }
     h->have_traj = true;
+    h->dense = ensure_stage_checkpoint(h, h->n_total);
   }
   build_segments(h);
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
@@ -1582,6 +1707,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     stats->kernel_ms = ms;
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
+    stats->stage_checkpoint = c.AD ? 1 : 0;
   }
   return 0;
 }
@@ -1780,6 +1906,12 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   const int wb = (int)((h->n_total * pl.tab.s - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb);
+  if (c.AD && h->n_total > 0) {     // stage checkpoint: the record the first reverse launch reads
+    const long long nr = h->n_total - 1;
+    const double t_nr = h->t_steps.empty() ? h->ts[Tn - 1] - h_last : h->t_steps[nr];
+    hipLaunchKernelGGL(k_rebuild_first, slot_grid(h), dim3(kThreads), 0, h->stream, c, stage_coef(pl.tab, pl.tab.s - 2), pl.tab.s - 1, nr, h_last, t_nr);
+    h->launches++;
+  }
   if (fork_groups(h)) return 2;
   for (int si = nseg - 1; si >= 0; --si)
     for (int gi = 0; gi < (int)h->groups.size(); ++gi)
@@ -1801,6 +1933,7 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
     stats->kernel_ms = ms;
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
+    stats->stage_checkpoint = c.AD ? 1 : 0;
   }
   return 0;
 }

@@ -113,6 +113,8 @@ typedef struct dfx_stats {
   double kernel_ms;                       /* device time of the integration loop (HIP events)    */
   double stage_kernel_us;                 /* mean duration of one stage-kernel launch incl. gap  */
   int64_t streams;                        /* member groups integrated concurrently (one HIP stream each) */
+  int64_t stage_checkpoint;               /* 1: the forward pass also kept the stage accelerations of every step, so the
+                                             reverse sweep runs without recompute launches (chosen when it fits in HBM) */
 } dfx_stats;
 
 typedef struct dfx_handle dfx_handle;

@@ -207,3 +207,21 @@ def test_recorded_signal_as_prescribed_displacement(hip_lib):
 def test_several_dofs_of_one_block_share_a_time_function(hip_lib):
     """The three DOF lanes of the driven block add into the same parameter-gradient entries (atomic adds in the kernel)."""
     parity.check_several_dofs_of_one_block_share_a_time_function(None)
+
+
+@pytest.mark.parametrize("stage_checkpoint", ["0", "1"])
+@pytest.mark.parametrize("lattice,n,integrator", [("quads", 5, "dopri5"), ("kagome", 3, "rk4")])
+def test_reverse_sweep_with_and_without_stage_checkpoint(hip_lib, monkeypatch, stage_checkpoint, lattice, n, integrator):
+    """Two ways through the reverse sweep: stage accelerations of every step kept by the forward pass (records rebuilt
+    elementwise, s launches per step) or only the step states (records recomputed, 2s - 1 launches per step).  The engine
+    picks the first whenever it fits in HBM; both must agree with the oracle."""
+    monkeypatch.setenv("DFX_STAGE_CHECKPOINT", stage_checkpoint)
+    parity.check_trajectory_and_adjoint(None, lattice, n, integrator, spi=np.array([3, 7, 2, 5]), own_step_times=True)
+    c = Case(lattice, n, True, True, seed=2, lib=None, cutoff_deg=125.0 if lattice == "kagome" else 42.0, integrator=integrator, batch=3)
+    ts = np.linspace(0, 2e-4, 3)
+    f = c.solver(c.random_state(0.05, 0.02, 5.0), ts, c.cp, keep_trajectory=True, steps_per_interval=300)   # several graph segments
+    assert c.solver.stats["stage_checkpoint"] == int(stage_checkpoint)
+    c.solver.vjp(np.ones_like(f))
+    s_launch = 6 if integrator == "dopri5" else 4
+    per_step = c.solver.adjoint_stats["launches"] / 600.0
+    assert abs(per_step - (s_launch if stage_checkpoint == "1" else 2 * s_launch - 1)) < 0.2
