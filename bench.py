@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md, chip-level parameters
 # algorithmic bytes per rigid unit per launch
 BYTES_FWD_STAGE = 272 + 72    # one RHS evaluation (quads + contact) + its share of the stage combine (432/6)
 BYTES_ADJ_STAGE = 272 + 96 + 256  # stage data + lambda/Ybar read-write + parameter-gradient RMW
+# with the stage checkpoint 5 of the 6 reverse launches of a step also rebuild the next stage record: the forward's stage
+# combine (72 B per stage, SURVEY 8(d): 432 B per 6 stages) moves into the reverse launch instead of a recompute launch
+BYTES_ADJ_STAGE_REBUILD = BYTES_ADJ_STAGE + 72 * 5 / 6
 
 
 def c3_problem(size, seed, members, lib=None, device=0):
@@ -224,6 +227,30 @@ def main():
         rr = run_once(fwr, objr, desr, Kr, adjoint=not args.forward_only)
         fwr.solve_dynamics.engine.close()
         del fwr, objr
+    single = None
+    if rank == 0 and world == 1 and args.members > 1 and not args.forward_only and not args.no_single:
+        # the same config with ONE design per GPU (launch-bound: one wave per SIMD), for reference; measured before the
+        # timed job (the first solves after releasing a > 200 GB checkpoint were seen to run at half speed)
+        fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
+        K1 = min(K, 2500)
+        fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 2, keep_trajectory=True)
+        run_once(fw1, obj1, des1, SPI)
+        if K1 % SPI:
+            run_once(fw1, obj1, des1, K1 % SPI)
+        prepare(fw1, des1, K1)
+        spin_up(fw1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r1 = execute(fw1, obj1)
+        torch.cuda.synchronize()
+        w1 = time.perf_counter() - t1
+        single = {"members_per_gpu": 1, "steps": K1, "value": K1 * args.size * args.size / w1,
+                  "forward_only_value": K1 * args.size * args.size / (r1["fwd_ms"] * 1e-3),
+                  "fwd_launch_us": 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]),
+                  "stage_checkpoint": bool(r1.get("stage_checkpoint", False)),
+                  "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
+        fw1.solve_dynamics.engine.close()
+        del fw1, obj1
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
     fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=not args.forward_only)
     if W:
@@ -299,10 +326,12 @@ def main():
                          "measured_with": "1 stream, HIP events around the forward region / launches"},
         }
         if adj_us:
-            a2 = BYTES_ADJ_STAGE * n_units * args.members / (adj_us * 1e-6) / 1e9
+            adj_bytes = BYTES_ADJ_STAGE_REBUILD if rr.get("stage_checkpoint") else BYTES_ADJ_STAGE
+            a2 = adj_bytes * n_units * args.members / (adj_us * 1e-6) / 1e9
             line["roofline_adjoint_kernel"] = {"kernel": "k_adj_stage<nonlinear,contact>", "achieved": a2, "peak": HBM_PEAK_GBS,
                                                "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS, "launch_us": adj_us,
-                                               "bytes_per_launch": BYTES_ADJ_STAGE * n_units * args.members}
+                                               "bytes_per_launch": adj_bytes * n_units * args.members,
+                                               "rebuilds_stage_records": bool(rr.get("stage_checkpoint"))}
         if streams > 1:
             # (2) the timed job itself: `streams` member groups overlap on the chip; aggregate algorithmic bytes / region time
             f_eff, a_eff = per_launch(res, streams)
@@ -311,28 +340,11 @@ def main():
             agg["fwd_frac"] = agg["fwd_achieved"] / HBM_PEAK_GBS
             if a_eff:
                 agg["adj_stage_period_us"] = a_eff
-                agg["adj_achieved"] = BYTES_ADJ_STAGE * n_units * args.members / (a_eff * 1e-6) / 1e9
+                agg["adj_achieved"] = (BYTES_ADJ_STAGE_REBUILD if res.get("stage_checkpoint") else BYTES_ADJ_STAGE) * n_units * args.members / (a_eff * 1e-6) / 1e9
                 agg["adj_frac"] = agg["adj_achieved"] / HBM_PEAK_GBS
             line["roofline_concurrent"] = agg
-        if args.members > 1 and not args.forward_only and not args.no_single and world == 1:
-            # the same config with ONE design per GPU (latency-bound: one wave per SIMD), for reference
-            fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
-            K1 = min(K, 2500)
-            fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 2, keep_trajectory=True)
-            run_once(fw1, obj1, des1, SPI)
-            prepare(fw1, des1, K1)
-            spin_up(fw1)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            r1 = execute(fw1, obj1)
-            torch.cuda.synchronize()
-            w1 = time.perf_counter() - t1
-            line["single_system"] = {"members_per_gpu": 1, "steps": K1, "value": K1 * n_units / w1,
-                                     "forward_only_value": K1 * n_units / (r1["fwd_ms"] * 1e-3),
-                                     "fwd_launch_us": 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]),
-                                     "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
-            fw1.solve_dynamics.engine.close()
-            del fw1, obj1
+        if single is not None:
+            line["single_system"] = single
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.size, 3)
         print(json.dumps(line), flush=True)
