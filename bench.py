@@ -255,7 +255,11 @@ def main():
     fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=not args.forward_only)
     if W:
         run_once(fw, obj, designs, W, adjoint=not args.forward_only)
-    if K % SPI:      # the graphs of the shorter last interval are instantiated here, not inside the timed region
+    # hipGraphs are instantiated on first use: make sure every segment length the K timed steps replay has been used once
+    # (a full output interval and the shorter last interval), whatever W was
+    if K >= SPI and (W < SPI or W % SPI):
+        run_once(fw, obj, designs, SPI, adjoint=not args.forward_only)
+    if K % SPI:
         run_once(fw, obj, designs, K % SPI, adjoint=not args.forward_only)
 
     def barrier():
