@@ -226,3 +226,11 @@ def test_bench_host_path_on_cpu_port(cpu_lib):
     line = bench.cpu_baseline(8, 3, budget_s=1.0)
     assert line["kind"] == "port" and line["value"] > 0 and line["cores"] >= 1
     assert bench.load_pmc_traffic(16) > 16 * bench.BYTES_FWD_STAGE * 128 * 128     # PMC traffic >= algorithmic bytes
+
+
+def test_bench_times_exactly_k_steps():
+    import bench
+    for k in (1, 20, 250, 251, 777, 5000):
+        ts, counts = bench.step_grid(k)
+        total = int(np.sum(np.broadcast_to(counts, (len(ts) - 1,))))
+        assert total == k and abs(ts[-1] - k * bench.DT) < 1e-18 and np.all(np.diff(ts) > 0)
