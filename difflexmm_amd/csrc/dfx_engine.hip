@@ -1,26 +1,25 @@
-// dfx_engine.hip -- libdfx: the MI355X (gfx950) engine behind include/dfx.h.
+// dfx_engine.hip -- libdfx: the MI355X (gfx950) engine behind include/dfx.h (host side; kernels in dfx_kernels.h).
 //
 // Execution model
-//   * one lane per (block, node slot): 4 lanes = one rigid unit, 16 units per 64-wide wavefront,
-//     256-thread workgroups, grid = (ceil(4*n_blocks/256), batch members).  Every ligament is evaluated
-//     by both of its end lanes ("gather form"); the 4 slot contributions of a unit are summed with
-//     quad shuffles; lanes 0..2 of the quad then own DOF x, y, theta for the integrator epilogue.
-//     No atomics anywhere: results are bit-reproducible.
-//   * one kernel launch per Runge-Kutta stage (the neighbour exchange of an explicit stage is a grid-wide
-//     dependency; a kernel boundary is the cheapest grid barrier on this chip).
-//   * a launch never chases an index: the epilogue of stage i assembles the stage record of stage i+1
-//     (64 B per unit: x y th cos(th/2) sin(th/2) vx vy vth) AND pushes the 5 numbers a neighbour needs
-//     into that neighbour's "mailbox" slot, so every load address of the next launch is known at wave
-//     start (one latency level instead of index -> gather).  All parameter tables are 16-byte rows
-//     indexed by the lane's own slot (coalesced dwordx4).
-//   * the time loop is replayed from hipGraphs (one graph = one segment of <= kMaxGraphSteps steps);
-//     what changes between replays (time, step size, checkpoint slot) is one 64-byte record in device
-//     memory, refreshed by a 1-thread tick kernel at the head of each graph.
-//   * the reverse sweep re-reads the checkpointed trajectory (one 64-B record per unit per step, kept in
-//     HBM), recomputes the stage records of a step and runs one Dual-number kernel per stage.
+//   * one lane per (block, node slot): 4 lanes = one rigid unit, 16 units per 64-wide wavefront, 256-thread workgroups,
+//     grid = (ceil(4*n_blocks/256), members of the group).  Every ligament is evaluated by both of its end lanes
+//     ("gather form"); the 4 slot contributions of a unit are summed with DPP quad moves; lanes 0..2 of the quad own DOF
+//     x, y, theta in the integrator epilogue.  No LDS; atomics only for the (rare) time-function parameter gradients that
+//     several DOFs of one block share: results are reproducible run to run.
+//   * one kernel launch per Runge-Kutta stage (the neighbour exchange of an explicit stage is a grid-wide dependency; a
+//     kernel boundary is the cheapest grid barrier on this chip).  The epilogue of stage i assembles the
+//     stage record of stage i+1 (48 B per unit: x y th cos(th/2) sin(th/2) pad, plus 24 B of velocity); a lane gathers its
+//     partner's record from a guessed slot in the same batch of loads as everything else.
+//   * the time loop is replayed from hipGraphs (one graph = one segment of <= kMaxGraphSteps steps, per member group and
+//     direction); what changes between replays (time, step size, checkpoint slot) is one 64-byte record in device memory,
+//     refreshed by a 1-thread tick kernel at the head of each graph.  Member groups advance on concurrent streams.
+//   * the reverse sweep reads the checkpointed trajectory (72 B per unit and step) and runs one dual-number kernel per
+//     stage; the stage records it linearises about are either rebuilt elementwise from the stage checkpoint (stage
+//     accelerations of every step, kept when they fit in HBM) or recomputed by forward launches.
 //
 // The per-ligament physics (dfx_physics.h) is shared with the CPU port of the oracle.
 #include <hip/hip_runtime.h>
+
 
 #include <algorithm>
 #include <chrono>
@@ -31,933 +30,8 @@
 #include <string>
 #include <vector>
 
-#include "dfx_stage.h"
 
-using namespace dfx;
-
-// occupancy hints for the two stage kernels (waves per SIMD the register allocator must leave room for).
-// Forward: 5 waves (96 VGPRs + 100 B/lane of scratch) measured +7 % forward-only at 16 members per GPU over the
-// allocator's own choice (120 VGPRs, 4 waves), neutral at 1..8 members; 6 waves lose it again to spills.  Reverse: any
-// forced occupancy spills heavily (-25 %), left to the allocator (150 VGPRs, 3 waves).
-#ifndef DFX_FWD_OCC
-#define DFX_FWD_OCC __attribute__((amdgpu_waves_per_eu(5)))
-#endif
-#ifndef DFX_ADJ_OCC
-#define DFX_ADJ_OCC
-#endif
-
-namespace {
-
-// Index arithmetic inside the stage kernels is 32-bit (one s_mul / v_mad instead of a 64-bit multiply chain per array);
-// dfx_create refuses ensembles whose largest per-handle array would not fit (check_index_range).  The trajectory
-// checkpoint and the cotangent table keep 64-bit offsets.
-typedef unsigned u32;
-
-constexpr int kThreads = 256;
-constexpr int kAccCap = 1 << 20;   // accepted step times recorded per member (adaptive)
-constexpr int kMaxGraphSteps = 256;
-constexpr int kPos = 6;   // doubles per unit position record: x y th cos(th/2) sin(th/2) pad   (three 16-byte chunks)
-constexpr int kStep = 9;  // doubles per unit in a trajectory checkpoint: position record + velocity (3)
-
-struct Seg {            // one graph replay worth of steps
-  double t_interval;    // timepoints[k]
-  double h;             // step size of the interval
-  double h_prev;        // step size of the previous interval (reverse sweep, first step of an interval)
-  long long base_step;  // global index of the first step of the segment
-  int j0;               // index of that step inside its interval
-  int interval;         // k
-  int n_steps;
-  int pad;
-};
-
-// adaptive mode: every member carries its own clock and step-size controller state
-struct Clock {
-  double t, h;            // start time and size of the step being attempted
-  double t_last, h_acc;   // start and size of the last accepted step (dense output)
-  long long attempts, accepted;
-  int state;              // 0 running, 1 finished, 2 non-finite error estimate, 3 step size underflow
-  int fin_next;           // the last output was produced in this round: finished from the next round on
-  int accept;             // decision of the last controller run
-  int out_lo, out_hi;     // outputs [out_lo, out_hi) lie inside the step just accepted
-  int out_idx;            // next output to produce
-};
-
-// next-stage coefficients of one launch, passed by value (lands in SGPRs)
-struct StageCoef {
-  double cv[kMaxStages];  // a[r][l]   : V_{r} = v_n + h sum_l cv[l] A_l
-  double cq[kMaxStages];  // (a*a)[r][l]: Q_{r} = q_n + h c_r v_n + h^2 sum_l cq[l] A_l
-  double c_i, c_next;     // stage times
-};
-
-// reverse-stage coefficients: kbar_{i-1} = h (b_{i-1} lambda + sum_{j>=i} a[j][i-1] Ybar_j)
-struct AdjCoef {
-  double col[kMaxStages + 1];  // col[j] = a[j][i-1] for j in i..s-1, col[s] = b_{i-1};  at i == 0: col[s] = b_{s-1}
-  double c_i;
-};
-
-struct DevCtx {
-  int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
-  int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
-  int pred[4];            // guessed partner slot = own slot + pred[node slot]
-  int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
-  long long traj_stride;  // elements between members in traj
-  const int32_t* slot_info;
-  const int32_t* block_special;
-  const dfx_special* special;
-  // per-member parameter images, rows indexed by the lane's own slot / DOF (coalesced)
-  const double* p_r;      // n_slots*2   own centroid->node vector
-  const double* p_l;      // n_slots*2   reference vector of the slot's ligament
-  const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
-  const double* p_phi;    // n_slots     undeformed void angle: phi1 on end-0 slots, phi2 on end-1 slots (the other one is gathered from the partner slot)
-  const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
-  const double* l_dict;   // 256*4   lx ly |l0| 1/|l0|
-  int l_dict_on, damping_uniform;
-  const double* cst;      // 16           min_angle cutoff_angle k_contact | uniform k_stretch k_shear k_rot
-  const double* inv_m;    // n_blocks*3
-  const double* damping;  // n_blocks*3
-  const TimeFn* fns;
-  const Seg* cur;         // the segment being replayed
-  Clock* clock;           // per-member clocks (adaptive mode) or null
-  double* err_partial;    // batch * n_wg*4 per-wave partial sums of the squared error ratio
-  int* step_counts;       // batch * (n_timepoints-1) accepted steps per output interval (adaptive)
-  double* acc_times;      // batch * acc_cap end times of the accepted steps (adaptive)
-  int acc_cap;
-  const double* t_steps;  // n_total+1 step boundaries of a caller-chosen grid, or null: equal steps (Seg.h)
-  double* AD;             // stage checkpoint: batch * (N * s * n_dof) stage accelerations of EVERY step, or null
-  long long ad_stride;    // elements between members in AD
-  const double* ts_dev;   // output times (adaptive mode)
-  double* fields_dev;     // batch * T * n_blocks*6 (adaptive mode writes its dense output here)
-  double rtol, atol;
-  // state: (s+1) stage buffers per member; buffer 0 = current step state
-  double* traj;           // batch * traj_stride   checkpoints: per step [POS n_blocks*6 | VEL n_blocks*3]
-  double* POS;            // batch * (s+1) * n_blocks*kPos
-  double* VEL;            // batch * (s+1) * n_blocks*3
-  double* A;              // batch * s * n_blocks*3
-  // reverse
-  double* YB;             // batch * s * n_blocks*6
-  double* LAM;            // batch * n_blocks*6
-  double* W;              // batch * 2 * n_blocks*3
-  double* KQ;             // batch * 2 * n_blocks*3
-  const double* G;        // T * batch * n_blocks*6 (time-major)
-  double* g_r;            // batch * n_slots*2     d/d(own node vector)
-  double* g_phi;          // batch * n_slots       d/d(void angle): phi1 on the end-0 slot of a ligament, phi2 on its end-1 slot
-  double* g_b;            // batch * n_slots*8     d/d(l0(2), k(3), contact(3)) (end-1 slots) or null
-  double* blk_m;          // batch * n_blocks*3    d/d(inertia)
-  double* blk_c;          // batch * n_blocks*3    d/d(damping) or null
-  double* fn_g;           // batch * n_special*MAX_FNS*FN_PARAMS or null
-};
-
-// ---- quad (4-lane) data movement on DPP: no LDS traffic, no bank conflicts --------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_sum(double v) {
-  v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
-  return v;
-}
-// accumulate into an array that several lanes of one launch may hit (time-function parameter gradients of a block whose
-// DOFs share a function): hardware fp64 atomic add performed in L2, result not returned
-__device__ __forceinline__ void acc_add(double* p, double v) { (void)unsafeAtomicAdd(p, v); }
-
-template <int J>
-__device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<J | (J << 2) | (J << 4) | (J << 6)>(v); }
-
-// XCD-aware workgroup order: hardware deals workgroups round-robin over the 8 XCDs (id % 8 share an L2);
-// give every XCD one contiguous band of the lattice so neighbour gathers mostly hit that XCD's own L2.
-__device__ __forceinline__ int logical_wg(int bid, int n_wg) {
-  const int x = bid & 7, q = bid >> 3, per = n_wg >> 3, rem = n_wg & 7;
-  return x * per + (x < rem ? x : rem) + q;
-}
-
-__device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
-  return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep;
-}
-__device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.VEL + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * 3;
-  return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep + (size_t)c.n_blocks * kPos;
-}
-
-__global__ void k_tick(const Seg* segs, int* seg_idx, int delta, Seg* cur) {
-  int i = *seg_idx + delta;
-  *seg_idx = i;
-  *cur = segs[i];
-}
-
-struct TimeVals { double g, gt; };
-
-// value of the prescribed displacement of DOF d of special block sp at time t (and its rate)
-__device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, const dfx_special& sp, int d, double t) {
-  TimeVals r{0.0, 0.0};
-  double gp[kMaxFnParams];
-  for (int f = 0; f < c.n_fns; ++f)
-    if (sp.con_coef[d][f] != 0.0) {
-      double g, gt;
-      eval_time_fn(c.fns[(size_t)m * DFX_MAX_FNS + f], t, g, gt, gp);
-      r.g += sp.con_coef[d][f] * g;
-      r.gt += sp.con_coef[d][f] * gt;
-    }
-  return r;
-}
-
-// records of a full (2, n_blocks, 3) state at time t0 -> stage buffer `buf`  (constrained DOFs follow c(t0), c'(t0))
-__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf) {
-  const int m = blockIdx.y + c.m0;
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= c.n_slots) return;
-  const int b = tid >> 2, d = tid & 3;
-  if (d == 3) return;
-  const size_t nd = (size_t)c.n_blocks * 3;
-  double q = state0[(size_t)m * 2 * nd + b * 3 + d], v = state0[(size_t)m * 2 * nd + nd + b * 3 + d];
-  const int sidx = c.block_special[b];
-  if (sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1)) {
-    TimeVals tv = constrained_value(c, m, c.special[sidx], d, t0);
-    q = tv.g; v = tv.gt;
-  }
-  double* pr = c.POS + ((size_t)m * c.nbuf + buf) * c.n_blocks * kPos + (size_t)b * kPos;
-  pr[d] = q;
-  c.VEL[((size_t)m * c.nbuf + buf) * nd + b * 3 + d] = v;
-  if (d == 2) {
-    double sn, cs;
-    fast_sincos(0.5 * q, &sn, &cs);
-    pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
-  }
-}
-
-// fields[m, k] <- (disp, vel) of stage buffer 0
-__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad) {
-  const int m = blockIdx.y + c.m0;
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= c.n_blocks * 3) return;
-  const int b = tid / 3, d = tid % 3;
-  double* f = fields + ((size_t)m * c.n_timepoints + k) * c.n_blocks * 6;
-  const double q = c.POS[(size_t)m * c.nbuf * c.n_blocks * kPos + (size_t)b * kPos + d];
-  const double v = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + tid];
-  f[tid] = q;
-  f[(size_t)c.n_blocks * 3 + tid] = v;
-  if (!isfinite(q) || !isfinite(v)) *bad = k + 1;   // any writer wins: only "some output row is not finite" matters
-}
-
-// copy stage buffer 0 into checkpoint slot n (only for the initial state)
-__global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
-  const int m = blockIdx.y + c.m0;
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= c.n_blocks * kStep) return;
-  double* t = c.traj + (size_t)m * c.traj_stride;
-  if (tid < c.n_blocks * kPos) t[tid] = c.POS[(size_t)m * c.nbuf * c.n_blocks * kPos + tid];
-  else t[tid] = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + (tid - c.n_blocks * kPos)];
-}
-
-// Addressing: every array access in the stage kernels is  uniform base (SGPR pair: kernel argument + member / buffer
-// offsets, scalar arithmetic)  +  32-bit per-lane byte offset (one VGPR, shared by all arrays that are indexed the same
-// way).  Written this way the compiler emits the `global_load v, v_off, s[base:base+1]` form: no 64-bit vector address
-// arithmetic and no VGPR pair per array.
-template <class T>
-__device__ __forceinline__ T ldg(const void* base, u32 byte_off) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-template <class T>
-__device__ __forceinline__ void stg(void* base, u32 byte_off, T v) {
-  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
-}
-
-// uniform bases of member m's parameter arrays
-struct MemberBases {
-  const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict;
-  const uint8_t* p_lidx;
-};
-__device__ __forceinline__ MemberBases member_bases(const DevCtx& c, int m) {
-  MemberBases B;
-  const size_t ps = (size_t)m * (u32)c.n_slots;
-  B.p_r = c.p_r + ps * 2; B.p_phi = c.p_phi + ps; B.p_l = c.p_l + ps * 2; B.p_k = c.p_k + ps * 4;
-  B.cst = c.cst + (size_t)m * 16; B.l_dict = c.l_dict + (size_t)m * 1024; B.p_lidx = c.p_lidx + ps;
-  return B;
-}
-
-struct LaneIn {
-  BlockRec<double> o, p;
-  double rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, phi1, phi2, am, ac, kc, sgn;
-  int info, pslot, guess;
-};
-
-struct Partner {
-  double2 b0, b1, rp;
-  double b2, phi;
-};
-
-template <int CONTACT>
-__device__ __forceinline__ void load_partner(const MemberBases& B, int pslot, const double* POSin, Partner& P) {
-  const u32 rec = (u32)(pslot >> 2) * (kPos * 8);
-  P.b0 = ldg<double2>(POSin, rec);
-  P.b1 = ldg<double2>(POSin, rec + 16);
-  P.b2 = ldg<double>(POSin, rec + 32);
-  P.rp = ldg<double2>(B.p_r, (u32)pslot * 16);
-  P.phi = CONTACT ? ldg<double>(B.p_phi, (u32)pslot * 8) : 0.0;
-}
-
-// Everything a lane needs for its ligament, in two phases so that every load that does not depend on another
-// load is in flight before the first wait:
-//   issue_lane   own data (one coalesced 16-byte chunk per lane, spread over the quad by DPP later), slot_info, and
-//                the partner's data from a GUESSED slot (own slot + the lattice's usual offset for this node slot);
-//                the kernels then issue their own epilogue operands;
-//   resolve_lane what depends on loaded values: the dictionary entry of the reference vector, and a second gather
-//                only for lanes whose real partner is not the guessed one (irregular connectivity).
-// Partner data comes from the same arrays the owners read (lines served by the XCD's L2).
-struct LaneRaw {
-  Partner P;
-  double2 pc, ro, lv;
-  double ks, ksh, kr, phi;
-  int info, guess, lidx;
-};
-
-template <int CONTACT>
-__device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B, int slot, const double* POSin, LaneRaw& R) {
-  const int b = slot >> 2, k = slot & 3;
-  R.info = ldg<int>(c.slot_info, (u32)slot * 4);
-  R.pc = k < 3 ? ldg<double2>(POSin, ((u32)b * kPos + 2 * k) * 8) : make_double2(0.0, 0.0);
-  R.ro = ldg<double2>(B.p_r, (u32)slot * 16);
-  // branch-free (a branch here would end the batch of loads): the unused one of the two reads one shared valid address
-  R.lidx = (int)ldg<uint8_t>(c.l_dict_on ? (const void*)B.p_lidx : (const void*)B.cst, c.l_dict_on ? (u32)slot : 0u);
-  R.lv = ldg<double2>(c.l_dict_on ? B.cst : B.p_l, c.l_dict_on ? 0u : (u32)slot * 16);
-  R.ks = R.ksh = R.kr = 0.0;
-  if (!c.k_uniform) { R.ks = ldg<double>(B.p_k, (u32)slot * 32); R.ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); R.kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
-  R.phi = CONTACT ? ldg<double>(B.p_phi, (u32)slot * 8) : 0.0;
-  const int delta = k == 0 ? c.pred[0] : (k == 1 ? c.pred[1] : (k == 2 ? c.pred[2] : c.pred[3]));   // selects: a dynamic index would be a memory load
-  R.guess = min(max(slot + delta, 0), c.n_slots - 1);
-  load_partner<CONTACT>(B, R.guess, POSin, R.P);
-}
-
-template <int CONTACT>
-__device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases& B, const double* POSin, LaneRaw& R, LaneIn& L) {
-  const int info = R.info;
-  L.info = info;
-  double2 lv = R.lv, ln = make_double2(0.0, 0.0);
-  if (c.l_dict_on) {
-    lv = ldg<double2>(B.l_dict, (u32)R.lidx * 32);
-    ln = ldg<double2>(B.l_dict, (u32)R.lidx * 32 + 16);
-  }
-  const int pslot = info < 0 ? R.guess : (info >> 1);
-  L.pslot = pslot; L.guess = R.guess;
-  if (pslot != R.guess) load_partner<CONTACT>(B, pslot, POSin, R.P);
-  const double* cst = B.cst;
-  if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
-  else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
-  if (CONTACT) {
-    L.phi1 = (info & 1) ? R.P.phi : R.phi;
-    L.phi2 = (info & 1) ? R.phi : R.P.phi;
-    L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2];
-  }
-  L.o.x = quad_bcast<0>(R.pc.x); L.o.y = quad_bcast<0>(R.pc.y);
-  L.o.th = quad_bcast<1>(R.pc.x); L.o.ch = quad_bcast<1>(R.pc.y);
-  L.o.sh = quad_bcast<2>(R.pc.x);
-  L.p.x = R.P.b0.x; L.p.y = R.P.b0.y; L.p.th = R.P.b1.x; L.p.ch = R.P.b1.y; L.p.sh = R.P.b2;
-  L.rox = R.ro.x; L.roy = R.ro.y; L.rpx = R.P.rp.x; L.rpy = R.P.rp.y;
-  L.lx = lv.x; L.ly = lv.y;
-  if (c.l_dict_on) { L.l0 = ln.x; L.il0 = ln.y; }
-  else {
-    L.l0 = info < 0 ? 1.0 : sqrt(lv.x * lv.x + lv.y * lv.y);
-    L.il0 = 1.0 / L.l0;
-  }
-  L.sgn = (info & 1) ? 1.0 : -1.0;
-}
-
-template <int CONTACT>
-__device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, const double* POSin, LaneIn& L) {
-  const MemberBases B = member_bases(c, m);
-  LaneRaw R;
-  issue_lane<CONTACT>(c, B, slot, POSin, R);
-  resolve_lane<CONTACT>(c, B, POSin, R, L);
-}
-
-// ---- forward stage ---------------------------------------------------------------------------
-//   in_buf  : stage buffer holding this stage's records, or -1: the checkpoint of step n (reverse recompute, i == 0)
-//   out_buf : buffer for the next stage's records (-1: none)
-//   y_buf   : 0: step base state (q_n, v_n) in buffer 0;  -1: in the checkpoint of step n
-//   write_traj: also store the new record into the checkpoint of step n+1 (last stage, keep_trajectory)
-template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
-                                                        int y_buf, int mode) {
-  const int m = blockIdx.y + c.m0;
-  const int lwg = logical_wg(blockIdx.x, c.n_wg);
-  int slot = lwg * kThreads + threadIdx.x;
-  const int write_traj = mode & 1, err_mode = mode & 2;
-  const bool valid = slot < c.n_slots;
-  if (!valid) {
-    if (!err_mode) return;
-    slot = c.n_slots - 4 + (threadIdx.x & 3);   // keep the wave whole for the reduction: redo the last unit, contribute 0
-  }
-  if (c.ablate & 4) return;
-  const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
-  Seg sg = *c.cur;
-  if (c.clock) {          // adaptive: this member's own time and step
-    const Clock ck = c.clock[m];
-    if (ck.state | ck.fin_next) return;
-    sg.t_interval = ck.t; sg.h = ck.h; sg.j0 = 0; sg.base_step = 0; j = 0;
-  }
-  const long long n = sg.base_step + j;
-  const u32 nd = (u32)c.n_blocks * 3;
-  // ---- load phase
-  const double* POSin = pos_in(c, m, in_buf, n);
-  const MemberBases B = member_bases(c, m);
-  LaneRaw R;
-  issue_lane<CONTACT>(c, B, slot, POSin, R);
-  const int dof = b * 3 + kd;
-  const u32 o_dof = (u32)dof * 8, o_rec = ((u32)b * kPos + kd) * 8;      // per-lane byte offsets shared by all per-DOF arrays
-  const double qn = ldg<double>(pos_in(c, m, y_buf, n), o_rec);
-  const double vn = ldg<double>(vel_in(c, m, y_buf, n), o_dof);
-  const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
-  // stage accelerations: the per-member scratch set, or (stage checkpoint) this step's own slot, kept for the reverse sweep
-  // (the last stage's acceleration is not kept: no stage record depends on it)
-  const bool keep_stages = c.AD && !c.clock;
-  double* Am = keep_stages ? c.AD + (size_t)m * c.ad_stride + (size_t)n * ((u32)(c.s - 1) * nd) : c.A + (size_t)m * (u32)(c.s + 1) * nd;
-  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
-  const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
-  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
-  // earlier stage accelerations: all loads issued together (a rolled loop waits for each one in turn)
-  double al[kMaxStages - 1];
-#pragma unroll
-  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? ldg<double>(Am + (size_t)l * nd, o_dof) : 0.0;
-  LaneIn L;
-  resolve_lane<CONTACT>(c, B, POSin, R, L);
-  double sv = 0.0, sq = 0.0;
-#pragma unroll
-  for (int l = 0; l < kMaxStages - 1; ++l) {
-    sv += sc.cv[l] * al[l];
-    sq += sc.cq[l] * al[l];
-  }
-  // ---- ligament + contact of this slot
-  double fx = 0.0, fy = 0.0, fth = 0.0;
-  if (c.ablate & 1) {
-    fx = L.o.x + L.p.x + L.rox + L.rpx + L.lx + L.l0; fy = L.o.y + L.p.y + L.roy + L.rpy + L.ly + L.il0;
-    fth = L.o.th + L.p.th + L.o.ch + L.p.ch + L.o.sh + L.p.sh + (CONTACT ? L.phi1 + L.phi2 : 0.0);
-  } else if (L.info >= 0) {
-    BondGrad<double> g;
-    bond_grad<MODEL, double>(L.o, L.p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
-    fx = g.fx; fy = g.fy; fth = g.fth;
-    if (CONTACT) {
-      ContactGrad<double> cg;
-      contact_grad<double>(L.sgn * (L.o.th - L.p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
-      fth += L.sgn * cg.dkap;
-    }
-  }
-  fx = quad_sum(fx);
-  fy = quad_sum(fy);
-  fth = quad_sum(fth);
-  // ---- DOF epilogue on lanes 0..2
-  double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
-  if (c.t_steps && !c.clock) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
-  double qnext = 0.0, vnext = 0.0;
-  if (k < 3) {
-    const double dE = k == 0 ? fx : (k == 1 ? fy : fth);
-    bool constrained = false;
-    double fload = 0.0;
-    if (sidx >= 0) {
-      const dfx_special& sp = c.special[sidx];
-      constrained = (sp.con_mask >> k) & 1;
-      if (!constrained) {
-        double gp[kMaxFnParams];
-        for (int f = 0; f < c.n_fns; ++f)
-          if (sp.load_coef[k][f] != 0.0) {
-            double g, gt;
-            eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + sc.c_i * h, g, gt, gp);
-            fload += sp.load_coef[k][f] * g;
-          }
-      }
-    }
-    const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-    if (!(keep_stages && i == c.s - 1)) stg<double>(Am + (size_t)i * nd, o_dof, a);
-    sv += sc.cv[i] * a;
-    sq += sc.cq[i] * a;
-    qnext = qn + h * (sc.c_next * vn + h * sq);
-    vnext = vn + h * sv;
-    if (err_mode) {
-      // i == 6 evaluated at the candidate y1: with (cv, cq) = (e, ee) the sums are the embedded error estimate
-      double r2 = 0.0;
-      if (!constrained) {
-        const double q1 = ldg<double>(POSin, o_rec);
-        const double eq = h * h * sq, ev = h * sv;
-        const double tq = c.atol + c.rtol * fmax(fabs(qn), fabs(q1)), tv = c.atol + c.rtol * fmax(fabs(vn), fabs(v_i));
-        r2 = (eq / tq) * (eq / tq) + (ev / tv) * (ev / tv);
-      }
-      qnext = r2;
-    }
-    if (constrained && out_buf >= 0) {
-      TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
-      qnext = tv.g; vnext = tv.gt;
-    }
-  }
-  if (err_mode) {
-    // per-wave sum of the squared error ratios (fixed order -> deterministic); lane 0 of each wave stores it
-    double r2 = (k < 3 && valid) ? qnext : 0.0;
-    for (int off = 32; off > 0; off >>= 1) r2 += __shfl_down(r2, off, 64);
-    if ((threadIdx.x & 63) == 0) c.err_partial[((u32)m * c.n_wg + lwg) * 4 + (threadIdx.x >> 6)] = r2;
-    return;
-  }
-  if (out_buf < 0) return;
-  // ---- publish the next stage record: lanes 0..2 each store one aligned 16-byte chunk (x,y) (th,ch) (sh,0)
-  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
-  double sn, cs;
-  fast_sincos(0.5 * th2, &sn, &cs);
-  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
-  if (k < 3 && !(c.ablate & 2)) {
-    const u32 o_chunk = ((u32)b * kPos + 2 * k) * 8;
-    stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
-    stg<double>(c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
-    if (write_traj) {
-      double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)(n + 1) * c.n_blocks * kStep;
-      stg<double2>(tr, o_chunk, chunk);
-      stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
-    }
-  }
-}
-
-
-
-// ---- adaptive step control (jax.experimental.ode semantics) --------------------------------------
-// one workgroup per member: reduce the per-wave partials in a fixed order, decide, advance the clock
-__global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, double two_n_free, int n_timepoints) {
-  const int m = blockIdx.x;
-  __shared__ double red[kThreads];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n_partials; i += kThreads) acc += c.err_partial[(size_t)m * c.n_wg * 4 + i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x != 0) return;
-  Clock ck = c.clock[m];
-  if (ck.state) return;
-  if (ck.fin_next) { ck.state = 1; ck.accept = 0; c.clock[m] = ck; return; }
-  const double ratio = sqrt(red[0] / two_n_free);
-  ck.attempts++;
-  if (!(ratio == ratio)) { ck.state = 2; c.clock[m] = ck; return; }
-  const double h_new = dopri_next_step(ck.h, ratio);
-  ck.accept = ratio <= 1.0;
-  if (ck.accept) {
-    ck.t_last = ck.t; ck.h_acc = ck.h; ck.t = ck.t + ck.h; ck.accepted++;
-    ck.out_lo = ck.out_idx;
-    if (c.acc_times && ck.accepted <= c.acc_cap) c.acc_times[(size_t)m * c.acc_cap + ck.accepted - 1] = ck.t;
-    if (c.step_counts && n_timepoints > 1) c.step_counts[(size_t)m * (n_timepoints - 1) + min(max(ck.out_idx - 1, 0), n_timepoints - 2)]++;
-    while (ck.out_idx < n_timepoints && c.ts_dev[ck.out_idx] <= ck.t) ck.out_idx++;
-    ck.out_hi = ck.out_idx;
-    if (ck.out_idx >= n_timepoints) ck.fin_next = 1;
-  }
-  ck.h = h_new;
-  if (!(h_new > 0.0)) ck.state = 3;
-  c.clock[m] = ck;
-}
-
-// elementwise: dense output for the outputs crossed by an accepted step, commit (y_n <- y1, k_1 <- k_7), and the
-// stage-1 record of the next attempt with the new step size.  cm / cma: mid-point weights (velocity / position form).
-struct DenseCoef { double cm[7], cma[7]; double a10; };
-
-__global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, int n_timepoints) {
-  const int m = blockIdx.y + c.m0;
-  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
-  if (slot >= c.n_slots) return;
-  const Clock ck = c.clock[m];
-  if (ck.state) return;
-  const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
-  const size_t nd = (size_t)c.n_blocks * 3;
-  const int dof = b * 3 + kd;
-  double* POS0 = c.POS + ((size_t)m * c.nbuf + 0) * c.n_blocks * kPos + (size_t)b * kPos;
-  double* VEL0 = c.VEL + ((size_t)m * c.nbuf + 0) * nd;
-  const double* POS3 = c.POS + ((size_t)m * c.nbuf + 3) * c.n_blocks * kPos + (size_t)b * kPos;
-  const double* VEL3 = c.VEL + ((size_t)m * c.nbuf + 3) * nd;
-  double* Am = c.A + (size_t)m * (c.s + 1) * nd;
-  double qn = POS0[kd], vn = VEL0[dof], a0 = Am[dof];
-  const int sidx = c.block_special[b];
-  const bool constrained = sidx >= 0 && k < 3 && ((c.special[sidx].con_mask >> k) & 1);
-  if (ck.accept) {
-    const double q1 = POS3[kd], v1 = VEL3[dof], a6 = Am[(size_t)6 * nd + dof];
-    if (k < 3 && ck.out_hi > ck.out_lo) {
-      const double h = ck.h_acc;
-      double sm = dc.cm[0] * a0 + dc.cm[6] * a6, sma = dc.cma[0] * a0 + dc.cma[6] * a6;
-      for (int l = 1; l < 6; ++l) { const double al = Am[(size_t)l * nd + dof]; sm += dc.cm[l] * al; sma += dc.cma[l] * al; }
-      const double qmid = qn + h * (0.5 * vn + h * sma), vmid = vn + h * sm;
-      for (int kk = ck.out_lo; kk < ck.out_hi; ++kk) {
-        const double tk = c.ts_dev[kk];
-        const double r = (tk - ck.t_last) / (ck.t - ck.t_last);
-        double oq = dopri_dense(qn, q1, qmid, vn, v1, h, r), ov = dopri_dense(vn, v1, vmid, a0, a6, h, r);
-        if (constrained) { TimeVals tv = constrained_value(c, m, c.special[sidx], k, tk); oq = tv.g; ov = tv.gt; }
-        double* f = c.fields_dev + ((size_t)m * n_timepoints + kk) * c.n_blocks * 6;
-        f[dof] = oq;
-        f[nd + dof] = ov;
-      }
-    }
-    // commit
-    if (k < 3) {
-      *reinterpret_cast<double2*>(POS0 + 2 * k) = *reinterpret_cast<const double2*>(POS3 + 2 * k);
-      VEL0[dof] = v1;
-      Am[dof] = a6;
-    }
-    qn = q1; vn = v1; a0 = a6;
-  }
-  // stage-1 record of the next attempt: Q_1 = q_n + h a10 v_n, V_1 = v_n + h a10 A_0
-  double qnext = qn + ck.h * dc.a10 * vn, vnext = vn + ck.h * dc.a10 * a0;
-  if (constrained) { TimeVals tv = constrained_value(c, m, c.special[sidx], k, ck.t + dc.a10 * ck.h); qnext = tv.g; vnext = tv.gt; }
-  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
-  double sn, cs;
-  fast_sincos(0.5 * th2, &sn, &cs);
-  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
-  if (k < 3) {
-    *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
-    c.VEL[((size_t)m * c.nbuf + 1) * nd + dof] = vnext;
-  }
-}
-
-// per-member time for k_init (initial-step probe): records of state `y` at time tm[m] into buffer buf
-__global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* state0, const double* tm, int buf) {
-  const int m = blockIdx.y + c.m0;
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= c.n_slots) return;
-  const int b = tid >> 2, d = tid & 3;
-  if (d == 3) return;
-  const size_t nd = (size_t)c.n_blocks * 3;
-  double q = state0[(size_t)m * 2 * nd + b * 3 + d], v = state0[(size_t)m * 2 * nd + nd + b * 3 + d];
-  const int sidx = c.block_special[b];
-  if (sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1)) {
-    TimeVals tv = constrained_value(c, m, c.special[sidx], d, tm[m]);
-    q = tv.g; v = tv.gt;
-  }
-  double* pr = c.POS + ((size_t)m * c.nbuf + buf) * c.n_blocks * kPos + (size_t)b * kPos;
-  pr[d] = q;
-  c.VEL[((size_t)m * c.nbuf + buf) * nd + b * 3 + d] = v;
-  if (d == 2) {
-    double sn, cs;
-    fast_sincos(0.5 * q, &sn, &cs);
-    pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
-  }
-}
-
-template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
-  const int m = blockIdx.y + c.m0;
-  const int slot = blockIdx.x * kThreads + threadIdx.x;
-  if (slot >= c.n_slots) return;
-  LaneIn L;
-  load_lane<CONTACT>(c, m, slot, pos_in(c, m, 0, 0), L);
-  double e = 0.0;
-  if (L.info >= 0 && !(L.info & 1)) {
-    BondGrad<double> g;
-    bond_grad<MODEL, double>(L.o, L.p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
-    e = g.e;
-    if (CONTACT) {
-      ContactGrad<double> cg;
-      contact_grad<double>(L.sgn * (L.o.th - L.p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
-      e += cg.e;
-    }
-  }
-  e_slot[(size_t)m * c.n_slots + slot] = e;
-}
-
-// ---- stage checkpoint: rebuild a stage record in the reverse sweep --------------------------------------------------
-// Record r (1 <= r < s) of step nr from what the forward pass kept: (q, v) of the step in the trajectory checkpoint and
-// the stage accelerations A_0 .. A_{r-1} of that step in AD.  The stage state of a DOF depends on its own history only,
-// so this is elementwise; it is the forward epilogue run again.  All four lanes of a quad must call it (DPP).
-//   rc: stage_coef(tableau, r - 1)  (row r of the tableau; c_next = c_r),  h, t: size and start time of step nr
-__device__ __forceinline__ void rebuild_record(const DevCtx& c, int m, int b, int k, const StageCoef& rc, int r, long long nr,
-                                               double h, double t) {
-  const int kd = k < 3 ? k : 2;
-  const u32 nd = (u32)c.n_blocks * 3;
-  const u32 o_dof = ((u32)b * 3 + kd) * 8;
-  const double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)nr * c.n_blocks * kStep;
-  const double qn = ldg<double>(tr, ((u32)b * kPos + kd) * 8);
-  const double vn = ldg<double>(tr + (size_t)c.n_blocks * kPos, o_dof);
-  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
-  const double* Ad = c.AD + (size_t)m * c.ad_stride + (size_t)nr * ((u32)(c.s - 1) * nd);
-  double al[kMaxStages - 1];
-#pragma unroll
-  for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < r ? ldg<double>(Ad + (size_t)l * nd, o_dof) : 0.0;
-  double sv = 0.0, sq = 0.0;
-#pragma unroll
-  for (int l = 0; l < kMaxStages - 1; ++l) { sv += rc.cv[l] * al[l]; sq += rc.cq[l] * al[l]; }
-  double qnext = qn + h * (rc.c_next * vn + h * sq);
-  double vnext = vn + h * sv;
-  if (k < 3 && sidx >= 0 && ((c.special[sidx].con_mask >> k) & 1)) {
-    const TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + rc.c_next * h);
-    qnext = tv.g; vnext = tv.gt;
-  }
-  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
-  double sn, cs;
-  fast_sincos(0.5 * th2, &sn, &cs);
-  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
-  if (k < 3) {
-    stg<double2>(c.POS + ((size_t)m * c.nbuf + r) * (u32)c.n_blocks * kPos, ((u32)b * kPos + 2 * k) * 8, chunk);
-    stg<double>(c.VEL + ((size_t)m * c.nbuf + r) * nd, o_dof, vnext);
-  }
-}
-
-// record s-1 of the LAST step, before the reverse sweep starts (every later record is rebuilt by the reverse launch
-// that precedes its reader)
-__global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef rc, int r, long long nr, double h, double t) {
-  const int m = blockIdx.y + c.m0;
-  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
-  if (slot >= c.n_slots) return;
-  rebuild_record(c, m, slot >> 2, slot & 3, rc, r, nr, h, t);
-}
-
-// ---- reverse stage ---------------------------------------------------------------------------
-//   in_buf: stage buffer with the stage records (recomputed), or -1: the checkpoint of step n (i == 0)
-//   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
-//   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
-//   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS>
-//   rb > 0 (stage checkpoint): after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
-//   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
-__global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
-                                                        int local_only, StageCoef rc, int rb) {
-  const int m = blockIdx.y + c.m0;
-  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
-  if (slot >= c.n_slots) return;
-  const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
-  const Seg sg = *c.cur;
-  const long long n = sg.base_step + j;
-  // the reverse sweep visits forward ordinals n*s+i in decreasing order, so the buffer parity alternates
-  const int win = wbuf_static >= 0 ? wbuf_static : (int)((n * c.s + i) & 1);
-  const u32 nd = (u32)c.n_blocks * 3, nd6 = (u32)c.n_blocks * 6;
-  // ---- load phase
-  const double* POSin = pos_in(c, m, in_buf, n);
-  const MemberBases B = member_bases(c, m);
-  LaneRaw R;
-  issue_lane<CONTACT>(c, B, slot, POSin, R);
-  const int dof = b * 3 + kd;
-  const u32 o_dof = (u32)dof * 8, o_b6 = ((u32)b * 6 + kd) * 8;          // per-lane byte offsets shared by the per-DOF arrays
-  const double* Win = c.W + ((size_t)m * 2 + win) * nd;
-  const double w_d = ldg<double>(Win, o_dof);
-  // partner's w from the guessed slot (same batch as everything else)
-  double wpx, wpy, wpth;
-  { const u32 gb = (u32)(R.guess >> 2) * 24; wpx = ldg<double>(Win, gb); wpy = ldg<double>(Win, gb + 8); wpth = ldg<double>(Win, gb + 16); }
-  const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
-  const double kq_in = ldg<double>(c.KQ + ((size_t)m * 2 + win) * nd, o_dof);
-  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
-  const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
-  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
-  double* YBm = c.YB + (size_t)m * (u32)c.s * nd6;
-  double* LAMm = c.LAM + (size_t)m * nd6;
-  double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
-  if (!local_only) {
-    lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24);
-    double yq[kMaxStages], yv[kMaxStages];
-#pragma unroll
-    for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
-      const bool on = jj > i && jj < c.s;
-      yq[jj] = on ? ldg<double>(YBm + (size_t)jj * nd6, o_b6) : 0.0;
-      yv[jj] = on ? ldg<double>(YBm + (size_t)jj * nd6, o_b6 + 24) : 0.0;
-    }
-#pragma unroll
-    for (int jj = 1; jj < kMaxStages; ++jj) {
-      const double cf = i > 0 ? ac.col[jj] : 1.0;
-      sq += cf * yq[jj];
-      sv += cf * yv[jj];
-    }
-  }
-  LaneIn L;
-  resolve_lane<CONTACT>(c, B, POSin, R, L);
-  if (L.pslot != L.guess) { const u32 pb = (u32)(L.pslot >> 2) * 24; wpx = ldg<double>(Win, pb); wpy = ldg<double>(Win, pb + 8); wpth = ldg<double>(Win, pb + 16); }
-  const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
-  // ---- Hessian-vector product + mixed parameter derivatives of this slot
-  double hx = 0.0, hy = 0.0, hth = 0.0;
-  double ex = 0.0, ey = 0.0, eth = 0.0;   // dE/du of this slot (value parts): gives the stage acceleration without re-reading it
-  if (L.info >= 0) {
-    BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
-    BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);
-    BondGrad<Dual> g;
-    bond_grad<MODEL, Dual>(o, p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
-    hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
-    ex = g.fx.v; ey = g.fy.v; eth = g.fth.v;
-    ContactGrad<Dual> cg;
-    if (CONTACT) {
-      contact_grad<Dual>(L.sgn * (o.th - p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
-      hth += L.sgn * cg.dkap.e;
-      eth += L.sgn * cg.dkap.v;
-    }
-    // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
-    // Every accumulator address has exactly one writer per launch: plain load-add-store.  (Fire-and-forget L2 atomics,
-    // global_atomic_add_f64 without return, would spare the round trip for the old value but were measured 10-25 %
-    // slower per launch: four fp64 atomics per lane saturate the L2 atomic units.)
-    const size_t ms = (size_t)m * (u32)c.n_slots;
-    double* grm = c.g_r + ms * 2;
-    double2 r = ldg<double2>(grm, (u32)slot * 16);
-    r.x -= g.rx.e; r.y -= g.ry.e;
-    stg<double2>(grm, (u32)slot * 16, r);
-    // both ends hold the same contact dual: each accumulates one of the two void-angle derivatives (8 B per lane)
-    if (CONTACT) stg<double>(c.g_phi + ms, (u32)slot * 8, ldg<double>(c.g_phi + ms, (u32)slot * 8) - ((L.info & 1) ? cg.p2.e : cg.p1.e));
-    if (!(L.info & 1)) {
-      if (BOND_GRADS) {
-        double* q = c.g_b + (ms + slot) * 8;
-        q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
-        if (CONTACT) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
-      }
-    }
-  }
-  hx = quad_sum(hx);
-  hy = quad_sum(hy);
-  hth = quad_sum(hth);
-  ex = quad_sum(ex);
-  ey = quad_sum(ey);
-  eth = quad_sum(eth);
-  // ---- DOF epilogue
-  double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
-  if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
-  if (k < 3) {
-    const double hw = k == 0 ? hx : (k == 1 ? hy : hth);
-    const double dE = k == 0 ? ex : (k == 1 ? ey : eth);
-    bool constrained = false;
-    double fload = 0.0;
-    if (sidx >= 0) {
-      const dfx_special& sp = c.special[sidx];
-      constrained = (sp.con_mask >> k) & 1;
-      const double t_i = t_n + ac.c_i * h;
-      double gp[kMaxFnParams];
-      for (int f = 0; f < c.n_fns; ++f) {
-        const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
-        const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
-        if ((coef != 0.0 && c.fn_g) || loaded) {
-          double g, gt;
-          eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
-          if (loaded) fload += sp.load_coef[k][f] * g;
-          if (coef != 0.0 && c.fn_g) {
-            double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
-            for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * gp[kk]);   // up to 3 DOF lanes of a block share q
-          }
-        }
-      }
-    }
-    const double a_i = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-    double ybq = 0.0, ybv = 0.0;
-    if (!constrained) {
-      ybq = -hw;
-      ybv = kq_in - damp * w_d;
-      double* bm = c.blk_m + (size_t)m * nd;
-      stg<double>(bm, o_dof, ldg<double>(bm, o_dof) - w_d * a_i);
-      if (c.blk_c) { double* bc = c.blk_c + (size_t)m * nd; stg<double>(bc, o_dof, ldg<double>(bc, o_dof) - w_d * v_i); }
-    }
-    stg<double>(YBm + (size_t)i * nd6, o_b6, ybq);
-    stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv);
-    if (!local_only) {
-      double kq, kv;
-      if (i > 0) {
-        kq = h * (ac.col[c.s] * lq + ac.col[i] * ybq + sq);
-        kv = h * (ac.col[c.s] * lv + ac.col[i] * ybv + sv);
-      } else {
-        lq += ybq + sq;
-        lv += ybv + sv;
-        const bool first = (sg.j0 + j) == 0;
-        if (first && c.G && !constrained) {
-          const double* G = c.G + ((size_t)sg.interval * c.batch + m) * (size_t)nd6;
-          lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
-        }
-        if (constrained) { lq = 0.0; lv = 0.0; }
-        stg<double>(LAMm, o_b6, lq);
-        stg<double>(LAMm, o_b6 + 24, lv);
-        kq = h_before * ac.col[c.s] * lq;
-        kv = h_before * ac.col[c.s] * lv;
-      }
-      stg<double>(c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
-      stg<double>(c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
-    }
-  }
-  if (rb > 0) {
-    if (i > 0) rebuild_record(c, m, b, k, rc, rb, n, h, t_n);
-    else if (n > 0) rebuild_record(c, m, b, k, rc, rb, n - 1, h_before, c.t_steps ? c.t_steps[n - 1] : t_n - h_before);
-  }
-}
-
-// start of the reverse sweep: lambda_N = G_last; kbar_{s-1} of the last step into buffer `buf`
-__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf) {
-  const int m = blockIdx.y + c.m0;
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= c.n_slots) return;
-  const int b = tid >> 2, d = tid & 3;
-  if (d == 3) return;
-  const size_t nd = (size_t)c.n_blocks * 3, nd6 = (size_t)c.n_blocks * 6;
-  const int sidx = c.block_special[b];
-  const bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
-  const double* G = c.G + ((size_t)(c.n_timepoints - 1) * c.batch + m) * nd6;
-  const double lq = con ? 0.0 : G[b * 6 + d], lv = con ? 0.0 : G[b * 6 + 3 + d];
-  c.LAM[(size_t)m * nd6 + b * 6 + d] = lq;
-  c.LAM[(size_t)m * nd6 + b * 6 + 3 + d] = lv;
-  c.KQ[((size_t)m * 2 + buf) * nd + b * 3 + d] = h_last * b_last * lq;
-  c.W[((size_t)m * 2 + buf) * nd + b * 3 + d] = con ? 0.0 : h_last * b_last * lv * c.inv_m[(size_t)m * nd + b * 3 + d];
-}
-
-// test hook: w = lam_v / m, kbar_q = lam_q  into buffer 0
-__global__ __launch_bounds__(kThreads) void k_seed_vjp(DevCtx c, const double* lam) {
-  const int m = blockIdx.y + c.m0;
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= c.n_blocks * 3) return;
-  const int b = tid / 3, d = tid % 3;
-  const size_t nd = (size_t)c.n_blocks * 3;
-  const int sidx = c.block_special[b];
-  const bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
-  const double* l = lam + (size_t)m * c.n_blocks * 6;
-  c.W[(size_t)m * 2 * nd + tid] = con ? 0.0 : l[nd + tid] * c.inv_m[(size_t)m * nd + tid];
-  c.KQ[(size_t)m * 2 * nd + tid] = l[tid];
-}
-
-// fields_bar (batch, T, 2, n_blocks, 3) -> G (T, batch, n_blocks, 6)
-__global__ __launch_bounds__(kThreads) void k_pack_G(DevCtx c, const double* fields_bar, double* G) {
-  const size_t total = (size_t)c.batch * c.n_timepoints * c.n_blocks * 3;
-  const size_t tid = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (tid >= total) return;
-  const size_t mk = tid / ((size_t)c.n_blocks * 3);
-  const int r = (int)(tid % ((size_t)c.n_blocks * 3));
-  const int b = r / 3, d = r % 3;
-  const double* f = fields_bar + mk * c.n_blocks * 6;
-  const size_t m_ = mk / c.n_timepoints, k_ = mk % c.n_timepoints;
-  double* g = G + (k_ * c.batch + m_) * c.n_blocks * 6;
-  g[b * 6 + d] = f[r];
-  g[b * 6 + 3 + d] = f[(size_t)c.n_blocks * 3 + r];
-}
-
-// kinetic-energy objective: G <- m v on target blocks; per-member objective by one workgroup
-__global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fields, const int32_t* target, int n_target,
-                                                      double* G, double* objective) {
-  const int m = blockIdx.x;
-  __shared__ double red[kThreads];
-  double acc = 0.0;
-  const int per_t = n_target * 3;
-  const long long total = (long long)c.n_timepoints * per_t;
-  for (long long idx = threadIdx.x; idx < total; idx += kThreads) {
-    const int k = (int)(idx / per_t), r = (int)(idx % per_t);
-    const int b = target[r / 3], d = r % 3;
-    const double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
-    const double mass = 1.0 / c.inv_m[(size_t)m * c.n_blocks * 3 + b * 3 + d];
-    acc += 0.5 * mass * v * v;
-    if (G) G[((size_t)k * c.batch + m) * c.n_blocks * 6 + b * 6 + 3 + d] = mass * v;
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && objective) objective[m] = red[0];
-}
-
-// explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_m
-__global__ void k_kinetic_mass_grad(DevCtx c, const double* fields, const int32_t* target, int n_target) {
-  const int m = blockIdx.y + c.m0;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_target * 3) return;
-  const int b = target[r / 3], d = r % 3;
-  double acc = 0.0;
-  for (int k = 0; k < c.n_timepoints; ++k) {
-    const double v = fields[((size_t)m * c.n_timepoints + k) * c.n_blocks * 6 + (size_t)c.n_blocks * 3 + b * 3 + d];
-    acc += 0.5 * v * v;
-  }
-  c.blk_m[((size_t)m * c.n_blocks + b) * 3 + d] += acc;
-}
-
-}  // namespace
+#include "dfx_kernels.h"
 
 // ================================================================================================
 // host side
