@@ -19,7 +19,7 @@ using namespace dfx;
 // occupancy hints for the two stage kernels (waves per SIMD the register allocator must leave room for).
 // Forward: 5 waves (96 VGPRs + 100 B/lane of scratch) measured +7 % forward-only at 16 members per GPU over the
 // allocator's own choice (120 VGPRs, 4 waves), neutral at 1..8 members; 6 waves lose it again to spills.  Reverse: any
-// forced occupancy spills heavily (-25 %), left to the allocator (150 VGPRs, 3 waves).
+// forced occupancy spills into the load batch (-20..25 %), left to the allocator (126 VGPRs, 4 waves).
 #ifndef DFX_FWD_OCC
 #define DFX_FWD_OCC __attribute__((amdgpu_waves_per_eu(5)))
 #endif
