@@ -109,10 +109,10 @@ struct DevCtx {
   const double* ts_dev;   // output times (adaptive mode)
   double* fields_dev;     // batch * T * n_blocks*6 (adaptive mode writes its dense output here)
   double rtol, atol;
-  // state: (s+1) stage buffers per member; buffer 0 = current step state
+  // state: nbuf = 2s stage buffers per member (two sets for the two-chain reverse sweep); buffer 0 = current step state
   double* traj;           // batch * traj_stride   checkpoints: per step [POS n_blocks*6 | VEL n_blocks*3]
-  double* POS;            // batch * (s+1) * n_blocks*kPos
-  double* VEL;            // batch * (s+1) * n_blocks*3
+  double* POS;            // batch * nbuf * n_blocks*kPos
+  double* VEL;            // batch * nbuf * n_blocks*3
   double* A;              // batch * s * n_blocks*3
   // reverse
   double* YB;             // batch * s * n_blocks*6
