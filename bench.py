@@ -169,6 +169,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     args = ap.parse_args()
+    if not os.path.exists(os.path.join(ROOT, "difflexmm_amd", "libdfx.so")):
+        # build artefact missing (fresh checkout): compile it the way __graft_entry__.build() does, before any GPU call
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "difflexmm_amd", "csrc")], stdout=subprocess.DEVNULL)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
