@@ -747,6 +747,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
   double ex = 0.0, ey = 0.0, eth = 0.0;   // dE/du of this slot (value parts): gives the stage acceleration without re-reading it
+  double d_rx = 0.0, d_ry = 0.0, d_phi = 0.0;   // this launch's contributions to the node-vector / void-angle gradients
   if (L.info >= 0) {
     BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
     BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);
@@ -761,30 +762,40 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
       eth += L.sgn * cg.dkap.v;
     }
     // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
-    // Every accumulator address has exactly one writer per launch: plain load-add-store.  (Fire-and-forget L2 atomics,
-    // global_atomic_add_f64 without return, would spare the round trip for the old value but were measured 10-25 %
-    // slower per launch: four fp64 atomics per lane saturate the L2 atomic units.)
-    const size_t ms = (size_t)m * (u32)c.n_slots;
-    double* grm = c.g_r + ms * 2;
-    double2 r = ldg<double2>(grm, (u32)slot * 16);
-    r.x -= g.rx.e; r.y -= g.ry.e;
-    stg<double2>(grm, (u32)slot * 16, r);
+    d_rx = g.rx.e; d_ry = g.ry.e;
     // both ends hold the same contact dual: each accumulates one of the two void-angle derivatives (8 B per lane)
-    if (CONTACT) stg<double>(c.g_phi + ms, (u32)slot * 8, ldg<double>(c.g_phi + ms, (u32)slot * 8) - ((L.info & 1) ? cg.p2.e : cg.p1.e));
+    if (CONTACT) d_phi = (L.info & 1) ? cg.p2.e : cg.p1.e;
     if (!(L.info & 1)) {
       if (BOND_GRADS) {
-        double* q = c.g_b + (ms + slot) * 8;
+        double* q = c.g_b + ((size_t)m * (u32)c.n_slots + slot) * 8;
         q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
         if (CONTACT) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
       }
     }
   }
+  // ---- gradient accumulators.  Every address has exactly one writer per launch: plain load-add-store, with the old values of
+  // ALL accumulators requested in one batch (issued here, consumed after the epilogue arithmetic) instead of one memory round
+  // trip each at the end of the kernel.  (Fire-and-forget L2 atomics would spare the loads but were measured 10-25 % slower:
+  // four fp64 atomics per lane saturate the L2 atomic units.)  Lanes without a ligament / constrained DOFs add zero.
+  const size_t ms = (size_t)m * (u32)c.n_slots;
+  double* grm = c.g_r + ms * 2;
+  double* gpm = c.g_phi + ms;
+  double* bmm = c.blk_m + (size_t)m * nd;
+  double* bcm = c.blk_c + (size_t)m * nd;
+  const double2 r_old = ldg<double2>(grm, (u32)slot * 16);
+  const double p_old = CONTACT ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
+  const double bm_old = ldg<double>(bmm, o_dof);
+  const double bc_old = c.blk_c ? ldg<double>(bcm, o_dof) : 0.0;
   hx = quad_sum(hx);
   hy = quad_sum(hy);
   hth = quad_sum(hth);
   ex = quad_sum(ex);
   ey = quad_sum(ey);
   eth = quad_sum(eth);
+  if (L.info >= 0) {
+    stg<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
+    if (CONTACT) stg<double>(gpm, (u32)slot * 8, p_old - d_phi);
+  }
   // ---- DOF epilogue
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
   if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
@@ -817,9 +828,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
-      double* bm = c.blk_m + (size_t)m * nd;
-      stg<double>(bm, o_dof, ldg<double>(bm, o_dof) - w_d * a_i);
-      if (c.blk_c) { double* bc = c.blk_c + (size_t)m * nd; stg<double>(bc, o_dof, ldg<double>(bc, o_dof) - w_d * v_i); }
+      stg<double>(bmm, o_dof, bm_old - w_d * a_i);
+      if (c.blk_c) stg<double>(bcm, o_dof, bc_old - w_d * v_i);
     }
     stg<double>(YBm + (size_t)i * nd6, o_b6, ybq);
     stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv);
