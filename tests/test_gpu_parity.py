@@ -225,3 +225,47 @@ def test_reverse_sweep_with_and_without_stage_checkpoint(hip_lib, monkeypatch, s
     s_launch = 6 if integrator == "dopri5" else 4
     per_step = c.solver.adjoint_stats["launches"] / 600.0
     assert abs(per_step - (s_launch if stage_checkpoint == "1" else 2 * s_launch - 1)) < 0.2
+
+
+@pytest.mark.parametrize("streams,stage_checkpoint", [("3", "1"), ("3", "0"), ("2", "1")])
+def test_member_groups_on_concurrent_streams_match_cpu_port(hip_lib, cpu_lib, monkeypatch, streams, stage_checkpoint):
+    """5 members split into groups that advance on their own HIP streams with their own graphs (what bench.py runs with 16
+    members in 2 groups): fields and gradients of every member equal the CPU port's, in both reverse-sweep modes."""
+    monkeypatch.setenv("DFX_STREAMS", streams)
+    monkeypatch.setenv("DFX_STAGE_CHECKPOINT", stage_checkpoint)
+    res = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("quads", 8, True, True, seed=21, lib=lib, cutoff_deg=42.0, batch=5)
+        cps = [c.cp._replace(constraint_params=dict(amplitude=a, loading_rate=3000.0, input_delay=1e-5)) for a in (7.5, 3.0, -4.0, 6.0, 1.0)]
+        ts = np.linspace(0, 3e-4, 4)
+        y0 = c.random_state(0.05, 0.02, 5.0)
+        f = c.solver(y0, ts, cps, keep_trajectory=True, steps_per_interval=270)     # > 256 steps: two graph segments per interval
+        if name == "hip":
+            assert c.solver.stats["streams"] == int(streams) and c.solver.stats["stage_checkpoint"] == int(stage_checkpoint)
+        fb = np.random.default_rng(5).normal(size=f.shape)
+        trees, s0 = c.solver.vjp(fb)
+        res[name] = (f, np.stack([t.geometrical_params.centroid_node_vectors for t in trees]),
+                     np.array([t.constraint_params["amplitude"] for t in trees]), s0)
+    assert relerr(res["hip"][0], res["cpu"][0]) < 1e-10
+    assert relerr(res["hip"][1], res["cpu"][1]) < 1e-8
+    assert relerr(res["hip"][2], res["cpu"][2]) < 1e-8
+    assert relerr(res["hip"][3], res["cpu"][3]) < 1e-8
+
+
+@pytest.mark.parametrize("dual_chain", ["0", "1"])
+def test_single_system_reverse_sweep_on_two_chains(hip_lib, cpu_lib, monkeypatch, dual_chain):
+    """One system, state checkpoint only: the recompute launches of step n-1 overlap the reverse launches of step n on a
+    second stream (double-buffered stage records) -- same gradient as the single chain and as the CPU port."""
+    monkeypatch.setenv("DFX_DUAL_CHAIN", dual_chain)
+    monkeypatch.setenv("DFX_STAGE_CHECKPOINT", "0")
+    res = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("quads", 8, True, True, seed=22, lib=lib, cutoff_deg=42.0)
+        cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+        ts = np.linspace(0, 3e-4, 4)
+        f = c.solver(c.random_state(0.05, 0.02, 5.0), ts, cp, keep_trajectory=True, steps_per_interval=270)
+        fb = np.random.default_rng(6).normal(size=f.shape)
+        tree, s0 = c.solver.vjp(fb)
+        res[name] = (f, tree.geometrical_params.centroid_node_vectors, s0)
+    for a, b, tol in zip(res["hip"], res["cpu"], (1e-10, 1e-8, 1e-8)):
+        assert relerr(a, b) < tol
