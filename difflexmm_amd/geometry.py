@@ -127,11 +127,30 @@ def compute_edge_lengths(cnv):
 
 # -- void angles of the undeformed design (energy.py:204-219 + geometry.py:181-253 at u = 0) -----
 
+_EDGE_INDEX_CACHE = {}
+
+
+def _edge_index(bonds, n):
+    """(b1, l1, next, prev, b2, l2, next, prev) of every bond; cached per connectivity array (it is static per lattice and
+    the integer divisions below were a third of the per-design host time)."""
+    key = (id(bonds), np.shape(bonds), n)
+    hit = _EDGE_INDEX_CACHE.get(key)
+    if hit is not None and hit[0] is bonds:
+        return hit[1]
+    bb = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
+    b1, l1 = bb[:, 0] // n, bb[:, 0] % n
+    b2, l2 = bb[:, 1] // n, bb[:, 1] % n
+    idx = (b1, l1, (l1 + 1) % n, (l1 - 1) % n, b2, l2, (l2 + 1) % n, (l2 - 1) % n)
+    if len(_EDGE_INDEX_CACHE) > 64:
+        _EDGE_INDEX_CACHE.clear()
+    _EDGE_INDEX_CACHE[key] = (bonds, idx)       # the array is kept alive, so its id cannot be reused while cached
+    return idx
+
+
 def _edge_pairs(cnv, bonds):
     n = cnv.shape[1]
-    b1, l1 = bonds[:, 0] // n, bonds[:, 0] % n
-    b2, l2 = bonds[:, 1] // n, bonds[:, 1] % n
-    idx = (b1, l1, (l1 + 1) % n, (l1 - 1) % n, b2, l2, (l2 + 1) % n, (l2 - 1) % n)
+    idx = _edge_index(bonds, n)
+    b1, l1, b2, l2 = idx[0], idx[1], idx[4], idx[5]
     e1p = cnv[b1, idx[2]] - cnv[b1, l1]   # edge node1 -> next node   (block_1_node_1, unnormalised)
     e1m = cnv[b1, idx[3]] - cnv[b1, l1]   # edge node1 -> previous node
     e2p = cnv[b2, idx[6]] - cnv[b2, l2]
@@ -147,7 +166,6 @@ def void_angles0(cnv, bonds):
     """(n_bonds, 2): the two void angles of every bond in the undeformed design.  During the motion the
     angles are  wrap(phi1 + th_A - th_B), wrap(phi2 + th_B - th_A)  (rigid blocks: translations cancel)."""
     cnv = np.asarray(cnv, dtype=float)
-    bonds = np.asarray(bonds, dtype=np.int64)
     _, e1p, e1m, e2p, e2m = _edge_pairs(cnv, bonds)
     return np.stack([_angle(e2m, e1p), _angle(e1m, e2p)], 1)   # geometry.py:248-249
 
@@ -155,7 +173,6 @@ def void_angles0(cnv, bonds):
 def void_angles0_vjp(cnv, bonds, phi_bar):
     """cnv_bar for a cotangent (n_bonds, 2) of void_angles0."""
     cnv = np.asarray(cnv, dtype=float)
-    bonds = np.asarray(bonds, dtype=np.int64)
     (b1, l1, n1, p1, b2, l2, n2, p2), e1p, e1m, e2p, e2m = _edge_pairs(cnv, bonds)
     out = np.zeros_like(cnv)
 
@@ -177,7 +194,6 @@ def void_angles0_vjp(cnv, bonds, phi_bar):
 def compute_edge_angles(nodes, bonds):
     """geometry.py:234-253 on explicit node positions (n_blocks, n_npb, 2): void_1, void_2, block_1, block_2."""
     nodes = np.asarray(nodes, dtype=float)
-    bonds = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
     _, e1p, e1m, e2p, e2m = _edge_pairs(nodes, bonds)
     return _angle(e2m, e1p), _angle(e1m, e2p), _angle(e1p, e1m), _angle(e2p, e2m)
 
