@@ -26,6 +26,9 @@ from .loading import as_time_function, zero
 from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentParams, MechanicalParams)
 
 
+_FLAT_CACHE = {}      # id(centroid_node_vectors) -> (weakref, bonds, density, inertia, void_angle0)
+
+
 def _bcast(x, n):
     return np.broadcast_to(np.asarray(x, dtype=float), (n,)).copy()
 
@@ -96,7 +99,12 @@ class DynamicSolver:
             "reference_vector": np.broadcast_to(np.asarray(bp.reference_vector, dtype=float), (nbd, 2)),
             "k_bond": np.stack([_bcast(bp.k_stretch, nbd), _bcast(bp.k_shear, nbd), _bcast(bp.k_rot, nbd)], 1),
         }
-        if mp.inertia is None:   # dynamics.py:157-163
+        cached = _FLAT_CACHE.get(id(cnv)) if mp.inertia is None else None
+        if cached is not None and cached[0]() is cnv and cached[1] is self.bonds and np.array_equal(cached[2], mp.density):
+            out["inertia"] = cached[3]        # same design seen through another solver (multi-input problems): reuse
+            if self.spec.contact and cached[4] is not None:
+                out["void_angle0"] = cached[4]
+        elif mp.inertia is None:   # dynamics.py:157-163
             out["inertia"] = compute_inertia(cnv, mp.density)
         else:
             out["inertia"] = np.asarray(mp.inertia, dtype=float).reshape(self.n_blocks, 3)
@@ -106,8 +114,17 @@ class DynamicSolver:
         out["damping"] = damping
         if self.spec.contact:
             c = mp.contact_params
-            out["void_angle0"] = void_angles0(cnv, self.bonds)
+            if "void_angle0" not in out:
+                out["void_angle0"] = void_angles0(cnv, self.bonds)
             out["contact"] = np.array([c.min_angle, c.cutoff_angle, c.k_contact], dtype=float)
+        if mp.inertia is None and cached is None and not cnv.flags.writeable:
+            # geometry arrays that come out of the design cache are read-only and shared: remember what was derived from them
+            import weakref
+            key = id(cnv)
+            if len(_FLAT_CACHE) > 1024:
+                _FLAT_CACHE.clear()
+            _FLAT_CACHE[key] = (weakref.ref(cnv, lambda _r, k=key: _FLAT_CACHE.pop(k, None)), self.bonds, np.array(mp.density, copy=True),
+                                out["inertia"], out.get("void_angle0"))
         fnp = [f.resolve(cp.constraint_params) for f in self.con_terms] + [f.resolve(cp.loading_params) for f in self.load_terms]
         if fnp:
             out["fn_params"] = np.stack(fnp)
@@ -229,6 +246,16 @@ class DynamicSolver:
         self.adjoint_stats = stats
         trees, s0 = self._unflatten_grads(grads, None)
         return (obj[0] if self.batch == 1 else obj), trees, s0
+
+    def kinetic_energy_value_and_raw(self, target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia")):
+        """Same objective; returns the engine's raw gradient arrays (batch-leading) for the requested parameter groups only.
+        The maps from these to a design (void-angle and inertia chain rules, lattice map) are linear in the cotangent, so a
+        caller that sums several solves of ONE design (multi-input problems) applies them once to the sum."""
+        obj = self.engine.objective_kinetic(target_blocks)
+        which = tuple(w for w in which if not (w == "void_angle0" and not self.spec.contact))
+        grads, stats = self.engine.adjoint_kinetic(target_blocks, which=which)
+        self.adjoint_stats = stats
+        return obj, grads
 
     def _unflatten_grads(self, g, fields_bar):
         cps, flats, ts = self._last

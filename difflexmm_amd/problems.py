@@ -17,6 +17,29 @@ from .geometry import KagomeGeometry, QuadGeometry, compute_inertia
 from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentParams, MechanicalParams, SolutionData)
 
 
+_GEOMETRY_CACHE = {}   # (lattice signature, ids of the design arrays) -> (design arrays, block_centroids, centroid_node_vectors)
+
+
+def geometry_from_design_cached(geometry, design):
+    """``geometry.geometry_from_design(*design)`` remembered per design OBJECT: the forward problems of a multi-input
+    objective (one solver per input) all ask for the geometry of the same design tuple in the same round."""
+    sig = getattr(geometry, "_signature", None)
+    if sig is None:
+        sig = geometry._signature = (type(geometry).__name__,) + tuple(
+            sorted((k, float(v)) for k, v in vars(geometry).items() if isinstance(v, (int, float)) and not k.startswith("_")))
+    key = (sig,) + tuple(id(a) for a in design)
+    hit = _GEOMETRY_CACHE.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], design)):
+        return hit[1], hit[2]
+    centroids, cnv = geometry.geometry_from_design(*design)
+    centroids.flags.writeable = False
+    cnv.flags.writeable = False
+    if len(_GEOMETRY_CACHE) > 1024:
+        _GEOMETRY_CACHE.clear()
+    _GEOMETRY_CACHE[key] = (tuple(design), centroids, cnv)      # holds the design arrays: their ids cannot be reused meanwhile
+    return centroids, cnv
+
+
 def _tile3(blocks):
     blocks = np.asarray(blocks, dtype=np.int64)
     n = len(blocks)
@@ -145,7 +168,7 @@ class QuadsFocusingForward:
         self.is_setup = True
 
     def control_params(self, design):
-        centroids, cnv = self.geometry.geometry_from_design(*design)
+        centroids, cnv = geometry_from_design_cached(self.geometry, design)
         return ControlParams(
             geometrical_params=GeometricalParams(block_centroids=centroids, centroid_node_vectors=cnv),
             mechanical_params=MechanicalParams(
@@ -354,20 +377,40 @@ class MultiInputTargetKineticEnergy:
         return float(self.weights @ self.individual(design))
 
     def value_and_grad(self, design):
-        """design: one design tuple, or a list of them (one per ensemble member of the batched forward problems)."""
+        """design: one design tuple, or a list of them (one per ensemble member of the batched forward problems).
+        The engine's raw gradients of the individual inputs are summed with the weights first; the chain rules back to the
+        design (void angles, inertia, lattice map -- all linear in the cotangent and all functions of the SAME design) are
+        then applied once per design instead of once per input."""
+        from .geometry import compute_inertia_vjp, void_angles0_vjp
         many = isinstance(design, list)
-        vals, total = [], None
+        designs = design if many else [design]
+        vals, sums = [], None
         for w, o in zip(self.weights, self.objectives):
-            v, g = o.value_and_grad(design)
+            fw = o.forward
+            fw.solve(design, keep_trajectory=True)
+            v, g = fw.solve_dynamics.kinetic_energy_value_and_raw(o.target_blocks)
+            o.device_ms = getattr(o, "device_ms", 0.0) + fw.solve_dynamics.stats["kernel_ms"] + fw.solve_dynamics.adjoint_stats["kernel_ms"]
             vals.append(np.asarray(v, dtype=float))
-            gl = g if many else [g]
-            total = [[w * gi for gi in gm] for gm in gl] if total is None else \
-                [[t + w * gi for t, gi in zip(tm, gm)] for tm, gm in zip(total, gl)]
-        self.last_individual = np.array(vals)                      # (n_inputs,) or (n_inputs, n_members)
-        value = self.weights @ self.last_individual
+            if sums is None:
+                sums = {k: w * a for k, a in g.items()}
+            else:
+                for k, a in g.items():
+                    sums[k] += w * a
+        self.last_individual = np.array(vals) if many else np.array(vals)[:, 0]
+        value = self.weights @ np.array(vals)
+        fw0 = self.objectives[0].forward
+        geo, bonds = fw0.geometry, fw0.solve_dynamics.bonds
+        grads = []
+        for m, d in enumerate(designs):
+            _, cnv = geometry_from_design_cached(geo, d)
+            cnv_bar = sums["centroid_node_vectors"][m].copy()
+            if "void_angle0" in sums:
+                cnv_bar += void_angles0_vjp(cnv, bonds, sums["void_angle0"][m])
+            cnv_bar += compute_inertia_vjp(cnv, fw0.density, sums["inertia"][m])[0]
+            grads.append(geo.vjp(d, cnv_bar, None))
         if many:
-            return list(value), [tuple(t) for t in total]
-        return float(value), tuple(total[0])
+            return list(value), grads
+        return float(value[0]), grads[0]
 
 
 def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bound=None, upper_bound=None,
