@@ -10,7 +10,8 @@ NLopt uses it --
     approximation  g(x + d) = f(x) + sum_j [ f'_j s_j^2 d_j + (|f'_j| s_j + rho s_j^2 / 2) d_j^2 ] / (s_j^2 - d_j^2),
     with moving asymptote widths s_j and a conservativeness parameter rho per function;
   * the approximate problem is solved through its dual (one multiplier per constraint; the inner minimisation over d is
-    separable and closed-form), here with bound-constrained L-BFGS on the concave dual;
+    separable and closed-form), here with bound-constrained L-BFGS on the concave dual, restricted to a working set of
+    constraints that is grown until nothing outside it is violated (the lattices have thousands of slack constraints);
   * the candidate is accepted when every approximation is conservative at it (g >= f), otherwise the rho of the
     offending functions grow and the sub-problem is solved again (inner iterations);
   * after an accepted step rho shrinks and s_j shrinks for oscillating coordinates / grows for monotone ones.
@@ -69,7 +70,6 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
     x_prev = x_prev2 = x.copy()
     best = (f, x.copy()) if feasible else (np.inf, x.copy())
     y = np.zeros(m)
-    dual_bounds = scipy.optimize.Bounds(np.zeros(m), np.full(m, np.inf)) if m else None
     history = [f]
     k = 0
     status = "maxeval"
@@ -101,14 +101,29 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
                 return fc + J @ (s2 * w) + Jabs @ (sigma * w2) + 0.5 * rhoc * np.sum(s2 * w2)
 
             if m:
-                def neg_dual(yv):
-                    d = primal(yv)
-                    gc = approx_constraints(d)
-                    val = f + approx(d, g, rho) + yv @ gc
-                    return -val, -gc
-                res = scipy.optimize.minimize(neg_dual, y, jac=True, method="L-BFGS-B", bounds=dual_bounds,
-                                              options=dict(maxiter=100, ftol=1e-12, gtol=1e-8))
-                y = np.maximum(res.x, 0.0)
+                # The geometric constraints number in the thousands and almost all of them are slack: solve the dual on a
+                # working set (multipliers of the others are zero) and grow it until the approximate problem's solution
+                # violates no constraint outside it -- the same KKT point as the dual over all of them.
+                active = (y > 0.0) | (fc > -0.05 * max(1e-300, np.abs(fc).max()))
+                for _pass in range(20):
+                    idx = np.flatnonzero(active)
+                    if idx.size:
+                        def neg_dual(ya):
+                            yv = np.zeros(m); yv[idx] = ya
+                            d = primal(yv)
+                            gc = approx_constraints(d)[idx]
+                            val = f + approx(d, g, rho) + ya @ gc
+                            return -val, -gc
+                        res = scipy.optimize.minimize(neg_dual, y[idx], jac=True, method="L-BFGS-B",
+                                                      bounds=scipy.optimize.Bounds(np.zeros(idx.size), np.full(idx.size, np.inf)),
+                                                      options=dict(maxiter=100, ftol=1e-12, gtol=1e-8))
+                        y = np.zeros(m); y[idx] = np.maximum(res.x, 0.0)
+                    else:
+                        y = np.zeros(m)
+                    violated = (approx_constraints(primal(y)) > 1e-10) & ~active
+                    if not violated.any():
+                        break
+                    active |= violated
             d = primal(y)
             x_new = x + d
             f_new, g_new = yield x_new
