@@ -178,7 +178,8 @@ class DynamicSolver:
         return spis, grid
 
     # -- solve -----------------------------------------------------------------------------------------
-    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None, step_times=None):
+    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None, step_times=None,
+                 want_fields=True):
         cps = self._members(control_params)
         flats = [self._flatten(cp) for cp in cps]
         self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
@@ -196,9 +197,13 @@ class DynamicSolver:
         if spi is None:   # the reverse sweep needs a fixed grid: freeze the one the adaptive controller chooses
             spi, step_times = self.adaptive_grid(state0, timepoints, flats)
             control = "adaptive-grid"
-        fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times)
+        # want_fields=False: the histories stay on the device (objectives evaluated there do not need them on the host)
+        fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times,
+                                            want_fields=want_fields)
         self._last = (cps, flats, np.asarray(timepoints, dtype=float))
         self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control=control)
+        if fields is None:
+            return None
         return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
 
     # -- reverse mode ------------------------------------------------------------------------------------

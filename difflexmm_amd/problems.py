@@ -177,12 +177,15 @@ class QuadsFocusingForward:
                 contact_params=ContactParams(min_angle=self.min_angle, cutoff_angle=self.cutoff_angle, k_contact=self.k_contact)),
             constraint_params=dict(amplitude=self.signed_amplitude, loading_rate=self.loading_rate, input_delay=self.input_delay))
 
-    def solve(self, design, keep_trajectory=False):
-        """design = (horizontal_shifts, vertical_shifts), or a list of ``batch`` such tuples."""
+    def solve(self, design, keep_trajectory=False, want_fields=True):
+        """design = (horizontal_shifts, vertical_shifts), or a list of ``batch`` such tuples.
+        want_fields=False leaves the histories on the device (for objectives the engine evaluates there) and returns None."""
         many = isinstance(design, list)
         cps = [self.control_params(d) for d in design] if many else self.control_params(design)
-        fields = self.solve_dynamics(self.state0, self.timepoints, cps, keep_trajectory=keep_trajectory)
+        fields = self.solve_dynamics(self.state0, self.timepoints, cps, keep_trajectory=keep_trajectory, want_fields=want_fields)
         self._last_design = design
+        if fields is None:
+            return None
         if many:
             return [SolutionData(cp.geometrical_params.block_centroids, cp.geometrical_params.centroid_node_vectors,
                                  self.bond_connectivity, self.timepoints, f) for cp, f in zip(cps, fields)]
@@ -290,7 +293,7 @@ class TargetKineticEnergy:
 
     def value_and_grad(self, design):
         fw = self.forward
-        fw.solve(design, keep_trajectory=True)
+        fw.solve(design, keep_trajectory=True, want_fields=False)
         obj, trees, _ = fw.solve_dynamics.kinetic_energy_value_and_vjp(self.target_blocks)
         # device time of this evaluation (forward + reverse sweep), for throughput reports
         self.device_ms = getattr(self, "device_ms", 0.0) + fw.solve_dynamics.stats["kernel_ms"] + fw.solve_dynamics.adjoint_stats["kernel_ms"]
@@ -387,7 +390,7 @@ class MultiInputTargetKineticEnergy:
         vals, sums = [], None
         for w, o in zip(self.weights, self.objectives):
             fw = o.forward
-            fw.solve(design, keep_trajectory=True)
+            fw.solve(design, keep_trajectory=True, want_fields=False)
             v, g = fw.solve_dynamics.kinetic_energy_value_and_raw(o.target_blocks)
             o.device_ms = getattr(o, "device_ms", 0.0) + fw.solve_dynamics.stats["kernel_ms"] + fw.solve_dynamics.adjoint_stats["kernel_ms"]
             vals.append(np.asarray(v, dtype=float))

@@ -3,4 +3,4 @@ sys.argv=['x','--members',sys.argv[1] if len(sys.argv)>1 else '32','--iterations
 sys.path.insert(0,'examples')
 import multi_input_ensemble as M
 cProfile.run('M.main()','/tmp/prof.out')
-p=pstats.Stats('/tmp/prof.out'); p.sort_stats('tottime').print_stats(25)
+p=pstats.Stats('/tmp/prof.out'); p.sort_stats('cumulative').print_stats('difflexmm_amd|examples', 30)
