@@ -369,6 +369,7 @@ class MultiInputTargetKineticEnergy:
 
     def __init__(self, forward_problems, target_size, target_shift, weights):
         self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
+        self.concurrent_inputs = True
         self.weights = np.asarray(weights, dtype=float)
         self.target_blocks = self.objectives[0].target_blocks
         self.forward = forward_problems[0]
@@ -387,12 +388,30 @@ class MultiInputTargetKineticEnergy:
         from .geometry import compute_inertia_vjp, void_angles0_vjp
         many = isinstance(design, list)
         designs = design if many else [design]
-        vals, sums = [], None
-        for w, o in zip(self.weights, self.objectives):
+        def one(o):
             fw = o.forward
             fw.solve(design, keep_trajectory=True, want_fields=False)
             v, g = fw.solve_dynamics.kinetic_energy_value_and_raw(o.target_blocks)
             o.device_ms = getattr(o, "device_ms", 0.0) + fw.solve_dynamics.stats["kernel_ms"] + fw.solve_dynamics.adjoint_stats["kernel_ms"]
+            return v, g
+
+        # The inputs are independent solves on their own engine handles (own HIP streams); the C calls release the GIL, so
+        # running them from a few threads lets their launches overlap on the GPU -- small lattices are launch-bound, one
+        # input alone leaves most of the chip idle.  (Geometry of the designs first, once, from this thread: the cache.)
+        for d in designs:
+            geometry_from_design_cached(self.objectives[0].forward.geometry, d)
+        # Only when every engine advances its members as ONE group on ONE stream (small ensembles; known from the statistics of
+        # the previous solve, so the first evaluation runs the inputs one after the other): three engines with two member
+        # groups each -- six streams with fork/join events -- were seen to stall on the four hardware queues.
+        single_stream = all(getattr(o.forward.solve_dynamics, "stats", {}).get("streams", 0) == 1 for o in self.objectives)
+        if self.concurrent_inputs and single_stream and len(self.objectives) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(len(self.objectives)) as pool:
+                results = list(pool.map(one, self.objectives))
+        else:
+            results = [one(o) for o in self.objectives]
+        vals, sums = [], None
+        for w, (v, g) in zip(self.weights, results):
             vals.append(np.asarray(v, dtype=float))
             if sums is None:
                 sums = {k: w * a for k, a in g.items()}

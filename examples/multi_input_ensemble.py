@@ -88,8 +88,9 @@ def main():
         print(f"{args.members} designs x 3 inputs x {args.iterations} evaluations on {world} rank(s): {wall:.1f} s, "
               f"{solves / wall:.1f} forward+adjoint solves/s, {solves * steps * nb / wall:.3e} timesteps*units/s")
         dev = sum(getattr(o, "device_ms", 0.0) for o in objective.objectives) * 1e-3
-        print(f"device time (forward + reverse sweeps) {dev:.1f} s of {wall:.1f} s; the rest is host work per round: design -> "
-              f"ControlParams -> packed arrays, gradient maps back to the design, the MMA sub-problems")
+        print(f"device time of the forward + reverse sweeps, summed over the three engines: {dev:.1f} s (wall {wall:.1f} s; the engines of "
+              f"the three inputs overlap when each runs a single stream); the rest is host work per round: design -> ControlParams "
+              f"-> packed arrays, gradient maps back to the design, the MMA sub-problems")
         print("objective, first evaluation :", np.array2string(first, precision=3, max_line_width=160))
         print("objective, best feasible    :", np.array2string(final, precision=3, max_line_width=160))
 
