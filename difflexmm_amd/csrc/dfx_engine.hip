@@ -129,7 +129,9 @@ struct dfx_handle {
   bool have_adaptive_record = false;
   long long n_total = 0;
   std::map<std::pair<int, int>, hipGraphExec_t> graphs;
-  DevCtx graph_ctx_snapshot;
+  // what the cached graphs have baked in: every kernel argument (the DevCtx passed by value) and the addresses the tick node
+  // reads and writes (segment table, cursors) -- any of them changing (a buffer re-allocated by a larger solve) drops the graphs
+  struct GraphKey { DevCtx ctx; const void* segs; const void* seg_idx; const void* cur; } graph_key;
   bool graph_ctx_valid = false;
   long long launches = 0;
 };
@@ -291,14 +293,17 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
 
 static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int kind) {
   if (!h->use_graph) { enqueue_segment(h, c, gi, n_steps, kind); return 0; }
-  DevCtx key_ctx = c;
-  key_ctx.n_timepoints = 0;  // not read by the stage kernels
-  if (!h->graph_ctx_valid || memcmp(&h->graph_ctx_snapshot, &key_ctx, sizeof(DevCtx)) != 0) {
+  dfx_handle::GraphKey gk;
+  memset(&gk, 0, sizeof(gk));          // padding bytes take part in the memcmp
+  memcpy(&gk.ctx, &c, sizeof(DevCtx));
+  gk.ctx.n_timepoints = 0;  // not read by the stage kernels
+  gk.segs = h->d_segs.p; gk.seg_idx = h->d_seg_idx.p; gk.cur = h->d_cur.p;
+  if (!h->graph_ctx_valid || memcmp(&h->graph_key, &gk, sizeof(gk)) != 0) {
     drop_graphs(h);
-    h->graph_ctx_snapshot = key_ctx;
+    memcpy(&h->graph_key, &gk, sizeof(gk));
     h->graph_ctx_valid = true;
   }
-  auto key = std::make_pair(n_steps, kind * 64 + gi);
+  auto key = std::make_pair(n_steps, kind * kMaxGroups + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
   const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD) ? s : 2 * s - 1);   // launches in the graph
@@ -309,10 +314,12 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
     const long long before = h->launches;
     HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     enqueue_segment(h, c, gi, n_steps, kind);
-    HIP_OK(hipStreamEndCapture(st, &graph));
+    hipError_t ce = hipStreamEndCapture(st, &graph);     // always ends the capture, also after a failed launch inside it
     h->launches = before;
-    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
+    if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ce != hipSuccess) { h->err = std::string("graph capture / instantiate: ") + hipGetErrorString(ce); return 2; }
+    (void)hipGraphUpload(exec, st);                      // device-side setup now, not inside the first timed replay
     it = h->graphs.emplace(key, exec).first;
   }
   HIP_OK(hipGraphLaunch(it->second, st));
@@ -388,7 +395,7 @@ static int ensure_work_buffers(dfx_handle* h) {
   HIP_OK(h->d_VEL.ensure(B * (2 * s) * nb * 3));
   HIP_OK(h->d_A.ensure(B * (s + 1) * nb * 3));
   HIP_OK(h->d_state0.ensure(B * nb * 6));
-  HIP_OK(h->d_cur.ensure(64));
+  HIP_OK(h->d_cur.ensure(kMaxGroups));
   return 0;
 }
 
@@ -563,7 +570,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     const char* e = getenv("DFX_STREAMS");
     const long long waves = (long long)h->pl.batch * ((h->pl.n_slots + 63) / 64);
     int want = e ? atoi(e) : (waves >= 2048 ? 2 : 1);
-    int ng = std::max(1, std::min(want, h->pl.batch));
+    int ng = std::max(1, std::min({want, h->pl.batch, kMaxGroups}));
     (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming);
     // the recompute/reverse overlap pays when the chip is otherwise idle (one system: measured -20 % reverse time for one
@@ -583,8 +590,8 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   }
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
-            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2 + 64) == hipSuccess &&
-            h->d_cur.ensure(64) == hipSuccess;
+            h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2 + kMaxGroups) == hipSuccess &&
+            h->d_cur.ensure(kMaxGroups) == hipSuccess;
   if (!ok) { h->err = "hipMalloc (static tables) failed"; return fail(2); }
   (void)hipMemcpy(h->d_slot_info.p, pl.slot_info.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
   (void)hipMemcpy(h->d_block_special.p, pl.block_special.data(), sizeof(int32_t) * pl.n_blocks, hipMemcpyHostToDevice);
@@ -734,7 +741,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
-  std::vector<int> cursors(2 + 64, -1);   // [0] unused, [1] non-finite flag, [2+g] segment cursor of group g
+  std::vector<int> cursors(2 + kMaxGroups, -1);   // [0] unused, [1] non-finite flag, [2+g] segment cursor of group g
   cursors[1] = 0;
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
@@ -914,10 +921,11 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     const long long before = h->launches;
     HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     for (int a = 0; a < kAttemptsPerGraph; ++a) enqueue_attempt();
-    HIP_OK(hipStreamEndCapture(h->stream, &graph));
+    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
     h->launches = before;
-    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
+    if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ce != hipSuccess) { h->err = std::string("graph capture / instantiate: ") + hipGetErrorString(ce); h->adaptive = false; return 2; }
   }
   long long attempts_issued = 0;
   int rc = 0;
@@ -973,7 +981,7 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
   h->launches = 0;
   if (zero_grad_accumulators(h)) return 2;
   const int nseg = (int)h->segs.size();
-  std::vector<int> cursors(64, nseg);
+  std::vector<int> cursors(kMaxGroups, nseg);
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p + 2, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   const double h_last = Tn > 1 ? (h->t_steps.empty() ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]
                                                      : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;

@@ -37,6 +37,7 @@ typedef unsigned u32;
 constexpr int kThreads = 256;
 constexpr int kAccCap = 1 << 20;   // accepted step times recorded per member (adaptive)
 constexpr int kMaxGraphSteps = 256;
+constexpr int kMaxGroups = 64;   // member groups (one stream each): size of the cursor tables and stride of the graph-cache key
 constexpr int kPos = 6;   // doubles per unit position record: x y th cos(th/2) sin(th/2) pad   (three 16-byte chunks)
 constexpr int kStep = 9;  // doubles per unit in a trajectory checkpoint: position record + velocity (3)
 

@@ -7,8 +7,10 @@ algorithm it documents: Svanberg's globally convergent MMA / CCSA (K. Svanberg, 
 NLopt uses it --
 
   * every function (objective and each constraint) is replaced around the current point x by the separable convex
-    approximation  g(x + d) = f(x) + sum_j [ f'_j s_j^2 d_j + (|f'_j| s_j + rho s_j^2 / 2) d_j^2 ] / (s_j^2 - d_j^2),
-    with moving asymptote widths s_j and a conservativeness parameter rho per function;
+    approximation  g(x + d) = f(x) + sum_j [ f'_j s_j^2 d_j + (|f'_j| s_j + rho / 2) d_j^2 ] / (s_j^2 - d_j^2),
+    with moving asymptote widths s_j and a conservativeness parameter rho per function (nlopt/mma.c dual_func:
+    v = |df| sigma + rho / 2; the rho update uses w = sum_j d_j^2 / (s_j^2 - d_j^2) / 2, so that one update of rho makes the
+    approximation exactly conservative at the rejected candidate);
   * the approximate problem is solved through its dual (one multiplier per constraint; the inner minimisation over d is
     separable and closed-form), here with bound-constrained L-BFGS on the concave dual, restricted to a working set of
     constraints that is grown until nothing outside it is violated (the lattices have thousands of slack constraints);
@@ -33,10 +35,12 @@ def _abs(J):
 
 
 def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=0.0, xtol_rel=0.0,
-              callback=None, verbose=False):
+              callback=None, verbose=False, constraint_tol=0.0):
     """The algorithm as a coroutine: ``yield x`` asks the driver for ``(value, gradient)`` of the objective at x
     (``generator.send((f, g))``); the generator returns the :class:`MMAResult`.  Lets many optimisations advance in
-    lock-step with their objective evaluations batched into one engine call (:func:`mma_minimize_ensemble`)."""
+    lock-step with their objective evaluations batched into one engine call (:func:`mma_minimize_ensemble`).
+    ``constraint_tol``: a point counts as feasible when every constraint is <= this (the ``tol`` argument of NLopt's
+    ``add_inequality_mconstraint``; it only enters the feasibility judgement, the sub-problems use the constraints as given)."""
     x = np.array(x0, dtype=float).ravel()
     n = x.size
     lb = np.full(n, -np.inf) if lower is None else np.broadcast_to(np.asarray(lower, dtype=float), (n,)).copy()
@@ -65,7 +69,7 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
     fc, J = eval_constraints(x)
     m = fc.size
     rho, rhoc = 1.0, np.ones(m)
-    feasible = bool(np.all(fc <= 0))
+    feasible = bool(np.all(fc <= constraint_tol))
     infeasibility = fc.max() if m else 0.0
     x_prev = x_prev2 = x.copy()
     best = (f, x.copy()) if feasible else (np.inf, x.copy())
@@ -84,7 +88,7 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
             # ---- dual of the separable approximation
             def primal(yv):
                 u = s2 * (g + (J.T @ yv if m else 0.0))
-                v = sigma * (np.abs(g) + (Jabs.T @ yv if m else 0.0)) + 0.5 * s2 * (rho + (rhoc @ yv if m else 0.0))
+                v = sigma * (np.abs(g) + (Jabs.T @ yv if m else 0.0)) + 0.5 * (rho + (rhoc @ yv if m else 0.0))
                 with np.errstate(divide="ignore", invalid="ignore"):
                     d = np.where(np.abs(u) < 1e-3 * (v + 1e-300), -0.5 * u / np.maximum(v, 1e-300) * 1.0,
                                  (s2 / u) * (-v + np.sqrt(np.maximum(v * v - u * u / s2, 0.0))))
@@ -93,12 +97,12 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
 
             def approx(d, grad, r):
                 """g(x+d) - f(x) for one function with gradient grad and conservativeness r."""
-                return np.sum((grad * s2 * d + (np.abs(grad) * sigma + 0.5 * r * s2) * d * d) / (s2 - d * d))
+                return np.sum((grad * s2 * d + (np.abs(grad) * sigma + 0.5 * r) * d * d) / (s2 - d * d))
 
             def approx_constraints(d):
                 w = d / (s2 - d * d)
                 w2 = d * d / (s2 - d * d)
-                return fc + J @ (s2 * w) + Jabs @ (sigma * w2) + 0.5 * rhoc * np.sum(s2 * w2)
+                return fc + J @ (s2 * w) + Jabs @ (sigma * w2) + 0.5 * rhoc * np.sum(w2)
 
             if m:
                 # The geometric constraints number in the thousands and almost all of them are slack: solve the dual on a
@@ -131,7 +135,7 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
             fc_new = eval_constraint_values(x_new)
             g0 = f + approx(d, g, rho)
             gc = approx_constraints(d) if m else np.zeros(0)
-            feas_new = bool(np.all(fc_new <= 0))
+            feas_new = bool(np.all(fc_new <= constraint_tol))
             infeas_new = fc_new.max() if m else 0.0
             # NLopt's acceptance of a new best point: feasible and better, or less infeasible while none is feasible yet
             if (feas_new and (f_new < best[0] or not feasible)) or (not feasible and infeas_new < infeasibility):

@@ -25,8 +25,11 @@ def geometry_from_design_cached(geometry, design):
     objective (one solver per input) all ask for the geometry of the same design tuple in the same round."""
     sig = getattr(geometry, "_signature", None)
     if sig is None:
+        # every public attribute that defines the lattice: scalars by value, arrays (kagome direct_basis) by content
         sig = geometry._signature = (type(geometry).__name__,) + tuple(
-            sorted((k, float(v)) for k, v in vars(geometry).items() if isinstance(v, (int, float)) and not k.startswith("_")))
+            sorted((k, float(v) if isinstance(v, (int, float)) else (np.asarray(v).shape, np.asarray(v, dtype=float).tobytes()))
+                   for k, v in vars(geometry).items()
+                   if isinstance(v, (int, float, np.ndarray, list, tuple)) and not k.startswith("_")))
     key = (sig,) + tuple(id(a) for a in design)
     hit = _GEOMETRY_CACHE.get(key)
     if hit is not None and all(a is b for a, b in zip(hit[0], design)):
@@ -467,17 +470,17 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
             def ca(x, i=i):
                 r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
                 logs[i]["constraints_violation"]["angles"].append(float(r.max()))
-                return r - 1e-8
+                return r
             cons.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
         if min_edge_length is not None:
             def ce(x, i=i):
                 r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
                 logs[i]["constraints_violation"]["edge_lengths"].append(float(r.max()))
-                return r - 1e-8
+                return r
             cons.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
         per_member.append(dict(constraints=cons))
     res = mma_maximize_ensemble(batch_fun, [_flatten_design(d) for d in initial_guesses], per_member_kw=per_member,
-                                lower=lower_bound, upper=upper_bound, maxeval=n_iterations)
+                                lower=lower_bound, upper=upper_bound, maxeval=n_iterations, constraint_tol=1e-8)
     for log, r in zip(logs, res):
         log["mma"] = r
     return [_unflatten_design(g, r.x) for r in res], logs
@@ -661,17 +664,18 @@ class OptimizationProblem:
             def ca(x):
                 r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
                 self.constraints_violation["angles"].append(float(r.max()))
-                return r - 1e-8                                  # nlopt tolerance of the reference: 1e-8 per constraint
+                return r
             constraints.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
         if min_edge_length is not None:
             def ce(x):
                 r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
                 self.constraints_violation["edge_lengths"].append(float(r.max()))
-                return r - 1e-8
+                return r
             constraints.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
         try:
             res = mma_maximize(fun, _flatten_design(initial_guess), lower=lower_bound, upper=upper_bound,
-                               constraints=constraints, maxeval=n_iterations)
+                               constraints=constraints, maxeval=n_iterations,
+                               constraint_tol=1e-8)      # the reference passes 1e-8 per constraint to add_inequality_mconstraint
             self.mma_result = res
             best = _unflatten_design(g, res.x)
         except _TimeUp:

@@ -1,0 +1,168 @@
+"""-m gpu: the HIP engine at BASELINE.json's FULL sizes against the independent torch-autograd oracle (not the CPU port,
+which is built from the product's own per-ligament headers), and the configurations round 1 left untested:
+
+* C3 size (128x128 quads) and C4 size (64x64-cell kagome): one RHS + every VJP, and a short trajectory + discrete adjoint
+  w.r.t. the design, both with contact forced ACTIVE (cutoff above the rest void angles);
+* C4 with its per-GPU batch of 8 designs;
+* C5: `run_optimization_nlopt` (method of moving asymptotes), three inputs, an 8-member lock-step ensemble;
+* one handle re-used for a second solve that needs a larger segment table (stale hipGraph arguments).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from difflexmm_amd import problems as P
+
+from . import parity
+from .common import Case, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lattice,n", [("quads", 128), ("kagome", 64)])
+def test_full_size_rhs_and_vjp_match_autograd(hip_lib, lattice, n):
+    """Size-dependent code (32-bit offsets, guessed partner slots, XCD remap of the workgroup order) against autograd
+    through the oracle's energy at the size the bench runs; `check_rhs_and_vjp` asserts that contact is active."""
+    parity.check_rhs_and_vjp(None, lattice, n, True, True)
+
+
+@pytest.mark.parametrize("lattice,n,spi,n_out", [("quads", 32, 3, 3), ("quads", 128, 12, 2), ("kagome", 64, 12, 2)])
+def test_full_size_trajectory_and_adjoint_match_unrolled_oracle(hip_lib, lattice, n, spi, n_out):
+    """Forward fields vs the oracle's fixed-grid solver and design / amplitude / state0 gradients vs torch.autograd through
+    the unrolled oracle (`OD.solve_fixed_differentiable`), contact active, at C2 / C3 / C4 lattice sizes."""
+    parity.check_trajectory_and_adjoint(None, lattice, n, "dopri5", spi=spi, n_out=n_out)
+
+
+def test_c3_128x128_contact_active_over_graph_segments(hip_lib, cpu_lib):
+    """128x128 with `cutoff_deg` above the rest void angles (40 deg / 140 deg), 600 steps (several hipGraph segments, stage
+    checkpoint, 2 members on 2 streams): the contact branch is taken at full size; HIP vs the CPU port on fields, objective
+    and design gradient, plus the vacuity check that the contact energy really is non-zero."""
+    ts = np.linspace(0.0, 1.2e-3, 3)
+    res = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("quads", 128, True, True, seed=3, lib=lib, cutoff_deg=42.0, batch=2 if lib is None else 1)
+        cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=2000.0, input_delay=1e-5))
+        cps = [cp, cp] if lib is None else cp
+        f = c.solver(np.zeros((2, 128 * 128, 3)), ts, cps, keep_trajectory=True, steps_per_interval=300)
+        mid = 64 * 128
+        obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(np.array([mid + 1, mid + 2, mid + 129, mid + 130], dtype=np.int32))
+        if lib is None:
+            assert np.array_equal(f[0], f[1])
+            e_with = c.solver.engine.energy(f[:, -1, 0])[0]
+            f, obj, tree = f[0], obj[0], tree[0]
+            nc = Case("quads", 128, True, False, seed=3, lib=None)
+            flat = nc.solver._flatten(nc.cp)
+            nc.solver.engine.set_params(**{k: v[None] for k, v in flat.items()})
+            e_without = nc.solver.engine.energy(f[-1, 0][None])[0]
+            assert e_with - e_without > 1e-6 * abs(e_with), "contact inactive: the test would be vacuous"
+        res[name] = (f, obj, tree.geometrical_params.centroid_node_vectors)
+    assert res["cpu"][1] > 0
+    assert relerr(res["hip"][0], res["cpu"][0]) < 1e-9
+    assert abs(res["hip"][1] - res["cpu"][1]) / res["cpu"][1] < 1e-9
+    assert relerr(res["hip"][2], res["cpu"][2]) < 1e-7
+
+
+def test_c4_kagome_64x64_batch_of_8_designs(hip_lib, cpu_lib):
+    """BASELINE config C4 per GPU: 8 designs (seeds 100..107) of the 64x64-cell kagome integrated side by side, forward +
+    target-kinetic-energy gradient w.r.t. the three shift fields; every member against the CPU port run one by one."""
+    ts = np.linspace(0.0, 3e-4, 3)
+    mid = 2 * 64 * 32
+    target = np.array([mid + 2, mid + 3, mid + 4, mid + 5], dtype=np.int32)
+    seeds = list(range(100, 108))
+    cases = [Case("kagome", 64, True, True, seed=s, lib=cpu_lib, cutoff_deg=125.0) for s in seeds]
+    fast = dict(amplitude=7.5, loading_rate=5000.0, input_delay=1e-6)
+    cb = Case("kagome", 64, True, True, seed=100, lib=None, cutoff_deg=125.0, batch=8)
+    cps = [c.cp._replace(constraint_params=fast) for c in cases]
+    fb = cb.solver(np.zeros((2, cb.geo.n_blocks, 3)), ts, cps, keep_trajectory=True, steps_per_interval=20)
+    objs, trees, _ = cb.solver.kinetic_energy_value_and_vjp(target)
+    assert cb.solver.stats["steps"] == 40 and fb.shape[0] == 8
+    for m, c in enumerate(cases):
+        f = c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, cps[m], keep_trajectory=True, steps_per_interval=20)
+        obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(target)
+        assert obj > 0 and relerr(fb[m], f) < 1e-10 and abs(objs[m] - obj) / obj < 1e-10
+        gh = cb.geo.vjp(c.design, trees[m].geometrical_params.centroid_node_vectors, trees[m].geometrical_params.block_centroids)
+        gc = c.geo.vjp(c.design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
+        for a, b in zip(gh, gc):
+            assert relerr(a, b) < 1e-8
+    assert len({float(o) for o in objs}) == 8          # eight different designs, eight different objectives
+
+
+def _fw5(side, shift, batch=1, lib=None, n_timepoints=11, spi=40):
+    fw = P.QuadsFocusingForward(
+        n1_blocks=24, n2_blocks=16, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5,
+        density=6.18e-9, damping=0.0186 * np.array([2 * math.sqrt(0.36125 * 6.18e-9 * 225 * 1.19)] * 2 +
+                                                   [2 * math.sqrt(0.02175026 * 6.18e-9 * 15.0 ** 4 * 1.5)]) * np.ones((384, 1)),
+        amplitude=7.5, loading_rate=300.0, input_delay=1e-4, n_excited_blocks=2, loaded_side=side, input_shift=shift,
+        simulation_time=4e-3, n_timepoints=n_timepoints, use_contact=True, k_contact=1.5, min_angle=-15 * math.pi / 180,
+        cutoff_angle=-10 * math.pi / 180, steps_per_interval=spi, batch=batch, _lib=lib)
+    fw.setup()
+    return fw
+
+
+def _design5(fw, seed):
+    rng = np.random.default_rng(seed)
+    base = fw.geometry.get_design_from_rotated_square(25 * math.pi / 180)
+    return tuple(b + rng.uniform(-0.3, 0.3, b.shape) for b in base)
+
+
+_INPUTS = (("left", 0), ("right", -2), ("bottom", -4))          # problems/quads_focusing_multi_input, paper notebook cell 7
+_CONS = dict(lower_bound=-3.0, upper_bound=3.0, min_void_angle=5 * math.pi / 180, min_block_angle=5 * math.pi / 180,
+             min_edge_length=1.0)
+
+
+def test_c5_mma_loop_three_inputs_single_design(hip_lib, cpu_lib):
+    """BASELINE config C5's loop for one design: `run_optimization_nlopt` (MMA under the angle / edge-length constraints)
+    on the three-input focusing objective of the paper's 24x16 lattice, 4 objective evaluations on the HIP engine; the CPU
+    port driven by the same loop visits the same iterates."""
+    runs = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        mi = P.MultiInputTargetKineticEnergy([_fw5(s, sh, lib=lib) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
+        opt = P.OptimizationProblem(mi)
+        x = opt.run_optimization_nlopt(_design5(mi.forward, 1000), 4, verbose=False, **_CONS)
+        runs[name] = (np.array(opt.objective_values), x, opt)
+    oh, oc = runs["hip"][0], runs["cpu"][0]
+    assert len(oh) == 4 and oh[0] > 0
+    assert np.allclose(oh, oc, rtol=1e-8)
+    assert max(oh[1:]) > oh[0]                                  # the loop makes progress
+    for a, b in zip(runs["hip"][1], runs["cpu"][1]):
+        assert np.abs(a - b).max() < 1e-8
+    g = runs["hip"][2].objective.forward.geometry
+    assert P.angle_constraints(g, runs["hip"][1], _CONS["min_void_angle"], _CONS["min_block_angle"]).max() <= 2e-8
+
+
+def test_c5_ensemble_of_8_designs_in_lock_step(hip_lib):
+    """8 multi-input designs (seeds 1000..1007) optimised side by side: every MMA round is ONE batched forward + reverse sweep
+    per input (24 solves); members visit exactly the iterates they visit alone (checked for two of them on the HIP engine)."""
+    mi8 = P.MultiInputTargetKineticEnergy([_fw5(s, sh, batch=8) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
+    x0s = [_design5(mi8.forward, 1000 + i) for i in range(8)]
+    best, logs = P.run_ensemble_optimization(mi8, x0s, 3, **_CONS)
+    assert all(len(l["objective_values"]) == 3 and l["objective_values"][0] > 0 for l in logs)
+    assert sum(max(l["objective_values"]) > l["objective_values"][0] for l in logs) >= 3     # 3 evaluations: first MMA steps may be rejected
+    mi1 = P.MultiInputTargetKineticEnergy([_fw5(s, sh) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
+    for m in (0, 5):
+        opt = P.OptimizationProblem(mi1)
+        x = opt.run_optimization_nlopt(x0s[m], 3, verbose=False, **_CONS)
+        assert np.allclose(opt.objective_values, logs[m]["objective_values"], rtol=1e-9)
+        assert all(np.abs(a - b).max() < 1e-9 for a, b in zip(x, best[m]))
+
+
+def test_second_solve_with_a_larger_segment_table_on_one_handle(hip_lib, cpu_lib):
+    """Two forward + adjoint solves on ONE handle, same timepoints and the same total number of steps, the second with step
+    counts that need more graph segments: the segment table is re-allocated while every other buffer (hence the kernels'
+    argument block) stays as it was.  The cached hipGraphs must not be replayed with the freed table's address."""
+    ts = np.linspace(0.0, 6e-4, 3)
+    spis = [np.array([256, 256], dtype=np.int32), np.array([255, 257], dtype=np.int32)]      # 2 segments, then 3
+    c = Case("quads", 8, True, True, seed=21, lib=None, cutoff_deg=42.0)
+    cc = Case("quads", 8, True, True, seed=21, lib=cpu_lib, cutoff_deg=42.0)
+    cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    fb = np.random.default_rng(5).normal(size=(3, 2, 64, 3))
+    for spi in spis:
+        out = []
+        for case in (c, cc):
+            f = case.solver(y0, ts, cp, keep_trajectory=True, steps_per_interval=spi)
+            tree, s0 = case.solver.vjp(fb)
+            out.append((f, tree.geometrical_params.centroid_node_vectors, s0))
+        assert relerr(out[0][0], out[1][0]) < 1e-10
+        assert relerr(out[0][1], out[1][1]) < 1e-8 and relerr(out[0][2], out[1][2]) < 1e-8

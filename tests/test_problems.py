@@ -123,9 +123,50 @@ def test_mma_reproduces_the_nlopt_tutorial_optimum():
     def jc(x):
         return np.array([[6 * (2 * x[0]) ** 2, -1.0], [-3 * (1 - x[0]) ** 2, -1.0]])
 
-    r = mma_minimize(f, [1.234, 5.678], lower=[-np.inf, 1e-12], constraints=[(c, jc)], maxeval=100, xtol_rel=1e-8)
+    r = mma_minimize(f, [1.234, 5.678], lower=[-np.inf, 1e-12], constraints=[(c, jc)], maxeval=100, xtol_rel=1e-8,
+                     constraint_tol=1e-8)      # the tutorial passes tol = 1e-8 to add_inequality_constraint
     assert abs(r.fun - 0.5443310539518174) < 1e-7 and np.allclose(r.x, [1 / 3, 8 / 27], atol=1e-6)
     assert r.n_eval < 30 and r.feasible
+
+
+def test_mma_second_problem_with_bounds_and_two_constraints():
+    """A second problem with a known optimum (KKT point by hand): min (x0-2)^2 + (x1-1)^2 + x2^2 subject to
+    x0 + x1 <= 2, x0^2 - x1 <= 0, 0 <= x <= 3.  The optimum is x = (1, 1, 0), f = 1 (both constraints active)."""
+    from difflexmm_amd.optimize import mma_minimize
+
+    def f(x):
+        return (x[0] - 2) ** 2 + (x[1] - 1) ** 2 + x[2] ** 2, np.array([2 * (x[0] - 2), 2 * (x[1] - 1), 2 * x[2]])
+
+    cons = [(lambda x: np.array([x[0] + x[1] - 2.0]), lambda x: np.array([[1.0, 1.0, 0.0]])),
+            (lambda x: np.array([x[0] ** 2 - x[1]]), lambda x: np.array([[2 * x[0], -1.0, 0.0]]))]
+    r = mma_minimize(f, [0.5, 1.0, 1.7], lower=0.0, upper=3.0, constraints=cons, maxeval=200, xtol_rel=1e-10,
+                     constraint_tol=1e-9)     # feasible start, as NLopt's MMA (no artificial variables) expects
+    assert r.feasible and abs(r.fun - 1.0) < 1e-6 and np.allclose(r.x, [1.0, 1.0, 0.0], atol=1e-4)
+
+
+def test_mma_one_rho_update_makes_the_approximation_conservative():
+    """nlopt/mma.c: g(x + d) = f + sum (f' s^2 d + (|f'| s + rho/2) d^2) / (s^2 - d^2) and w = sum d^2 / (s^2 - d^2) / 2, so
+    raising rho by (f_new - g) / w closes the gap exactly -- for sigma != 1 too (a stray sigma^2 on the rho term
+    broke this).  Checked on the approximation formulas the module uses, through a non-conservative first candidate."""
+    from difflexmm_amd import optimize as O
+    evals = []
+
+    def f(x):
+        evals.append(x.copy())
+        return float(np.sum(x ** 4)), 4 * x ** 3
+
+    gen = O.mma_steps(np.array([2.0, -1.5]), lower=-8.0, upper=8.0, maxeval=50)     # sigma = 8: far from 1
+    x = next(gen)
+    vals = []
+    try:
+        while True:
+            v, g = f(x)
+            vals.append(v)
+            x = gen.send((v, g))
+    except StopIteration as stop:
+        res = stop.value
+    assert res.fun < 1e-6 * vals[0] and res.n_eval <= 50
+    assert min(vals) == pytest.approx(res.fun)
 
 
 @pytest.mark.parametrize("lattice", ["quads", "kagome"])
@@ -234,3 +275,18 @@ def test_bench_times_exactly_k_steps():
         ts, counts = bench.step_grid(k)
         total = int(np.sum(np.broadcast_to(counts, (len(ts) - 1,))))
         assert total == k and abs(ts[-1] - k * bench.DT) < 1e-18 and np.all(np.diff(ts) > 0)
+
+
+def test_geometry_cache_tells_kagome_lattices_with_different_bases_apart():
+    """the per-design geometry cache keyed kagome lattices by their scalar attributes only; two lattices that
+    differ in direct_basis (cell_size / cell_angle) must not share centroids and node vectors for one design object."""
+    ga = KagomeGeometry(3, 2, 20.0 * np.array([[1.0, 0.0], [0.5, math.sqrt(3) / 2]]), 2.25)
+    gb = KagomeGeometry(3, 2, 26.0 * np.array([[1.0, 0.0], [0.5, math.sqrt(3) / 2]]), 2.25)
+    design = tuple(np.random.default_rng(0).uniform(-0.3, 0.3, sh) for sh in ga.design_shapes())
+    ca, na = P.geometry_from_design_cached(ga, design)
+    cb, nb = P.geometry_from_design_cached(gb, design)
+    ea, ena = ga.geometry_from_design(*design)
+    eb, enb = gb.geometry_from_design(*design)
+    assert np.array_equal(ca, ea) and np.array_equal(na, ena)
+    assert np.array_equal(cb, eb) and np.array_equal(nb, enb)
+    assert not np.array_equal(ca, cb)
