@@ -53,7 +53,7 @@ class dfx_stats(C.Structure):
 
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid",
            "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
-           "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
+           "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
 
 
@@ -74,6 +74,7 @@ def declare(lib):
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
     lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
+    lib.dfx_kinetic_value_and_grad.argtypes = [H, _ip, C.c_int32, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_rhs.argtypes = [H, _dp, C.c_double, _dp]
     lib.dfx_rhs_vjp.argtypes = [H, _dp, C.c_double, _dp, _dp, C.POINTER(dfx_grads)]
     lib.dfx_energy.argtypes = [H, _dp, _dp]
@@ -201,7 +202,7 @@ class Engine:
     # -- solves -------------------------------------------------------------------------------
     def forward(self, state0, timepoints, steps_per_interval, keep_trajectory=False, want_fields=True, step_times=None):
         B, nb = self.batch, self.n_blocks
-        state0 = _f64(state0, (B, 2, nb, 3))
+        state0 = _f64(state0, (B, 2, nb, 3)) if state0 is not None else None      # None: at rest (no upload)
         ts = _f64(timepoints)
         T = len(ts)
         fields = np.empty((B, T, 2, nb, 3)) if want_fields else None
@@ -284,6 +285,27 @@ class Engine:
         self._check(self.lib.dfx_adjoint_kinetic(self._h, tb.ctypes.data_as(_ip), len(tb), C.byref(g), C.byref(st)),
                     "dfx_adjoint_kinetic")
         return out, _stats(st)
+
+    def kinetic_value_and_grad(self, target_blocks, which=ALL_GRADS):
+        """objective (batch,) and the requested gradients in ONE call; the arrays are read-only views of library-owned pinned
+        memory (valid until the next call on this engine: copy what must outlive it)."""
+        tb = np.ascontiguousarray(target_blocks, dtype=np.int32)
+        sh = self.shapes()
+        want, views = dfx_grads(), dfx_grads()
+        names = [n for n in which if not (n == "fn_params" and self.n_fns == 0) and not (n in ("void_angle0", "contact") and not self.contact)]
+        flag = np.zeros(1)
+        for n in names:
+            setattr(want, n, _ptr(flag))
+        obj = np.zeros(self.batch)
+        st = dfx_stats()
+        self._check(self.lib.dfx_kinetic_value_and_grad(self._h, tb.ctypes.data_as(_ip), len(tb), _ptr(obj), C.byref(want),
+                                                        C.byref(views), C.byref(st)), "dfx_kinetic_value_and_grad")
+        out = {}
+        for n in names:
+            a = np.ctypeslib.as_array(getattr(views, n), shape=sh[n])
+            a.flags.writeable = False
+            out[n] = a
+        return obj, out, _stats(st)
 
     # -- test hooks ---------------------------------------------------------------------------
     def rhs(self, y, t):

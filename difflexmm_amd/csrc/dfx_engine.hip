@@ -90,7 +90,7 @@ struct dfx_handle {
   std::vector<Group> groups;
   bool dual_chain = true;
   hipEvent_t ev_fork2 = nullptr;
-  PinnedBuf stage;
+  PinnedBuf stage, obj_stage;
   hipEvent_t ev_fork = nullptr;
   PackedParams pp;
   std::string err;
@@ -100,7 +100,8 @@ struct dfx_handle {
   bool have_params = false, have_traj = false, have_fields = false;
   bool use_graph = true;
   bool want_bond_grads = true, want_fn_grads = true, want_damping_grads = true;
-  DevBuf<int32_t> d_slot_info, d_block_special;
+  DevBuf<int32_t> d_slot_info, d_block_special, d_slot_bond;
+  DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<dfx_special> d_special;
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict;
   DevBuf<uint8_t> d_l_idx;
@@ -291,6 +292,42 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   }
 }
 
+// Short solves are launched eagerly, the launches of the member groups interleaved stage by stage: a hipGraph of ~100 nodes
+// takes about as long to launch as a 20-step solve takes to run (measured: first kernel 0.7 - 2.9 ms after the call), and
+// launching one group's graph after the other's staggers the groups by that time; eager launches cost ~3.5 us of host time
+// each, less than a stage kernel runs, and the first kernel starts at once.  Long solves replay graphs: the launch of
+// segment k+1 hides behind segment k.  DFX_EAGER_STEPS overrides the threshold (steps per solve).
+static bool solve_is_eager(const dfx_handle* h) {
+  if (!h->use_graph) return true;
+  const char* e = getenv("DFX_EAGER_STEPS");
+  return h->n_total <= (e ? atoll(e) : 128LL);
+}
+
+static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int kind) {
+  const int s = h->pl.tab.s, ng = (int)h->groups.size();
+  if (kind == 1 && !cbase.AD) {      // recompute chains (events per group): group by group
+    for (int gi = 0; gi < ng; ++gi) enqueue_segment(h, cbase, gi, n_steps, kind);
+    return;
+  }
+  std::vector<DevCtx> cg(ng, cbase);
+  for (int gi = 0; gi < ng; ++gi) {
+    cg[gi] = group_ctx(h, cbase, gi);
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->groups[gi].stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
+    h->launches++;
+  }
+  if (kind == 0) {
+    for (int j = 0; j < n_steps; ++j)
+      for (int i = 0; i < s; ++i)
+        for (int gi = 0; gi < ng; ++gi)
+          launch_fwd(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j, fin(i), fout(i, s), 0, (i == s - 1 && cbase.traj) ? 1 : 0);
+  } else {
+    for (int j = n_steps - 1; j >= 0; --j)
+      for (int i = s - 1; i >= 0; --i)
+        for (int gi = 0; gi < ng; ++gi)
+          launch_adj(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j, i == 0 ? -1 : i, -1, 0);
+  }
+}
+
 static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int kind) {
   if (!h->use_graph) { enqueue_segment(h, c, gi, n_steps, kind); return 0; }
   dfx_handle::GraphKey gk;
@@ -429,23 +466,34 @@ static int zero_grad_accumulators(dfx_handle* h) {
   return 0;
 }
 
-// download the accumulators and scatter them into dfx_grads
-static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
-  // Only what the caller asked for crosses PCIe, and it is scattered straight from the pinned staging area into the
-  // caller's arrays (a solve of a few steps is otherwise dominated by this function).
+// Gradient accumulators -> the layouts of dfx_grads.  The big ones (node vectors, void angles, inertia, damping, state0) are
+// re-laid-out by ONE device kernel, so that what crosses PCIe is final: a single batch of DMA transfers into the pinned staging
+// area and no scatter loops on the host (a solve of a few steps is otherwise dominated by this function).  `grads` (caller
+// buffers, may be null) receives copies; `views` (may be null) receives pointers INTO the staging area, valid until the next
+// call on the handle -- the zero-copy form the Python layer wraps in NumPy arrays.  Entries that are non-null in `want`
+// are produced.
+static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_grads* views, bool with_state0) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, NS = pl.n_slots, nbd = pl.n_bonds;
   const size_t nsp = std::max(1, pl.n_special);
-  HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipGetLastError());
-  if (!grads) return 0;
-  const bool w_r = grads->centroid_node_vectors, w_phi = grads->void_angle0 && pl.contact;
-  const bool w_b = h->want_bond_grads && (grads->reference_vector || grads->k_bond || grads->contact);
-  const bool w_m = grads->inertia, w_c = grads->damping && h->want_damping_grads, w_fn = grads->fn_params && h->want_fn_grads;
-  const bool w_lam = with_state0 && grads->state0;
-  const size_t n_r = w_r ? B * NS * 2 : 0, n_phi = w_phi ? B * NS : 0, n_b = w_b ? B * NS * 8 : 0, n_m = w_m ? B * nb * 3 : 0,
+  const int npb = pl.n_npb;
+  if (views) memset(views, 0, sizeof(*views));
+  if (!want) {
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+  const bool w_r = want->centroid_node_vectors, w_phi = want->void_angle0 && pl.contact;
+  const bool w_b = h->want_bond_grads && (want->reference_vector || want->k_bond || want->contact);
+  const bool w_m = want->inertia, w_c = want->damping && h->want_damping_grads, w_fn = want->fn_params && h->want_fn_grads;
+  const bool w_lam = with_state0 && want->state0;
+  const size_t n_r = w_r ? B * nb * npb * 2 : 0, n_phi = w_phi ? B * nbd * 2 : 0, n_b = w_b ? B * NS * 8 : 0, n_m = w_m ? B * nb * 3 : 0,
                n_c = w_c ? B * nb * 3 : 0, n_fn = w_fn ? B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS : 0, n_lam = w_lam ? B * nb * 6 : 0;
-  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_m + n_c + n_fn + n_lam + 8) * sizeof(double)));
+  // small host-side results (bond parameters, time-function parameters) live behind the DMA area
+  const size_t n_small = (want->reference_vector ? B * nbd * 2 : 0) + (want->k_bond ? B * nbd * 3 : 0) + (want->contact ? B * 3 : 0) +
+                         (want->fn_params ? B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS : 0) + (want->damping && !w_c ? B * nb * 3 : 0) +
+                         (want->void_angle0 && !w_phi ? B * nbd * 2 : 0);
+  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_m + n_c + n_fn + n_lam + n_small + 8) * sizeof(double)));
   double* g_r = reinterpret_cast<double*>(h->stage.p);
   double* g_phi = g_r + n_r;
   double* g_b = g_phi + n_phi;
@@ -453,63 +501,78 @@ static int collect_grads(dfx_handle* h, dfx_grads* grads, bool with_state0) {
   double* g_c = g_m + n_m;
   double* fn_g = g_c + n_c;
   double* lam = fn_g + n_fn;
+  double* small = lam + n_lam;
+  // device-side re-layout: kagome node vectors (3 of 4 slots), void angles (slot -> (bond, end)), state0 (q | v planes)
+  const bool pack_r = w_r && npb != kSlots;
+  if (pack_r || w_phi || w_lam) {
+    if (pack_r) HIP_OK(h->d_out_r.ensure(n_r));
+    if (w_phi) HIP_OK(h->d_out_phi.ensure(n_phi));
+    if (w_lam) HIP_OK(h->d_out_lam.ensure(n_lam));
+    DevCtx c = make_ctx(h);
+    hipLaunchKernelGGL(k_pack_grads, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const int32_t*)h->d_slot_bond.p, npb, (int)nbd,
+                       pack_r ? h->d_out_r.p : (double*)nullptr, w_phi ? h->d_out_phi.p : (double*)nullptr,
+                       w_lam ? h->d_out_lam.p : (double*)nullptr);
+  }
   auto pull = [&](double* dst, const double* src, size_t n) {
     return n ? hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
   };
-  HIP_OK(pull(g_r, h->d_g_r.p, n_r));
-  HIP_OK(pull(g_phi, h->d_g_phi.p, n_phi));
+  HIP_OK(pull(g_r, pack_r ? h->d_out_r.p : h->d_g_r.p, n_r));
+  HIP_OK(pull(g_phi, h->d_out_phi.p, n_phi));
   HIP_OK(pull(g_b, h->d_g_b.p, n_b));
   HIP_OK(pull(g_m, h->d_blk_m.p, n_m));
   HIP_OK(pull(g_c, h->d_blk_c.p, n_c));
   HIP_OK(pull(fn_g, h->d_fn_g.p, n_fn));
-  HIP_OK(pull(lam, h->d_LAM.p, n_lam));
+  HIP_OK(pull(lam, h->d_out_lam.p, n_lam));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
-  const int npb = pl.n_npb;
-  if (w_r)
-    for (size_t m = 0; m < B; ++m)
-      for (size_t b = 0; b < nb; ++b)
-        memcpy(grads->centroid_node_vectors + ((m * nb + b) * npb) * 2, g_r + (m * NS + b * kSlots) * 2, sizeof(double) * 2 * npb);
-  if (grads->void_angle0) memset(grads->void_angle0, 0, sizeof(double) * B * nbd * 2);
-  if (grads->reference_vector) memset(grads->reference_vector, 0, sizeof(double) * B * nbd * 2);
-  if (grads->k_bond) memset(grads->k_bond, 0, sizeof(double) * B * nbd * 3);
-  if (grads->contact) memset(grads->contact, 0, sizeof(double) * B * 3);
-  if (w_phi || w_b)
+  dfx_grads v;
+  memset(&v, 0, sizeof(v));
+  if (w_r) v.centroid_node_vectors = g_r;
+  if (w_phi) v.void_angle0 = g_phi;
+  if (w_m) v.inertia = g_m;
+  if (w_c) v.damping = g_c;
+  if (w_lam) v.state0 = lam;
+  auto take = [&](size_t n) { double* q = small; small += n; memset(q, 0, sizeof(double) * n); return q; };
+  if (want->void_angle0 && !w_phi) v.void_angle0 = take(B * nbd * 2);
+  if (want->damping && !w_c) v.damping = take(B * nb * 3);
+  if (want->reference_vector) v.reference_vector = take(B * nbd * 2);
+  if (want->k_bond) v.k_bond = take(B * nbd * 3);
+  if (want->contact) v.contact = take(B * 3);
+  if (w_b)
     for (size_t m = 0; m < B; ++m)
       for (size_t sl = 0; sl < NS; ++sl) {
         const int info = pl.slot_info[sl];
         if (info < 0 || (info & 1)) continue;            // one entry per ligament: its end-0 slot
-        const size_t bond = (size_t)pl.slot_bond[sl], i = m * NS + sl;
-        if (w_phi) {
-          grads->void_angle0[(m * nbd + bond) * 2] = g_phi[i];
-          grads->void_angle0[(m * nbd + bond) * 2 + 1] = g_phi[m * NS + (size_t)(info >> 1)];
-        }
-        if (w_b) {
-          const double* q = g_b + i * 8;
-          if (grads->reference_vector) { grads->reference_vector[(m * nbd + bond) * 2] = q[0]; grads->reference_vector[(m * nbd + bond) * 2 + 1] = q[1]; }
-          if (grads->k_bond) for (int c = 0; c < 3; ++c) grads->k_bond[(m * nbd + bond) * 3 + c] = q[2 + c];
-          if (grads->contact) for (int c = 0; c < 3; ++c) grads->contact[m * 3 + c] += q[5 + c];
-        }
+        const size_t bond = (size_t)pl.slot_bond[sl];
+        const double* q = g_b + (m * NS + sl) * 8;
+        if (v.reference_vector) { v.reference_vector[(m * nbd + bond) * 2] = q[0]; v.reference_vector[(m * nbd + bond) * 2 + 1] = q[1]; }
+        if (v.k_bond) for (int c = 0; c < 3; ++c) v.k_bond[(m * nbd + bond) * 3 + c] = q[2 + c];
+        if (v.contact) for (int c = 0; c < 3; ++c) v.contact[m * 3 + c] += q[5 + c];
       }
-  if (grads->inertia) memcpy(grads->inertia, g_m, sizeof(double) * B * nb * 3);
-  if (grads->damping) { if (w_c) memcpy(grads->damping, g_c, sizeof(double) * B * nb * 3); else memset(grads->damping, 0, sizeof(double) * B * nb * 3); }
-  if (grads->fn_params) {
+  if (want->fn_params) {
+    v.fn_params = take(B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS);
     const int W = DFX_MAX_FNS * DFX_FN_PARAMS;
     for (size_t m = 0; m < B; ++m)
       for (int f = 0; f < pl.n_fns; ++f)
         for (int i = 0; i < DFX_FN_PARAMS; ++i) {
           double acc = 0.0;
           if (w_fn) for (int sidx = 0; sidx < pl.n_special; ++sidx) acc += fn_g[(m * pl.n_special + sidx) * W + f * DFX_FN_PARAMS + i];
-          grads->fn_params[(m * pl.n_fns + f) * DFX_FN_PARAMS + i] = acc;
+          v.fn_params[(m * pl.n_fns + f) * DFX_FN_PARAMS + i] = acc;
         }
   }
-  if (w_lam)
-    for (size_t m = 0; m < B; ++m)
-      for (size_t b = 0; b < nb; ++b)
-        for (int d = 0; d < 3; ++d) {
-          grads->state0[m * nb * 6 + b * 3 + d] = lam[m * nb * 6 + b * 6 + d];
-          grads->state0[m * nb * 6 + nb * 3 + b * 3 + d] = lam[m * nb * 6 + b * 6 + 3 + d];
-        }
+  if (grads) {
+    auto give = [&](double* dst, const double* src, size_t n) { if (dst && src) memcpy(dst, src, sizeof(double) * n); };
+    give(grads->centroid_node_vectors, v.centroid_node_vectors, B * nb * npb * 2);
+    give(grads->void_angle0, v.void_angle0, B * nbd * 2);
+    give(grads->reference_vector, v.reference_vector, B * nbd * 2);
+    give(grads->k_bond, v.k_bond, B * nbd * 3);
+    give(grads->contact, v.contact, B * 3);
+    give(grads->inertia, v.inertia, B * nb * 3);
+    give(grads->damping, v.damping, B * nb * 3);
+    give(grads->fn_params, v.fn_params, B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS);
+    give(grads->state0, v.state0, B * nb * 6);
+  }
+  if (views) *views = v;
   return 0;
 }
 
@@ -590,11 +653,13 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   }
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
+            h->d_slot_bond.ensure(pl.n_slots) == hipSuccess &&
             h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2 + kMaxGroups) == hipSuccess &&
             h->d_cur.ensure(kMaxGroups) == hipSuccess;
   if (!ok) { h->err = "hipMalloc (static tables) failed"; return fail(2); }
   (void)hipMemcpy(h->d_slot_info.p, pl.slot_info.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
   (void)hipMemcpy(h->d_block_special.p, pl.block_special.data(), sizeof(int32_t) * pl.n_blocks, hipMemcpyHostToDevice);
+  (void)hipMemcpy(h->d_slot_bond.p, pl.slot_bond.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
   if (pl.n_special)
     (void)hipMemcpy(h->d_special.p, pl.special.data(), sizeof(dfx_special) * pl.n_special, hipMemcpyHostToDevice);
   *out = h;
@@ -606,7 +671,8 @@ int dfx_destroy(dfx_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
-  h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release();
+  h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release();
+  h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
@@ -614,7 +680,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
-  h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release();
+  h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release();
   for (auto& gr : h->groups) { for (auto e : gr.ev_a) (void)hipEventDestroy(e); for (auto e : gr.ev_b) (void)hipEventDestroy(e); if (gr.stream2) (void)hipStreamDestroy(gr.stream2); if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
@@ -744,7 +810,13 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   std::vector<int> cursors(2 + kMaxGroups, -1);   // [0] unused, [1] non-finite flag, [2+g] segment cursor of group g
   cursors[1] = 0;
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
+  if (state0) {       // through the pinned staging area (pageable DMA is slow here); NULL = every member starts at rest
+    HIP_OK(h->stage.ensure(sizeof(double) * B * nb * 6));
+    memcpy(h->stage.p, state0, sizeof(double) * B * nb * 6);
+    HIP_OK(hipMemcpyAsync(h->d_state0.p, h->stage.p, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIP_OK(hipMemsetAsync(h->d_state0.p, 0, sizeof(double) * B * nb * 6, h->stream));
+  }
   DevCtx c = make_ctx(h);
   h->launches = 0;
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0);
@@ -754,10 +826,12 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
+  const bool eager = solve_is_eager(h);
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
+    if (eager) enqueue_interleaved(h, c, sg.n_steps, 0);
     for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
-      if (int rc = run_segment(h, c, gi, sg.n_steps, 0)) return rc;
+      if (!eager) if (int rc = run_segment(h, c, gi, sg.n_steps, 0)) return rc;
       if (sg.j0 + sg.n_steps == h->spis[sg.interval]) {   // buffer 0 holds the state at the end of the interval
         const Group& gr = h->groups[gi];
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
@@ -972,11 +1046,11 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
 }
 
 // reverse sweep with the output cotangents already in h->d_G
-static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool kinetic, int n_target) {
+static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_grads* views, dfx_stats* stats, bool kinetic, int n_target) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch;
   const int Tn = (int)h->ts.size();
-  set_grad_wishes(h, grads);
+  set_grad_wishes(h, want);
   DevCtx c = make_ctx(h);
   h->launches = 0;
   if (zero_grad_accumulators(h)) return 2;
@@ -995,16 +1069,19 @@ static int run_adjoint(dfx_handle* h, dfx_grads* grads, dfx_stats* stats, bool k
     h->launches++;
   }
   if (fork_groups(h)) return 2;
-  for (int si = nseg - 1; si >= 0; --si)
+  const bool eager = solve_is_eager(h);
+  for (int si = nseg - 1; si >= 0; --si) {
+    if (eager) { enqueue_interleaved(h, c, h->segs[si].n_steps, 1); continue; }
     for (int gi = 0; gi < (int)h->groups.size(); ++gi)
       if (int rc = run_segment(h, c, gi, h->segs[si].n_steps, 1)) return rc;
+  }
   if (join_groups(h)) return 2;
   if (kinetic) {
     dim3 g((unsigned)((n_target * 3 + 63) / 64), (unsigned)B);
     hipLaunchKernelGGL(k_kinetic_mass_grad, g, dim3(64), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_target.p, n_target);
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
-  if (int rc = collect_grads(h, grads, true)) return rc;
+  if (int rc = collect_grads(h, want, grads, views, true)) return rc;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;
@@ -1059,7 +1136,7 @@ int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_s
   const size_t total = B * Tn * nb * 3;
   hipLaunchKernelGGL(k_pack_G, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream, c,
                      (const double*)h->d_tmp.p, h->d_G.p);
-  return run_adjoint(h, grads, stats, false, 0);
+  return run_adjoint(h, grads, grads, nullptr, stats, false, 0);
 }
 
 static int upload_targets(dfx_handle* h, const int32_t* target_blocks, int32_t n_target) {
@@ -1083,7 +1160,8 @@ int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n
   return 0;
 }
 
-int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, dfx_grads* grads, dfx_stats* stats) {
+static int adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective, const dfx_grads* want,
+                           dfx_grads* grads, dfx_grads* views, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_traj || !h->have_fields) { h->err = "adjoint_kinetic: run forward with keep_trajectory=1 first"; return 1; }
   const Plan& pl = h->pl;
@@ -1096,7 +1174,22 @@ int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_t
   DevCtx c = make_ctx(h);
   hipLaunchKernelGGL(k_kinetic, dim3(h->pl.batch), dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p,
                      (const int32_t*)h->d_target.p, n_target, h->d_G.p, h->d_obj.p);
-  return run_adjoint(h, grads, stats, true, n_target);
+  if (objective) {   // rides along with the reverse sweep: read after the sweep's final synchronisation
+    HIP_OK(h->obj_stage.ensure(sizeof(double) * B));
+    HIP_OK(hipMemcpyAsync(h->obj_stage.p, h->d_obj.p, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (int rc = run_adjoint(h, want, grads, views, stats, true, n_target)) return rc;
+  if (objective) memcpy(objective, h->obj_stage.p, sizeof(double) * B);
+  return 0;
+}
+
+int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, dfx_grads* grads, dfx_stats* stats) {
+  return adjoint_kinetic(h, target_blocks, n_target, nullptr, grads, grads, nullptr, stats);
+}
+
+int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
+                               const dfx_grads* want, dfx_grads* views, dfx_stats* stats) {
+  return adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, views, stats);
 }
 
 // ---- test hooks ------------------------------------------------------------------------------
@@ -1161,7 +1254,7 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   launch_adj(h, c, 0, 0, 0, 0, 1);
   std::vector<double> YB(B * pl.tab.s * nb * 6);
   HIP_OK(hipMemcpyAsync(YB.data(), h->d_YB.p, sizeof(double) * YB.size(), hipMemcpyDeviceToHost, h->stream));
-  if (int rc = collect_grads(h, grads, false)) return rc;
+  if (int rc = collect_grads(h, grads, grads, nullptr, false)) return rc;
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) {

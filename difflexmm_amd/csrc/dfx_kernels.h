@@ -910,6 +910,30 @@ __global__ __launch_bounds__(kThreads) void k_pack_G(DevCtx c, const double* fie
   g[b * 6 + 3 + d] = f[(size_t)c.n_blocks * 3 + r];
 }
 
+// gradient accumulators -> the caller's layouts (dfx_grads), so that what crosses PCIe is final:
+//   out_r   (batch, n_blocks, npb, 2)  node-vector gradients without the padding slot (kagome)
+//   out_phi (batch, n_bonds, 2)        void-angle gradients: every ligament end holds one of the two
+//   out_lam (batch, 2, n_blocks, 3)    state0 cotangent, (q | v) planes
+__global__ __launch_bounds__(kThreads) void k_pack_grads(DevCtx c, const int32_t* slot_bond, int npb, int n_bonds, double* out_r,
+                                                         double* out_phi, double* out_lam) {
+  const int m = blockIdx.y;
+  const int slot = blockIdx.x * kThreads + threadIdx.x;
+  if (slot >= c.n_slots) return;
+  const int b = slot >> 2, k = slot & 3;
+  const size_t ms = (size_t)m * c.n_slots;
+  if (out_r && k < npb)
+    *reinterpret_cast<double2*>(out_r + (((size_t)m * c.n_blocks + b) * npb + k) * 2) = *reinterpret_cast<const double2*>(c.g_r + (ms + slot) * 2);
+  if (out_phi) {
+    const int info = c.slot_info[slot];
+    if (info >= 0) out_phi[((size_t)m * n_bonds + slot_bond[slot]) * 2 + (info & 1)] = c.g_phi[ms + slot];
+  }
+  if (out_lam && k < 3) {
+    const size_t nd = (size_t)c.n_blocks * 3, o = (size_t)m * c.n_blocks * 6;
+    out_lam[o + (size_t)b * 3 + k] = c.LAM[o + (size_t)b * 6 + k];
+    out_lam[o + nd + (size_t)b * 3 + k] = c.LAM[o + (size_t)b * 6 + 3 + k];
+  }
+}
+
 // kinetic-energy objective: G <- m v on target blocks; per-member objective by one workgroup
 __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fields, const int32_t* target, int n_target,
                                                       double* G, double* objective) {

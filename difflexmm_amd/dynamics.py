@@ -245,20 +245,20 @@ class DynamicSolver:
 
     def kinetic_energy_value_and_vjp(self, target_blocks):
         """objective = sum_t sum_{b in target} m v^2/2 (energy.py:494-499 over problems/quads_focusing.py:461-467),
-        evaluated and differentiated on the device."""
-        obj = self.engine.objective_kinetic(target_blocks)
-        grads, stats = self.engine.adjoint_kinetic(target_blocks)
+        evaluated and differentiated on the device (one engine call: the objective rides along with the reverse sweep)."""
+        obj, grads, stats = self.engine.kinetic_value_and_grad(target_blocks)
         self.adjoint_stats = stats
+        grads = {k: np.array(v) for k, v in grads.items()}      # the gradient tree outlives the engine's result area
         trees, s0 = self._unflatten_grads(grads, None)
         return (obj[0] if self.batch == 1 else obj), trees, s0
 
     def kinetic_energy_value_and_raw(self, target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia")):
-        """Same objective; returns the engine's raw gradient arrays (batch-leading) for the requested parameter groups only.
+        """Same objective; returns the engine's raw gradient arrays (batch-leading) for the requested parameter groups only:
+        read-only views of the engine's pinned result area, valid until the next call on this solver.
         The maps from these to a design (void-angle and inertia chain rules, lattice map) are linear in the cotangent, so a
         caller that sums several solves of ONE design (multi-input problems) applies them once to the sum."""
-        obj = self.engine.objective_kinetic(target_blocks)
         which = tuple(w for w in which if not (w == "void_angle0" and not self.spec.contact))
-        grads, stats = self.engine.adjoint_kinetic(target_blocks, which=which)
+        obj, grads, stats = self.engine.kinetic_value_and_grad(target_blocks, which=which)
         self.adjoint_stats = stats
         return obj, grads
 

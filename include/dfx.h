@@ -131,7 +131,8 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params);
 int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_t keep_trajectory);
 
 /* Integrate from timepoints[0] with `steps_per_interval` equal RK steps between consecutive
- * timepoints.  state0: (batch, 2, n_blocks, 3); fields: (batch, T, 2, n_blocks, 3), row 0 is the
+ * timepoints.  state0: (batch, 2, n_blocks, 3), or NULL: every member starts at rest (the reference's problems all do,
+ * problems/quads_focusing.py:300); fields: (batch, T, 2, n_blocks, 3) or NULL (they stay on the device), row 0 is the
  * reconstructed initial state.  keep_trajectory != 0 checkpoints every step state in HBM so that
  * dfx_adjoint can run afterwards. */
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
@@ -173,6 +174,13 @@ int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_s
 int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective);
 int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, dfx_grads* grads,
                         dfx_stats* stats);
+
+/* The same objective and gradient in one call and without host-side copies: what jit(value_and_grad(objective)) returns at
+ * problems/quads_focusing.py:565.  `objective` (batch,) may be NULL.  Non-NULL entries of `want` select the gradients; `views`
+ * receives pointers to them in LIBRARY-OWNED (pinned) memory, laid out as in dfx_grads, valid until the next call on the handle.
+ * The accumulators are re-laid-out on the device, so the host does no scatter work. */
+int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
+                               const dfx_grads* want, dfx_grads* views, dfx_stats* stats);
 
 /* Test hooks: one RHS evaluation and its vector-Jacobian product on full-DOF arrays.
  * y, dy, lam, y_bar: (batch, 2, n_blocks, 3).  Constrained DOFs of y are ignored (they follow the

@@ -39,6 +39,8 @@ struct dfx_handle {
   std::vector<std::vector<double>> acc_times;  // end times of the accepted steps per member (adaptive)
   std::vector<double> t_steps;       // caller-chosen step boundaries (empty: equal steps)
   bool have_traj = false;
+  std::vector<double> view_store[9];  // dfx_kinetic_value_and_grad: arrays behind the returned views
+  std::vector<double> zero_state;
 };
 
 static Tables member_tables(const dfx_handle* h, int m) {
@@ -163,6 +165,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     for (int k = 0; k < Tn; ++k)
       if (h->t_steps[h->step0[k]] != timepoints[k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
   }
+  if (!state0) { h->zero_state.assign((size_t)B * nb * 6, 0.0); state0 = h->zero_state.data(); }   // NULL: at rest
   const bool own_grid = !h->t_steps.empty();
   auto t_begin = std::chrono::steady_clock::now();
   h->ts.assign(timepoints, timepoints + Tn);
@@ -508,6 +511,26 @@ int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_t
             double v = h->fields[((size_t)m * Tn + k) * nb * 6 + nb * 3 + dof];
             grads->inertia[(size_t)m * nb * 3 + dof] += 0.5 * v * v;
           }
+  return 0;
+}
+
+int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
+                               const dfx_grads* want, dfx_grads* views, dfx_stats* stats) {
+  // same contract as the HIP engine: results in handle-owned memory, valid until the next call on the handle
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks, nbd = pl.n_bonds;
+  const size_t sizes[9] = {B * nb * pl.n_npb * 2, B * nbd * 2, B * nbd * 3, B * nb * 3, B * nb * 3, B * nbd * 2, B * 3,
+                           B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS, B * nb * 6};
+  dfx_grads g;
+  double** gp = reinterpret_cast<double**>(&g);
+  double* const* wp = reinterpret_cast<double* const*>(want);
+  for (int i = 0; i < 9; ++i) {
+    gp[i] = nullptr;
+    if (want && wp[i]) { h->view_store[i].assign(sizes[i], 0.0); gp[i] = h->view_store[i].data(); }
+  }
+  if (objective) if (int rc = dfx_objective_kinetic(h, target_blocks, n_target, objective)) return rc;
+  if (int rc = dfx_adjoint_kinetic(h, target_blocks, n_target, &g, stats)) return rc;
+  if (views) *views = g;
   return 0;
 }
 

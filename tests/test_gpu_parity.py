@@ -51,6 +51,7 @@ def test_hip_matches_cpu_port_32x32_with_segments(hip_lib, cpu_lib):
 def test_graph_replay_equals_plain_launches(hip_lib, monkeypatch):
     ts = np.linspace(0.0, 3e-4, 4)
     outs = []
+    monkeypatch.setenv("DFX_EAGER_STEPS", "0")        # short solves would otherwise be launched eagerly in both legs
     for no_graph in ("0", "1"):
         monkeypatch.setenv("DFX_NO_GRAPH", no_graph)
         c = Case("quads", 6, True, True, seed=4, lib=None, cutoff_deg=42.0)
@@ -60,6 +61,24 @@ def test_graph_replay_equals_plain_launches(hip_lib, monkeypatch):
         outs.append((f, tree.geometrical_params.centroid_node_vectors, s0))
     for a, b in zip(*outs):
         assert np.array_equal(a, b)   # same kernels, same order: bit-identical
+
+
+@pytest.mark.parametrize("streams", ["1", "3"])
+def test_short_solves_launched_eagerly_equal_graph_replay(hip_lib, monkeypatch, streams):
+    """Solves of <= DFX_EAGER_STEPS steps skip the hipGraphs (launches of the member groups interleaved stage by stage);
+    same kernels in the same per-stream order -> bit-identical fields and gradients."""
+    monkeypatch.setenv("DFX_STREAMS", streams)
+    ts = np.linspace(0.0, 3e-4, 4)
+    outs = []
+    for eager_steps in ("0", "1000"):
+        monkeypatch.setenv("DFX_EAGER_STEPS", eager_steps)
+        c = Case("quads", 6, True, True, seed=4, lib=None, cutoff_deg=42.0, batch=3)
+        y0 = c.random_state(0.05, 0.02, 5.0)
+        f = c.solver(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=7)
+        trees, s0 = c.solver.vjp(np.ones_like(f))
+        outs.append((f, np.stack([t.geometrical_params.centroid_node_vectors for t in trees]), s0))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
 
 
 def test_batch_members_are_independent(hip_lib):
