@@ -4,23 +4,31 @@
 Workload (BASELINE.json configs[2], SURVEY 8(d) "C3"): 128x128 quad lattice (16 384 rigid units), nonlinear
 ligaments + viscous damping + angle-based contact, raised-cosine displacement pulse on 2 left-edge blocks,
 clamped corners, Dormand-Prince tableau on a fixed grid with dt = (2/f)/50 000, one output every 250 steps,
-objective = kinetic energy of the 2x2 target blocks, gradient w.r.t. the 66 048 geometry parameters.
-One "step" = one RK step (6 RHS evaluations) of one member, forward AND reverse.  `--steps K` times exactly K
+objective = kinetic energy of 2x2 target blocks, gradient w.r.t. the 66 048 geometry parameters.
+One "step" = one RK step (6 RHS evaluations) of every member, forward AND reverse.  `--steps K` times exactly K
 steps (output intervals of 250 steps and, if K is not a multiple of 250, one shorter last interval); the full config is
-K = 50 000.  Default: K = 5 000 with 16 independent designs per GPU, the largest member count whose state checkpoint AND
-stage checkpoint (72 + 120 B per unit and step: the reverse sweep then needs no recompute launches) fit the 288 GB;
-longer runs fall back to the state checkpoint alone (K = 10 000) and then to fewer members (K = 50 000: 4).
+K = 50 000.  16 independent designs per GPU while the state checkpoint AND the stage checkpoint (72 + 120 B per unit and
+step: the reverse sweep then needs no recompute launches) fit the 288 GB; longer runs fall back to the state checkpoint
+alone and then to fewer members.
+
+Two deviations from the C3 text, both so that a SHORT timed window differentiates something (round-1 verdict: with the
+paper's input delay of 0.1/f = 3.3 ms and the target 21 x 25 blocks away, the first 20 steps -- 27 us -- integrate a lattice
+at rest and the reverse sweep propagates exact zeros): the pulse starts at t = 0 (`--input-delay`), and the 2x2 target sits
+next to the driven blocks (`--target-shift`; the C3 placement is `--target-shift 21 25`).  Neither changes a launch or a byte.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--members M] [--size 128]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank integrates its own design (weak
-scaling, no data-path collective), objectives are gathered with one RCCL all_gather.
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU, every rank integrates its own designs (weak scaling, no data-path collective), objectives are
+gathered with ONE RCCL all-gather inside libdfx.  Launched either by the driver (`python -m torch.distributed.run ...
+bench.py --gpus N`: the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) or, when WORLD_SIZE is not set, by this
+script itself: it starts N rank processes BEFORE touching the GPU and relays rank 0's line.
+Host code is Python + ctypes + NumPy: no PyTorch.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -33,15 +41,13 @@ SPI = 250                     # steps between outputs: 50 000 steps / 200 output
 FREQ = 30.0
 DT = (2.0 / FREQ) / 50000.0
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md, chip-level parameters
-# algorithmic bytes per rigid unit per launch
-BYTES_FWD_STAGE = 272 + 72    # one RHS evaluation (quads + contact) + its share of the stage combine (432/6)
-BYTES_ADJ_STAGE = 272 + 96 + 256  # stage data + lambda/Ybar read-write + parameter-gradient RMW
-# with the stage checkpoint 5 of the 6 reverse launches of a step also rebuild the next stage record: the forward's stage
-# combine (72 B per stage, SURVEY 8(d): 432 B per 6 stages) moves into the reverse launch instead of a recompute launch
-BYTES_ADJ_STAGE_REBUILD = BYTES_ADJ_STAGE + 72 * 5 / 6
+# ALGORITHMIC bytes per rigid unit per launch
+BYTES_FWD_STAGE = 272 + 72          # one RHS evaluation (quads + contact) + its share of the stage combine (432 / 6)
+BYTES_ADJ_STAGE = 272 + 96 + 256    # stage data + lambda / Ybar read-write + parameter-gradient read-modify-write = 624
+ROOFLINE_LEG_STEPS = 250            # length of the per-launch measurement (1 stream, all members per launch), whatever K is
 
 
-def c3_problem(size, seed, members, lib=None, device=0):
+def c3_problem(size, seed, members, lib=None, device=0, input_delay=0.0, target_shift=None):
     from difflexmm_amd.problems import QuadsFocusingForward, TargetKineticEnergy
     spacing, bond = 15.0, 2.25
     rho, ksh, kr = 6.18e-9, 1.19, 1.5
@@ -50,12 +56,14 @@ def c3_problem(size, seed, members, lib=None, device=0):
                                  2 * math.sqrt(0.02175026 * rho * spacing ** 4 * kr)]) * np.ones((size * size, 1))
     fw = QuadsFocusingForward(
         n1_blocks=size, n2_blocks=size, spacing=spacing, bond_length=bond, k_stretch=120.0, k_shear=ksh, k_rot=kr,
-        density=rho, damping=damping, amplitude=7.5, loading_rate=FREQ, input_delay=0.1 / FREQ, n_excited_blocks=2,
+        density=rho, damping=damping, amplitude=7.5, loading_rate=FREQ, input_delay=input_delay, n_excited_blocks=2,
         loaded_side="left", input_shift=0, simulation_time=2.0 / FREQ, n_timepoints=201, use_contact=True,
         k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180, steps_per_interval=SPI,
         batch=members, device=device, _lib=lib)
     fw.setup()
-    obj = TargetKineticEnergy(fw, (2, 2), (size // 6, size // 5))
+    if target_shift is None:
+        target_shift = (1 - (size - 2) // 2, 0)        # columns 1-2 of the two driven rows: next to the driven blocks
+    obj = TargetKineticEnergy(fw, (2, 2), tuple(target_shift))
     designs = []
     for m in range(members):
         rng = np.random.default_rng(seed + m)
@@ -85,19 +93,24 @@ def prepare(fw, designs, n_steps, spi=SPI):
 
 
 def execute(fw, obj, adjoint=True, spi=SPI):
-    """The hot path on resident inputs: forward (+ objective + reverse sweep); returns device milliseconds + stats."""
+    """The hot path on resident inputs: forward (members start at rest: no upload) + objective + reverse sweep, gradients
+    returned as views of the engine's pinned result area; returns device milliseconds + stats."""
     eng = fw.solve_dynamics.engine
-    _, st_f = eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), fw.timepoints, fw.step_counts, keep_trajectory=adjoint,
-                          want_fields=False)
+    _, st_f = eng.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=adjoint, want_fields=False)
     out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "streams": max(1, int(st_f.get("streams", 1))),
            "objective": None, "adj_ms": 0.0, "adj_launches": 0}
     if adjoint:
-        out["objective"] = eng.objective_kinetic(obj.target_blocks)
-        grads, st_a = eng.adjoint_kinetic(obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
+        out["objective"], grads, st_a = eng.kinetic_value_and_grad(
+            obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
         out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
-        out["grad_norm"] = float(np.linalg.norm(grads["centroid_node_vectors"]))
+        out["grads"] = grads
     return out
+
+
+def grad_norm(res):
+    g = res.get("grads")
+    return None if g is None else float(np.sqrt(sum(float(np.vdot(a, a)) for a in g.values())))
 
 
 def spin_up(fw, n_steps=500, spi=SPI):
@@ -105,19 +118,45 @@ def spin_up(fw, n_steps=500, spi=SPI):
     for tens of milliseconds and the first launches after an idle period run at a lower clock."""
     eng = fw.solve_dynamics.engine
     ts = np.arange(n_steps // spi + 1) * (spi * DT)
-    eng.forward(np.zeros((eng.batch, 2, eng.n_blocks, 3)), ts, spi, keep_trajectory=False, want_fields=False)
+    eng.forward(None, ts, spi, keep_trajectory=False, want_fields=False)
 
 
 def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
     prepare(fw, designs, n_steps, spi)
-    if fw.solve_dynamics.engine.lib.dfx_device_count() > 0:
-        spin_up(fw, spi=spi) if spi == SPI else None
+    if fw.solve_dynamics.engine.lib.dfx_device_count() > 0 and spi == SPI:
+        spin_up(fw, spi=spi)
     return execute(fw, obj, adjoint, spi)
 
 
-def cpu_baseline(size, seed, budget_s=20.0):
+def usable_cpus():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host is
+    often granted a handful; spinning 256 OpenMP threads on them takes minutes per step)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = float(txt[0])
+                period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
     """The CPU port of the oracle (same algorithm, same tableau, OpenMP over blocks) on a bounded sample of the same
-    workload: forward + adjoint of a few steps of the same lattice.  Thread count: the best of a short sweep."""
+    workload: `n_steps` Dopri5 steps forward + adjoint of the same lattice, one member.  SURVEY 8(d) protocol: 1 thread and
+    all usable cores, one warm-up run, median of `repeats` timed runs each; `value` is the faster of the two.  A 4-step probe
+    per leg shortens the sample when the host is too slow for the time budget (and says so)."""
     import ctypes
     from oracle.cpu import load
     lib = load()
@@ -125,32 +164,85 @@ def cpu_baseline(size, seed, budget_s=20.0):
         gomp = ctypes.CDLL("libgomp.so.1")
     except OSError:
         gomp = None
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     fw, obj, designs = c3_problem(size, seed, 1, lib=lib)
-    ncpu = os.cpu_count() or 1
-    run_once(fw, obj, designs, 2, spi=2)                      # touch everything once
-    best = (None, 0.0)
-    for nt in sorted({1, min(8, ncpu), min(32, ncpu), min(96, ncpu)}):
+    ncpu = usable_cpus()
+    thread_counts = [1, ncpu] if gomp is not None and ncpu > 1 else [1]
+    legs, notes = {}, []
+    for nt in thread_counts:
         if gomp is not None:
             gomp.omp_set_num_threads(nt)
-        elif nt != 1:
-            continue
+        prepare(fw, designs, 4, spi=2)
+        execute(fw, obj, spi=2)                                # touch everything once
         prepare(fw, designs, 4, spi=2)
         t0 = time.perf_counter()
         execute(fw, obj, spi=2)
-        rate = 4 / (time.perf_counter() - t0)
-        if rate > best[1]:
-            best = (nt, rate)
-    nt, rate = best
-    if gomp is not None:
-        gomp.omp_set_num_threads(nt)
-    n = int(max(4, min(2000, (budget_s * rate) // 2 * 2)))
-    prepare(fw, designs, n, spi=2)               # same split as the GPU leg: inputs prepared outside the timed region
-    t0 = time.perf_counter()
-    execute(fw, obj, spi=2)
-    dt = time.perf_counter() - t0
-    return {"value": n * size * size / dt, "unit": "timesteps*units/s", "cores": nt, "kind": "port",
-            "sample": f"{n} Dopri5 steps forward+adjoint of the same {size}x{size} lattice, 1 member "
-                      f"(C++ port of the oracle, OpenMP, {nt} threads = best of a sweep on {ncpu} logical CPUs)"}
+        per_step = (time.perf_counter() - t0) / 4
+        n = n_steps
+        leg_budget = budget_s / len(thread_counts)
+        if per_step * n * (repeats + 1) > leg_budget:
+            n = int(max(4, leg_budget / (per_step * (repeats + 1)) // 2 * 2))
+            notes.append(f"{nt} thread(s): {n} steps instead of {n_steps} (time budget)")
+        spi = min(n, 50)
+        prepare(fw, designs, n, spi=spi)
+        execute(fw, obj, spi=spi)                              # warm-up (first call excluded, scripts/pulse_RS.py:93-108)
+        times = []
+        for _ in range(repeats):
+            prepare(fw, designs, n, spi=spi)                  # same split as the GPU leg: inputs prepared outside the timed region
+            t0 = time.perf_counter()
+            execute(fw, obj, spi=spi)
+            times.append(time.perf_counter() - t0)
+        legs[nt] = n * size * size / float(np.median(times))
+    best = max(legs, key=legs.get)
+    return {"value": legs[best], "unit": "timesteps*units/s", "cores": best, "kind": "port",
+            "one_thread": legs.get(1), "all_cores": legs.get(ncpu) if ncpu > 1 else None, "usable_cpus": ncpu,
+            "logical_cpus": os.cpu_count(),
+            "sample": f"{n_steps} Dopri5 steps forward+adjoint of the same {size}x{size} lattice, 1 member; C++ port of the "
+                      f"oracle (OpenMP over blocks), 1 thread and {ncpu} threads, 1 warm-up + median of {repeats} runs each"
+                      + ("; " + "; ".join(notes) if notes else "")}
+
+
+def launch_ranks(n, argv):
+    """`--gpus N` without a launcher: start the N rank processes (fresh interpreters, before this process has made any GPU
+    call), relay rank 0's output, return the worst exit code."""
+    import socket
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    uid_file = os.path.join(tempfile.gettempdir(), f"dfx_uid_{port}_{os.getpid()}")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DFX_UID_FILE=uid_file, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    return max(p.wait() for p in procs)
+
+
+def make_comm(args, world, rank, local_rank):
+    """Communicator of the N > 1 run.  RCCL (inside libdfx) is the collective; a TCP control channel comes first so that the
+    ranks agree on whether it came up -- if it did not on any rank, all of them say so in the JSON line and gather the
+    objectives over the control channel instead of hanging."""
+    from difflexmm_amd import ensemble
+    if world == 1:
+        return ensemble.SerialComm(), "none (1 rank)"
+    ctrl = ensemble.SocketComm(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                               int(os.environ.get("DFX_SOCKET_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 11)))
+    if args.backend == "socket":
+        return ctrl, "socket (rehearsal)"
+    err = ""
+    comm = None
+    try:
+        comm = ensemble.init_from_env("rccl", device=local_rank)
+    except Exception as e:            # noqa: BLE001 -- reported, not swallowed
+        err = f"{type(e).__name__}: {e}"
+    ok = ctrl.all_reduce([0.0 if err else 1.0], "min")[0] > 0
+    if ok:
+        return comm, "rccl"
+    if rank == 0:
+        print(f"bench: RCCL did not come up ({err or 'on another rank'}); objectives gathered over TCP", file=sys.stderr)
+    return ctrl, f"socket-fallback ({err or 'rccl failed on another rank'})"
 
 
 def main():
@@ -166,87 +258,86 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="member groups advanced concurrently, one HIP stream each")
     ap.add_argument("--no-single", action="store_true", help="skip the extra 1-member reference measurement")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
+    ap.add_argument("--no-roofline-leg", action="store_true", help="skip the separate 1-stream per-launch measurement")
+    ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx) | socket (rehearsal on one GPU)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
+    ap.add_argument("--input-delay", type=float, default=0.0, help="pulse delay in s (C3 text: 0.1/f = 3.33e-3)")
+    ap.add_argument("--target-shift", type=int, nargs=2, default=None, help="target placement (C3 text: 21 25); default: next to the drive")
     args = ap.parse_args()
-    if not os.path.exists(os.path.join(ROOT, "difflexmm_amd", "libdfx.so")):
-        # build artefact missing (fresh checkout): compile it the way __graft_entry__.build() does, before any GPU call
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "difflexmm_amd", "csrc")], stdout=subprocess.DEVNULL)
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    import torch
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not os.path.exists(os.path.join(ROOT, "difflexmm_amd", "libdfx.so")):
+        # build artefact missing (fresh checkout): compile it the way __graft_entry__.build() does, before any GPU call
+        if rank == 0:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "difflexmm_amd", "csrc")], stdout=subprocess.DEVNULL)
+        else:
+            while not os.path.exists(os.path.join(ROOT, "difflexmm_amd", "libdfx.so")):
+                time.sleep(0.5)
+    from difflexmm_amd import _binding as B
     if args.all_ranks_device >= 0:
         local_rank = args.all_ranks_device
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    dev = "cuda" if args.backend == "nccl" else "cpu"
+    comm, collective = make_comm(args, world, rank, local_rank)
     os.environ["DFX_STREAMS"] = str(args.streams)
     K = max(1, args.steps)                      # EXACTLY K steps are timed
     W = max(0, args.warmup)
+    adjoint = not args.forward_only
     requested_members = args.members
-    if not args.forward_only and args.backend == "nccl":
+    prob = dict(input_delay=args.input_delay, target_shift=args.target_shift)
+    reserve_steps = max(K, W, ROOFLINE_LEG_STEPS)
+    if adjoint:
         # the reverse sweep reads a checkpoint of every step: 72 B per unit per step per member
-        free_b, _ = torch.cuda.mem_get_info(local_rank)
+        free_b, total_b = B.mem_info(local_rank)
         per_member = 72.0 * args.size * args.size * (max(K, W) + 1) + 64e6
         args.members = max(1, min(args.members, int(0.85 * free_b / per_member)))
-        if dist is not None:                    # same work on every rank (weak scaling): take the smallest cap
-            tm = torch.tensor([args.members], device=dev, dtype=torch.int64)
-            dist.all_reduce(tm, op=dist.ReduceOp.MIN)
-            args.members = int(tm.item())
+        args.members = int(comm.all_reduce([float(args.members)], "min")[0])     # same work on every rank (weak scaling)
         if args.members < args.streams:
             args.streams = args.members
             os.environ["DFX_STREAMS"] = str(args.streams)
         # Stage checkpoint (+120 B per unit and step: the reverse sweep then needs no recompute launches): the engine takes
-        # it whenever it fits; decide here, by the same rule, so that the roofline leg below and the timed job run the
-        # same kernels.
+        # it whenever it fits; decide here, by the same rule, so that every leg below runs the same kernels.
         if "DFX_STAGE_CHECKPOINT" not in os.environ:
-            free_b, total_b = torch.cuda.mem_get_info(local_rank)
             need = (72.0 * (max(K, W) + 1) + 120.0 * max(K, W)) * args.size * args.size * args.members
             os.environ["DFX_STAGE_CHECKPOINT"] = "1" if need + 0.05 * total_b + 2e9 < free_b else "0"
-    # (1) per-launch roofline of the dominant kernel: ONE stream, every launch integrates all `members` designs.
-    #     This is the regime rocprofv3 can observe (its kernel trace serialises queues): `python bench.py --streams 1` under
-    #     rocprofv3 --kernel-trace --stats reports the same average duration.  Measured on rank 0 BEFORE the timed job, on
-    #     its own engine (closed again: HIP multiplexes streams onto few hardware queues, and the big checkpoint of the
-    #     timed job is allocated afterwards).
+
+    def sync():
+        B.device_synchronize(local_rank)
+
+    # (1) per-launch roofline of the two stage kernels: ONE stream, every launch integrates all `members` designs, a fixed
+    #     ROOFLINE_LEG_STEPS steps whatever K is (a 20-step region is too short to average over).  This is the regime
+    #     rocprofv3 can observe (its kernel trace serialises queues): `python bench.py --streams 1 --steps 250` under
+    #     rocprofv3 --kernel-trace --stats reports the same average durations (profiles/).  Rank 0, before the timed job, on its
+    #     own engine (closed again before the big checkpoint of the timed job is allocated).
     rr = None
-    if rank == 0 and args.streams > 1:
+    if rank == 0 and not args.no_roofline_leg:
         os.environ["DFX_STREAMS"] = "1"
-        fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
+        fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank, **prob)
         os.environ["DFX_STREAMS"] = str(args.streams)
-        Kr = min(K, 1000)
-        fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 2, keep_trajectory=not args.forward_only)
-        run_once(fwr, objr, desr, SPI, adjoint=not args.forward_only)
-        if Kr % SPI:
-            run_once(fwr, objr, desr, Kr % SPI, adjoint=not args.forward_only)
-        torch.cuda.synchronize()
-        rr = run_once(fwr, objr, desr, Kr, adjoint=not args.forward_only)
+        Kr = ROOFLINE_LEG_STEPS
+        fwr.solve_dynamics.engine.reserve(Kr, Kr // SPI + 2, keep_trajectory=adjoint)
+        run_once(fwr, objr, desr, Kr, adjoint=adjoint)           # warm-up of the same length (graphs, clocks)
+        sync()
+        rr = run_once(fwr, objr, desr, Kr, adjoint=adjoint)
+        rr.pop("grads", None)
         fwr.solve_dynamics.engine.close()
         del fwr, objr
     single = None
-    if rank == 0 and world == 1 and args.members > 1 and not args.forward_only and not args.no_single:
-        # the same config with ONE design per GPU (launch-bound: one wave per SIMD), for reference; measured before the
-        # timed job (the first solves after releasing a > 200 GB checkpoint were seen to run at half speed)
-        fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank)
-        K1 = min(K, 2500)
+    if rank == 0 and world == 1 and args.members > 1 and adjoint and not args.no_single:
+        # the same config with ONE design per GPU (launch-bound: one wave per SIMD), for reference
+        fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank, **prob)
+        K1 = min(max(K, 250), 2500)
         fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 2, keep_trajectory=True)
-        run_once(fw1, obj1, des1, SPI)
-        if K1 % SPI:
-            run_once(fw1, obj1, des1, K1 % SPI)
+        run_once(fw1, obj1, des1, K1)
         prepare(fw1, des1, K1)
         spin_up(fw1)
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
         r1 = execute(fw1, obj1)
-        torch.cuda.synchronize()
+        sync()
         w1 = time.perf_counter() - t1
         single = {"members_per_gpu": 1, "steps": K1, "value": K1 * args.size * args.size / w1,
                   "forward_only_value": K1 * args.size * args.size / (r1["fwd_ms"] * 1e-3),
@@ -254,23 +345,22 @@ def main():
                   "stage_checkpoint": bool(r1.get("stage_checkpoint", False)),
                   "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
         fw1.solve_dynamics.engine.close()
-        del fw1, obj1
-    fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank)
-    fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=not args.forward_only)
+        del fw1, obj1, r1
+    fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank, **prob)
+    fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=adjoint)
     if W:
-        run_once(fw, obj, designs, W, adjoint=not args.forward_only)
+        run_once(fw, obj, designs, W, adjoint=adjoint)
     # hipGraphs are instantiated on first use: make sure every segment length the K timed steps replay has been used once
     # (a full output interval and the shorter last interval), whatever W was
     if K >= SPI and (W < SPI or W % SPI):
-        run_once(fw, obj, designs, SPI, adjoint=not args.forward_only)
+        run_once(fw, obj, designs, SPI, adjoint=adjoint)
     if K % SPI:
-        run_once(fw, obj, designs, K % SPI, adjoint=not args.forward_only)
+        run_once(fw, obj, designs, K % SPI, adjoint=adjoint)
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+        comm.barrier()
+        sync()
 
     tp0 = time.perf_counter()
     prepare(fw, designs, K)                    # inputs resident in HBM before the timed region
@@ -278,25 +368,20 @@ def main():
     spin_up(fw)
     barrier()
     t0 = time.perf_counter()
-    res = execute(fw, obj, adjoint=not args.forward_only)
+    res = execute(fw, obj, adjoint=adjoint)
     barrier()
     wall = time.perf_counter() - t0
+    gnorm = grad_norm(res)
     objective = res["objective"] if res["objective"] is not None else np.zeros(args.members)
-    if dist is not None:
-        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-        mine = torch.tensor(np.asarray(objective, dtype=np.float64), device=dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)          # the single collective of the path: objectives over xGMI
-        objective = torch.cat(gathered).cpu().numpy()
+    wall = float(comm.all_reduce([wall], "max")[0])                    # MAX over ranks
+    objective = comm.all_gather(objective).ravel()                     # the single collective of the path: objectives over xGMI
     if rank == 0:
         n_units = args.size * args.size
         total_units_steps = K * n_units * args.members * world
         streams = res["streams"]
 
         def per_launch(r, n_streams):
-            """(fwd launch us, adj launch us): region device time / launches issued per stream."""
+            """(fwd launch us, adj launch us): region device time (HIP events on the engine's stream) / launches per stream."""
             f_us = 1e3 * r["fwd_ms"] / max(1.0, r["fwd_launches"] / n_streams)
             a_us = None
             if r["adj_launches"] and r.get("stage_checkpoint"):
@@ -307,71 +392,86 @@ def main():
             return f_us, a_us
 
         fw.solve_dynamics.engine.close()
-        if rr is None:
-            rr = res
-        fwd_us, adj_us = per_launch(rr, 1)
-        roof_bytes = BYTES_FWD_STAGE * n_units * args.members
-        achieved = roof_bytes / (fwd_us * 1e-6) / 1e9
+        leg = rr if rr is not None else res
+        leg_streams = 1 if rr is not None else streams
+        fwd_us, adj_us = per_launch(leg, leg_streams)
+        mpl = args.members / leg_streams
+        traffic = load_pmc_traffic()
+
+        def roof(kernel, bytes_per_unit, us, extra=None):
+            ach = bytes_per_unit * n_units * mpl / (us * 1e-6) / 1e9
+            d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                 "traffic": None, "algorithmic_bytes_per_unit": bytes_per_unit, "bytes_per_launch": bytes_per_unit * n_units * mpl,
+                 "launch_us": us, "members_per_launch": mpl,
+                 "measured_with": (f"separate leg: 1 stream, {ROOFLINE_LEG_STEPS} steps, HIP events on the engine's stream around the "
+                                   "region / launches" if rr is not None else "the timed region / launches per stream")}
+            d.update(extra or {})
+            return d
+
         line = {
-            "metric": "timesteps*rigid-units/s (forward + adjoint)" if not args.forward_only else "timesteps*rigid-units/s (forward)",
+            "metric": "timesteps*rigid-units/s (forward + adjoint)" if adjoint else "timesteps*rigid-units/s (forward)",
             "value": total_units_steps / wall, "unit": "timesteps*units/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * wall / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C3: {args.size}x{args.size} quads, nonlinear ligaments + damping + angle contact, "
                                    f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
-                                   f"{'forward only' if args.forward_only else 'forward + adjoint wrt 66048 geometry params'}",
+                                   f"{'forward + adjoint wrt 66048 geometry params' if adjoint else 'forward only'}",
                        "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams,
                        "stage_checkpoint": bool(res.get("stage_checkpoint", False)), "integrator": "dopri5-fixed",
-                       "steps_per_output": SPI},
+                       "steps_per_output": SPI, "input_delay_s": args.input_delay,
+                       "target_blocks": [int(b) for b in obj.target_blocks], "collective": collective},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
             "host_prepare_ms": host_prepare_ms, "value_with_host_prepare": total_units_steps / (wall + 1e-3 * host_prepare_ms),
             "launches": {"forward": res["fwd_launches"], "adjoint": res["adj_launches"]},
-            "objective": [float(x) for x in np.atleast_1d(objective)][:8],
-            "roofline": {"bound": "hbm", "kernel": "k_fwd_stage<nonlinear,contact>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(args.members),
-                         "bytes_per_launch": roof_bytes, "launch_us": fwd_us, "members_per_launch": args.members,
-                         "measured_with": "1 stream, HIP events around the forward region / launches"},
+            "objective": [float(x) for x in np.atleast_1d(objective)][:8], "grad_norm": gnorm,
         }
         if adj_us:
-            adj_bytes = BYTES_ADJ_STAGE_REBUILD if rr.get("stage_checkpoint") else BYTES_ADJ_STAGE
-            a2 = adj_bytes * n_units * args.members / (adj_us * 1e-6) / 1e9
-            line["roofline_adjoint_kernel"] = {"kernel": "k_adj_stage<nonlinear,contact>", "achieved": a2, "peak": HBM_PEAK_GBS,
-                                               "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS, "launch_us": adj_us,
-                                               "bytes_per_launch": adj_bytes * n_units * args.members,
-                                               "rebuilds_stage_records": bool(rr.get("stage_checkpoint"))}
+            # the dominant kernel: the reverse stage.  SURVEY 8(d) counts 624 B per unit; with the stage checkpoint 5 of the 6
+            # reverse launches of a step also rebuild a stage record (+60 B on average: the forward's stage combine moved here)
+            line["roofline"] = roof("k_adj_stage<nonlinear,contact>", BYTES_ADJ_STAGE, adj_us,
+                                    {"rebuilds_stage_records": bool(leg.get("stage_checkpoint")),
+                                     "own_count_bytes_per_unit": BYTES_ADJ_STAGE + (60 if leg.get("stage_checkpoint") else 0),
+                                     "traffic": None if traffic is None else traffic.get("k_adj_stage_bytes_per_member_launch", 0) * mpl or None,
+                                     "traffic_source": None if traffic is None else traffic.get("source")})
+            line["roofline_forward_kernel"] = roof("k_fwd_stage<nonlinear,contact>", BYTES_FWD_STAGE, fwd_us,
+                                                   {"traffic": None if traffic is None else traffic.get("k_fwd_stage_bytes_per_member_launch", 0) * mpl or None})
+        else:
+            line["roofline"] = roof("k_fwd_stage<nonlinear,contact>", BYTES_FWD_STAGE, fwd_us,
+                                    {"traffic": None if traffic is None else traffic.get("k_fwd_stage_bytes_per_member_launch", 0) * mpl or None,
+                                     "traffic_source": None if traffic is None else traffic.get("source")})
         if streams > 1:
             # (2) the timed job itself: `streams` member groups overlap on the chip; aggregate algorithmic bytes / region time
             f_eff, a_eff = per_launch(res, streams)
             agg = {"concurrent_streams": streams, "members_per_launch": args.members / streams,
-                   "fwd_stage_period_us": f_eff, "fwd_achieved": roof_bytes / (f_eff * 1e-6) / 1e9}
+                   "fwd_stage_period_us": f_eff, "fwd_achieved": BYTES_FWD_STAGE * n_units * args.members / (f_eff * 1e-6) / 1e9}
             agg["fwd_frac"] = agg["fwd_achieved"] / HBM_PEAK_GBS
             if a_eff:
                 agg["adj_stage_period_us"] = a_eff
-                agg["adj_achieved"] = (BYTES_ADJ_STAGE_REBUILD if res.get("stage_checkpoint") else BYTES_ADJ_STAGE) * n_units * args.members / (a_eff * 1e-6) / 1e9
+                agg["adj_achieved"] = BYTES_ADJ_STAGE * n_units * args.members / (a_eff * 1e-6) / 1e9
                 agg["adj_frac"] = agg["adj_achieved"] / HBM_PEAK_GBS
             line["roofline_concurrent"] = agg
+        # end to end in SURVEY 8(d)'s per-step accounting: 2 064 B forward + 3 792 B reverse per step and unit
+        per_step_bytes = (6 * BYTES_FWD_STAGE) + (48 + 6 * BYTES_ADJ_STAGE if adjoint else 0)
+        line["end_to_end_frac_of_hbm_peak"] = per_step_bytes * total_units_steps / wall / 1e9 / HBM_PEAK_GBS
         if single is not None:
             line["single_system"] = single
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.size, 3)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
-def load_pmc_traffic(members_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
-    bytes per member and launch, with the guide's x2 correction of FETCH_SIZE), or null."""
+def load_pmc_traffic():
+    """HBM bytes per member and launch of the two stage kernels from this round's committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json: FETCH_SIZE with the guide's x2 correction for gfx950 + WRITE_SIZE, separate passes), or None.
+    Counters cannot be read from inside the run; the file names the command they were collected with."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(p):
-        try:
-            d = json.load(open(p))
-            return d.get("k_fwd_stage_bytes_per_member_launch") * members_per_launch
-        except Exception:
-            return None
-    return None
+    try:
+        return json.load(open(p))
+    except Exception:       # noqa: BLE001
+        return None
 
 
 if __name__ == "__main__":

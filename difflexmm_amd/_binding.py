@@ -55,6 +55,11 @@ EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx
            "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
+# multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
+COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rank", "dfx_comm_size",
+                "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
+                "dfx_mem_info", "dfx_device_synchronize"]
+EXPORTS = EXPORTS + COMM_EXPORTS
 
 
 def declare(lib):
@@ -81,9 +86,36 @@ def declare(lib):
     lib.dfx_device_count.restype = C.c_int
     lib.dfx_version.restype = C.c_char_p
     for name in EXPORTS:
-        if name not in ("dfx_last_error", "dfx_version"):
+        if name not in ("dfx_last_error", "dfx_version", "dfx_comm_last_error") and (name not in COMM_EXPORTS or hasattr(lib, name)):
             getattr(lib, name).restype = C.c_int
+    if hasattr(lib, "dfx_comm_init"):
+        lib.dfx_comm_unique_id.argtypes = [C.c_char_p]
+        lib.dfx_comm_init.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(H)]
+        for n in ("dfx_comm_destroy", "dfx_comm_rank", "dfx_comm_size", "dfx_comm_barrier"):
+            getattr(lib, n).argtypes = [H]
+        lib.dfx_gather_objectives.argtypes = [H, _dp, C.c_int32, _dp]
+        lib.dfx_reduce_grads.argtypes = [H, _dp, C.c_int64]
+        lib.dfx_comm_allreduce.argtypes = [H, _dp, C.c_int64, C.c_int32]
+        lib.dfx_comm_last_error.argtypes = []
+        lib.dfx_comm_last_error.restype = C.c_char_p
+        lib.dfx_mem_info.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.dfx_device_synchronize.argtypes = [C.c_int32]
     return lib
+
+
+def mem_info(device=0, lib=None):
+    """(free, total) bytes of HBM on a device."""
+    lib = lib if lib is not None else load_library()
+    f, t = C.c_int64(0), C.c_int64(0)
+    if lib.dfx_mem_info(int(device), C.byref(f), C.byref(t)) != 0:
+        raise RuntimeError("dfx_mem_info failed: " + lib.dfx_comm_last_error().decode())
+    return f.value, t.value
+
+
+def device_synchronize(device=0, lib=None):
+    lib = lib if lib is not None else load_library()
+    if lib.dfx_device_synchronize(int(device)) != 0:
+        raise RuntimeError("dfx_device_synchronize failed: " + lib.dfx_comm_last_error().decode())
 
 
 _LIB = None

@@ -2,26 +2,230 @@
 
 Reference: the only multi-device construct of DifFlexMM is one ``pmap`` over independent forward inputs
 (``problems/quads_kinetic_energy_static_tuning.py:454-478``) and the sequential list of forward problems in
-``problems/quads_focusing_multi_input.py:66-77``.  Here: one process per GPU (``torch.distributed``; backend "nccl" is
-RCCL over xGMI on ROCm, "gloo" on CPU for tests), members are dealt to ranks in contiguous equal chunks, every rank
-integrates its members with no data-path communication, and the objectives (8 B per member) are combined with ONE
-``all_gather`` -- latency-bound, so ring vs tree is irrelevant.  Gradients of different designs stay on their rank;
-gradients w.r.t. a SHARED design (multi-input problems) are summed with one ``all_reduce``.
+``problems/quads_focusing_multi_input.py:66-77``.  Here: one process per GPU, members are dealt to ranks in contiguous equal
+chunks, every rank integrates its members with no data-path communication, and the objectives (8 B per member) are
+combined with ONE all-gather -- latency-bound, so ring vs tree is irrelevant.  Gradients of different designs stay on their
+rank; gradients w.r.t. a SHARED design (multi-input problems) are summed with one all-reduce.
+
+The collective is native: ``RcclComm`` calls ``dfx_comm_init / dfx_gather_objectives / dfx_reduce_grads`` of libdfx (RCCL
+over xGMI inside the library, ``include/dfx.h``); the unique id travels from rank 0 to the others through a file named by the
+launcher (``DFX_UID_FILE``, or derived from ``MASTER_PORT`` and the launcher's pid).  ``SocketComm`` is a plain-TCP stand-in
+with the same methods for rehearsing the N > 1 path where RCCL cannot run (several ranks on ONE GPU, or no GPU at all);
+any object with ``rank``, ``world``, ``all_gather``, ``all_reduce`` and ``barrier`` can be passed as ``comm=``.
+No PyTorch anywhere in this module.
 """
+import ctypes as C
+import os
+import pickle
+import socket
+import struct
+import time
+
 import numpy as np
 
-
-def _dist():
-    import sys
-    if "torch.distributed" not in sys.modules:      # nobody initialised a process group: single process, no torch import
-        return None
-    import torch.distributed as dist
-    return dist if dist.is_available() and dist.is_initialized() else None
+_DEFAULT = None          # communicator used when a function is called without comm=
 
 
-def world():
-    d = _dist()
-    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+class SerialComm:
+    rank, world = 0, 1
+
+    def all_gather(self, local):
+        return np.asarray(local, dtype=np.float64)[None].copy()
+
+    def all_reduce(self, array, op="sum"):
+        return np.array(array, dtype=np.float64, copy=True)
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class RcclComm:
+    """RCCL over xGMI through libdfx (one rank per GPU)."""
+
+    def __init__(self, rank, world, device, uid_file, lib=None, timeout=300.0):
+        from ._binding import load_library
+        self.lib = lib if lib is not None else load_library()
+        self.rank, self.world = int(rank), int(world)
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(self.lib.dfx_comm_unique_id(uid), "dfx_comm_unique_id")
+            tmp = f"{uid_file}.tmp{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(uid.raw)
+            os.replace(tmp, uid_file)                     # atomic: readers see nothing or all 128 bytes
+        else:
+            t0 = time.time()
+            while not (os.path.exists(uid_file) and os.path.getsize(uid_file) == 128):
+                if time.time() - t0 > timeout:
+                    raise RuntimeError(f"RcclComm: rank 0 did not publish {uid_file} within {timeout} s")
+                time.sleep(0.01)
+            with open(uid_file, "rb") as f:
+                uid = C.create_string_buffer(f.read(), 128)
+        self._c = C.c_void_p()
+        self._check(self.lib.dfx_comm_init(self.rank, self.world, uid, int(device), C.byref(self._c)), "dfx_comm_init")
+        self.barrier()
+        if self.rank == 0:
+            try:
+                os.remove(uid_file)
+            except OSError:
+                pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: " + self.lib.dfx_comm_last_error().decode())
+
+    def all_gather(self, local):
+        local = np.ascontiguousarray(local, dtype=np.float64).ravel()
+        out = np.empty((self.world, local.size))
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.dfx_gather_objectives(self._c, local.ctypes.data_as(dp), local.size, out.ctypes.data_as(dp)),
+                    "dfx_gather_objectives")
+        return out
+
+    def all_reduce(self, array, op="sum"):
+        a = np.array(array, dtype=np.float64, copy=True, order="C")
+        dp = C.POINTER(C.c_double)
+        if op == "sum":
+            self._check(self.lib.dfx_reduce_grads(self._c, a.ctypes.data_as(dp), a.size), "dfx_reduce_grads")
+        else:
+            self._check(self.lib.dfx_comm_allreduce(self._c, a.ctypes.data_as(dp), a.size, {"max": 1, "min": 2}[op]),
+                        "dfx_comm_allreduce")
+        return a
+
+    def barrier(self):
+        self._check(self.lib.dfx_comm_barrier(self._c), "dfx_comm_barrier")
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self.lib.dfx_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+
+class SocketComm:
+    """The same three operations over TCP through rank 0 (a star; payloads are a few bytes to a few KB).  A stand-in for
+    rehearsals and CPU tests -- not the production collective."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=29511, timeout=300.0):
+        self.rank, self.world = int(rank), int(world)
+        self._peers = []
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, int(port)))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            peers = {}
+            while len(peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                peers[self._recv(conn)] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    s = socket.create_connection((addr, int(port)), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() - t0 > timeout:
+                        raise
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._send(s, self.rank)
+            self._peers = [s]
+
+    @staticmethod
+    def _send(sock, obj):
+        data = pickle.dumps(obj, protocol=4)
+        sock.sendall(struct.pack("<Q", len(data)) + data)
+
+    @staticmethod
+    def _recv(sock):
+        def read(n):
+            buf = b""
+            while len(buf) < n:
+                chunk = sock.recv(n - len(buf))
+                if not chunk:
+                    raise ConnectionError("SocketComm: peer closed the connection")
+                buf += chunk
+            return buf
+        (n,) = struct.unpack("<Q", read(8))
+        return pickle.loads(read(n))
+
+    def _exchange(self, local, combine):
+        if self.world == 1:
+            return combine([local])
+        if self.rank == 0:
+            parts = [local] + [self._recv(p) for p in self._peers]
+            out = combine(parts)
+            for p in self._peers:
+                self._send(p, out)
+            return out
+        self._send(self._peers[0], local)
+        return self._recv(self._peers[0])
+
+    def all_gather(self, local):
+        return self._exchange(np.asarray(local, dtype=np.float64).ravel(), lambda parts: np.stack(parts))
+
+    def all_reduce(self, array, op="sum"):
+        f = {"sum": np.sum, "max": np.max, "min": np.min}[op]
+        return self._exchange(np.asarray(array, dtype=np.float64), lambda parts: f(np.stack(parts), axis=0))
+
+    def barrier(self):
+        self._exchange(0.0, lambda parts: 0.0)
+
+    def close(self):
+        for p in self._peers:
+            try:
+                p.close()
+            except OSError:
+                pass
+        self._peers = []
+
+
+def init_from_env(backend="rccl", device=None, lib=None):
+    """Communicator of this process from the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT --
+    what ``torch.distributed.run`` and ``bench.py``'s own launcher export) and make it the module default."""
+    global _DEFAULT
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world_size == 1:
+        _DEFAULT = SerialComm()
+    elif backend == "rccl":
+        port = os.environ.get("MASTER_PORT", "29500")
+        # all ranks of one launch share the launcher process: its pid tells two launches on the same port apart
+        uid_file = os.environ.get("DFX_UID_FILE") or os.path.join(
+            os.environ.get("TMPDIR", "/tmp"), f"dfx_uid_{port}_{os.getppid()}")
+        _DEFAULT = RcclComm(rank, world_size, local_rank if device is None else device, uid_file, lib=lib)
+    elif backend == "socket":
+        _DEFAULT = SocketComm(rank, world_size, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                              int(os.environ.get("DFX_SOCKET_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 11)))
+    else:
+        raise ValueError(f"unknown backend {backend!r} (rccl | socket)")
+    return _DEFAULT
+
+
+def set_default(comm):
+    global _DEFAULT
+    _DEFAULT = comm
+
+
+def _comm(comm):
+    if comm is not None:
+        return comm
+    return _DEFAULT if _DEFAULT is not None else SerialComm()
+
+
+def world(comm=None):
+    c = _comm(comm)
+    return c.rank, c.world
 
 
 def shard_bounds(n_items, rank, world_size):
@@ -31,45 +235,29 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _tensor(x):
-    import torch
-    d = _dist()
-    t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64))
-    if d is not None and d.get_backend() == "nccl":
-        t = t.cuda()
-    return t
-
-
-def gather_objectives(local_values, n_total):
-    """All ranks receive the (n_total,) vector of objectives in member order."""
-    import torch
-    d = _dist()
+def gather_objectives(local_values, n_total, comm=None):
+    """All ranks receive the (n_total,) vector of objectives in member order (ONE all-gather of equal-size slots)."""
+    c = _comm(comm)
     local_values = np.atleast_1d(np.asarray(local_values, dtype=np.float64))
-    if d is None:
+    if c.world == 1:
         return local_values
-    rank, ws = d.get_rank(), d.get_world_size()
-    width = -(-n_total // ws)                      # equal-size slots so one all_gather suffices
+    width = -(-n_total // c.world)
     buf = np.zeros(width)
     buf[:len(local_values)] = local_values
-    mine = _tensor(buf)
-    out = [torch.empty_like(mine) for _ in range(ws)]
-    d.all_gather(out, mine)
+    out = c.all_gather(buf)
     parts = []
-    for r in range(ws):
-        lo, hi = shard_bounds(n_total, r, ws)
-        parts.append(out[r].cpu().numpy()[:hi - lo])
+    for r in range(c.world):
+        lo, hi = shard_bounds(n_total, r, c.world)
+        parts.append(out[r][:hi - lo])
     return np.concatenate(parts)
 
 
-def sum_shared_gradients(arrays):
-    """Sum gradient arrays of a design shared by all ranks (one all_reduce over the flattened concatenation)."""
-    import torch
-    d = _dist()
-    if d is None:
+def sum_shared_gradients(arrays, comm=None):
+    """Sum gradient arrays of a design shared by all ranks (one all-reduce over the flattened concatenation)."""
+    c = _comm(comm)
+    if c.world == 1:
         return arrays
-    flat = _tensor(np.concatenate([np.ravel(a) for a in arrays]))
-    d.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
-    flat = flat.cpu().numpy()
+    flat = c.all_reduce(np.concatenate([np.ravel(a) for a in arrays]), "sum")
     out, pos = [], 0
     for a in arrays:
         out.append(flat[pos:pos + a.size].reshape(np.shape(a)))
@@ -77,12 +265,12 @@ def sum_shared_gradients(arrays):
     return out
 
 
-def evaluate_ensemble(objective, designs):
+def evaluate_ensemble(objective, designs, comm=None):
     """Every rank evaluates ``objective.value_and_grad`` on its chunk of ``designs`` (as one batch if the forward
     problem was set up with ``batch`` = chunk size, else one by one) and returns (all objectives, local gradients,
     (lo, hi))."""
-    rank, ws = world()
-    lo, hi = shard_bounds(len(designs), rank, ws)
+    c = _comm(comm)
+    lo, hi = shard_bounds(len(designs), c.rank, c.world)
     mine = list(designs[lo:hi])
     batch = getattr(objective.forward, "batch", 1)
     vals, grads = [], []
@@ -94,4 +282,4 @@ def evaluate_ensemble(objective, designs):
         for dsg in mine:
             v, g = objective.value_and_grad(dsg)
             vals.append(float(v)); grads.append(g)
-    return gather_objectives(vals, len(designs)), grads, (lo, hi)
+    return gather_objectives(vals, len(designs), c), grads, (lo, hi)

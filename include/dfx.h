@@ -194,6 +194,31 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy);
 int dfx_device_count(void);
 const char* dfx_version(void);
 
+/* ---- multi-GPU: one process per GPU, independent members per rank, ONE collective per evaluation -------------
+ * Replaces the reference's pmap over forward inputs + host sum (problems/quads_kinetic_energy_static_tuning.py:454-478) and the
+ * sequential list of forward problems of problems/quads_focusing_multi_input.py:66-86.  RCCL over xGMI inside the library;
+ * all buffers are HOST arrays (payloads are 8 B per member / a few KB of shared-design gradient: latency-bound).
+ * Rank 0 creates the unique id; the launcher hands it to the other ranks (file / environment). */
+#define DFX_COMM_UID_BYTES 128
+enum { DFX_REDUCE_SUM = 0, DFX_REDUCE_MAX = 1, DFX_REDUCE_MIN = 2 };
+typedef struct dfx_comm dfx_comm;
+int dfx_comm_unique_id(char* uid128);
+int dfx_comm_init(int32_t rank, int32_t nranks, const char* uid128, int32_t device, dfx_comm** out);
+int dfx_comm_destroy(dfx_comm* c);
+int dfx_comm_rank(const dfx_comm* c);
+int dfx_comm_size(const dfx_comm* c);
+/* all[r * n_local + i] = local[i] of rank r, on every rank (one ncclAllGather) */
+int dfx_gather_objectives(dfx_comm* c, const double* local, int32_t n_local, double* all);
+/* sum over ranks, in place (one ncclAllReduce): gradients w.r.t. a design every rank shares */
+int dfx_reduce_grads(dfx_comm* c, double* inout, int64_t n);
+int dfx_comm_allreduce(dfx_comm* c, double* inout, int64_t n, int32_t op /* DFX_REDUCE_* */);
+int dfx_comm_barrier(dfx_comm* c);
+const char* dfx_comm_last_error(void);
+
+/* device helpers (free / total HBM of a device, wait for everything queued on it) */
+int dfx_mem_info(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
+int dfx_device_synchronize(int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,3 +59,22 @@ def test_batched_ensemble_equals_one_by_one(hip_lib):
         assert abs(vals_b[i] - v) <= 1e-12 * abs(v)
         for a, b in zip(grads_b[i], g):
             assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max()
+
+
+def test_native_rccl_communicator_single_rank(hip_lib, tmp_path):
+    """The collective entry points of libdfx (RCCL inside the library: dfx_comm_init / dfx_gather_objectives /
+    dfx_reduce_grads) on a one-rank communicator -- what one GPU can check: unique id hand-over through the file, communicator
+    creation on the device, an all-gather and the three all-reduces, the device helpers."""
+    from difflexmm_amd import _binding as B
+    comm = ensemble.RcclComm(0, 1, 0, str(tmp_path / "uid"))
+    assert hip_lib.dfx_comm_size(comm._c) == 1 and hip_lib.dfx_comm_rank(comm._c) == 0
+    x = np.arange(5.0) + 0.25
+    assert np.array_equal(comm.all_gather(x), x[None])
+    for op in ("sum", "max", "min"):
+        assert np.array_equal(comm.all_reduce(x.reshape(5, 1), op), x.reshape(5, 1))
+    comm.barrier()
+    assert np.array_equal(ensemble.gather_objectives([1.0, 2.0], 2, comm), [1.0, 2.0])
+    comm.close()
+    free_b, total_b = B.mem_info(0)
+    assert 0 < free_b <= total_b and total_b > 200e9
+    B.device_synchronize(0)

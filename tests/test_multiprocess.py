@@ -1,5 +1,7 @@
-"""world_size-2 gloo test of the N>1 path (runs on CPU): designs sharded over ranks, no data-path collective,
-objectives combined by one all_gather, shared-design gradients by one all_reduce."""
+"""world_size-2 tests of the N>1 path on CPU: designs sharded over ranks, no data-path collective, objectives combined by one
+all-gather, shared-design gradients by one all-reduce.  Two communicators drive the same `difflexmm_amd.ensemble` code:
+a gloo adapter (torch.distributed lives only here, in the tests) and the package's plain-TCP `SocketComm`.  The production
+communicator (`RcclComm`, RCCL inside libdfx) has the same three methods; it needs one GPU per rank."""
 import os
 import sys
 
@@ -28,25 +30,56 @@ def _make(lib):
     return fw, obj, designs
 
 
-def _worker(rank, world_size, port, out_dir):
+class GlooComm:
+    """torch.distributed (gloo) behind the communicator interface of difflexmm_amd.ensemble."""
+
+    def __init__(self, rank, world_size, port):
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        self.dist, self.rank, self.world = dist, rank, world_size
+
+    def all_gather(self, local):
+        import torch
+        mine = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float64).ravel())
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return np.stack([o.numpy() for o in out])
+
+    def all_reduce(self, array, op="sum"):
+        import torch
+        t = torch.as_tensor(np.array(array, dtype=np.float64))
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}[op])
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def _worker(rank, world_size, port, out_dir, kind):
     sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
     from difflexmm_amd import ensemble
     from oracle.cpu import load
+    comm = GlooComm(rank, world_size, port) if kind == "gloo" else ensemble.SocketComm(rank, world_size, "127.0.0.1", port)
+    ensemble.set_default(comm)
     fw, obj, designs = _make(load())
     values, grads, (lo, hi) = ensemble.evaluate_ensemble(obj, designs)
     shared = ensemble.sum_shared_gradients([np.full((2, 3), float(rank + 1)), np.arange(4.0) * (rank + 1)])
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), values=values, lo=lo, hi=hi, g0=grads[0][0], s0=shared[0], s1=shared[1])
-    dist.barrier()
-    dist.destroy_process_group()
+    slowest = comm.all_reduce([float(rank)], "max")
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), values=values, lo=lo, hi=hi, g0=grads[0][0], s0=shared[0], s1=shared[1],
+             slowest=slowest)
+    comm.barrier()
+    comm.close()
 
 
-def test_two_ranks_shard_designs_and_gather_objectives(tmp_path, cpu_lib):
+@pytest.mark.parametrize("kind", ["gloo", "socket"])
+def test_two_ranks_shard_designs_and_gather_objectives(tmp_path, cpu_lib, kind):
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (0 if kind == "gloo" else 2017)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
     fw, obj, designs = _make(cpu_lib)
     ref = [obj.value_and_grad(d) for d in designs]
     ref_vals = np.array([r[0] for r in ref])
@@ -58,6 +91,7 @@ def test_two_ranks_shard_designs_and_gather_objectives(tmp_path, cpu_lib):
         np.testing.assert_allclose(d["g0"], ref[int(d["lo"])][1][0], rtol=1e-10, atol=1e-300)
         np.testing.assert_allclose(d["s0"], np.full((2, 3), 3.0))               # 1 + 2
         np.testing.assert_allclose(d["s1"], np.arange(4.0) * 3)
+        assert float(d["slowest"][0]) == 1.0
 
 
 def test_shard_bounds_cover_everything():

@@ -261,12 +261,44 @@ def test_bench_host_path_on_cpu_port(cpu_lib):
     assert len(designs) == 2 and fw.solve_dynamics.engine.batch == 2
     bench.prepare(fw, designs, 4, spi=2)
     res = bench.execute(fw, obj, spi=2)
-    # (a few microseconds of simulated time: the pulse has not reached the target blocks yet, objective and gradient are 0)
-    assert res["objective"].shape == (2,) and np.all(np.isfinite(res["objective"])) and np.isfinite(res["grad_norm"])
+    # the pulse starts at t = 0 and the target sits next to the driven blocks: already a few steps give a non-zero objective and
+    # a non-zero gradient (round-1 verdict: the timed job must not differentiate a zero)
+    assert res["objective"].shape == (2,) and np.all(res["objective"] > 0) and bench.grad_norm(res) > 0
+    assert set(obj.target_blocks) == {3 * 8 + 1, 3 * 8 + 2, 4 * 8 + 1, 4 * 8 + 2} and list(fw.driven_blocks_ids) == [3 * 8, 4 * 8]
     assert res["fwd_launches"] == 0 and res["streams"] >= 1                          # the CPU port launches no kernels
-    line = bench.cpu_baseline(8, 3, budget_s=1.0)
-    assert line["kind"] == "port" and line["value"] > 0 and line["cores"] >= 1
-    assert bench.load_pmc_traffic(16) > 16 * bench.BYTES_FWD_STAGE * 128 * 128     # PMC traffic >= algorithmic bytes
+    line = bench.cpu_baseline(8, 3, n_steps=20, repeats=3)
+    assert line["kind"] == "port" and line["value"] > 0 and line["cores"] >= 1 and line["one_thread"] > 0
+    t = bench.load_pmc_traffic()
+    assert t is None or t["k_adj_stage_bytes_per_member_launch"] > bench.BYTES_ADJ_STAGE * 128 * 128 * 0.9
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
+    """`bench.py --gpus 2` without a launcher starts 2 rank processes itself (before any GPU call) and gives each the
+    environment the ranks read; with a launcher whose WORLD_SIZE disagrees it refuses.  (No GPU here: the ranks are replaced by a
+    stub that reports its environment.)"""
+    import subprocess, sys, textwrap, bench, os
+    stub = tmp_path / "stub.py"
+    stub.write_text(textwrap.dedent("""
+        import os, sys
+        open(os.path.join(os.path.dirname(__file__), "rank%s.txt" % os.environ["RANK"]), "w").write(
+            " ".join(os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "DFX_UID_FILE")) + " " + " ".join(sys.argv[1:]))
+        sys.exit(3 if os.environ["RANK"] == "1" else 0)
+    """))
+    real = bench.__file__
+    try:
+        bench.__file__ = str(stub)                       # launch_ranks starts `python <this file> argv`
+        import types
+        launch = types.FunctionType(bench.launch_ranks.__code__, dict(bench.__dict__, __file__=str(stub)))
+        rc = launch(2, ["--gpus", "2", "--steps", "20"])
+    finally:
+        bench.__file__ = real
+    assert rc == 3                                       # the worst exit code is propagated
+    r0, r1 = (tmp_path / "rank0.txt").read_text().split(), (tmp_path / "rank1.txt").read_text().split()
+    assert r0[:4] == ["0", "0", "2", "127.0.0.1"] and r1[:4] == ["1", "1", "2", "127.0.0.1"] and r0[4] == r1[4]
+    assert r0[5:] == ["--gpus", "2", "--steps", "20"]
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, real, "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
 
 
 def test_bench_times_exactly_k_steps():
