@@ -104,6 +104,7 @@ def execute(fw, obj, adjoint=True, spi=SPI):
             obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
         out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
+        out["checkpoint"] = "records" if st_a.get("checkpoint_records", 0) else ("stages" if st_a.get("stage_checkpoint", 0) else "state")
         out["grads"] = grads
     return out
 
@@ -298,11 +299,15 @@ def main():
         if args.members < args.streams:
             args.streams = args.members
             os.environ["DFX_STREAMS"] = str(args.streams)
-        # Stage checkpoint (+120 B per unit and step: the reverse sweep then needs no recompute launches): the engine takes
-        # it whenever it fits; decide here, by the same rule, so that every leg below runs the same kernels.
-        if "DFX_STAGE_CHECKPOINT" not in os.environ:
-            need = (72.0 * (max(K, W) + 1) + 120.0 * max(K, W)) * args.size * args.size * args.members
-            os.environ["DFX_STAGE_CHECKPOINT"] = "1" if need + 0.05 * total_b + 2e9 < free_b else "0"
+        # What the forward pass keeps for the reverse sweep (the engine takes the richest level that fits; decide here, by the
+        # same rule, so that every leg below runs the same kernels): records 432 B per unit and step (reverse launches read
+        # their stage record directly), stages 72 + 120 B (records rebuilt elementwise), state 72 B (records recomputed).
+        if "DFX_CHECKPOINT" not in os.environ and "DFX_STAGE_CHECKPOINT" not in os.environ:
+            n_ck = max(K, W, ROOFLINE_LEG_STEPS)
+            units = args.size * args.size * args.members
+            room = free_b - 0.05 * total_b - 2e9
+            os.environ["DFX_CHECKPOINT"] = ("records" if 432.0 * (n_ck + 1) * units < room else
+                                            "stages" if (72.0 * (n_ck + 1) + 120.0 * n_ck) * units < room else "state")
 
     def sync():
         B.device_synchronize(local_rank)
@@ -342,7 +347,7 @@ def main():
         single = {"members_per_gpu": 1, "steps": K1, "value": K1 * args.size * args.size / w1,
                   "forward_only_value": K1 * args.size * args.size / (r1["fwd_ms"] * 1e-3),
                   "fwd_launch_us": 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]),
-                  "stage_checkpoint": bool(r1.get("stage_checkpoint", False)),
+                  "checkpoint": r1.get("checkpoint"),
                   "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
         fw1.solve_dynamics.engine.close()
         del fw1, obj1, r1
@@ -384,8 +389,8 @@ def main():
             """(fwd launch us, adj launch us): region device time (HIP events on the engine's stream) / launches per stream."""
             f_us = 1e3 * r["fwd_ms"] / max(1.0, r["fwd_launches"] / n_streams)
             a_us = None
-            if r["adj_launches"] and r.get("stage_checkpoint"):
-                a_us = 1e3 * r["adj_ms"] / (r["adj_launches"] / n_streams)     # reverse stages only (stage checkpoint kept)
+            if r["adj_launches"] and r.get("checkpoint") in ("records", "stages"):
+                a_us = 1e3 * r["adj_ms"] / (r["adj_launches"] / n_streams)     # reverse stages only (no recompute launches)
             elif r["adj_launches"]:
                 n_adj = r["adj_launches"] * 6.0 / 11.0 / n_streams   # per reverse step: 5 recomputed forward stages + 6 reverse stages
                 a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * (5.0 / 6.0) * f_us) / n_adj)
@@ -417,7 +422,7 @@ def main():
                                    f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
                                    f"{'forward + adjoint wrt 66048 geometry params' if adjoint else 'forward only'}",
                        "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams,
-                       "stage_checkpoint": bool(res.get("stage_checkpoint", False)), "integrator": "dopri5-fixed",
+                       "checkpoint": res.get("checkpoint"), "integrator": "dopri5-fixed",
                        "steps_per_output": SPI, "input_delay_s": args.input_delay,
                        "target_blocks": [int(b) for b in obj.target_blocks], "collective": collective},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
@@ -430,8 +435,8 @@ def main():
             # the dominant kernel: the reverse stage.  SURVEY 8(d) counts 624 B per unit; with the stage checkpoint 5 of the 6
             # reverse launches of a step also rebuild a stage record (+60 B on average: the forward's stage combine moved here)
             line["roofline"] = roof("k_adj_stage<nonlinear,contact>", BYTES_ADJ_STAGE, adj_us,
-                                    {"rebuilds_stage_records": bool(leg.get("stage_checkpoint")),
-                                     "own_count_bytes_per_unit": BYTES_ADJ_STAGE + (60 if leg.get("stage_checkpoint") else 0),
+                                    {"checkpoint": leg.get("checkpoint"),
+                                     "own_count_bytes_per_unit": BYTES_ADJ_STAGE + (60 if leg.get("checkpoint") == "stages" else 0),
                                      "traffic": None if traffic is None else traffic.get("k_adj_stage_bytes_per_member_launch", 0) * mpl or None,
                                      "traffic_source": None if traffic is None else traffic.get("source")})
             line["roofline_forward_kernel"] = roof("k_fwd_stage<nonlinear,contact>", BYTES_FWD_STAGE, fwd_us,

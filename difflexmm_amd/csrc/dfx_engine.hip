@@ -124,7 +124,8 @@ struct dfx_handle {
   int n_counts = 0;
   DevBuf<double> d_acc_times, d_tsteps;
   DevBuf<double> d_AD;             // stage checkpoint (stage accelerations of every step)
-  bool dense = false;              // the last fixed-grid forward kept the stage checkpoint
+  bool dense = false;              // the last fixed-grid forward kept the stage checkpoint (stage accelerations of every step)
+  bool records = false;            // ... or the records checkpoint (every stage record of every step): no rebuild, no recompute
   std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps)
   std::vector<long long> accepted_per_member;
   bool have_adaptive_record = false;
@@ -166,7 +167,8 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.t_steps = (!h->adaptive && !h->t_steps.empty()) ? h->d_tsteps.p : nullptr;
   c.rtol = h->rtol; c.atol = h->atol;
   c.traj = h->have_traj ? h->d_traj.p : nullptr;
-  c.AD = (h->have_traj && h->dense) ? h->d_AD.p : nullptr;
+  c.rps = (h->have_traj && h->records) ? pl.tab.s : 1;
+  c.AD = (h->have_traj && h->dense && !h->records) ? h->d_AD.p : nullptr;
   c.ad_stride = pl.batch ? (long long)(h->d_AD.n / pl.batch) : 0;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
@@ -227,8 +229,9 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   const int s = h->pl.tab.s;
   const int rb = (c.AD && !local_only) ? (i >= 2 ? i - 1 : (i == 0 ? s - 1 : 0)) : 0;
   const StageCoef rc = stage_coef(h->pl.tab, rb > 0 ? rb - 1 : 0);
-  if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
-  else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  else if (c.AD) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
   const Plan& pl = h->pl;
@@ -243,6 +246,14 @@ static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf,
 // forward: stage i reads buffer fin(i), writes fout(i); buffer 0 is the step state
 static int fin(int i) { return i == 0 ? 0 : 1 + ((i - 1) & 1); }
 static int fout(int i, int s) { return i == s - 1 ? 0 : 1 + (i & 1); }
+// one forward stage of step j of the segment: with the records checkpoint the records live in the trajectory only (stage i reads
+// record i of step n and writes record i+1; record s of step n is the state of step n+1), else in the ping-pong stage buffers
+static void launch_fwd_step_stage(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j) {
+  const int s = h->pl.tab.s;
+  if (c.rps > 1) launch_fwd(h, c, st, grid, i, j, -1 - i, -1 - (i + 1), -1, 0);
+  else launch_fwd(h, c, st, grid, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
+}
+static int adj_in_buf(const DevCtx& c, int i) { return c.rps > 1 ? -1 - i : (i == 0 ? -1 : i); }
 
 // enqueue one segment (kind 0: forward steps; kind 1: reverse steps) of group gi on that group's stream
 static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_steps, int kind) {
@@ -254,11 +265,11 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   h->launches++;
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
-      for (int i = 0; i < s; ++i) launch_fwd(h, c, g.stream, grid, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
-  } else if (c.AD) {
+      for (int i = 0; i < s; ++i) launch_fwd_step_stage(h, c, g.stream, grid, i, j);
+  } else if (c.AD || c.rps > 1) {
     // stage checkpoint: no recompute launches; every reverse launch also rebuilds the record its successor reads
     for (int j = n_steps - 1; j >= 0; --j)
-      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, i == 0 ? -1 : i, -1, 0);
+      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, adj_in_buf(c, i), -1, 0);
   } else if (!h->dual_chain) {
     for (int j = n_steps - 1; j >= 0; --j) {
       // recompute the stage records of step n from its checkpoint: stage i -> buffer i+1
@@ -292,20 +303,24 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   }
 }
 
-// Short solves are launched eagerly, the launches of the member groups interleaved stage by stage: a hipGraph of ~100 nodes
-// takes about as long to launch as a 20-step solve takes to run (measured: first kernel 0.7 - 2.9 ms after the call), and
-// launching one group's graph after the other's staggers the groups by that time; eager launches cost ~3.5 us of host time
-// each, less than a stage kernel runs, and the first kernel starts at once.  Long solves replay graphs: the launch of
-// segment k+1 hides behind segment k.  DFX_EAGER_STEPS overrides the threshold (steps per solve).
+// Eager launches, the member groups interleaved stage by stage, vs hipGraph replay.  Measured (16 x 128x128, profiles/
+// r02_eager_vs_graph.txt): a graph of ~100 nodes takes 0.7 - 2.9 ms from the call to its first kernel -- as long as a 20-step
+// solve runs -- and one group's graph launched after the other's staggers the groups by that time; an eager launch costs ~3.5 us of
+// host time, less than a stage kernel that fills the chip runs (13 - 45 us), and the first kernel starts at once: eager is
+// 10 - 35 % faster up to a few hundred steps and still 1 % faster at 5 000.  Graphs keep the launch cost off the host where the
+// kernels are short (small lattices / few members: launch-bound at ~5 us per stage, below the eager launch rate) and the solve is
+// long enough to hide the first launch.  Rule: eager when the launches fill the chip (>= 2 waves per SIMD) or the solve is short
+// (<= 128 steps); DFX_EAGER_STEPS=<n> overrides the step threshold for every size (0: always graphs).
 static bool solve_is_eager(const dfx_handle* h) {
   if (!h->use_graph) return true;
-  const char* e = getenv("DFX_EAGER_STEPS");
-  return h->n_total <= (e ? atoll(e) : 128LL);
+  if (const char* e = getenv("DFX_EAGER_STEPS")) return h->n_total <= atoll(e);
+  const long long waves = (long long)h->pl.batch * ((h->pl.n_slots + 63) / 64);
+  return waves >= 2048 || h->n_total <= 128;
 }
 
 static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int kind) {
   const int s = h->pl.tab.s, ng = (int)h->groups.size();
-  if (kind == 1 && !cbase.AD) {      // recompute chains (events per group): group by group
+  if (kind == 1 && !cbase.AD && cbase.rps == 1) {      // recompute chains (events per group): group by group
     for (int gi = 0; gi < ng; ++gi) enqueue_segment(h, cbase, gi, n_steps, kind);
     return;
   }
@@ -319,12 +334,12 @@ static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps,
     for (int j = 0; j < n_steps; ++j)
       for (int i = 0; i < s; ++i)
         for (int gi = 0; gi < ng; ++gi)
-          launch_fwd(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j, fin(i), fout(i, s), 0, (i == s - 1 && cbase.traj) ? 1 : 0);
+          launch_fwd_step_stage(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j);
   } else {
     for (int j = n_steps - 1; j >= 0; --j)
       for (int i = s - 1; i >= 0; --i)
         for (int gi = 0; gi < ng; ++gi)
-          launch_adj(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j, i == 0 ? -1 : i, -1, 0);
+          launch_adj(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j, adj_in_buf(cg[gi], i), -1, 0);
   }
 }
 
@@ -343,7 +358,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
   auto key = std::make_pair(n_steps, kind * kMaxGroups + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
-  const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD) ? s : 2 * s - 1);   // launches in the graph
+  const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD || c.rps > 1) ? s : 2 * s - 1);   // launches in the graph
   hipStream_t st = h->groups[gi].stream;
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -383,21 +398,42 @@ static int join_groups(dfx_handle* h) {
 // One segment = one graph replay of n_steps steps inside one output interval.  Intervals with the most frequent step
 // count are cut into chunks of kMaxGraphSteps; the others into power-of-two chunks, so that the number of distinct
 // graphs stays <= log2(kMaxGraphSteps) + 3 whatever the counts are.
-// Stage checkpoint: also keep the first s-1 stage accelerations of every step (+24 (s-1) B per unit and step on top of
-// the 72 B of the state checkpoint) whenever that fits beside it: the reverse sweep then needs no recompute launches (s instead of
-// 2s - 1 launches per step).  DFX_STAGE_CHECKPOINT=0/1 overrides the choice.  Returns whether the buffer is there.
-static bool ensure_stage_checkpoint(dfx_handle* h, long long n_steps) {
+//
+// What the forward pass keeps for the reverse sweep -- three levels, the richest that fits in HBM is taken:
+//   records  every stage record of every step (72 s B per unit and step): the reverse launch of stage i reads the record it
+//            linearises about straight from the checkpoint -- s launches per step, nothing rebuilt, nothing recomputed; the forward
+//            pass writes its records there instead of into the ping-pong buffers, i.e. no extra forward traffic;
+//   stages   the step states + the first s-1 stage accelerations of every step (72 + 24 (s-1) B): s launches per step, each
+//            reverse launch rebuilds the record its successor reads (elementwise);
+//   state    the step states only (72 B): 2s - 1 launches per step (s - 1 forward launches recompute the records).
+// DFX_CHECKPOINT=records|stages|state overrides (DFX_STAGE_CHECKPOINT=1/0 = stages / state, kept for older scripts).
+enum { kCkState = 0, kCkStages = 1, kCkRecords = 2 };
+
+static int choose_checkpoint(dfx_handle* h, long long n_steps) {
   const Plan& pl = h->pl;
-  const char* e = getenv("DFX_STAGE_CHECKPOINT");
-  const size_t want = (size_t)pl.batch * (size_t)std::max<long long>(n_steps, 1) * (pl.tab.s - 1) * pl.n_blocks * 3;
-  bool use = e ? e[0] != '0' : true;
-  if (use && h->d_AD.n < want) {
-    size_t free_b = 0, total_b = 0;
-    // leave room: at most what is free minus 5 % of the device
-    if (!e && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (want - h->d_AD.n) * sizeof(double) + total_b / 20 > free_b)) use = false;
-    if (use && h->d_AD.ensure(want) != hipSuccess) { (void)hipGetLastError(); use = false; }
+  const size_t B = pl.batch, rec = (size_t)pl.n_blocks * kStep, N = (size_t)std::max<long long>(n_steps, 1);
+  const size_t want_rec = B * (N * pl.tab.s + 1) * rec;
+  const size_t want_state = B * (N + 1) * rec;
+  const size_t want_ad = B * N * (pl.tab.s - 1) * pl.n_blocks * 3;
+  int forced = -1;
+  if (const char* e = getenv("DFX_CHECKPOINT")) forced = e[0] == 'r' ? kCkRecords : (e[0] == 's' && e[2] == 'a' && e[3] == 'g' ? kCkStages : kCkState);
+  else if (const char* e2 = getenv("DFX_STAGE_CHECKPOINT")) forced = e2[0] != '0' ? kCkStages : kCkState;
+  size_t free_b = 0, total_b = 0;
+  const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+  auto fits = [&](size_t grow_elems) { return have_info && grow_elems * sizeof(double) + total_b / 20 <= free_b; };   // leave 5 % of the device
+  const size_t have_t = h->d_traj.n, have_a = h->d_AD.n;
+  auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
+  int mode = forced;
+  if (mode < 0) {
+    if (fits(grow(want_rec, have_t))) mode = kCkRecords;
+    else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
+    else mode = kCkState;
   }
-  return use;
+  // allocate; a failed allocation falls back one level (forced modes included: the solve still runs)
+  if (mode == kCkRecords && h->d_traj.ensure(want_rec) != hipSuccess) { (void)hipGetLastError(); mode = kCkStages; }
+  if (mode != kCkRecords && h->d_traj.ensure(want_state) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (mode == kCkStages && h->d_AD.ensure(want_ad) != hipSuccess) { (void)hipGetLastError(); mode = kCkState; }
+  return mode;
 }
 
 static void build_segments(dfx_handle* h) {
@@ -748,11 +784,8 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
   HIP_OK(h->d_target.ensure(nb));
   HIP_OK(h->d_obj.ensure(B));
   HIP_OK(h->d_segs.ensure((size_t)max_timepoints * (2 + (size_t)(max_steps / std::max(1, max_timepoints - 1)) / kMaxGraphSteps)));
-  if (keep_trajectory) {
-    hipError_t e = h->d_traj.ensure(B * (size_t)(max_steps + 1) * rec);
-    if (e != hipSuccess) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
-    (void)ensure_stage_checkpoint(h, max_steps);
-  }
+  if (keep_trajectory && choose_checkpoint(h, max_steps) < 0) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
+  (void)rec;
   return 0;
 }
 
@@ -795,13 +828,14 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
   h->have_traj = false;
   if (keep_trajectory) {
-    hipError_t e = h->d_traj.ensure(B * (size_t)(h->n_total + 1) * rec);
-    if (e != hipSuccess) {
+    const int mode = choose_checkpoint(h, h->n_total);
+    if (mode < 0) {
       h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string((B * (h->n_total + 1) * rec * 8) >> 20) + " MiB)";
       return 2;
     }
     h->have_traj = true;
-    h->dense = ensure_stage_checkpoint(h, h->n_total);
+    h->records = mode == kCkRecords;
+    h->dense = mode == kCkStages;
   }
   build_segments(h);
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
@@ -823,7 +857,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
   const bool eager = solve_is_eager(h);
@@ -834,8 +868,9 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
       if (!eager) if (int rc = run_segment(h, c, gi, sg.n_steps, 0)) return rc;
       if (sg.j0 + sg.n_steps == h->spis[sg.interval]) {   // buffer 0 holds the state at the end of the interval
         const Group& gr = h->groups[gi];
+        // end of the interval: the state is in buffer 0, or (records checkpoint) only in the trajectory
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
-                           h->d_seg_idx.p + 1);
+                           h->d_seg_idx.p + 1, c.rps > 1 ? -1 : 0, (long long)h->step0[sg.interval + 1]);
       }
     }
   }
@@ -863,6 +898,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
+    stats->checkpoint_records = c.rps > 1 ? 1 : 0;
   }
   return 0;
 }
@@ -914,7 +950,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   h->launches = 0;
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
   std::vector<double> A((size_t)B * 7 * nd), V0(B * 7 * nd);
   HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1093,6 +1129,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
+    stats->checkpoint_records = c.rps > 1 ? 1 : 0;
   }
   return 0;
 }

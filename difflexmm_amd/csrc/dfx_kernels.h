@@ -83,6 +83,7 @@ struct DevCtx {
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
+  int rps, pad_rps;       // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   const int32_t* slot_info;
   const int32_t* block_special;
   const dfx_special* special;
@@ -156,13 +157,18 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
   return x * per + (x < rem ? x : rem) + q;
 }
 
+// buf >= 0: stage buffer `buf`;  buf < 0: record (-1 - buf) of step n in the trajectory checkpoint (record 0 = the step state;
+// records 1 .. s-1 exist in the records checkpoint only; record s of step n IS record 0 of step n + 1)
+__device__ __forceinline__ double* traj_rec(const DevCtx& c, int m, int buf, long long n) {
+  return c.traj + (size_t)m * c.traj_stride + ((size_t)n * c.rps + (size_t)(-1 - buf)) * ((size_t)c.n_blocks * kStep);
+}
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
   if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
-  return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep;
+  return traj_rec(c, m, buf, n);
 }
 __device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
   if (buf >= 0) return c.VEL + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * 3;
-  return c.traj + (size_t)m * c.traj_stride + (size_t)n * c.n_blocks * kStep + (size_t)c.n_blocks * kPos;
+  return traj_rec(c, m, buf, n) + (size_t)c.n_blocks * kPos;
 }
 
 __global__ void k_tick(const Seg* segs, int* seg_idx, int delta, Seg* cur) {
@@ -211,15 +217,15 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
   }
 }
 
-// fields[m, k] <- (disp, vel) of stage buffer 0
-__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad) {
+// fields[m, k] <- (disp, vel) of stage buffer `buf` (or, buf < 0, of the checkpointed state of step n)
+__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad, int buf, long long n) {
   const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * 3) return;
   const int b = tid / 3, d = tid % 3;
   double* f = fields + ((size_t)m * c.n_timepoints + k) * c.n_blocks * 6;
-  const double q = c.POS[(size_t)m * c.nbuf * c.n_blocks * kPos + (size_t)b * kPos + d];
-  const double v = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + tid];
+  const double q = pos_in(c, m, buf, n)[(size_t)b * kPos + d];
+  const double v = vel_in(c, m, buf, n)[tid];
   f[tid] = q;
   f[(size_t)c.n_blocks * 3 + tid] = v;
   if (!isfinite(q) || !isfinite(v)) *bad = k + 1;   // any writer wins: only "some output row is not finite" matters
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       }
       qnext = r2;
     }
-    if (constrained && out_buf >= 0) {
+    if (constrained && out_buf != -1) {
       TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
       qnext = tv.g; vnext = tv.gt;
     }
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
     if ((threadIdx.x & 63) == 0) c.err_partial[((u32)m * c.n_wg + lwg) * 4 + (threadIdx.x >> 6)] = r2;
     return;
   }
-  if (out_buf < 0) return;
+  if (out_buf == -1) return;
   // ---- publish the next stage record: lanes 0..2 each store one aligned 16-byte chunk (x,y) (th,ch) (sh,0)
   const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
   double sn, cs;
@@ -488,10 +494,14 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
   if (k < 3 && !(c.ablate & 2)) {
     const u32 o_chunk = ((u32)b * kPos + 2 * k) * 8;
-    stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
-    stg<double>(c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
-    if (write_traj) {
-      double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)(n + 1) * c.n_blocks * kStep;
+    if (out_buf >= 0) {
+      stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
+      stg<double>(c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
+    }
+    if (write_traj || out_buf < -1) {
+      // state checkpoint: the new step state, once more; records checkpoint (out_buf < -1): the record goes ONLY there, the
+      // next launch reads it from there and so does the reverse sweep
+      double* tr = out_buf < -1 ? traj_rec(c, m, out_buf, n) : traj_rec(c, m, -1, n + 1);
       stg<double2>(tr, o_chunk, chunk);
       stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
     }
@@ -691,8 +701,8 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS>
-//   rb > 0 (stage checkpoint): after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD>
+//   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
       stg<double>(c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
     }
   }
-  if (rb > 0) {
+  if (REBUILD && rb > 0) {
     if (i > 0) rebuild_record(c, m, b, k, rc, rb, n, h, t_n);
     else if (n > 0) rebuild_record(c, m, b, k, rc, rb, n - 1, h_before, c.t_steps ? c.t_steps[n - 1] : t_n - h_before);
   }

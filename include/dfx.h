@@ -115,6 +115,9 @@ typedef struct dfx_stats {
   int64_t streams;                        /* member groups integrated concurrently (one HIP stream each) */
   int64_t stage_checkpoint;               /* 1: the forward pass also kept the stage accelerations of every step, so the
                                              reverse sweep runs without recompute launches (chosen when it fits in HBM) */
+  int64_t checkpoint_records;             /* 1: the forward pass kept EVERY stage record of every step (72 s B per unit and step): the
+                                             reverse launches read them directly, nothing is rebuilt or recomputed (richest level,
+                                             taken when it fits; then stage_checkpoint = 0) */
 } dfx_stats;
 
 typedef struct dfx_handle dfx_handle;

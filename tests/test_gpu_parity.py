@@ -228,6 +228,41 @@ def test_several_dofs_of_one_block_share_a_time_function(hip_lib):
     parity.check_several_dofs_of_one_block_share_a_time_function(None)
 
 
+@pytest.mark.parametrize("lattice,n,integrator", [("quads", 5, "dopri5"), ("kagome", 3, "rk4")])
+def test_reverse_sweep_reading_the_records_checkpoint(hip_lib, monkeypatch, lattice, n, integrator):
+    """Third (richest) checkpoint level: the forward pass leaves EVERY stage record in the trajectory (its launches read and write
+    them there instead of the ping-pong buffers), the reverse launches read the record they linearise about directly: s launches
+    per step, no rebuild, no recompute.  Against the oracle, on a grid with its own step boundaries, and over graph segments."""
+    monkeypatch.setenv("DFX_CHECKPOINT", "records")
+    monkeypatch.setenv("DFX_EAGER_STEPS", "0")
+    parity.check_trajectory_and_adjoint(None, lattice, n, integrator, spi=np.array([3, 7, 2, 5]), own_step_times=True)
+    c = Case(lattice, n, True, True, seed=2, lib=None, cutoff_deg=125.0 if lattice == "kagome" else 42.0, integrator=integrator, batch=3)
+    ts = np.linspace(0, 2e-4, 3)
+    f = c.solver(c.random_state(0.05, 0.02, 5.0), ts, c.cp, keep_trajectory=True, steps_per_interval=300)   # several graph segments
+    assert c.solver.stats["checkpoint_records"] == 1 and c.solver.stats["stage_checkpoint"] == 0
+    c.solver.vjp(np.ones_like(f))
+    s_launch = 6 if integrator == "dopri5" else 4
+    assert abs(c.solver.adjoint_stats["launches"] / 600.0 - s_launch) < 0.2
+
+
+def test_three_checkpoint_levels_give_the_same_gradient(hip_lib, monkeypatch):
+    """records / stages / state on one problem: same forward fields bit for bit (the same arithmetic, only the place the records
+    are kept differs), gradients equal to rounding."""
+    outs = {}
+    for level in ("records", "stages", "state"):
+        monkeypatch.setenv("DFX_CHECKPOINT", level)
+        c = Case("quads", 7, True, True, seed=12, lib=None, cutoff_deg=42.0, batch=2)
+        cps = [c.cp._replace(constraint_params=dict(amplitude=a, loading_rate=3000.0, input_delay=1e-5)) for a in (7.5, -3.0)]
+        ts = np.linspace(0, 3e-4, 4)
+        f = c.solver(c.random_state(0.05, 0.02, 5.0), ts, cps, keep_trajectory=True, steps_per_interval=9)
+        assert (c.solver.stats["checkpoint_records"], c.solver.stats["stage_checkpoint"]) == {"records": (1, 0), "stages": (0, 1), "state": (0, 0)}[level]
+        trees, s0 = c.solver.vjp(np.random.default_rng(3).normal(size=f.shape))
+        outs[level] = (f, np.stack([t.geometrical_params.centroid_node_vectors for t in trees]), s0)
+    for level in ("stages", "state"):
+        assert np.array_equal(outs[level][0], outs["records"][0])
+        assert relerr(outs[level][1], outs["records"][1]) < 1e-12 and relerr(outs[level][2], outs["records"][2]) < 1e-12
+
+
 @pytest.mark.parametrize("stage_checkpoint", ["0", "1"])
 @pytest.mark.parametrize("lattice,n,integrator", [("quads", 5, "dopri5"), ("kagome", 3, "rk4")])
 def test_reverse_sweep_with_and_without_stage_checkpoint(hip_lib, monkeypatch, stage_checkpoint, lattice, n, integrator):

@@ -8,9 +8,10 @@ TAG=${1:-rXX}; M=${2:-16}
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-ARGS="bench.py --streams 1 --members $M --steps 1000 --warmup 250 --no-cpu-baseline --no-single"
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+ARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-PARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single"
+PARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg"
 export DFX_DUAL_CHAIN=0
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $PARGS > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python3 $PARGS > /dev/null 2> $OUT/pmc_write.err
