@@ -1,0 +1,205 @@
+"""TEST INFRASTRUCTURE -- restatement of the reference's problem layer (the callers of the hot path).
+
+Follows, construct by construct (NumPy standing in for jax.numpy; same tile / arange / concatenate calls, same ordering):
+
+* ``problems/quads_focusing.py:104-222``  driven / clamped block-DOF pairs, loading vector, block id lists, pulse
+* ``problems/quads_focusing.py:447-467``  target blocks and the target-kinetic-energy objective
+* ``problems/kagome_focusing.py:96-172``  the same for the kagome lattice (left-loaded only), ``:403-424`` targets
+* ``problems/quads_focusing_multi_input.py:43-86``  weighted sum over forward problems that share one design
+
+The objective is evaluated through the oracle's own solver (``oracle.ref_dynamics``) and differentiated with
+``torch.autograd`` where the reference calls ``jit(value_and_grad(objective))`` (``problems/quads_focusing.py:565``).
+Parity pinning: the reference cannot be imported here (no JAX) and holds no index fixtures, so this file is pinned by the
+hand-checkable counts of SURVEY appendix C (42 constrained DOFs on the paper lattice, 48 on the kagome one) and frozen in
+``tests/golden/problems_*.npz``; only ``tests/`` imports it.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ref_dynamics as OD
+from . import ref_energy as OE
+from . import ref_geometry as OG
+
+F64 = torch.float64
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float64))
+
+
+def _dofs012(n):
+    return np.array([0] * n + [1] * n + [2] * n)
+
+
+def quads_constraints(n1_blocks, n2_blocks, n_excited_blocks, loaded_side, input_shift, n_blocks_clamped_corner=2):
+    """problems/quads_focusing.py:104-209.  Returns a dict with the arrays the reference builds, under its own names."""
+    n_blocks = n1_blocks * n2_blocks
+    ne, nc = n_excited_blocks, n_blocks_clamped_corner
+    if loaded_side == "left":            # :106-114
+        driven = np.array([np.tile(np.arange((n2_blocks - ne) // 2 + input_shift, (n2_blocks + ne) // 2 + input_shift) * n1_blocks, 3),
+                           np.array([0] * ne + [1] * ne + [2] * ne)]).T
+    elif loaded_side == "right":         # :115-123
+        driven = np.array([np.tile(np.arange((n2_blocks - ne) // 2 + input_shift, (n2_blocks + ne) // 2 + input_shift) * n1_blocks
+                                   + (n1_blocks - 1), 3),
+                           np.array([0] * ne + [1] * ne + [2] * ne)]).T
+    elif loaded_side == "bottom":        # :124-132
+        driven = np.array([np.tile(np.arange((n1_blocks - ne) // 2 + input_shift, (n1_blocks + ne) // 2 + input_shift), 3),
+                           np.array([1] * ne + [0] * ne + [2] * ne)]).T
+    elif loaded_side == "top":           # :133-141
+        driven = np.array([np.tile(np.arange((n1_blocks - ne) // 2 + input_shift, (n1_blocks + ne) // 2 + input_shift)
+                                   + n1_blocks * (n2_blocks - 1), 3),
+                           np.array([1] * ne + [0] * ne + [2] * ne)]).T
+    else:                                # :142-145
+        raise ValueError(f"Unknown loaded_side: {loaded_side}. Should be either 'left', 'right', 'bottom' or 'top'.")
+    k = 2 * nc - 1
+    bl = np.array([np.tile(np.concatenate([np.arange(0, nc), np.array([0 + i * n1_blocks for i in range(1, nc)], dtype=int)]), 3),
+                   _dofs012(k)]).T                                                                            # :147-156
+    br = np.array([np.tile(np.concatenate([np.arange(n1_blocks - nc, n1_blocks),
+                                           np.array([(i + 1) * n1_blocks - 1 for i in range(1, nc)], dtype=int)]), 3),
+                   _dofs012(k)]).T                                                                            # :157-167
+    tr = np.array([np.tile(np.concatenate([np.arange(n_blocks - nc, n_blocks),
+                                           np.array([n_blocks - i * n1_blocks - 1 for i in range(1, nc)], dtype=int)]), 3),
+                   _dofs012(k)]).T                                                                            # :168-177
+    tl = np.array([np.tile(np.concatenate([np.arange(n_blocks - n1_blocks, n_blocks - n1_blocks + nc),
+                                           np.array([n_blocks - n1_blocks - i * n1_blocks for i in range(1, nc)], dtype=int)]), 3),
+                   _dofs012(k)]).T                                                                            # :178-188
+    pairs = np.concatenate([driven, bl, br, tr, tl])                                                          # :189-192
+    vec = np.zeros((len(pairs),))
+    vec[:ne] = 1                                                                                              # :193-196
+    clamped_ids = np.unique(np.concatenate([bl, br, tr, tl])[:, 0])                                           # :198-203
+    moving_ids = np.setdiff1d(np.arange(n_blocks), clamped_ids)                                               # :204-207
+    driven_ids = np.unique(driven[:, 0])                                                                      # :208
+    return dict(constrained_block_DOF_pairs=pairs, constrained_DOFs_loading_vector=vec, clamped_blocks_ids=clamped_ids,
+                moving_blocks_ids=moving_ids, driven_blocks_ids=driven_ids)
+
+
+def kagome_constraints(n1_cells, n2_cells, n_excited_blocks, n_blocks_clamped_corner=2, loaded_side="left"):
+    """problems/kagome_focusing.py:96-172."""
+    n_cells = n1_cells * n2_cells
+    ne, nc = n_excited_blocks, n_blocks_clamped_corner
+    if loaded_side == "left":            # :99-106
+        driven = np.array([np.tile(np.arange(2 * n1_cells * ((n2_cells - ne) // 2), 2 * n1_cells * ((n2_cells + ne) // 2), 2 * n1_cells), 3),
+                           np.array([0] * ne + [1] * ne + [2] * ne)]).T
+    else:                                # :107-109
+        raise ValueError(f"Unknown loaded_side: {loaded_side}. Only 'left' is implemented.")
+    bl = np.array([np.tile(np.concatenate([np.arange(0, nc), np.array([0 + i * n1_cells for i in range(1, nc)], dtype=int)]), 3) * 2,
+                   _dofs012(2 * nc - 1)]).T                                                                   # :112-121
+    br = np.array([np.tile(np.concatenate([np.arange(n1_cells - nc, n1_cells) * 2,
+                                           np.array([(i + 1) * 2 * n1_cells - 1 for i in range(0, nc)], dtype=int)]), 3),
+                   _dofs012(2 * nc)]).T                                                                       # :122-132
+    tr = np.array([np.tile(np.concatenate([np.arange(n_cells - nc, n_cells),
+                                           np.array([n_cells - i * n1_cells - 1 for i in range(1, nc)], dtype=int)]) * 2 + 1, 3),
+                   _dofs012(2 * nc - 1)]).T                                                                   # :133-141
+    tl = np.array([np.tile(np.concatenate([np.arange(n_cells - n1_cells, n_cells - n1_cells + nc) * 2 + 1,
+                                           np.array([n_cells - n1_cells - i * n1_cells for i in range(0, nc)], dtype=int) * 2]), 3),
+                   _dofs012(2 * nc)]).T                                                                       # :142-152
+    pairs = np.concatenate([driven, bl, br, tr, tl])                                                          # :153-156
+    vec = np.zeros((len(pairs),))
+    vec[:ne] = 1                                                                                              # :157-160
+    clamped_ids = np.unique(np.concatenate([bl, br, tr, tl])[:, 0])
+    moving_ids = np.setdiff1d(np.arange(2 * n_cells), clamped_ids)
+    driven_ids = np.unique(driven[:, 0])
+    return dict(constrained_block_DOF_pairs=pairs, constrained_DOFs_loading_vector=vec, clamped_blocks_ids=clamped_ids,
+                moving_blocks_ids=moving_ids, driven_blocks_ids=driven_ids)
+
+
+def pulse(t, amplitude, loading_rate):
+    """problems/quads_focusing.py:211-216 (identical in kagome_focusing.py:174-179)."""
+    t = _t(t)
+    return amplitude * torch.where((t > 0.) & (t < loading_rate ** -1), (1 - torch.cos(2 * math.pi * loading_rate * t)) / 2,
+                                   torch.zeros((), dtype=F64))
+
+
+def make_constrained_DOFs_fn(loading_vector):
+    """problems/quads_focusing.py:218-222."""
+    vec = _t(loading_vector)
+
+    def constrained_DOFs_fn(t, amplitude, loading_rate, input_delay):
+        return pulse(_t(t) - input_delay, amplitude, loading_rate) * vec
+    return constrained_DOFs_fn
+
+
+def quads_target_blocks(n1_blocks, n2_blocks, target_size, target_shift):
+    """problems/quads_focusing.py:447-451 (and quads_focusing_multi_input.py:58-62)."""
+    return np.array([j * n1_blocks + i
+                     for i in range((n1_blocks - target_size[0]) // 2 + target_shift[0], (n1_blocks + target_size[0]) // 2 + target_shift[0])
+                     for j in range((n2_blocks - target_size[1]) // 2 + target_shift[1], (n2_blocks + target_size[1]) // 2 + target_shift[1])])
+
+
+def kagome_target_blocks(n1_cells, n2_cells, target_size, target_shift):
+    """problems/kagome_focusing.py:403-407."""
+    return np.array([(2 * (j * n1_cells + i), 2 * (j * n1_cells + i) + 1)
+                     for i in range((n1_cells - target_size[0]) // 2 + target_shift[0], (n1_cells + target_size[0]) // 2 + target_shift[0])
+                     for j in range((n2_cells - target_size[1]) // 2 + target_shift[1], (n2_cells + target_size[1]) // 2 + target_shift[1])]).flatten()
+
+
+class ForwardProblem:
+    """``ForwardProblem.setup`` / ``.solve`` of problems/quads_focusing.py:82-317 and kagome_focusing.py:73-273 on the oracle.
+    ``lattice``: "quads" (n1 x n2 blocks) or "kagome" (n1 x n2 cells)."""
+
+    def __init__(self, lattice, n1, n2, spacing, bond_length, k_stretch, k_shear, k_rot, density, damping, amplitude, loading_rate,
+                 input_delay, n_excited_blocks, simulation_time, n_timepoints, loaded_side="left", input_shift=0,
+                 linearized_strains=False, use_contact=True, k_contact=1.0, min_angle=0.0, cutoff_angle=5 * math.pi / 180,
+                 n_blocks_clamped_corner=2):
+        self.lattice = lattice
+        if lattice == "quads":
+            self.geometry = OG.QuadGeometry(n1, n2, spacing, bond_length)
+            bc = quads_constraints(n1, n2, n_excited_blocks, loaded_side, input_shift, n_blocks_clamped_corner)
+        else:
+            basis = spacing * np.array([[1.0, 0.0], [math.cos(math.pi / 3), math.sin(math.pi / 3)]])   # kagome_focusing.py:83-88
+            self.geometry = OG.KagomeGeometry(n1, n2, basis, bond_length)
+            bc = kagome_constraints(n1, n2, n_excited_blocks, n_blocks_clamped_corner, loaded_side)
+        self.__dict__.update(bc)
+        self.n1, self.n2 = n1, n2
+        self.bonds = self.geometry.bond_connectivity()
+        self.reference_bond_vectors = self.geometry.reference_bond_vectors()
+        strain = OE.build_strain_energy(self.bonds, OE.ligament_energy_linearized if linearized_strains else OE.ligament_energy)
+        energy = OE.combine_block_energies(strain, OE.build_contact_energy(self.bonds)) if use_contact else strain    # :229-237
+        self.energy = energy
+        self.solver_args = dict(constrained_block_DOF_pairs=self.constrained_block_DOF_pairs,
+                                constrained_DOFs_fn=make_constrained_DOFs_fn(self.constrained_DOFs_loading_vector),
+                                damped_blocks=np.arange(self.geometry.n_blocks))                               # :101, :239-248
+        self.timepoints = np.linspace(0, simulation_time, n_timepoints)                                          # :251
+        self.state0 = np.zeros((2, self.geometry.n_blocks, 3))                                                   # :254
+        # flip the amplitude if loading from right or top (:257)
+        self.signed_amplitude = amplitude if loaded_side in ("left", "bottom") else -amplitude
+        self.p = dict(k_stretch=k_stretch, k_shear=k_shear, k_rot=k_rot, density=density, damping=damping, loading_rate=loading_rate,
+                      input_delay=input_delay, k_contact=k_contact, min_angle=min_angle, cutoff_angle=cutoff_angle)
+
+    def control_params(self, design):
+        """:266-292.  ``design``: tuple of tensors (kept on the autograd tape)."""
+        p = self.p
+        return OE.ControlParams(
+            OE.GeometricalParams(self.geometry.block_centroids(*design), self.geometry.centroid_node_vectors(*design)),
+            OE.MechanicalParams(OE.LigamentParams(_t(p["k_stretch"]), _t(p["k_shear"]), _t(p["k_rot"]), _t(self.reference_bond_vectors)),
+                                _t(p["density"]), None, _t(p["damping"]),
+                                OE.ContactParams(_t(p["min_angle"]), _t(p["cutoff_angle"]), _t(p["k_contact"]))),
+            constraint_params=dict(amplitude=_t(self.signed_amplitude), loading_rate=_t(p["loading_rate"]), input_delay=_t(p["input_delay"])))
+
+    def velocity_history(self, design, steps_per_interval):
+        """Free-DOF history (T, 2, n_free) of the fixed-grid solve on the autograd tape + the solver (for its DOF ids)."""
+        solver = OD.setup_dynamic_solver(self.geometry, self.energy, integrator="fixed", steps_per_interval=steps_per_interval,
+                                         **self.solver_args)
+        hist, _ = OD.solve_fixed_differentiable(solver, self.geometry, _t(self.state0), self.timepoints, self.control_params(design),
+                                                steps_per_interval)
+        return hist, solver
+
+
+def target_kinetic_energy(problem, design, target_blocks, steps_per_interval):
+    """problems/quads_focusing.py:453-467: kinetic_energy(fields[:, 1, target_blocks, :], compute_inertia(cnv, density)[target_blocks])
+    with energy.py:494-499 (sum over time, blocks and DOFs of m v^2 / 2).  The target blocks are free blocks: their velocities
+    are entries of the free-DOF history."""
+    hist, solver = problem.velocity_history(design, steps_per_interval)
+    free = list(solver.free_DOF_ids)
+    cols = torch.as_tensor([[free.index(int(b) * 3 + d) for d in range(3)] for b in target_blocks], dtype=torch.long)
+    vel = hist[:, 1][:, cols]                                            # (T, n_target, 3)
+    inertia = OG.compute_inertia(problem.geometry.centroid_node_vectors(*design), _t(problem.p["density"]))[torch.as_tensor(target_blocks)]
+    return OE.kinetic_energy(vel, inertia)
+
+
+def multi_input_objective(problems, design, target_blocks, weights, steps_per_interval):
+    """problems/quads_focusing_multi_input.py:64-82: weights @ [target kinetic energy of every forward problem]."""
+    vals = torch.stack([target_kinetic_energy(p, design, target_blocks, steps_per_interval) for p in problems])
+    return (_t(weights) * vals).sum(), vals

@@ -1,0 +1,170 @@
+"""Known-answer tests from closed forms typed in here (not from the oracle, not from the engine): they check the ORACLE and the
+engine against something other than each other for the physics the reference's own tests leave unpinned.
+
+1. Angle-based contact of ONE ligament between two square blocks (energy.py:333-361 on the void angles of
+   energy.py:204-219 / geometry.py:181-253): with block B rotated by kappa about the hinge the two void angles are
+   phi1 - kappa and phi2 + kappa, phi computed here from the explicit edge vectors; energy and torque in closed form.
+2. Prescribed DOFs: fields[:, 0, dof] = c(t), fields[:, 1, dof] = c'(t) (dynamics.py:129-136,169-182) for the raised-cosine pulse
+   of problems/quads_focusing.py:211-222: c'(t) = A pi f sin(2 pi f tau) on 0 < tau < 1/f.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import difflexmm_amd as dm
+from difflexmm_amd import energy as en_mod
+from difflexmm_amd import geometry as geo_mod
+from difflexmm_amd import loading as ld
+from difflexmm_amd.dynamics import setup_dynamic_solver
+from oracle import ref_energy as OE
+
+
+def hinge():
+    """Two unit squares side by side (centroids 3 apart), one ligament from node 0 of block 0 (its right corner) to node 2 of block 1."""
+    cnv = np.array([[[1.0, 0.2], [0.1, 1.0], [-1.0, -0.1], [-0.2, -1.0]],
+                    [[1.0, -0.1], [0.3, 1.0], [-1.0, 0.15], [-0.1, -1.0]]])
+    cen = np.array([[0.0, 0.0], [3.0, 0.0]])
+    bonds = np.array([[0, 6]])
+    return cnv, cen, bonds
+
+
+def edge_angle(u, w):
+    return math.atan2(u[0] * w[1] - u[1] * w[0], u[0] * w[0] + u[1] * w[1])
+
+
+def closed_form_contact(kappa, cnv, am, ac, k):
+    """Void angles of geometry.py:245-249 for bond (n1 on block A, n2 on block B), B rotated by kappa relative to A:
+    a1 = angle(e-(n2) -> e+(n1)), a2 = angle(e-(n1) -> e+(n2)); e+/-(n) = unit vector from node n to the next / previous node."""
+    A, Bk = cnv[0], cnv[1]
+    c, s = math.cos(kappa), math.sin(kappa)
+    Bk = Bk @ np.array([[c, s], [-s, c]])                # rows rotated by +kappa
+    e1p, e1m = A[1] - A[0], A[3] - A[0]                  # node 0 of A: next = 1, prev = 3
+    e2p, e2m = Bk[3] - Bk[2], Bk[1] - Bk[2]              # node 2 of B: next = 3, prev = 1
+    a1, a2 = edge_angle(e2m, e1p), edge_angle(e1m, e2p)
+    D = ac - am
+
+    def E(a):
+        if not (am <= a < ac):
+            return 0.0, 0.0
+        x = (a - ac) / D
+        return k / 4 * D * D * (1 / (x + 1) - 1 / (x - 1) - 2), k / 4 * D * (-1 / (x + 1) ** 2 + 1 / (x - 1) ** 2)
+    (E1, d1), (E2, d2) = E(a1), E(a2)
+    return a1, a2, E1 + E2, d1, d2
+
+
+@pytest.mark.parametrize("kappa", [-0.35, -0.1, 0.0, 0.2, 0.45])
+def test_contact_energy_and_torque_closed_form_vs_oracle(kappa):
+    cnv, cen, bonds = hinge()
+    a1_0, a2_0, *_ = closed_form_contact(0.0, cnv, -1.0, 3.0, 1.0)
+    am, ac, k = min(a1_0, a2_0) - 0.6, max(a1_0, a2_0) + 0.3, 1.7      # both void angles inside [am, ac) for the kappas above
+    a1, a2, E, d1, d2 = closed_form_contact(kappa, cnv, am, ac, k)
+    assert abs(a1 - (a1_0 - kappa)) < 1e-12 and abs(a2 - (a2_0 + kappa)) < 1e-12       # rigid blocks: a = phi -+ kappa
+    u = torch.tensor([[0.3, -0.2, 0.1], [-0.4, 0.25, 0.1 + kappa]], dtype=torch.float64, requires_grad=True)   # any translation
+    cp = OE.ControlParams(OE.GeometricalParams(torch.as_tensor(cen), torch.as_tensor(cnv)),
+                          OE.MechanicalParams(None, None, None, None, OE.ContactParams(*(torch.tensor(v, dtype=torch.float64) for v in (am, ac, k)))))
+    e = OE.build_contact_energy(bonds)(u, cp)
+    assert abs(e.item() - E) < 1e-12 * max(1.0, abs(E)) and E > 0
+    (g,) = torch.autograd.grad(e, u)
+    # a1 = phi1 - (th_B - th_A), a2 = phi2 + (th_B - th_A): dE/dth_B = d2 - d1 = -dE/dth_A; no force on translations
+    assert abs(g[1, 2].item() - (d2 - d1)) < 1e-11 * max(1.0, abs(d2 - d1)) and abs(g[0, 2].item() + (d2 - d1)) < 1e-11 * max(1.0, abs(d2 - d1))
+    assert g[:, :2].abs().max().item() < 1e-12
+
+
+def engine_hinge(lib, am, ac, k):
+    cnv, cen, bonds = hinge()
+
+    class G:                       # the two-block "lattice"
+        n_blocks, n_npb = 2, 4
+    energy = en_mod.combine_block_energies(en_mod.build_strain_energy(bonds, en_mod.ligament_energy), en_mod.build_contact_energy(bonds))
+    s = setup_dynamic_solver(G(), energy, _lib=lib)
+    cp = dm.ControlParams(dm.GeometricalParams(cen, cnv),
+                          dm.MechanicalParams(dm.LigamentParams(0.0, 0.0, 0.0, np.array([[1.0, 0.0]])), None, np.ones((2, 3)), 0.0,
+                                              dm.ContactParams(am, ac, k)))
+    return s, cp
+
+
+def check_engine_contact_torque(lib):
+    """The engine's force on a two-block hinge with the ligament stiffnesses set to zero IS the contact torque: rhs = -dE/du / m."""
+    cnv, _, _ = hinge()
+    a1_0, a2_0, *_ = closed_form_contact(0.0, cnv, -1.0, 3.0, 1.0)
+    am, ac, k = min(a1_0, a2_0) - 0.6, max(a1_0, a2_0) + 0.3, 1.7
+    s, cp = engine_hinge(lib, am, ac, k)
+    flat = s._flatten(cp)
+    s.engine.set_params(**{key: v[None] for key, v in flat.items()})
+    for kappa in (-0.35, 0.0, 0.2, 0.45):
+        _, _, E, d1, d2 = closed_form_contact(kappa, cnv, am, ac, k)
+        y = np.zeros((1, 2, 2, 3))
+        y[0, 0] = [[0.3, -0.2, 0.1], [-0.4, 0.25, 0.1 + kappa]]
+        dy = s.engine.rhs(y, 0.0)[0]
+        assert abs(dy[1, 1, 2] + (d2 - d1)) < 1e-11 * max(1.0, abs(d2 - d1)) and abs(dy[1, 0, 2] - (d2 - d1)) < 1e-11 * max(1.0, abs(d2 - d1))
+        assert np.abs(dy[1, :, :2]).max() < 1e-12
+        assert abs(s.engine.energy(y[:, 0])[0] - E) < 1e-12 * max(1.0, E)
+
+
+def test_contact_torque_closed_form_vs_cpu_port(cpu_lib):
+    check_engine_contact_torque(cpu_lib)
+
+
+@pytest.mark.gpu
+def test_contact_torque_closed_form_vs_hip(hip_lib):
+    check_engine_contact_torque(None)
+
+
+def check_prescribed_dof_outputs(lib):
+    g = geo_mod.QuadGeometry(3, 3, 15.0, 2.25)
+    design = g.get_design_from_rotated_square(25 * math.pi / 180)
+    bonds = g.bond_connectivity()
+    con = np.array([[3, 0], [3, 1], [3, 2], [0, 0]])
+    vec = np.array([1.0, -0.5, 0.02, 0.0])
+    s = setup_dynamic_solver(g, en_mod.build_strain_energy(bonds, en_mod.ligament_energy), constrained_block_DOF_pairs=con,
+                             constrained_DOFs_fn=ld.Pulse(vec), _lib=lib)
+    A, f, td = 2.5, 400.0, 2e-4
+    cp = dm.ControlParams(dm.GeometricalParams(g.block_centroids(*design), g.centroid_node_vectors(*design)),
+                          dm.MechanicalParams(dm.LigamentParams(120.0, 1.19, 1.5, g.reference_bond_vectors()), 6.18e-9, None, 0.0),
+                          constraint_params=dict(amplitude=A, loading_rate=f, input_delay=td))
+    ts = np.linspace(0.0, 3.2e-3, 9)                       # before, inside and after the pulse window (1/f = 2.5e-3)
+    fields = s(np.zeros((2, 9, 3)), ts, cp, steps_per_interval=40)
+    tau = ts - td
+    on = (tau > 0) & (tau < 1 / f)
+    c = np.where(on, A * 0.5 * (1 - np.cos(2 * math.pi * f * tau)), 0.0)
+    cdot = np.where(on, A * math.pi * f * np.sin(2 * math.pi * f * tau), 0.0)
+    for (blk, d), w in zip(con, vec):
+        assert np.abs(fields[:, 0, blk, d] - w * c).max() < 1e-13 * A
+        assert np.abs(fields[:, 1, blk, d] - w * cdot).max() < 1e-12 * A * math.pi * f
+    assert np.abs(fields[:, :, 4]).max() > 0               # the free neighbour moves
+
+
+def test_prescribed_dof_outputs_closed_form_on_cpu_port(cpu_lib):
+    check_prescribed_dof_outputs(cpu_lib)
+
+
+@pytest.mark.gpu
+def test_prescribed_dof_outputs_closed_form_on_hip(hip_lib):
+    check_prescribed_dof_outputs(None)
+
+
+def test_prescribed_dof_outputs_closed_form_on_oracle():
+    """The same closed form against the ORACLE's reconstruction (kinematics + constrained_rate, dynamics.py:129-136)."""
+    from oracle import ref_dynamics as OD, ref_geometry as OG
+    from .common import torch_pulse
+    g = OG.QuadGeometry(3, 3, 15.0, 2.25)
+    design = g.get_design_from_rotated_square(25 * math.pi / 180)
+    con = np.array([[3, 0], [3, 1], [3, 2], [0, 0]])
+    vec = np.array([1.0, -0.5, 0.02, 0.0])
+    bonds = g.bond_connectivity()
+    sol = OD.setup_dynamic_solver(g, OE.build_strain_energy(bonds, OE.ligament_energy), constrained_block_DOF_pairs=con,
+                                  constrained_DOFs_fn=torch_pulse(vec), integrator="fixed", steps_per_interval=10)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    A, f, td = 2.5, 400.0, 2e-4
+    cp = OE.ControlParams(OE.GeometricalParams(g.block_centroids(*design), g.centroid_node_vectors(*design)),
+                          OE.MechanicalParams(OE.LigamentParams(T(120.0), T(1.19), T(1.5), T(g.reference_bond_vectors())), T(6.18e-9), None, T(0.0), None),
+                          constraint_params=dict(amplitude=T(A), loading_rate=T(f), input_delay=T(td)))
+    ts = np.linspace(0.0, 3.2e-3, 5)
+    fields = sol(np.zeros((2, 9, 3)), ts, cp).numpy()
+    tau = ts - td
+    on = (tau > 0) & (tau < 1 / f)
+    for (blk, d), w in zip(con, vec):
+        assert np.abs(fields[:, 0, blk, d] - w * np.where(on, A * 0.5 * (1 - np.cos(2 * math.pi * f * tau)), 0.0)).max() < 1e-13 * A
+        assert np.abs(fields[:, 1, blk, d] - w * np.where(on, A * math.pi * f * np.sin(2 * math.pi * f * tau), 0.0)).max() < 1e-10 * A * math.pi * f
