@@ -9,4 +9,4 @@ __version__ = "0.1.0"
 
 from .dynamics import setup_dynamic_solver  # noqa: F401
 from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentParams,  # noqa: F401
-                    MechanicalParams, SolutionData)
+                    MechanicalParams, SolutionData, StretchingTorsionalSpringParams)

@@ -11,7 +11,7 @@ import numpy as np
 DFX_MAX_FNS = 2
 DFX_FN_PARAMS = 5
 
-BOND_LINEARIZED, BOND_NONLINEAR = 0, 1
+BOND_LINEARIZED, BOND_NONLINEAR, BOND_SIMPLE_SPRING, BOND_STRETCH_TORSION = 0, 1, 2, 3
 CONTACT_NONE, CONTACT_ANGLE = 0, 1
 TABLEAU = {"dopri5": 0, "rk4": 1}
 FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_PULSE, FN_TABLE = range(8)
@@ -53,7 +53,7 @@ class dfx_stats(C.Structure):
 
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid",
            "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
-           "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
+           "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rank", "dfx_comm_size",
@@ -80,6 +80,7 @@ def declare(lib):
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
     lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_kinetic_value_and_grad.argtypes = [H, _ip, C.c_int32, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
+    lib.dfx_response_data.argtypes = [H, _dp, _dp, _dp, _dp]
     lib.dfx_rhs.argtypes = [H, _dp, C.c_double, _dp]
     lib.dfx_rhs_vjp.argtypes = [H, _dp, C.c_double, _dp, _dp, C.POINTER(dfx_grads)]
     lib.dfx_energy.argtypes = [H, _dp, _dp]
@@ -338,6 +339,20 @@ class Engine:
             a.flags.writeable = False
             out[n] = a
         return obj, out, _stats(st)
+
+    def response_data(self, strains=True, kinetic=True):
+        """Per-ligament strain energies (batch, T, n_bonds) x 3 and per-block kinetic energy (batch, T, n_blocks) of the last
+        forward solve, computed on the device from its resident history."""
+        B, T = self.batch, self.n_timepoints
+        out = {}
+        if strains:
+            for n in ("strain_energy_stretch", "strain_energy_shear", "strain_energy_bending"):
+                out[n] = np.empty((B, T, self.n_bonds))
+        if kinetic:
+            out["kinetic_energy"] = np.empty((B, T, self.n_blocks))
+        self._check(self.lib.dfx_response_data(self._h, _ptr(out.get("strain_energy_stretch")), _ptr(out.get("strain_energy_shear")),
+                                               _ptr(out.get("strain_energy_bending")), _ptr(out.get("kinetic_energy"))), "dfx_response_data")
+        return out
 
     # -- test hooks ---------------------------------------------------------------------------
     def rhs(self, y, t):

@@ -102,6 +102,7 @@ struct dfx_handle {
   bool want_bond_grads = true, want_fn_grads = true, want_damping_grads = true;
   DevBuf<int32_t> d_slot_info, d_block_special, d_slot_bond;
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
+  DevBuf<double> d_resp;                           // dfx_response_data outputs
   DevBuf<dfx_special> d_special;
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict;
   DevBuf<uint8_t> d_l_idx;
@@ -216,8 +217,9 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
 }
 static void launch_fwd(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   const Plan& pl = h->pl;
-  if (pl.model == kNonlinear) { if (pl.contact) launch_fwd_t<kNonlinear, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<kNonlinear, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); }
-  else { if (pl.contact) launch_fwd_t<kLinearized, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<kLinearized, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); }
+#define DFX_FWD_CASE(M) case M: if (pl.contact) launch_fwd_t<M, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<M, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); break;
+  switch (pl.model) { DFX_FWD_CASE(kNonlinear) DFX_FWD_CASE(kLinearized) DFX_FWD_CASE(kSimpleSpring) DFX_FWD_CASE(kStretchTorsion) }
+#undef DFX_FWD_CASE
   h->launches++;
 }
 static void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
@@ -235,8 +237,9 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
   const Plan& pl = h->pl;
-  if (pl.model == kNonlinear) { if (pl.contact) launch_adj_t<kNonlinear, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<kNonlinear, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); }
-  else { if (pl.contact) launch_adj_t<kLinearized, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<kLinearized, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); }
+#define DFX_ADJ_CASE(M) case M: if (pl.contact) launch_adj_t<M, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<M, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); break;
+  switch (pl.model) { DFX_ADJ_CASE(kNonlinear) DFX_ADJ_CASE(kLinearized) DFX_ADJ_CASE(kSimpleSpring) DFX_ADJ_CASE(kStretchTorsion) }
+#undef DFX_ADJ_CASE
   h->launches++;
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wbuf, int local_only) {
@@ -708,7 +711,7 @@ int dfx_destroy(dfx_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release();
-  h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release();
+  h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release(); h->d_resp.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
@@ -1010,13 +1013,9 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     // evaluations at S_1..S_5, candidate y1 into buffer 3, then the FSAL evaluation with the error estimate
     static const int inb[6] = {0, 1, 2, 1, 2, 1}, outb[6] = {0, 2, 1, 2, 1, 3};
     for (int i = 1; i <= 5; ++i) launch_fwd(h, c, i, 0, inb[i], outb[i], 0, 0);
-    if (pl.model == kNonlinear) {
-      if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<kNonlinear, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
-      else hipLaunchKernelGGL((k_fwd_stage<kNonlinear, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
-    } else {
-      if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<kLinearized, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
-      else hipLaunchKernelGGL((k_fwd_stage<kLinearized, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2);
-    }
+#define DFX_ERR_CASE(M) case M: if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); else hipLaunchKernelGGL((k_fwd_stage<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); break;
+    switch (pl.model) { DFX_ERR_CASE(kNonlinear) DFX_ERR_CASE(kLinearized) DFX_ERR_CASE(kSimpleSpring) DFX_ERR_CASE(kStretchTorsion) }
+#undef DFX_ERR_CASE
     hipLaunchKernelGGL(k_control, dim3((unsigned)B), dim3(kThreads), 0, h->stream, c, n_partials, 2.0 * (double)n_free, Tn);
     hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn);
     h->launches += 3;
@@ -1229,6 +1228,45 @@ int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int3
   return adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, views, stats);
 }
 
+// device -> caller memory through the pinned staging area, in chunks (outputs here can be GBs; pageable DMA is slow)
+static int download(dfx_handle* h, double* dst, const double* src, size_t n) {
+  const size_t chunk = (size_t)8 << 20;      // doubles per chunk: 64 MiB
+  HIP_OK(h->stage.ensure(std::min(n, chunk) * sizeof(double)));
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t cnt = std::min(chunk, n - off);
+    HIP_OK(hipMemcpyAsync(h->stage.p, src + off, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    memcpy(dst + off, h->stage.p, cnt * sizeof(double));
+  }
+  return 0;
+}
+
+int dfx_response_data(dfx_handle* h, double* strain_energy_stretch, double* strain_energy_shear, double* strain_energy_bending,
+                      double* kinetic_energy) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->have_fields || !h->have_params) { h->err = "response_data: run forward first"; return 1; }
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks, nbd = pl.n_bonds, T = h->ts.size();
+  const bool bonds = strain_energy_stretch || strain_energy_shear || strain_energy_bending;
+  HIP_OK(h->d_resp.ensure((bonds ? 3 * B * T * nbd : 0) + (kinetic_energy ? B * T * nb : 0) + 1));
+  double* d_s = h->d_resp.p;
+  double* d_sh = d_s + (bonds ? B * T * nbd : 0);
+  double* d_b = d_sh + (bonds ? B * T * nbd : 0);
+  double* d_k = d_b + (bonds ? B * T * nbd : 0);
+  DevCtx c = make_ctx(h);
+  dim3 grid((unsigned)((pl.n_slots + kThreads - 1) / kThreads), (unsigned)T, (unsigned)B);
+  hipLaunchKernelGGL(k_response, grid, dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_slot_bond.p, (int)nbd,
+                     bonds ? d_s : (double*)nullptr, bonds ? d_sh : (double*)nullptr, bonds ? d_b : (double*)nullptr,
+                     kinetic_energy ? d_k : (double*)nullptr);
+  HIP_OK(hipGetLastError());
+  if (strain_energy_stretch) if (int rc = download(h, strain_energy_stretch, d_s, B * T * nbd)) return rc;
+  if (strain_energy_shear) if (int rc = download(h, strain_energy_shear, d_sh, B * T * nbd)) return rc;
+  if (strain_energy_bending) if (int rc = download(h, strain_energy_bending, d_b, B * T * nbd)) return rc;
+  if (kinetic_energy) if (int rc = download(h, kinetic_energy, d_k, B * T * nb)) return rc;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ---- test hooks ------------------------------------------------------------------------------
 static int hook_prepare(dfx_handle* h, const double* y, double t) {
   const Plan& pl = h->pl;
@@ -1318,13 +1356,9 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
   HIP_OK(hipMemcpyAsync(h->d_POS.p, S.data(), sizeof(double) * S.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_tmp.ensure(B * pl.n_slots));
   DevCtx c = make_ctx(h);
-  if (pl.model == kNonlinear) {
-    if (pl.contact) hipLaunchKernelGGL((k_energy<kNonlinear, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p);
-    else hipLaunchKernelGGL((k_energy<kNonlinear, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p);
-  } else {
-    if (pl.contact) hipLaunchKernelGGL((k_energy<kLinearized, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p);
-    else hipLaunchKernelGGL((k_energy<kLinearized, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p);
-  }
+#define DFX_EN_CASE(M) case M: if (pl.contact) hipLaunchKernelGGL((k_energy<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); else hipLaunchKernelGGL((k_energy<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); break;
+  switch (pl.model) { DFX_EN_CASE(kNonlinear) DFX_EN_CASE(kLinearized) DFX_EN_CASE(kSimpleSpring) DFX_EN_CASE(kStretchTorsion) }
+#undef DFX_EN_CASE
   std::vector<double> e(B * pl.n_slots);
   HIP_OK(hipMemcpyAsync(e.data(), h->d_tmp.p, sizeof(double) * e.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));

@@ -944,6 +944,51 @@ __global__ __launch_bounds__(kThreads) void k_pack_grads(DevCtx c, const int32_t
   }
 }
 
+// ---- post-processing of a solve on the device-resident history (problems/quads_focusing.py:319-372) -------------------------
+// Per-ligament strain energies (stretch / shear / bending: energy.py:522-534 strains, then 1/2 k (strain l0)^2) and per-block
+// kinetic energy of EVERY output time: one launch, grid = (slots, T, members); the end-0 lane of a ligament writes its three
+// entries, lanes 0 of a quad the block's kinetic energy.  Reads the (T, 2, n, 3) fields and the resident parameter images.
+__global__ __launch_bounds__(kThreads) void k_response(DevCtx c, const double* fields, const int32_t* slot_bond, int n_bonds,
+                                                       double* e_stretch, double* e_shear, double* e_bend, double* e_kin) {
+  const int m = blockIdx.z, kt = blockIdx.y;
+  const int slot = blockIdx.x * kThreads + threadIdx.x;
+  if (slot >= c.n_slots) return;
+  const int b = slot >> 2, k = slot & 3;
+  const size_t nd = (size_t)c.n_blocks * 3;
+  const double* f = fields + ((size_t)m * c.n_timepoints + kt) * nd * 2;
+  if (e_kin && k == 0) {
+    const double* im = c.inv_m + (size_t)m * nd + (size_t)b * 3;
+    const double* v = f + nd + (size_t)b * 3;
+    e_kin[((size_t)m * c.n_timepoints + kt) * c.n_blocks + b] = 0.5 * (v[0] * v[0] / im[0] + v[1] * v[1] / im[1] + v[2] * v[2] / im[2]);
+  }
+  const int info = c.slot_info[slot];
+  if (info < 0 || (info & 1) || !(e_stretch || e_shear || e_bend)) return;       // one lane per ligament: its end-0 slot
+  const int ps = info >> 1, pb = ps >> 2;
+  const MemberBases B = member_bases(c, m);
+  BlockRec<double> o, p;
+  o.x = f[(size_t)b * 3]; o.y = f[(size_t)b * 3 + 1]; o.th = f[(size_t)b * 3 + 2];
+  p.x = f[(size_t)pb * 3]; p.y = f[(size_t)pb * 3 + 1]; p.th = f[(size_t)pb * 3 + 2];
+  fast_sincos(0.5 * o.th, &o.sh, &o.ch);
+  fast_sincos(0.5 * p.th, &p.sh, &p.ch);
+  const double2 ro = ldg<double2>(B.p_r, (u32)slot * 16), rp = ldg<double2>(B.p_r, (u32)ps * 16);
+  double lx, ly, l0, il0;
+  if (c.l_dict_on) {
+    const int li = B.p_lidx[slot];
+    lx = B.l_dict[li * 4]; ly = B.l_dict[li * 4 + 1]; l0 = B.l_dict[li * 4 + 2]; il0 = B.l_dict[li * 4 + 3];
+  } else {
+    lx = B.p_l[(size_t)slot * 2]; ly = B.p_l[(size_t)slot * 2 + 1]; l0 = sqrt(lx * lx + ly * ly); il0 = 1.0 / l0;
+  }
+  double ks, ksh, kr;
+  if (c.k_uniform) { ks = B.cst[3]; ksh = B.cst[4]; kr = B.cst[5]; }
+  else { ks = B.p_k[(size_t)slot * 4]; ksh = B.p_k[(size_t)slot * 4 + 1]; kr = B.p_k[(size_t)slot * 4 + 2]; }
+  BondGrad<double> g;
+  bond_grad<kNonlinear, double>(o, p, ro.x, ro.y, rp.x, rp.y, lx, ly, l0, il0, ks, ksh, kr, -1.0, g);   // g.ks = (eps l0)^2 / 2, ...
+  const size_t oi = ((size_t)m * c.n_timepoints + kt) * n_bonds + slot_bond[slot];
+  if (e_stretch) e_stretch[oi] = ks * g.ks;
+  if (e_shear) e_shear[oi] = ksh * g.ksh;
+  if (e_bend) e_bend[oi] = kr * g.kr;
+}
+
 // kinetic-energy objective: G <- m v on target blocks; per-member objective by one workgroup
 __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fields, const int32_t* target, int n_target,
                                                       double* G, double* objective) {

@@ -11,6 +11,8 @@
 //   node kinematics      difflexmm/kinematics.py:13-31   U = u_xy + (R(theta) - I) r
 //   nonlinear ligament   difflexmm/energy.py:120-176
 //   linearised ligament  difflexmm/energy.py:70-117
+//   simple spring        difflexmm/energy.py:30-48    E = k_stretch (|dU + l0| - |l0|)^2 / 2
+//   zero-length spring   difflexmm/energy.py:51-67    E = k_stretch |dU|^2 / 2 + k_rot (theta_2 - theta_1)^2 / 2
 //   angle-based contact  difflexmm/energy.py:204-219,333-361 + geometry.py:181-253
 //   driving functions    problems/quads_focusing.py:211-222, tests/test_difflexmm.py:85-86,
 //                        scripts/pulse_RS.py:49-50, problems/hinge_characterization.py:134-139
@@ -173,7 +175,7 @@ DFX_HD BlockRec<Dual> seed_rec(const BlockRec<double>& r, double wx, double wy, 
   return d;
 }
 
-enum BondModel { kLinearized = 0, kNonlinear = 1 };
+enum BondModel { kLinearized = 0, kNonlinear = 1, kSimpleSpring = 2, kStretchTorsion = 3 };
 
 // dE_bond / d(everything the OWN end of the bond owns) + bond parameters
 template <class T>
@@ -230,6 +232,32 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, P rox, P roy, 
     g.ly = gby - kse * (ly * il0) + kshg * gam * ly - kshg * lx;
     g.ks = 0.5 * (es * es);
     g.ksh = 0.5 * (l02 * (gam * gam));
+  } else if (MODEL == kSimpleSpring) {
+    // energy.py:30-48: the axial term of the nonlinear ligament alone (no shear, no bending: k_shear / k_rot are not read)
+    T bx = dUx + lx, by = dUy + ly;
+    T Lb = tsqrt(bx * bx + by * by);
+    T iLb = trcp(Lb);
+    T es = Lb - l0;
+    T kse = ks * es;
+    g.e = 0.5 * (kse * es);
+    gbx = kse * bx * iLb;
+    gby = kse * by * iLb;
+    gtb = T(0.0);
+    g.lx = gbx - kse * (lx * il0);
+    g.ly = gby - kse * (ly * il0);
+    g.ks = 0.5 * (es * es);
+    g.ksh = T(0.0);
+  } else if (MODEL == kStretchTorsion) {
+    // energy.py:51-67: zero-length spring between two coincident nodes (the reference vector is not read)
+    T kdx = ks * dUx, kdy = ks * dUy;
+    g.e = 0.5 * (kdx * dUx + kdy * dUy) + 0.5 * (kr * (kap * kap));
+    gbx = kdx;
+    gby = kdy;
+    gtb = T(0.0);
+    g.lx = T(0.0);
+    g.ly = T(0.0);
+    g.ks = 0.5 * (dUx * dUx + dUy * dUy);
+    g.ksh = T(0.0);
   } else {
     // energy.py:88-96,113-117
     T tb = 0.5 * (o.th + p.th);
@@ -249,8 +277,8 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, P rox, P roy, 
     g.ks = 0.5 * (es * es);
     g.ksh = 0.5 * (esh * esh);
   }
-  g.kr = 0.5 * (kap * kap);
-  T krk = kr * kap;
+  g.kr = MODEL == kSimpleSpring ? T(0.0) : 0.5 * (kap * kap);
+  T krk = MODEL == kSimpleSpring ? T(0.0) : kr * kap;
   g.fx = sgn * gbx;
   g.fy = sgn * gby;
   g.fth = sgn * (gby * qox - gbx * qoy) + 0.5 * gtb + sgn * krk;

@@ -44,7 +44,7 @@ inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
   if (!p || p->n_blocks <= 0 || (p->n_npb != 3 && p->n_npb != 4)) { err = "invalid problem: n_blocks/n_npb"; return 1; }
   if (p->batch <= 0) { err = "invalid problem: batch must be >= 1"; return 1; }
   if (p->n_fns < 0 || p->n_fns > DFX_MAX_FNS) { err = "invalid problem: n_fns out of range"; return 1; }
-  if (p->bond_model != DFX_BOND_LINEARIZED && p->bond_model != DFX_BOND_NONLINEAR) { err = "invalid bond_model"; return 1; }
+  if (p->bond_model < DFX_BOND_LINEARIZED || p->bond_model > DFX_BOND_STRETCH_TORSION) { err = "invalid bond_model"; return 1; }
   if (p->contact != DFX_CONTACT_NONE && p->contact != DFX_CONTACT_ANGLE) { err = "invalid contact model"; return 1; }
   pl.n_blocks = p->n_blocks; pl.n_npb = p->n_npb; pl.n_bonds = p->n_bonds; pl.batch = p->batch;
   pl.n_slots = p->n_blocks * kSlots;

@@ -23,7 +23,7 @@ from . import _binding as _b
 from .energy import _EnergyFn
 from .geometry import (DOFsInfo, compute_inertia, compute_inertia_vjp, void_angles0, void_angles0_vjp)
 from .loading import as_time_function, zero
-from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentParams, MechanicalParams)
+from .utils import (ContactParams, ControlParams, GeometricalParams, MechanicalParams)
 
 
 _FLAT_CACHE = {}      # id(centroid_node_vectors) -> (weakref, bonds, density, inertia, void_angle0)
@@ -87,6 +87,7 @@ class DynamicSolver:
                                 batch=self.batch, tableau=integrator, device=device, lib=lib,
                                 fn_tables=[getattr(f, "table", None) for f in self.con_terms + self.load_terms])
         self._last = None
+        self.solve_count = 0          # forward solves run so far (what the engine's resident history belongs to)
 
     # -- ControlParams -> engine arrays -------------------------------------------------------------
     def _flatten(self, cp: ControlParams):
@@ -94,10 +95,15 @@ class DynamicSolver:
         cnv = np.asarray(gp.centroid_node_vectors, dtype=float)
         nbd = len(self.bonds)
         bp = mp.bond_params
+        # the spring models read a subset of (k_stretch, k_shear, k_rot, reference_vector) (energy.py:30-67): what a model does not
+        # read is passed as 0 / a unit dummy vector and comes back with a zero gradient
+        zero = np.zeros(nbd)
         out = {
             "centroid_node_vectors": cnv,
-            "reference_vector": np.broadcast_to(np.asarray(bp.reference_vector, dtype=float), (nbd, 2)),
-            "k_bond": np.stack([_bcast(bp.k_stretch, nbd), _bcast(bp.k_shear, nbd), _bcast(bp.k_rot, nbd)], 1),
+            "reference_vector": np.broadcast_to(np.asarray(getattr(bp, "reference_vector", np.array([1.0, 0.0])), dtype=float), (nbd, 2)),
+            "k_bond": np.stack([_bcast(bp.k_stretch, nbd),
+                                _bcast(bp.k_shear, nbd) if self.spec.bond_model in (_b.BOND_LINEARIZED, _b.BOND_NONLINEAR) else zero,
+                                _bcast(bp.k_rot, nbd) if self.spec.bond_model != _b.BOND_SIMPLE_SPRING else zero], 1),
         }
         cached = _FLAT_CACHE.get(id(cnv)) if mp.inertia is None else None
         if cached is not None and cached[0]() is cnv and cached[1] is self.bonds and np.array_equal(cached[2], mp.density):
@@ -181,6 +187,7 @@ class DynamicSolver:
     def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None, step_times=None,
                  want_fields=True):
         cps = self._members(control_params)
+        self.solve_count += 1
         flats = [self._flatten(cp) for cp in cps]
         self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
         spi = steps_per_interval if steps_per_interval is not None else self.steps_per_interval
@@ -262,6 +269,21 @@ class DynamicSolver:
         self.adjoint_stats = stats
         return obj, grads
 
+    @staticmethod
+    def _bond_params_bar(bp, kb, refv_bar, like):
+        """Gradient tree with the structure of the bond parameters that were passed in (LigamentParams /
+        StretchingTorsionalSpringParams / any NamedTuple with a subset of their fields)."""
+        cols = {"k_stretch": 0, "k_shear": 1, "k_rot": 2}
+        vals = {}
+        for name in bp._fields:
+            if name in cols:
+                vals[name] = like(getattr(bp, name), kb[:, cols[name]])
+            elif name == "reference_vector":
+                vals[name] = refv_bar
+            else:
+                vals[name] = None
+        return type(bp)(**vals)
+
     def _unflatten_grads(self, g, fields_bar):
         cps, flats, ts = self._last
         trees = []
@@ -299,10 +321,7 @@ class DynamicSolver:
                 geometrical_params=GeometricalParams(block_centroids=np.zeros_like(np.asarray(gp.block_centroids, dtype=float)),
                                                      centroid_node_vectors=cnv_bar),
                 mechanical_params=MechanicalParams(
-                    bond_params=LigamentParams(k_stretch=like(mp.bond_params.k_stretch, kb[:, 0]),
-                                               k_shear=like(mp.bond_params.k_shear, kb[:, 1]),
-                                               k_rot=like(mp.bond_params.k_rot, kb[:, 2]),
-                                               reference_vector=g["reference_vector"][m]),
+                    bond_params=self._bond_params_bar(mp.bond_params, kb, g["reference_vector"][m], like),
                     density=density_bar, inertia=inertia_bar, damping=damping_bar, contact_params=contact_bar),
                 loading_params=load_bar, constraint_params=con_bar))
         state0_bar = g["state0"]

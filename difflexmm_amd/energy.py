@@ -5,7 +5,7 @@ post-processing and tests.  The per-time-step evaluation never goes through thes
 """
 import numpy as np
 
-from ._binding import BOND_LINEARIZED, BOND_NONLINEAR
+from ._binding import BOND_LINEARIZED, BOND_NONLINEAR, BOND_SIMPLE_SPRING, BOND_STRETCH_TORSION
 from .geometry import compute_edge_angles, rotation_matrix
 
 
@@ -63,6 +63,39 @@ ligament_energy_linearized = _BondEnergy("ligament_energy_linearized", BOND_LINE
 ligament_energy = _BondEnergy("ligament_energy", BOND_NONLINEAR, ligament_strains)
 
 
+class _SimpleSpring(_BondEnergy):
+    """energy.py:30-48."""
+
+    def __init__(self):
+        self.__name__, self.model = "simple_spring_energy", BOND_SIMPLE_SPRING
+
+    def __call__(self, nodal_DOFs, reference_vector=np.array([1., 0.]), k_stretch=1., **_ignored):
+        D1, D2 = (np.asarray(a, dtype=float) for a in nodal_DOFs)
+        rv = np.asarray(reference_vector, dtype=float)
+        l = np.linalg.norm(D2[:, :2] - D1[:, :2] + rv, axis=-1)
+        l0 = np.linalg.norm(rv, axis=-1)
+        return k_stretch * ((l / l0 - 1) * l0) ** 2 / 2
+
+
+class _StretchTorsionSpring(_BondEnergy):
+    """energy.py:51-67."""
+
+    def __init__(self):
+        self.__name__, self.model = "stretching_torsional_spring_energy", BOND_STRETCH_TORSION
+
+    def __call__(self, nodal_DOFs, k_stretch=1., k_rot=1., **_ignored):
+        D1, D2 = (np.asarray(a, dtype=float) for a in nodal_DOFs)
+        dU, dRot = D2[:, :2] - D1[:, :2], D2[:, 2] - D1[:, 2]
+        return k_stretch * np.sum(dU * dU, -1) / 2 + k_rot * dRot ** 2 / 2
+
+
+#: energy.py:30-48 -- linear spring between two nodes, rest length |reference_vector| (bond_params: anything with k_stretch and
+#: reference_vector, e.g. LigamentParams; its k_shear / k_rot are not used)
+simple_spring_energy = _SimpleSpring()
+#: energy.py:51-67 -- zero-length spring with a torsional term (bond_params: StretchingTorsionalSpringParams)
+stretching_torsional_spring_energy = _StretchTorsionSpring()
+
+
 class EnergySpec:
     """What the engine needs to know about a potential energy: connectivity, bond model, contact."""
 
@@ -103,7 +136,8 @@ def strain_energy_bond(bond_connectivity, bond_energy_fn=ligament_energy_lineari
 def build_strain_energy(bond_connectivity, bond_energy_fn=ligament_energy_linearized):
     """energy.py:410-449."""
     if not isinstance(bond_energy_fn, _BondEnergy):
-        raise TypeError("bond_energy_fn must be difflexmm_amd.energy.ligament_energy or ligament_energy_linearized")
+        raise TypeError("bond_energy_fn must be one of difflexmm_amd.energy.ligament_energy, ligament_energy_linearized, "
+                        "simple_spring_energy, stretching_torsional_spring_energy")
     bonds_fn = strain_energy_bond(bond_connectivity, bond_energy_fn)
 
     def host(block_displacement, control_params):

@@ -190,18 +190,38 @@ class QuadsFocusingForward:
         if fields is None:
             return None
         if many:
-            return [SolutionData(cp.geometrical_params.block_centroids, cp.geometrical_params.centroid_node_vectors,
+            sols = [SolutionData(cp.geometrical_params.block_centroids, cp.geometrical_params.centroid_node_vectors,
                                  self.bond_connectivity, self.timepoints, f) for cp, f in zip(cps, fields)]
-        return SolutionData(cps.geometrical_params.block_centroids, cps.geometrical_params.centroid_node_vectors,
-                            self.bond_connectivity, self.timepoints, fields)
+        else:
+            sols = [SolutionData(cps.geometrical_params.block_centroids, cps.geometrical_params.centroid_node_vectors,
+                                 self.bond_connectivity, self.timepoints, fields)]
+        # remembered so that compute_response_data can reduce THIS solve's histories on the device
+        self._last_solutions, self._last_solve_id, self.solution_data = sols, self.solve_dynamics.solve_count, sols[0]
+        return sols if many else sols[0]
 
 
-def _compute_response_data(self, solution_data):
+def _compute_response_data(self, solution_data=None):
     """Strain-energy and kinetic-energy histories of a solution (problems/quads_focusing.py:319-372): the fields of
-    SolutionData plus strain_energy_{stretch,shear,bending} (T, n_bonds) and kinetic_energy (T, n_blocks)."""
+    SolutionData plus strain_energy_{stretch,shear,bending} (T, n_bonds) and kinetic_energy (T, n_blocks).
+    For the solution(s) of the LAST solve -- ``solution_data`` omitted, as in the reference, or one of the objects that solve
+    returned -- the histories are reduced on the device from the resident fields (``dfx_response_data``); any other
+    SolutionData goes through the NumPy formulas on the host."""
+    last = getattr(self, "_last_solutions", None)
+    if solution_data is None:
+        if not last:
+            raise ValueError("No solution data available!")
+        solution_data = last[0]
     if type(solution_data) is not SolutionData:
         raise ValueError("Solution data is not of type SolutionData!")
     out = solution_data._asdict()
+    member = next((i for i, s_ in enumerate(last or []) if s_ is solution_data), None)
+    if member is not None and getattr(self, "_last_solve_id", None) == self.solve_dynamics.solve_count:
+        cache = getattr(self, "_response_cache", None)
+        if cache is None or cache[0] is not last:
+            cache = self._response_cache = (last, self.solve_dynamics.engine.response_data())
+        for k, v in cache[1].items():
+            out[k] = v[member]
+        return out
     axial, shear, bending = E.compute_ligament_strains_history(solution_data.fields[:, 0], solution_data.centroid_node_vectors,
                                                                solution_data.bond_connectivity, self.reference_bond_vectors)
     out["strain_energy_stretch"] = 0.5 * self.k_stretch * (axial * self.bond_length) ** 2
@@ -212,7 +232,41 @@ def _compute_response_data(self, solution_data):
     return out
 
 
+def _forward_to_dict(self):
+    """problems/quads_focusing.py:398-407: the dataclass fields (construction arguments) plus ``solution_data`` with the
+    SolutionData namedtuple(s) turned into plain dicts, ready for ``utils.save_data``.  Runtime handles (engine, library)
+    are not part of it."""
+    import dataclasses
+    out = {f.name: getattr(self, f.name) for f in dataclasses.fields(self) if not f.name.startswith("_")}
+    sol = getattr(self, "solution_data", None)
+    many = getattr(self, "_last_solutions", None)
+    if many is not None and len(many) > 1 and sol is many[0]:
+        out["solution_data"] = [s_._asdict() for s_ in many]
+    else:
+        out["solution_data"] = sol._asdict() if isinstance(sol, SolutionData) else None
+    return out
+
+
+def _forward_from_dict(cls, dict_in, _lib=None):
+    """problems/quads_focusing.py:384-396: rebuild the problem (not set up yet) and turn stored solutions back into
+    SolutionData."""
+    d = dict(dict_in)
+    sol = d.pop("solution_data", None)
+    fw = cls(**d, _lib=_lib)
+    if isinstance(sol, dict):
+        fw.solution_data = SolutionData(**sol)
+    elif isinstance(sol, list):
+        fw._stored_solutions = [SolutionData(**s_) for s_ in sol]
+        fw.solution_data = fw._stored_solutions[0]
+    else:
+        fw.solution_data = None
+    fw.is_setup = False
+    return fw
+
+
 QuadsFocusingForward.compute_response_data = _compute_response_data
+QuadsFocusingForward.to_dict = _forward_to_dict
+QuadsFocusingForward.from_dict = classmethod(_forward_from_dict)
 
 
 @dataclass
@@ -274,6 +328,8 @@ class KagomeFocusingForward:
     control_params = QuadsFocusingForward.control_params
     solve = QuadsFocusingForward.solve
     compute_response_data = _compute_response_data
+    to_dict = _forward_to_dict
+    from_dict = classmethod(_forward_from_dict)
 
 
 class TargetKineticEnergy:
@@ -285,6 +341,7 @@ class TargetKineticEnergy:
         if not getattr(forward, "is_setup", False):
             forward.setup()
         pick = kagome_target_blocks if isinstance(forward.geometry, KagomeGeometry) else quads_target_blocks
+        self.target_size, self.target_shift = tuple(target_size), tuple(target_shift)
         self.target_blocks = pick(forward.geometry, target_size, target_shift)
 
     def value(self, design):
@@ -372,6 +429,7 @@ class MultiInputTargetKineticEnergy:
 
     def __init__(self, forward_problems, target_size, target_shift, weights):
         self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
+        self.target_size, self.target_shift = tuple(target_size), tuple(target_shift)
         self.concurrent_inputs = True
         self.weights = np.asarray(weights, dtype=float)
         self.target_blocks = self.objectives[0].target_blocks
@@ -683,5 +741,34 @@ class OptimizationProblem:
         return best
 
     def to_dict(self):
-        return dict(name=self.name, objective_values=list(self.objective_values), design_values=list(self.design_values),
-                    constraints_violation=dict(self.constraints_violation))
+        """problems/quads_focusing.py:686-690 (multi-input: quads_focusing_multi_input.py:183-189): the forward problem(s) as
+        dicts + target placement + the histories of the loop, ready for ``utils.save_data``."""
+        obj = self.objective
+        out = dict(name=self.name, target_size=getattr(obj, "target_size", None), target_shift=getattr(obj, "target_shift", None),
+                   objective_values=list(self.objective_values), design_values=list(self.design_values),
+                   constraints_violation={k: list(v) for k, v in self.constraints_violation.items()})
+        if hasattr(obj, "objectives"):
+            out["forward_problems"] = [o.forward.to_dict() for o in obj.objectives]
+            out["weights"] = [float(w) for w in obj.weights]
+        else:
+            out["forward_problem"] = obj.forward.to_dict()
+        return out
+
+    @staticmethod
+    def from_dict(dict_in, _lib=None):
+        """problems/quads_focusing.py:677-684: rebuild the optimisation problem from a saved dict with its histories, so that a
+        run can be inspected or RESUMED -- ``opt.run_optimization_nlopt(opt.design_values[-1], n_more, ...)`` appends to them."""
+        d = dict(dict_in)
+
+        def forward(fd):
+            cls = KagomeFocusingForward if "n1_cells" in fd else QuadsFocusingForward
+            return cls.from_dict(fd, _lib=_lib)
+        if "forward_problems" in d:
+            objective = MultiInputTargetKineticEnergy([forward(fd) for fd in d["forward_problems"]], d["target_size"], d["target_shift"],
+                                                      d["weights"])
+        else:
+            objective = TargetKineticEnergy(forward(d["forward_problem"]), d["target_size"], d["target_shift"])
+        return OptimizationProblem(objective, objective_values=list(d.get("objective_values", [])),
+                                   design_values=list(d.get("design_values", [])),
+                                   constraints_violation={k: list(v) for k, v in d.get("constraints_violation", {"angles": [], "edge_lengths": []}).items()},
+                                   name=d.get("name", "quads_focusing"))

@@ -30,6 +30,15 @@ class LigamentParams(NamedTuple):
     reference_vector: Any
 
 
+class StretchingTorsionalSpringParams(NamedTuple):
+    """utils.py:80-91: zero-length springs (``stretching_torsional_spring_energy``); scalars or (n_bonds,) arrays."""
+    k_stretch: Any
+    k_rot: Any
+
+
+BondParams = Union[LigamentParams, StretchingTorsionalSpringParams]
+
+
 class ContactParams(NamedTuple):
     """utils.py:97-111."""
     min_angle: Any
@@ -39,7 +48,7 @@ class ContactParams(NamedTuple):
 
 class MechanicalParams(NamedTuple):
     """utils.py:128-142."""
-    bond_params: LigamentParams
+    bond_params: BondParams
     density: Any
     inertia: Optional[Any] = None
     damping: Any = 0.

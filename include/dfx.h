@@ -36,7 +36,10 @@ extern "C" {
 #define DFX_MAX_FNS 2         /* time functions per problem                                   */
 #define DFX_FN_PARAMS 5       /* parameters per time function                                 */
 
-enum { DFX_BOND_LINEARIZED = 0, DFX_BOND_NONLINEAR = 1 };       /* energy.py:99 / energy.py:158 */
+enum { DFX_BOND_LINEARIZED = 0, DFX_BOND_NONLINEAR = 1,         /* energy.py:99 / energy.py:158 */
+       DFX_BOND_SIMPLE_SPRING = 2,                              /* energy.py:30-48: k_stretch (|dU + l0| - |l0|)^2 / 2; k_bond[1..2] ignored */
+       DFX_BOND_STRETCH_TORSION = 3 };                          /* energy.py:51-67: zero-length spring, k_stretch |dU|^2/2 + k_rot dtheta^2/2;
+                                                                   k_bond[1] and reference_vector ignored (pass any non-zero vector) */
 enum { DFX_CONTACT_NONE = 0, DFX_CONTACT_ANGLE = 1 };           /* energy.py:364 (angle_based)  */
 enum { DFX_TABLEAU_DOPRI5 = 0, DFX_TABLEAU_RK4 = 1 };
 /* time-function library; parameters p[] in this order */
@@ -184,6 +187,13 @@ int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_t
  * The accumulators are re-laid-out on the device, so the host does no scatter work. */
 int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
                                const dfx_grads* want, dfx_grads* views, dfx_stats* stats);
+
+/* Post-processing of the last forward solve on its device-resident history (problems/quads_focusing.py:319-372 with
+ * energy.py:522-534): strain energies of every ligament 1/2 k (strain |l0|)^2 for the axial, shear and bending strain of
+ * the NONLINEAR kinematics, (batch, T, n_bonds) each, and the kinetic energy of every block sum_d m_d v_d^2 / 2,
+ * (batch, T, n_blocks).  Any pointer may be NULL. */
+int dfx_response_data(dfx_handle* h, double* strain_energy_stretch, double* strain_energy_shear, double* strain_energy_bending,
+                      double* kinetic_energy);
 
 /* Test hooks: one RHS evaluation and its vector-Jacobian product on full-DOF arrays.
  * y, dy, lam, y_bar: (batch, 2, n_blocks, 3).  Constrained DOFs of y are ignored (they follow the

@@ -77,8 +77,9 @@ static void fwd_stage_t(const Tables& tb, const Tableau& T, const FwdStage& st, 
 }
 
 static void fwd_stage(const Tables& tb, const Tableau& T, const FwdStage& st, double* energy = nullptr) {
-  if (tb.model == kNonlinear) { if (tb.contact) fwd_stage_t<kNonlinear, 1>(tb, T, st, energy); else fwd_stage_t<kNonlinear, 0>(tb, T, st, energy); }
-  else { if (tb.contact) fwd_stage_t<kLinearized, 1>(tb, T, st, energy); else fwd_stage_t<kLinearized, 0>(tb, T, st, energy); }
+#define CASE(M) case M: if (tb.contact) fwd_stage_t<M, 1>(tb, T, st, energy); else fwd_stage_t<M, 0>(tb, T, st, energy); break;
+  switch (tb.model) { CASE(kNonlinear) CASE(kLinearized) CASE(kSimpleSpring) CASE(kStretchTorsion) }
+#undef CASE
 }
 
 template <int MODEL, int CONTACT>
@@ -96,8 +97,9 @@ static void adj_stage_t(const Tables& tb, const Tableau& T, const AdjStage& st, 
 }
 
 static void adj_stage(const Tables& tb, const Tableau& T, const AdjStage& st, const GradAcc& acc) {
-  if (tb.model == kNonlinear) { if (tb.contact) adj_stage_t<kNonlinear, 1>(tb, T, st, acc); else adj_stage_t<kNonlinear, 0>(tb, T, st, acc); }
-  else { if (tb.contact) adj_stage_t<kLinearized, 1>(tb, T, st, acc); else adj_stage_t<kLinearized, 0>(tb, T, st, acc); }
+#define CASE(M) case M: if (tb.contact) adj_stage_t<M, 1>(tb, T, st, acc); else adj_stage_t<M, 0>(tb, T, st, acc); break;
+  switch (tb.model) { CASE(kNonlinear) CASE(kLinearized) CASE(kSimpleSpring) CASE(kStretchTorsion) }
+#undef CASE
 }
 
 static void snapshot(const double* S, int nb, double* out /* (2, nb, 3) */) {
@@ -534,6 +536,42 @@ int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int3
   return 0;
 }
 
+int dfx_response_data(dfx_handle* h, double* e_stretch, double* e_shear, double* e_bend, double* e_kin) {
+  const Plan& pl = h->pl;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size(), nbd = pl.n_bonds;
+  if (h->fields.empty()) { h->err = "response_data: run forward first"; return 1; }
+  for (int m = 0; m < B; ++m) {
+    Tables tb = member_tables(h, m);
+    for (int k = 0; k < Tn; ++k) {
+      const double* f = h->fields.data() + ((size_t)m * Tn + k) * nb * 6;
+      if (e_kin)
+        for (int b = 0; b < nb; ++b) {
+          double acc = 0.0;
+          for (int d = 0; d < 3; ++d) acc += 0.5 * f[nb * 3 + b * 3 + d] * f[nb * 3 + b * 3 + d] / tb.inv_m[b * 3 + d];
+          e_kin[((size_t)m * Tn + k) * nb + b] = acc;
+        }
+      for (int s = 0; s < pl.n_slots; ++s) {
+        const int info = pl.slot_info[s];
+        if (info < 0 || (info & 1)) continue;
+        const int ps = info >> 1;
+        BlockRec<double> o, p;
+        const double* uo = f + (size_t)(s >> 2) * 3; const double* up = f + (size_t)(ps >> 2) * 3;
+        o.x = uo[0]; o.y = uo[1]; o.th = uo[2]; o.ch = cos(0.5 * uo[2]); o.sh = sin(0.5 * uo[2]);
+        p.x = up[0]; p.y = up[1]; p.th = up[2]; p.ch = cos(0.5 * up[2]); p.sh = sin(0.5 * up[2]);
+        const double* sp = tb.slot_p + (size_t)s * kSlotParams; const double* pp = tb.slot_p + (size_t)ps * kSlotParams;
+        const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
+        BondGrad<double> g;
+        bond_grad<kNonlinear, double>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], -1.0, g);
+        const size_t oi = ((size_t)m * Tn + k) * nbd + pl.slot_bond[s];
+        if (e_stretch) e_stretch[oi] = sp[4] * g.ks;
+        if (e_shear) e_shear[oi] = sp[5] * g.ksh;
+        if (e_bend) e_bend[oi] = sp[6] * g.kr;
+      }
+    }
+  }
+  return 0;
+}
+
 int dfx_rhs(dfx_handle* h, const double* y, double t, double* dy) {
   if (!h->have_params) { h->err = "rhs: set_params first"; return 1; }
   const Plan& pl = h->pl;
@@ -586,9 +624,10 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
     for (int b = 0; b < nb; ++b) {
       double hs[3] = {0, 0, 0};
       for (int k = 0; k < kSlots; ++k) {
-        double hx, hy, hth;
-        if (tb.model == kNonlinear) { if (tb.contact) adj_slot<kNonlinear, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<kNonlinear, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); }
-        else { if (tb.contact) adj_slot<kLinearized, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<kLinearized, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); }
+        double hx = 0.0, hy = 0.0, hth = 0.0;
+#define CASE(M) case M: if (tb.contact) adj_slot<M, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<M, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); break;
+        switch (tb.model) { CASE(kNonlinear) CASE(kLinearized) CASE(kSimpleSpring) CASE(kStretchTorsion) }
+#undef CASE
         hs[0] += hx; hs[1] += hy; hs[2] += hth;
       }
       for (int d = 0; d < 3; ++d) {

@@ -108,6 +108,36 @@ def ligament_energy(nodal_DOFs, reference_vector, k_stretch=1.0, k_shear=1.0, k_
     return _bond_energy(ligament_strains(*nodal_DOFs, reference_vector), reference_vector, k_stretch, k_shear, k_rot)
 
 
+class StretchingTorsionalSpringParams(NamedTuple):
+    """utils.py:80-91."""
+    k_stretch: object
+    k_rot: object
+
+
+class SimpleSpringParams(NamedTuple):
+    """The keyword arguments of simple_spring_energy (energy.py:30): the reference has no NamedTuple for them."""
+    k_stretch: object
+    reference_vector: object
+
+
+def simple_spring_energy(nodal_DOFs, reference_vector, k_stretch=1.0):
+    """energy.py:30-48."""
+    D1, D2 = nodal_DOFs
+    dU = D2[:, :2] - D1[:, :2]
+    l = _norm(dU + reference_vector)
+    l0 = _norm(reference_vector)
+    axial_strain = l / l0 - 1
+    return k_stretch * (axial_strain * l0) ** 2 / 2
+
+
+def stretching_torsional_spring_energy(nodal_DOFs, k_stretch=1.0, k_rot=1.0):
+    """energy.py:51-67."""
+    D1, D2 = nodal_DOFs
+    dU = D2[:, :2] - D1[:, :2]
+    dRot = D2[:, 2] - D1[:, 2]
+    return k_stretch * torch.sum(dU * dU, -1) / 2 + k_rot * dRot ** 2 / 2
+
+
 def strain_energy_bond(bond_connectivity, bond_energy_fn=ligament_energy_linearized):
     """energy.py:179-197 + jax_md.smap.bond (0.2.5): gather both end nodes, per-bond energy, sum."""
     bonds = torch.as_tensor(np.asarray(bond_connectivity), dtype=torch.long)

@@ -78,3 +78,11 @@ def test_native_rccl_communicator_single_rank(hip_lib, tmp_path):
     free_b, total_b = B.mem_info(0)
     assert 0 < free_b <= total_b and total_b > 200e9
     B.device_synchronize(0)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_response_data_reduced_on_the_device(hip_lib, batch):
+    """per-ligament strain-energy and per-block kinetic-energy histories from the device-resident fields
+    (k_response), against the oracle's strains and the host formulas."""
+    from .test_problems import check_response_data
+    check_response_data(None, batch)

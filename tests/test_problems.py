@@ -93,20 +93,57 @@ def test_optimisation_loop_increases_objective_and_stays_feasible(cpu_lib):
     assert len(d["design_values"]) == len(d["objective_values"])
 
 
-def test_response_data_energies(cpu_lib):
-    """problems/quads_focusing.py:319-372: per-bond strain energies and per-block kinetic energy histories; the summed
-    strain energy equals the engine's potential energy (no contact active here)."""
-    fw = _quads(cpu_lib)
-    sol = fw.solve(_design(fw))
-    r = fw.compute_response_data(sol)
+def check_response_data(lib, batch=1):
+    """problems/quads_focusing.py:319-372: per-bond strain energies and per-block kinetic energy histories.  The engine reduces them
+    from its resident history (dfx_response_data); checked against the oracle's strains (torch restatement of energy.py:120-155,
+    522-534), against the host NumPy formulas, and against the engine's own potential energy (no contact active here)."""
+    import torch
+    from oracle import ref_energy as OE, ref_geometry as OG
+    fw = _quads(lib) if batch == 1 else None
+    if batch > 1:
+        fw = P.QuadsFocusingForward(
+            n1_blocks=6, n2_blocks=6, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5,
+            density=6.18e-9, damping=1e-4 * np.ones((36, 3)), amplitude=7.5, loading_rate=3000.0, input_delay=1e-5,
+            n_excited_blocks=2, loaded_side="left", input_shift=0, simulation_time=4e-4, n_timepoints=5,
+            use_contact=True, k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180,
+            steps_per_interval=10, batch=batch, _lib=lib)
+        fw.setup()
+    designs = [_design(fw, seed=s) for s in range(batch)]
+    sols = fw.solve(designs if batch > 1 else designs[0])
+    sols = sols if batch > 1 else [sols]
     T, nb = len(fw.timepoints), fw.geometry.n_blocks
-    assert r["strain_energy_stretch"].shape == (T, len(fw.bond_connectivity)) and r["kinetic_energy"].shape == (T, nb)
-    cp = fw.control_params(_design(fw))
-    flat = fw.solve_dynamics._flatten(cp)
-    fw.solve_dynamics.engine.set_params(**{k: v[None] for k, v in flat.items()})
-    e = fw.solve_dynamics.engine.energy(sol.fields[-1, 0][None])[0]
-    tot = (r["strain_energy_stretch"] + r["strain_energy_shear"] + r["strain_energy_bending"])[-1].sum()
-    assert abs(e - tot) / tot < 1e-10
+    for m, sol in enumerate(sols):
+        r = fw.compute_response_data(sol)                                  # device path: a solution of the last solve
+        assert r["strain_energy_stretch"].shape == (T, len(fw.bond_connectivity)) and r["kinetic_energy"].shape == (T, nb)
+        bonds = torch.as_tensor(np.asarray(fw.bond_connectivity, dtype=np.int64))
+        cnv = torch.as_tensor(sol.centroid_node_vectors)
+        refv = torch.as_tensor(fw.reference_bond_vectors)
+        for k in range(T):
+            nodes = OE.block_to_node_kinematics(torch.as_tensor(sol.fields[k, 0]), cnv).reshape(-1, 3)
+            ax, sh, be = OE.ligament_strains(nodes[bonds[:, 0]], nodes[bonds[:, 1]], refv)
+            for name, strain, stiff, scale in (("stretch", ax, fw.k_stretch, fw.bond_length), ("shear", sh, fw.k_shear, fw.bond_length),
+                                               ("bending", be, fw.k_rot, 1.0)):
+                want = 0.5 * stiff * (strain.numpy() * scale) ** 2
+                assert np.abs(r["strain_energy_" + name][k] - want).max() <= 1e-12 * max(want.max(), 1e-300) + 1e-30
+        inertia = OG.compute_inertia(cnv, 6.18e-9).numpy()
+        assert np.abs(r["kinetic_energy"] - np.sum(0.5 * sol.fields[:, 1] ** 2 * inertia, axis=-1)).max() <= 1e-12 * r["kinetic_energy"].max()
+        host = fw.compute_response_data(sol._replace(timepoints=sol.timepoints.copy()))     # another object: host NumPy path
+        for key in ("strain_energy_stretch", "strain_energy_shear", "strain_energy_bending", "kinetic_energy"):
+            assert np.abs(host[key] - r[key]).max() <= 1e-11 * max(np.abs(r[key]).max(), 1e-300)
+    r0 = fw.compute_response_data()                                         # the reference's call without arguments
+    assert np.array_equal(r0["kinetic_energy"], fw.compute_response_data(sols[0])["kinetic_energy"])
+    if batch == 1:
+        cp = fw.control_params(designs[0])
+        flat = fw.solve_dynamics._flatten(cp)
+        fw.solve_dynamics.engine.set_params(**{k: v[None] for k, v in flat.items()})
+        e = fw.solve_dynamics.engine.energy(sols[0].fields[-1, 0][None])[0]
+        tot = (r0["strain_energy_stretch"] + r0["strain_energy_shear"] + r0["strain_energy_bending"])[-1].sum()
+        assert abs(e - tot) / tot < 1e-10
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_response_data_energies(cpu_lib, batch):
+    check_response_data(cpu_lib, batch)
 
 
 def test_mma_reproduces_the_nlopt_tutorial_optimum():
@@ -322,3 +359,31 @@ def test_geometry_cache_tells_kagome_lattices_with_different_bases_apart():
     assert np.array_equal(ca, ea) and np.array_equal(na, ena)
     assert np.array_equal(cb, eb) and np.array_equal(nb, enb)
     assert not np.array_equal(ca, cb)
+
+
+def test_optimization_problem_round_trips_through_a_dict_and_resumes(cpu_lib, tmp_path):
+    """problems/quads_focusing.py:677-690: to_dict -> save_data -> load_data -> from_dict gives back the problem with its histories;
+    the loop then continues from the last design and appends to them."""
+    from difflexmm_amd.utils import load_data, save_data
+    fw = _quads(cpu_lib)
+    opt = P.OptimizationProblem(P.TargetKineticEnergy(fw, (2, 2), (1, 1)))
+    x0 = _design(fw, amp=0.05)
+    amin = 5 * math.pi / 180
+    kw = dict(lower_bound=-3.0, upper_bound=3.0, min_void_angle=amin, min_block_angle=amin, min_edge_length=1.0, verbose=False)
+    opt.run_optimization_nlopt(x0, 3, **kw)
+    fw.solve(opt.design_values[-1])
+    d = opt.to_dict()
+    assert d["forward_problem"]["n1_blocks"] == 6 and d["target_size"] == (2, 2) and isinstance(d["forward_problem"]["solution_data"], dict)
+    save_data(tmp_path / "opt.pkl", d)
+    back = P.OptimizationProblem.from_dict(load_data(tmp_path / "opt.pkl"), _lib=cpu_lib)
+    assert back.objective_values == opt.objective_values and len(back.design_values) == 3
+    assert np.array_equal(back.objective.target_blocks, opt.objective.target_blocks)
+    assert np.array_equal(back.objective.forward.solution_data.fields, fw.solution_data.fields)
+    v, _ = back.objective.value_and_grad(back.design_values[-1])
+    assert abs(v - opt.objective_values[-1]) <= 1e-12 * abs(v)          # same problem, same design, same objective
+    back.run_optimization_nlopt(back.design_values[-1], 2, **kw)
+    assert len(back.objective_values) == 5 and len(back.design_values) == 5
+    mi = P.MultiInputTargetKineticEnergy([_quads(cpu_lib, "left", 0), _quads(cpu_lib, "bottom", -1)], (2, 2), (1, 1), weights=(1.0, 0.5))
+    md = P.OptimizationProblem(mi).to_dict()
+    mb = P.OptimizationProblem.from_dict(md, _lib=cpu_lib)
+    assert [o.forward.loaded_side for o in mb.objective.objectives] == ["left", "bottom"] and list(mb.objective.weights) == [1.0, 0.5]
