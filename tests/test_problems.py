@@ -116,7 +116,7 @@ def check_response_data(lib, batch=1):
         r = fw.compute_response_data(sol)                                  # device path: a solution of the last solve
         assert r["strain_energy_stretch"].shape == (T, len(fw.bond_connectivity)) and r["kinetic_energy"].shape == (T, nb)
         bonds = torch.as_tensor(np.asarray(fw.bond_connectivity, dtype=np.int64))
-        cnv = torch.as_tensor(sol.centroid_node_vectors)
+        cnv = torch.as_tensor(np.array(sol.centroid_node_vectors))
         refv = torch.as_tensor(fw.reference_bond_vectors)
         for k in range(T):
             nodes = OE.block_to_node_kinematics(torch.as_tensor(sol.fields[k, 0]), cnv).reshape(-1, 3)
