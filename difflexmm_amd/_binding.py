@@ -12,7 +12,7 @@ DFX_MAX_FNS = 2
 DFX_FN_PARAMS = 5
 
 BOND_LINEARIZED, BOND_NONLINEAR, BOND_SIMPLE_SPRING, BOND_STRETCH_TORSION = 0, 1, 2, 3
-CONTACT_NONE, CONTACT_ANGLE = 0, 1
+CONTACT_NONE, CONTACT_ANGLE, CONTACT_DISTANCE = 0, 1, 2
 TABLEAU = {"dopri5": 0, "rk4": 1}
 FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_PULSE, FN_TABLE = range(8)
 
@@ -38,11 +38,11 @@ _PARAM_FIELDS = ["centroid_node_vectors", "reference_vector", "k_bond", "inertia
 
 
 class dfx_params(C.Structure):
-    _fields_ = [(n, _dp) for n in _PARAM_FIELDS]
+    _fields_ = [(n, _dp) for n in _PARAM_FIELDS + ["block_centroids"]]
 
 
 class dfx_grads(C.Structure):
-    _fields_ = [(n, _dp) for n in _PARAM_FIELDS + ["state0"]]
+    _fields_ = [(n, _dp) for n in _PARAM_FIELDS + ["state0", "block_centroids"]]
 
 
 class dfx_stats(C.Structure):
@@ -213,14 +213,14 @@ class Engine:
         B, nb, npb, nbd = self.batch, self.n_blocks, self.n_npb, self.n_bonds
         return {"centroid_node_vectors": (B, nb, npb, 2), "reference_vector": (B, nbd, 2), "k_bond": (B, nbd, 3),
                 "inertia": (B, nb, 3), "damping": (B, nb, 3), "void_angle0": (B, nbd, 2), "contact": (B, 3),
-                "fn_params": (B, max(1, self.n_fns), DFX_FN_PARAMS), "state0": (B, 2, nb, 3)}
+                "fn_params": (B, max(1, self.n_fns), DFX_FN_PARAMS), "state0": (B, 2, nb, 3), "block_centroids": (B, nb, 2)}
 
     def set_params(self, **arrays):
         """Arrays by ``dfx_params`` field name; shapes as in :meth:`shapes` (broadcast over batch)."""
         sh = self.shapes()
         p = dfx_params()
         keep = []
-        for name in _PARAM_FIELDS:
+        for name in _PARAM_FIELDS + ["block_centroids"]:
             a = arrays.get(name)
             if a is None:
                 continue
@@ -286,13 +286,14 @@ class Engine:
         for name in which:
             if name == "fn_params" and self.n_fns == 0:
                 continue
-            if name in ("void_angle0", "contact") and not self.contact:
+            if (name == "contact" and not self.contact) or (name == "void_angle0" and self.contact != CONTACT_ANGLE) or \
+                    (name == "block_centroids" and self.contact != CONTACT_DISTANCE):
                 continue
             out[name] = np.zeros(sh[name])
             setattr(g, name, _ptr(out[name]))
         return g, out
 
-    ALL_GRADS = tuple(_PARAM_FIELDS + ["state0"])
+    ALL_GRADS = tuple(_PARAM_FIELDS + ["state0", "block_centroids"])
 
     def adjoint(self, fields_bar, which=ALL_GRADS):
         B, nb = self.batch, self.n_blocks
@@ -325,7 +326,9 @@ class Engine:
         tb = np.ascontiguousarray(target_blocks, dtype=np.int32)
         sh = self.shapes()
         want, views = dfx_grads(), dfx_grads()
-        names = [n for n in which if not (n == "fn_params" and self.n_fns == 0) and not (n in ("void_angle0", "contact") and not self.contact)]
+        names = [n for n in which if not (n == "fn_params" and self.n_fns == 0) and not (n == "contact" and not self.contact)
+                 and not (n == "void_angle0" and self.contact != CONTACT_ANGLE)
+                 and not (n == "block_centroids" and self.contact != CONTACT_DISTANCE)]
         flag = np.zeros(1)
         for n in names:
             setattr(want, n, _ptr(flag))
@@ -362,7 +365,7 @@ class Engine:
         self._check(self.lib.dfx_rhs(self._h, _ptr(y), float(t), _ptr(dy)), "dfx_rhs")
         return dy
 
-    def rhs_vjp(self, y, t, lam, which=tuple(_PARAM_FIELDS)):
+    def rhs_vjp(self, y, t, lam, which=tuple(_PARAM_FIELDS + ["block_centroids"])):
         B, nb = self.batch, self.n_blocks
         y, lam = _f64(y, (B, 2, nb, 3)), _f64(lam, (B, 2, nb, 3))
         y_bar = np.empty_like(y)

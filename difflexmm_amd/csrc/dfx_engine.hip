@@ -104,7 +104,7 @@ struct dfx_handle {
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<double> d_resp;                           // dfx_response_data outputs
   DevBuf<dfx_special> d_special;
-  DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict;
+  DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict, d_p_c, d_g_c;
   DevBuf<uint8_t> d_l_idx;
   DevBuf<TimeFn> d_fns;
   DevBuf<double> d_fn_table[DFX_MAX_FNS];
@@ -160,6 +160,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.p_lidx = h->d_l_idx.p; c.l_dict = h->d_l_dict.p; c.l_dict_on = h->pp.l_dict_ok ? 1 : 0; c.damping_uniform = h->pp.damping_uniform ? 1 : 0;
   c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;
   c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.fns = h->d_fns.p;
+  c.p_c = h->d_p_c.p; c.g_c = h->d_g_c.p; c.n_npb = pl.n_npb;
   c.cur = h->d_cur.p;
   c.clock = h->adaptive ? h->d_clock.p : nullptr;
   c.err_partial = h->d_err_partial.p; c.ts_dev = h->d_ts.p; c.fields_dev = h->d_fields.p;
@@ -217,7 +218,7 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
 }
 static void launch_fwd(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   const Plan& pl = h->pl;
-#define DFX_FWD_CASE(M) case M: if (pl.contact) launch_fwd_t<M, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<M, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); break;
+#define DFX_FWD_CASE(M) case M: if (pl.contact == 2) launch_fwd_t<M, 2>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else if (pl.contact) launch_fwd_t<M, 1>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); else launch_fwd_t<M, 0>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode); break;
   switch (pl.model) { DFX_FWD_CASE(kNonlinear) DFX_FWD_CASE(kLinearized) DFX_FWD_CASE(kSimpleSpring) DFX_FWD_CASE(kStretchTorsion) }
 #undef DFX_FWD_CASE
   h->launches++;
@@ -237,7 +238,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {
   const Plan& pl = h->pl;
-#define DFX_ADJ_CASE(M) case M: if (pl.contact) launch_adj_t<M, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<M, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); break;
+#define DFX_ADJ_CASE(M) case M: if (pl.contact == 2) launch_adj_t<M, 2>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else if (pl.contact) launch_adj_t<M, 1>(h, c, st, grid, i, j, in_buf, wbuf, local_only); else launch_adj_t<M, 0>(h, c, st, grid, i, j, in_buf, wbuf, local_only); break;
   switch (pl.model) { DFX_ADJ_CASE(kNonlinear) DFX_ADJ_CASE(kLinearized) DFX_ADJ_CASE(kSimpleSpring) DFX_ADJ_CASE(kStretchTorsion) }
 #undef DFX_ADJ_CASE
   h->launches++;
@@ -488,6 +489,7 @@ static int ensure_adjoint_buffers(dfx_handle* h) {
   HIP_OK(h->d_g_b.ensure(B * pl.n_slots * 8));
   HIP_OK(h->d_blk_m.ensure(B * nb * 3));
   HIP_OK(h->d_blk_c.ensure(B * nb * 3));
+  if (pl.contact == DFX_CONTACT_DISTANCE) HIP_OK(h->d_g_c.ensure(B * nb * 2));
   HIP_OK(h->d_fn_g.ensure(B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS));
   return 0;
 }
@@ -500,6 +502,7 @@ static int zero_grad_accumulators(dfx_handle* h) {
   HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots, h->stream));
   if (h->want_bond_grads) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
   HIP_OK(hipMemsetAsync(h->d_blk_m.p, 0, sizeof(double) * B * nb * 3, h->stream));
+  if (pl.contact == DFX_CONTACT_DISTANCE) HIP_OK(hipMemsetAsync(h->d_g_c.p, 0, sizeof(double) * B * nb * 2, h->stream));
   if (h->want_damping_grads) HIP_OK(hipMemsetAsync(h->d_blk_c.p, 0, sizeof(double) * B * nb * 3, h->stream));
   HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
   return 0;
@@ -522,17 +525,19 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
     HIP_OK(hipGetLastError());
     return 0;
   }
-  const bool w_r = want->centroid_node_vectors, w_phi = want->void_angle0 && pl.contact;
+  const bool w_r = want->centroid_node_vectors, w_phi = want->void_angle0 && pl.contact == DFX_CONTACT_ANGLE;
+  const bool w_cen = want->block_centroids && pl.contact == DFX_CONTACT_DISTANCE;
   const bool w_b = h->want_bond_grads && (want->reference_vector || want->k_bond || want->contact);
   const bool w_m = want->inertia, w_c = want->damping && h->want_damping_grads, w_fn = want->fn_params && h->want_fn_grads;
   const bool w_lam = with_state0 && want->state0;
   const size_t n_r = w_r ? B * nb * npb * 2 : 0, n_phi = w_phi ? B * nbd * 2 : 0, n_b = w_b ? B * NS * 8 : 0, n_m = w_m ? B * nb * 3 : 0,
-               n_c = w_c ? B * nb * 3 : 0, n_fn = w_fn ? B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS : 0, n_lam = w_lam ? B * nb * 6 : 0;
+               n_c = w_c ? B * nb * 3 : 0, n_fn = w_fn ? B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS : 0, n_lam = w_lam ? B * nb * 6 : 0,
+               n_cen = w_cen ? B * nb * 2 : 0;
   // small host-side results (bond parameters, time-function parameters) live behind the DMA area
   const size_t n_small = (want->reference_vector ? B * nbd * 2 : 0) + (want->k_bond ? B * nbd * 3 : 0) + (want->contact ? B * 3 : 0) +
                          (want->fn_params ? B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS : 0) + (want->damping && !w_c ? B * nb * 3 : 0) +
-                         (want->void_angle0 && !w_phi ? B * nbd * 2 : 0);
-  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_m + n_c + n_fn + n_lam + n_small + 8) * sizeof(double)));
+                         (want->void_angle0 && !w_phi ? B * nbd * 2 : 0) + (want->block_centroids && !w_cen ? B * nb * 2 : 0);
+  HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_m + n_c + n_fn + n_lam + n_cen + n_small + 8) * sizeof(double)));
   double* g_r = reinterpret_cast<double*>(h->stage.p);
   double* g_phi = g_r + n_r;
   double* g_b = g_phi + n_phi;
@@ -540,7 +545,8 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   double* g_c = g_m + n_m;
   double* fn_g = g_c + n_c;
   double* lam = fn_g + n_fn;
-  double* small = lam + n_lam;
+  double* cen = lam + n_lam;
+  double* small = cen + n_cen;
   // device-side re-layout: kagome node vectors (3 of 4 slots), void angles (slot -> (bond, end)), state0 (q | v planes)
   const bool pack_r = w_r && npb != kSlots;
   if (pack_r || w_phi || w_lam) {
@@ -562,6 +568,7 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   HIP_OK(pull(g_c, h->d_blk_c.p, n_c));
   HIP_OK(pull(fn_g, h->d_fn_g.p, n_fn));
   HIP_OK(pull(lam, h->d_out_lam.p, n_lam));
+  HIP_OK(pull(cen, h->d_g_c.p, n_cen));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
   dfx_grads v;
@@ -571,9 +578,11 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   if (w_m) v.inertia = g_m;
   if (w_c) v.damping = g_c;
   if (w_lam) v.state0 = lam;
+  if (w_cen) v.block_centroids = cen;
   auto take = [&](size_t n) { double* q = small; small += n; memset(q, 0, sizeof(double) * n); return q; };
   if (want->void_angle0 && !w_phi) v.void_angle0 = take(B * nbd * 2);
   if (want->damping && !w_c) v.damping = take(B * nb * 3);
+  if (want->block_centroids && !w_cen) v.block_centroids = take(B * nb * 2);
   if (want->reference_vector) v.reference_vector = take(B * nbd * 2);
   if (want->k_bond) v.k_bond = take(B * nbd * 3);
   if (want->contact) v.contact = take(B * 3);
@@ -610,6 +619,7 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
     give(grads->damping, v.damping, B * nb * 3);
     give(grads->fn_params, v.fn_params, B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS);
     give(grads->state0, v.state0, B * nb * 6);
+    give(grads->block_centroids, v.block_centroids, B * nb * 2);
   }
   if (views) *views = v;
   return 0;
@@ -713,7 +723,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release();
   h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release(); h->d_resp.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
-  h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release();
+  h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release(); h->d_p_c.release(); h->d_g_c.release();
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release(); h->d_AD.release();
   h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
@@ -760,6 +770,10 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
       HIP_OK(hipMemcpyAsync(dst[i]->p, h->stage.p + off, bytes, hipMemcpyHostToDevice, h->stream));
       off += bytes;
     }
+  }
+  if (h->pl.contact == DFX_CONTACT_DISTANCE) {
+    HIP_OK(h->d_p_c.ensure(pp.centroid.size()));
+    HIP_OK(hipMemcpyAsync(h->d_p_c.p, pp.centroid.data(), sizeof(double) * pp.centroid.size(), hipMemcpyHostToDevice, h->stream));
   }
   HIP_OK(h->d_fns.ensure(pp.fns.size()));
   HIP_OK(hipMemcpyAsync(h->d_fns.p, pp.fns.data(), sizeof(TimeFn) * pp.fns.size(), hipMemcpyHostToDevice, h->stream));
@@ -1013,7 +1027,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     // evaluations at S_1..S_5, candidate y1 into buffer 3, then the FSAL evaluation with the error estimate
     static const int inb[6] = {0, 1, 2, 1, 2, 1}, outb[6] = {0, 2, 1, 2, 1, 3};
     for (int i = 1; i <= 5; ++i) launch_fwd(h, c, i, 0, inb[i], outb[i], 0, 0);
-#define DFX_ERR_CASE(M) case M: if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); else hipLaunchKernelGGL((k_fwd_stage<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); break;
+#define DFX_ERR_CASE(M) case M: if (pl.contact == 2) hipLaunchKernelGGL((k_fwd_stage<M, 2>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); else if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); else hipLaunchKernelGGL((k_fwd_stage<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); break;
     switch (pl.model) { DFX_ERR_CASE(kNonlinear) DFX_ERR_CASE(kLinearized) DFX_ERR_CASE(kSimpleSpring) DFX_ERR_CASE(kStretchTorsion) }
 #undef DFX_ERR_CASE
     hipLaunchKernelGGL(k_control, dim3((unsigned)B), dim3(kThreads), 0, h->stream, c, n_partials, 2.0 * (double)n_free, Tn);
@@ -1356,7 +1370,7 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
   HIP_OK(hipMemcpyAsync(h->d_POS.p, S.data(), sizeof(double) * S.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_tmp.ensure(B * pl.n_slots));
   DevCtx c = make_ctx(h);
-#define DFX_EN_CASE(M) case M: if (pl.contact) hipLaunchKernelGGL((k_energy<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); else hipLaunchKernelGGL((k_energy<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); break;
+#define DFX_EN_CASE(M) case M: if (pl.contact == 2) hipLaunchKernelGGL((k_energy<M, 2>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); else if (pl.contact) hipLaunchKernelGGL((k_energy<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); else hipLaunchKernelGGL((k_energy<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, h->d_tmp.p); break;
   switch (pl.model) { DFX_EN_CASE(kNonlinear) DFX_EN_CASE(kLinearized) DFX_EN_CASE(kSimpleSpring) DFX_EN_CASE(kStretchTorsion) }
 #undef DFX_EN_CASE
   std::vector<double> e(B * pl.n_slots);

@@ -91,6 +91,7 @@ struct DevCtx {
   const double* p_r;      // n_slots*2   own centroid->node vector
   const double* p_l;      // n_slots*2   reference vector of the slot's ligament
   const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
+  const double* p_c;      // n_blocks*2   block centroids (distance-based contact only)
   const double* p_phi;    // n_slots     undeformed void angle: phi1 on end-0 slots, phi2 on end-1 slots (the other one is gathered from the partner slot)
   const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
   const double* l_dict;   // 256*4   lx ly |l0| 1/|l0|
@@ -126,6 +127,8 @@ struct DevCtx {
   double* g_phi;          // batch * n_slots       d/d(void angle): phi1 on the end-0 slot of a ligament, phi2 on its end-1 slot
   double* g_b;            // batch * n_slots*8     d/d(l0(2), k(3), contact(3)) (end-1 slots) or null
   double* blk_m;          // batch * n_blocks*3    d/d(inertia)
+  double* g_c;            // batch * n_blocks*2    d/d(block_centroids) (distance-based contact only)
+  int n_npb, pad_npb;     // nodes per block (3 or 4)
   double* blk_c;          // batch * n_blocks*3    d/d(damping) or null
   double* fn_g;           // batch * n_special*MAX_FNS*FN_PARAMS or null
 };
@@ -256,7 +259,7 @@ __device__ __forceinline__ void stg(void* base, u32 byte_off, T v) {
 
 // uniform bases of member m's parameter arrays
 struct MemberBases {
-  const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict;
+  const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict, *p_c;
   const uint8_t* p_lidx;
 };
 __device__ __forceinline__ MemberBases member_bases(const DevCtx& c, int m) {
@@ -264,6 +267,7 @@ __device__ __forceinline__ MemberBases member_bases(const DevCtx& c, int m) {
   const size_t ps = (size_t)m * (u32)c.n_slots;
   B.p_r = c.p_r + ps * 2; B.p_phi = c.p_phi + ps; B.p_l = c.p_l + ps * 2; B.p_k = c.p_k + ps * 4;
   B.cst = c.cst + (size_t)m * 16; B.l_dict = c.l_dict + (size_t)m * 1024; B.p_lidx = c.p_lidx + ps;
+  B.p_c = c.p_c + (size_t)m * (u32)c.n_blocks * 2;
   return B;
 }
 
@@ -285,7 +289,7 @@ __device__ __forceinline__ void load_partner(const MemberBases& B, int pslot, co
   P.b1 = ldg<double2>(POSin, rec + 16);
   P.b2 = ldg<double>(POSin, rec + 32);
   P.rp = ldg<double2>(B.p_r, (u32)pslot * 16);
-  P.phi = CONTACT ? ldg<double>(B.p_phi, (u32)pslot * 8) : 0.0;
+  P.phi = CONTACT == 1 ? ldg<double>(B.p_phi, (u32)pslot * 8) : 0.0;
 }
 
 // Everything a lane needs for its ligament, in two phases so that every load that does not depend on another
@@ -314,7 +318,7 @@ __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B
   R.lv = ldg<double2>(c.l_dict_on ? B.cst : B.p_l, c.l_dict_on ? 0u : (u32)slot * 16);
   R.ks = R.ksh = R.kr = 0.0;
   if (!c.k_uniform) { R.ks = ldg<double>(B.p_k, (u32)slot * 32); R.ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); R.kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
-  R.phi = CONTACT ? ldg<double>(B.p_phi, (u32)slot * 8) : 0.0;
+  R.phi = CONTACT == 1 ? ldg<double>(B.p_phi, (u32)slot * 8) : 0.0;
   const int delta = k == 0 ? c.pred[0] : (k == 1 ? c.pred[1] : (k == 2 ? c.pred[2] : c.pred[3]));   // selects: a dynamic index would be a memory load
   R.guess = min(max(slot + delta, 0), c.n_slots - 1);
   load_partner<CONTACT>(B, R.guess, POSin, R.P);
@@ -335,11 +339,11 @@ __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases&
   const double* cst = B.cst;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
-  if (CONTACT) {
+  if (CONTACT == 1) {
     L.phi1 = (info & 1) ? R.P.phi : R.phi;
     L.phi2 = (info & 1) ? R.phi : R.P.phi;
-    L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2];
   }
+  if (CONTACT) { L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2]; }
   L.o.x = quad_bcast<0>(R.pc.x); L.o.y = quad_bcast<0>(R.pc.y);
   L.o.th = quad_bcast<1>(R.pc.x); L.o.ch = quad_bcast<1>(R.pc.y);
   L.o.sh = quad_bcast<2>(R.pc.x);
@@ -360,6 +364,35 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   LaneRaw R;
   issue_lane<CONTACT>(c, B, slot, POSin, R);
   resolve_lane<CONTACT>(c, B, POSin, R, L);
+}
+
+// ---- distance-based contact (CONTACT == 2; energy.py:222-330): what a lane needs beyond LaneIn ---------------------------------
+// Node vectors of the bonded node, its next and its previous node, for the own block (from the neighbouring lanes of the quad: DPP
+// rotations, 4- and 3-node blocks) and for the partner block (two more gathers), and the two block centroids.  Not part of the
+// single load batch: this variant has no caller in the reference's problems and is written for correctness first.
+// EVERY lane of a quad must call it (lanes without a ligament lend their node vector to their neighbours).
+struct DistIn {
+  double ro[3][2], rp[3][2], cox, coy, cpx, cpy;
+};
+template <int CTRL4, int CTRL3>
+__device__ __forceinline__ double quad_rot(double v, int npb) { return npb == 4 ? dpp_mov<CTRL4>(v) : dpp_mov<CTRL3>(v); }
+// value held by the lane of the NEXT node of this lane's node ([1,2,3,0] / [1,2,0,3]) and of the PREVIOUS one ([3,0,1,2] / [2,0,1,3])
+__device__ __forceinline__ double from_next(double v, int npb) { return quad_rot<0x39, 0xC9>(v, npb); }
+__device__ __forceinline__ double from_prev(double v, int npb) { return quad_rot<0x93, 0xD2>(v, npb); }
+
+__device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B, int slot, const LaneIn& L, DistIn& D) {
+  const int b = slot >> 2, n = c.n_npb;
+  const int pb = L.pslot >> 2, kp = L.pslot & 3;
+  const int kpn = kp + 1 >= n ? 0 : kp + 1, kpp = kp == 0 ? n - 1 : kp - 1;
+  const double2 co = ldg<double2>(B.p_c, (u32)b * 16), cp = ldg<double2>(B.p_c, (u32)pb * 16);
+  const double2 rpn = ldg<double2>(B.p_r, (u32)(pb * 4 + kpn) * 16), rpp = ldg<double2>(B.p_r, (u32)(pb * 4 + kpp) * 16);
+  D.cox = co.x; D.coy = co.y; D.cpx = cp.x; D.cpy = cp.y;
+  D.ro[0][0] = L.rox; D.ro[0][1] = L.roy;
+  D.ro[1][0] = from_next(L.rox, n); D.ro[1][1] = from_next(L.roy, n);
+  D.ro[2][0] = from_prev(L.rox, n); D.ro[2][1] = from_prev(L.roy, n);
+  D.rp[0][0] = L.rpx; D.rp[0][1] = L.rpy;
+  D.rp[1][0] = rpn.x; D.rp[1][1] = rpn.y;
+  D.rp[2][0] = rpp.x; D.rp[2][1] = rpp.y;
 }
 
 // ---- forward stage ---------------------------------------------------------------------------
@@ -412,6 +445,8 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? ldg<double>(Am + (size_t)l * nd, o_dof) : 0.0;
   LaneIn L;
   resolve_lane<CONTACT>(c, B, POSin, R, L);
+  DistIn D;
+  if (CONTACT == 2) load_dist(c, B, slot, L, D);
   double sv = 0.0, sq = 0.0;
 #pragma unroll
   for (int l = 0; l < kMaxStages - 1; ++l) {
@@ -422,15 +457,20 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   double fx = 0.0, fy = 0.0, fth = 0.0;
   if (c.ablate & 1) {
     fx = L.o.x + L.p.x + L.rox + L.rpx + L.lx + L.l0; fy = L.o.y + L.p.y + L.roy + L.rpy + L.ly + L.il0;
-    fth = L.o.th + L.p.th + L.o.ch + L.p.ch + L.o.sh + L.p.sh + (CONTACT ? L.phi1 + L.phi2 : 0.0);
+    fth = L.o.th + L.p.th + L.o.ch + L.p.ch + L.o.sh + L.p.sh + (CONTACT == 1 ? L.phi1 + L.phi2 : 0.0);
   } else if (L.info >= 0) {
     BondGrad<double> g;
     bond_grad<MODEL, double>(L.o, L.p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
     fx = g.fx; fy = g.fy; fth = g.fth;
-    if (CONTACT) {
+    if (CONTACT == 1) {
       ContactGrad<double> cg;
       contact_grad<double>(L.sgn * (L.o.th - L.p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
       fth += L.sgn * cg.dkap;
+    }
+    if (CONTACT == 2) {
+      DistContactGrad<double> dg;
+      distance_contact_grad<double, double>(L.o, L.p, D.cox, D.coy, D.cpx, D.cpy, D.ro, D.rp, L.info & 1, L.am, L.ac, L.kc, dg);
+      fx += dg.fx; fy += dg.fy; fth += dg.fth;
     }
   }
   fx = quad_sum(fx);
@@ -636,15 +676,22 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
   if (slot >= c.n_slots) return;
   LaneIn L;
   load_lane<CONTACT>(c, m, slot, pos_in(c, m, 0, 0), L);
+  DistIn D;
+  if (CONTACT == 2) load_dist(c, member_bases(c, m), slot, L, D);
   double e = 0.0;
   if (L.info >= 0 && !(L.info & 1)) {
     BondGrad<double> g;
     bond_grad<MODEL, double>(L.o, L.p, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, g);
     e = g.e;
-    if (CONTACT) {
+    if (CONTACT == 1) {
       ContactGrad<double> cg;
       contact_grad<double>(L.sgn * (L.o.th - L.p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
       e += cg.e;
+    }
+    if (CONTACT == 2) {
+      DistContactGrad<double> dg;
+      distance_contact_grad<double, double>(L.o, L.p, D.cox, D.coy, D.cpx, D.cpy, D.ro, D.rp, L.info & 1, L.am, L.ac, L.kc, dg);
+      e += dg.e;
     }
   }
   e_slot[(size_t)m * c.n_slots + slot] = e;
@@ -753,12 +800,15 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   }
   LaneIn L;
   resolve_lane<CONTACT>(c, B, POSin, R, L);
+  DistIn D;
+  if (CONTACT == 2) load_dist(c, B, slot, L, D);
   if (L.pslot != L.guess) { const u32 pb = (u32)(L.pslot >> 2) * 24; wpx = ldg<double>(Win, pb); wpy = ldg<double>(Win, pb + 8); wpth = ldg<double>(Win, pb + 16); }
   const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
   double ex = 0.0, ey = 0.0, eth = 0.0;   // dE/du of this slot (value parts): gives the stage acceleration without re-reading it
   double d_rx = 0.0, d_ry = 0.0, d_phi = 0.0;   // this launch's contributions to the node-vector / void-angle gradients
+  double dn_x = 0.0, dn_y = 0.0, dp_x = 0.0, dp_y = 0.0, d_cx = 0.0, d_cy = 0.0;   // distance contact: next / previous node, centroid
   if (L.info >= 0) {
     BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
     BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);
@@ -767,21 +817,43 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
     ex = g.fx.v; ey = g.fy.v; eth = g.fth.v;
     ContactGrad<Dual> cg;
-    if (CONTACT) {
+    DistContactGrad<Dual> dg;
+    if (CONTACT == 1) {
       contact_grad<Dual>(L.sgn * (o.th - p.th), L.phi1, L.phi2, L.am, L.ac, L.kc, cg);
       hth += L.sgn * cg.dkap.e;
       eth += L.sgn * cg.dkap.v;
     }
     // L += w . F = -w . grad E   =>   dL/dp = -eps(dE/dp)
     d_rx = g.rx.e; d_ry = g.ry.e;
+    if (CONTACT == 2) {
+      distance_contact_grad<Dual, double>(o, p, D.cox, D.coy, D.cpx, D.cpy, D.ro, D.rp, L.info & 1, L.am, L.ac, L.kc, dg);
+      hx += dg.fx.e; hy += dg.fy.e; hth += dg.fth.e;
+      ex += dg.fx.v; ey += dg.fy.v; eth += dg.fth.v;
+      d_rx += dg.r[0][0].e; d_ry += dg.r[0][1].e;
+      dn_x = dg.r[1][0].e; dn_y = dg.r[1][1].e; dp_x = dg.r[2][0].e; dp_y = dg.r[2][1].e;
+      d_cx = dg.cx.e; d_cy = dg.cy.e;
+    }
     // both ends hold the same contact dual: each accumulates one of the two void-angle derivatives (8 B per lane)
-    if (CONTACT) d_phi = (L.info & 1) ? cg.p2.e : cg.p1.e;
+    if (CONTACT == 1) d_phi = (L.info & 1) ? cg.p2.e : cg.p1.e;
     if (!(L.info & 1)) {
       if (BOND_GRADS) {
         double* q = c.g_b + ((size_t)m * (u32)c.n_slots + slot) * 8;
         q[0] -= g.lx.e; q[1] -= g.ly.e; q[2] -= g.ks.e; q[3] -= g.ksh.e; q[4] -= g.kr.e;
-        if (CONTACT) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
+        if (CONTACT == 1) { q[5] -= cg.am.e; q[6] -= cg.ac.e; q[7] -= cg.kc.e; }
+        if (CONTACT == 2) { q[5] -= dg.am.e; q[6] -= dg.ac.e; q[7] -= dg.kc.e; }
       }
+    }
+  }
+  if (CONTACT == 2) {
+    // node-vector gradients of the neighbouring nodes go to the lanes that own them: this lane's node is the NEXT node of its
+    // previous lane and the PREVIOUS node of its next lane; centroid gradient: sum over the block, lanes 0 / 1 keep x / y
+    d_rx += from_prev(dn_x, c.n_npb) + from_next(dp_x, c.n_npb);
+    d_ry += from_prev(dn_y, c.n_npb) + from_next(dp_y, c.n_npb);
+    d_cx = quad_sum(d_cx);
+    d_cy = quad_sum(d_cy);
+    if (k < 2) {
+      double* gc = c.g_c + ((size_t)m * (u32)c.n_blocks + b) * 2 + k;
+      *gc -= k == 0 ? d_cx : d_cy;
     }
   }
   // ---- gradient accumulators.  Every address has exactly one writer per launch: plain load-add-store, with the old values of
@@ -794,7 +866,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   double* bmm = c.blk_m + (size_t)m * nd;
   double* bcm = c.blk_c + (size_t)m * nd;
   const double2 r_old = ldg<double2>(grm, (u32)slot * 16);
-  const double p_old = CONTACT ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
+  const double p_old = CONTACT == 1 ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
   const double bm_old = ldg<double>(bmm, o_dof);
   const double bc_old = c.blk_c ? ldg<double>(bcm, o_dof) : 0.0;
   hx = quad_sum(hx);
@@ -803,9 +875,9 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   ex = quad_sum(ex);
   ey = quad_sum(ey);
   eth = quad_sum(eth);
-  if (L.info >= 0) {
+  if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
     stg<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
-    if (CONTACT) stg<double>(gpm, (u32)slot * 8, p_old - d_phi);
+    if (CONTACT == 1) stg<double>(gpm, (u32)slot * 8, p_old - d_phi);
   }
   // ---- DOF epilogue
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;

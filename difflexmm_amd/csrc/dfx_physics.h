@@ -14,6 +14,7 @@
 //   simple spring        difflexmm/energy.py:30-48    E = k_stretch (|dU + l0| - |l0|)^2 / 2
 //   zero-length spring   difflexmm/energy.py:51-67    E = k_stretch |dU|^2 / 2 + k_rot (theta_2 - theta_1)^2 / 2
 //   angle-based contact  difflexmm/energy.py:204-219,333-361 + geometry.py:181-253
+//   distance contact     difflexmm/energy.py:222-330,364-407 (angle_based=False)
 //   driving functions    problems/quads_focusing.py:211-222, tests/test_difflexmm.py:85-86,
 //                        scripts/pulse_RS.py:49-50, problems/hinge_characterization.py:134-139
 //
@@ -296,9 +297,9 @@ struct ContactGrad {
   T e;
 };
 
-template <class T, class P>
+template <class T, class P, bool WRAP = true>
 DFX_HD void contact_one(T a, P am, P ac, P kc, T& e, T& da, T& dam, T& dac, T& dkc) {
-  a = twrap(a);
+  if (WRAP) a = twrap(a);      // angles; the distance-based model passes lengths through the same penalty unwrapped
   if (val(a) >= val(am) && val(a) < val(ac)) {
     P D = ac - am;
     T x = (a - ac) * trcp(D);
@@ -328,6 +329,105 @@ DFX_HD void contact_grad(T kap, P phi1, P phi2, P am, P ac, P kc, ContactGrad<T>
   g.am = m1 + m2;
   g.ac = c1 + c2;
   g.kc = k1 + k2;
+}
+
+// ---------------------------------------------------------------------------------------
+// distance-based contact (energy.py:222-330; build_contact_energy(angle_based=False) :364-407)
+// ---------------------------------------------------------------------------------------
+// point_to_edge_distance (energy.py:222-251) in closest-point form: with t = (p - a).(b - a) / |b - a|^2 clamped to [0, 1] the
+// three branches of the reference are d = |p - (a + t (b - a))| (inside: sqrt(|p-a|^2 - t^2 |b-a|^2) is the same number, written
+// without the cancellation), and in every branch   d d/dp = n,  d d/da = -(1 - t) n,  d d/db = -t n,   n = (p - closest) / d.
+template <class T>
+DFX_HD void point_segment(T px, T py, T ax, T ay, T bx, T by, T& d, T& nx, T& ny, T& t) {
+  T ex = bx - ax, ey = by - ay, rx = px - ax, ry = py - ay;
+  t = (rx * ex + ry * ey) * trcp(ex * ex + ey * ey);
+  if (val(t) < 0.0) t = T(0.0);
+  else if (val(t) > 1.0) t = T(1.0);
+  T cx = rx - t * ex, cy = ry - t * ey;
+  d = tsqrt(cx * cx + cy * cy);
+  T id = trcp(d);
+  nx = cx * id;
+  ny = cy * id;
+}
+
+// edges_distance (energy.py:254-276): the smallest of the four end-point-to-other-edge distances, candidates in the reference's
+// order (B0 -> A, B1 -> A, A0 -> B, A1 -> B; the first smallest wins), and its gradient w.r.t. the four end points
+// (g[0..3] = A0, A1, B0, B1; x, y).  Selection by value; the selected candidate is evaluated in T.
+template <class T>
+DFX_HD void edges_distance(const T (&A0)[2], const T (&A1)[2], const T (&B0)[2], const T (&B1)[2], T& d, T (&g)[4][2]) {
+  const T* pts[4] = {B0, B1, A0, A1};
+  const T* e0[4] = {A0, A0, B0, B0};
+  const T* e1[4] = {A1, A1, B1, B1};
+  const int pi[4] = {2, 3, 0, 1}, ei0[4] = {0, 0, 2, 2}, ei1[4] = {1, 1, 3, 3};
+  int best = 0;
+  double dbest = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    double dk, nx, ny, t;
+    point_segment<double>(val(pts[k][0]), val(pts[k][1]), val(e0[k][0]), val(e0[k][1]), val(e1[k][0]), val(e1[k][1]), dk, nx, ny, t);
+    if (k == 0 || dk < dbest) { best = k; dbest = dk; }
+  }
+  T nx, ny, t;
+  point_segment<T>(pts[best][0], pts[best][1], e0[best][0], e0[best][1], e1[best][0], e1[best][1], d, nx, ny, t);
+  for (int k = 0; k < 4; ++k) { g[k][0] = T(0.0); g[k][1] = T(0.0); }
+  g[pi[best]][0] = nx; g[pi[best]][1] = ny;
+  T w0 = 1.0 - t;
+  g[ei0[best]][0] = -(w0 * nx); g[ei0[best]][1] = -(w0 * ny);
+  g[ei1[best]][0] = -(t * nx); g[ei1[best]][1] = -(t * ny);
+}
+
+// One ligament, seen from one of its ends: derivatives of the two void-edge-distance penalties w.r.t. everything the OWN block
+// owns.  Node order in ro / rp: the bonded node, its next node, its previous node on the block (geometry.py:192-202 numbering).
+template <class T>
+struct DistContactGrad {
+  T fx, fy, fth;     // dE/d(x, y, theta) of the own block
+  T r[3][2];         // dE/d(centroid_node_vector) of the bonded node [0], its next [1] and its previous [2] node
+  T cx, cy;          // dE/d(block_centroid) of the own block
+  T am, ac, kc;      // dE/d(min, cutoff, k_contact)   (lengths here: utils.py:101)
+  T e;
+};
+
+template <class T, class P>
+DFX_HD void distance_contact_grad(const BlockRec<T>& o, const BlockRec<T>& p, P cox, P coy, P cpx, P cpy, const P (&ro)[3][2],
+                                  const P (&rp)[3][2], int own_is_end2, P am, P ac, P kc, DistContactGrad<T>& g) {
+  T co = o.ch * o.ch - o.sh * o.sh, so = 2.0 * (o.sh * o.ch);
+  T cp = p.ch * p.ch - p.sh * p.sh, sp = 2.0 * (p.sh * p.ch);
+  T qo[3][2], O[3][2], Q[3][2];
+  for (int k = 0; k < 3; ++k) {           // current node positions: centroid + displacement + rotated node vector (energy.py:397-404)
+    qo[k][0] = co * ro[k][0] - so * ro[k][1];
+    qo[k][1] = so * ro[k][0] + co * ro[k][1];
+    O[k][0] = o.x + qo[k][0] + cox;
+    O[k][1] = o.y + qo[k][1] + coy;
+    Q[k][0] = p.x + (cp * rp[k][0] - sp * rp[k][1]) + cpx;
+    Q[k][1] = p.y + (sp * rp[k][0] + cp * rp[k][1]) + cpy;
+  }
+  // energy.py:301-326: block 1 holds node n1, block 2 node n2;  d1 = dist(edge(p1, p1_next), edge(p2, p2_prev)),
+  //                                                             d2 = dist(edge(p1, p1_prev), edge(p2, p2_next))
+  T G[3][2];                               // dE/d(own node positions)
+  for (int k = 0; k < 3; ++k) { G[k][0] = T(0.0); G[k][1] = T(0.0); }
+  g.e = T(0.0); g.am = T(0.0); g.ac = T(0.0); g.kc = T(0.0);
+  for (int j = 0; j < 2; ++j) {
+    // which own / partner neighbour node closes the edge: (next, prev) for d1 and (prev, next) for d2 as seen from block 1
+    const int n1 = j == 0 ? 1 : 2, n2 = j == 0 ? 2 : 1;
+    const int own_nb = own_is_end2 ? n2 : n1, par_nb = own_is_end2 ? n1 : n2;
+    T d, gg[4][2];
+    if (!own_is_end2) edges_distance<T>(O[0], O[own_nb], Q[0], Q[par_nb], d, gg);      // A = own edge, B = partner edge
+    else edges_distance<T>(Q[0], Q[par_nb], O[0], O[own_nb], d, gg);                   // A = partner edge, B = own edge
+    T e, da, dam, dac, dkc;
+    contact_one<T, P, false>(d, am, ac, kc, e, da, dam, dac, dkc);
+    g.e = g.e + e; g.am = g.am + dam; g.ac = g.ac + dac; g.kc = g.kc + dkc;
+    const int base = own_is_end2 ? 2 : 0;  // where the own edge's end points sit in gg
+    G[0][0] = G[0][0] + da * gg[base][0];      G[0][1] = G[0][1] + da * gg[base][1];
+    G[own_nb][0] = G[own_nb][0] + da * gg[base + 1][0];  G[own_nb][1] = G[own_nb][1] + da * gg[base + 1][1];
+  }
+  g.fx = T(0.0); g.fy = T(0.0); g.fth = T(0.0);
+  for (int k = 0; k < 3; ++k) {
+    g.fx = g.fx + G[k][0];
+    g.fy = g.fy + G[k][1];
+    g.fth = g.fth + (G[k][1] * qo[k][0] - G[k][0] * qo[k][1]);     // dX_k/dtheta = (-q_y, q_x)
+    g.r[k][0] = co * G[k][0] + so * G[k][1];                      // R^T G
+    g.r[k][1] = co * G[k][1] - so * G[k][0];
+  }
+  g.cx = g.fx; g.cy = g.fy;
 }
 
 // ---------------------------------------------------------------------------------------

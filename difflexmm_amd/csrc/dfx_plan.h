@@ -45,7 +45,7 @@ inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
   if (p->batch <= 0) { err = "invalid problem: batch must be >= 1"; return 1; }
   if (p->n_fns < 0 || p->n_fns > DFX_MAX_FNS) { err = "invalid problem: n_fns out of range"; return 1; }
   if (p->bond_model < DFX_BOND_LINEARIZED || p->bond_model > DFX_BOND_STRETCH_TORSION) { err = "invalid bond_model"; return 1; }
-  if (p->contact != DFX_CONTACT_NONE && p->contact != DFX_CONTACT_ANGLE) { err = "invalid contact model"; return 1; }
+  if (p->contact < DFX_CONTACT_NONE || p->contact > DFX_CONTACT_DISTANCE) { err = "invalid contact model"; return 1; }
   pl.n_blocks = p->n_blocks; pl.n_npb = p->n_npb; pl.n_bonds = p->n_bonds; pl.batch = p->batch;
   pl.n_slots = p->n_blocks * kSlots;
   pl.model = p->bond_model; pl.contact = p->contact; pl.n_fns = p->n_fns; pl.n_special = p->n_special;
@@ -103,6 +103,7 @@ struct PackedParams {
   std::vector<double> inv_m;    // batch * n_blocks * 3
   std::vector<double> damping;  // batch * n_blocks * 3
   std::vector<double> contact;  // batch * 3
+  std::vector<double> centroid; // batch * n_blocks * 2 (distance-based contact)
   std::vector<TimeFn> fns;      // batch * DFX_MAX_FNS
   // GPU image (structure of arrays, 16-byte rows so every lane issues aligned dwordx4 loads):
   std::vector<double> p_r;      // batch * n_slots * 2 : own node vector
@@ -122,13 +123,16 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
   if (!q || !q->centroid_node_vectors || !q->reference_vector || !q->k_bond || !q->inertia) {
     err = "set_params: centroid_node_vectors, reference_vector, k_bond and inertia are required"; return 1;
   }
-  if (pl.contact && (!q->void_angle0 || !q->contact)) { err = "set_params: contact model needs void_angle0 and contact"; return 1; }
+  if (pl.contact == DFX_CONTACT_ANGLE && (!q->void_angle0 || !q->contact)) { err = "set_params: contact model needs void_angle0 and contact"; return 1; }
+  if (pl.contact == DFX_CONTACT_DISTANCE && (!q->block_centroids || !q->contact)) { err = "set_params: distance-based contact needs block_centroids and contact"; return 1; }
   if (pl.n_fns && !q->fn_params) { err = "set_params: fn_params required"; return 1; }
   const int B = pl.batch, NS = pl.n_slots, NB = pl.n_blocks;
   out.slot.assign((size_t)B * NS * kSlotParams, 0.0);
   out.inv_m.assign((size_t)B * NB * 3, 0.0);
   out.damping.assign((size_t)B * NB * 3, 0.0);
   out.contact.assign((size_t)B * 3, 0.0);
+  out.centroid.assign((size_t)B * NB * 2, 0.0);
+  if (q->block_centroids) out.centroid.assign(q->block_centroids, q->block_centroids + (size_t)B * NB * 2);
   out.fns.assign((size_t)B * DFX_MAX_FNS, TimeFn{0, 0, {0, 0, 0, 0, 0}});
   for (int m = 0; m < B; ++m) {
     const double* cnv = q->centroid_node_vectors + (size_t)m * NB * pl.n_npb * 2;

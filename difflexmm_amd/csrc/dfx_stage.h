@@ -24,7 +24,7 @@ namespace dfx {
 
 // per-member device/host image of the static tables + packed parameters
 struct Tables {
-  int n_blocks, n_fns, model, contact;
+  int n_blocks, n_fns, model, contact, n_npb;
   const int32_t* slot_info;
   const int32_t* block_special;
   const dfx_special* special;
@@ -32,6 +32,7 @@ struct Tables {
   const double* inv_m;     // n_blocks * 3
   const double* damping;   // n_blocks * 3
   const double* contact_p; // 3
+  const double* centroid;  // n_blocks * 2 (distance-based contact)
   const TimeFn* fns;       // DFX_MAX_FNS
 };
 
@@ -40,6 +41,16 @@ DFX_HD BlockRec<double> load_rec(const double* S, int b) {
   BlockRec<double> o;
   o.x = r[0]; o.y = r[1]; o.th = r[2]; o.ch = r[3]; o.sh = r[4];
   return o;
+}
+
+// distance-based contact (CONTACT == 2): node vectors of the bonded node, its next and its previous node on the block
+DFX_HD void node_triple(const Tables& tb, int slot, double (&r)[3][2]) {
+  const int b = slot >> 2, k = slot & 3, n = tb.n_npb;
+  const int ks[3] = {k, (k + 1) % n, (k + n - 1) % n};
+  for (int i = 0; i < 3; ++i) {
+    const double* sp = tb.slot_p + (size_t)(b * kSlots + ks[i]) * kSlotParams;
+    r[i][0] = sp[0]; r[i][1] = sp[1];
+  }
 }
 
 // ---- forward -------------------------------------------------------------------------------
@@ -59,7 +70,16 @@ DFX_HD void fwd_slot(const Tables& tb, const double* S_in, int slot, double& fx,
   bond_grad<MODEL, double>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], sgn, g);
   fx = g.fx; fy = g.fy; fth = g.fth;
   double e = g.e;
-  if (CONTACT) {
+  if (CONTACT == 2) {
+    double ro[3][2], rp[3][2];
+    node_triple(tb, slot, ro);
+    node_triple(tb, ps, rp);
+    DistContactGrad<double> c;
+    distance_contact_grad<double, double>(o, p, tb.centroid[(slot >> 2) * 2], tb.centroid[(slot >> 2) * 2 + 1], tb.centroid[(ps >> 2) * 2],
+                                          tb.centroid[(ps >> 2) * 2 + 1], ro, rp, info & 1, tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
+    fx += c.fx; fy += c.fy; fth += c.fth;
+    e += c.e;
+  } else if (CONTACT) {
     ContactGrad<double> c;
     double kap = sgn * (o.th - p.th);
     contact_grad<double>(kap, sp[7], sp[8], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
@@ -162,6 +182,7 @@ struct GradAcc {
   double* slot_g;  // n_slots * kSlotGrads (or null)
   double* blk_g;   // n_blocks * 6        (or null)
   double* fn_g;    // n_special * DFX_MAX_FNS * DFX_FN_PARAMS (or null)
+  double* cen_g;   // n_blocks * 2: d/d(block_centroids) (distance-based contact; or null)
 };
 
 // Own-side Hessian-vector product of slot `slot` for direction W (n_blocks*3) at records S.
@@ -184,7 +205,27 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
   bond_grad<MODEL, Dual>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], sgn, g);
   hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
   ContactGrad<Dual> c;
-  if (CONTACT) {
+  DistContactGrad<Dual> dc;
+  if (CONTACT == 2) {
+    double ro[3][2], rpp[3][2];
+    node_triple(tb, slot, ro);
+    node_triple(tb, ps, rpp);
+    distance_contact_grad<Dual, double>(o, p, tb.centroid[bo * 2], tb.centroid[bo * 2 + 1], tb.centroid[bp * 2], tb.centroid[bp * 2 + 1], ro, rpp,
+                                        info & 1, tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], dc);
+    hx += dc.fx.e; hy += dc.fy.e; hth += dc.fth.e;
+    if (acc.slot_g) {
+      const int k = slot & 3, n = tb.n_npb, ks[3] = {k, (k + 1) % n, (k + n - 1) % n};
+      for (int i = 0; i < 3; ++i) {       // the three nodes sit on the own block: same thread in the block loop of the CPU port
+        double* q = acc.slot_g + (size_t)(bo * kSlots + ks[i]) * kSlotGrads;
+        q[0] -= dc.r[i][0].e; q[1] -= dc.r[i][1].e;
+      }
+      if (!(info & 1)) {
+        double* q = acc.slot_g + (size_t)slot * kSlotGrads;
+        q[9] -= dc.am.e; q[10] -= dc.ac.e; q[11] -= dc.kc.e;
+      }
+    }
+    if (acc.cen_g) { acc.cen_g[bo * 2] -= dc.cx.e; acc.cen_g[bo * 2 + 1] -= dc.cy.e; }
+  } else if (CONTACT) {
     Dual kap = sgn * (o.th - p.th);
     contact_grad<Dual>(kap, sp[7], sp[8], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
     hth += sgn * c.dkap.e;
@@ -197,7 +238,7 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
     if (!(info & 1)) {
       q[2] -= g.lx.e; q[3] -= g.ly.e;
       q[4] -= g.ks.e; q[5] -= g.ksh.e; q[6] -= g.kr.e;
-      if (CONTACT) {
+      if (CONTACT == 1) {
         q[7] -= c.p1.e; q[8] -= c.p2.e;
         q[9] -= c.am.e; q[10] -= c.ac.e; q[11] -= c.kc.e;
       }

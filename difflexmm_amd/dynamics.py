@@ -83,7 +83,7 @@ class DynamicSolver:
                 e[2][d, len(self.con_terms) + f] = _bcast(term.vector, n_load)[j]
         self._special = [(blk, e[0], e[1], e[2]) for blk, e in sorted(special.items())]
         self.engine = _b.Engine(self.n_blocks, self.n_npb, self.bonds, self.spec.bond_model,
-                                _b.CONTACT_ANGLE if self.spec.contact else _b.CONTACT_NONE, self._special, fn_types,
+                                int(self.spec.contact or 0), self._special, fn_types,
                                 batch=self.batch, tableau=integrator, device=device, lib=lib,
                                 fn_tables=[getattr(f, "table", None) for f in self.con_terms + self.load_terms])
         self._last = None
@@ -108,7 +108,7 @@ class DynamicSolver:
         cached = _FLAT_CACHE.get(id(cnv)) if mp.inertia is None else None
         if cached is not None and cached[0]() is cnv and cached[1] is self.bonds and np.array_equal(cached[2], mp.density):
             out["inertia"] = cached[3]        # same design seen through another solver (multi-input problems): reuse
-            if self.spec.contact and cached[4] is not None:
+            if self.spec.contact == _b.CONTACT_ANGLE and cached[4] is not None:
                 out["void_angle0"] = cached[4]
         elif mp.inertia is None:   # dynamics.py:157-163
             out["inertia"] = compute_inertia(cnv, mp.density)
@@ -120,7 +120,10 @@ class DynamicSolver:
         out["damping"] = damping
         if self.spec.contact:
             c = mp.contact_params
-            if "void_angle0" not in out:
+            if self.spec.contact == _b.CONTACT_DISTANCE:      # energy.py:397-404: absolute node positions enter
+                out["block_centroids"] = np.asarray(gp.block_centroids, dtype=float).reshape(self.n_blocks, 2)
+                out.pop("void_angle0", None)
+            elif "void_angle0" not in out:
                 out["void_angle0"] = void_angles0(cnv, self.bonds)
             out["contact"] = np.array([c.min_angle, c.cutoff_angle, c.k_contact], dtype=float)
         if mp.inertia is None and cached is None and not cnv.flags.writeable:
@@ -264,7 +267,9 @@ class DynamicSolver:
         read-only views of the engine's pinned result area, valid until the next call on this solver.
         The maps from these to a design (void-angle and inertia chain rules, lattice map) are linear in the cotangent, so a
         caller that sums several solves of ONE design (multi-input problems) applies them once to the sum."""
-        which = tuple(w for w in which if not (w == "void_angle0" and not self.spec.contact))
+        which = tuple(w for w in which if not (w == "void_angle0" and self.spec.contact != _b.CONTACT_ANGLE))
+        if self.spec.contact == _b.CONTACT_DISTANCE and "block_centroids" not in which:
+            which = which + ("block_centroids",)
         obj, grads, stats = self.engine.kinetic_value_and_grad(target_blocks, which=which)
         self.adjoint_stats = stats
         return obj, grads
@@ -291,7 +296,7 @@ class DynamicSolver:
             gp, mp = cp.geometrical_params, cp.mechanical_params
             cnv = flat["centroid_node_vectors"]
             cnv_bar = g["centroid_node_vectors"][m].copy()
-            if self.spec.contact:
+            if self.spec.contact == _b.CONTACT_ANGLE:
                 cnv_bar += void_angles0_vjp(cnv, self.bonds, g["void_angle0"][m])
             density_bar, inertia_bar = None, None
             if mp.inertia is None:
@@ -318,8 +323,10 @@ class DynamicSolver:
             for f, term in enumerate(self.load_terms):
                 term.scatter_grad(g["fn_params"][m][len(self.con_terms) + f], load_bar)
             trees.append(ControlParams(
-                geometrical_params=GeometricalParams(block_centroids=np.zeros_like(np.asarray(gp.block_centroids, dtype=float)),
-                                                     centroid_node_vectors=cnv_bar),
+                geometrical_params=GeometricalParams(
+                    block_centroids=(np.array(g["block_centroids"][m]).reshape(np.shape(gp.block_centroids)) if "block_centroids" in g
+                                     else np.zeros_like(np.asarray(gp.block_centroids, dtype=float))),
+                    centroid_node_vectors=cnv_bar),
                 mechanical_params=MechanicalParams(
                     bond_params=self._bond_params_bar(mp.bond_params, kb, g["reference_vector"][m], like),
                     density=density_bar, inertia=inertia_bar, damping=damping_bar, contact_params=contact_bar),

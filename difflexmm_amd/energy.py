@@ -112,7 +112,7 @@ class EnergySpec:
             raise ValueError("only one strain energy may be combined")
         return EnergySpec(self.bond_connectivity if self.bond_connectivity is not None else other.bond_connectivity,
                           self.bond_model if self.bond_model is not None else other.bond_model,
-                          self.contact or other.contact)
+                          max(int(self.contact or 0), int(other.contact or 0)))
 
 
 class _EnergyFn:
@@ -162,18 +162,49 @@ def contact_energy(current_void_angles, min_angle=0., cutoff_angle=2.0 * np.pi /
     return np.where(a < min_angle, 0.0, np.where(a < cutoff_angle, inner, 0.0))
 
 
+def point_to_edge_distance(point, edge):
+    """energy.py:222-251 (one point (2,), one edge (2, 2))."""
+    x0, x1 = np.asarray(edge[0], dtype=float), np.asarray(edge[1], dtype=float)
+    p = np.asarray(point, dtype=float)
+    t = np.dot(p - x0, x1 - x0) / np.dot(x1 - x0, x1 - x0)
+    if 0 <= t <= 1:
+        return np.sum((p - x0) ** 2 - (t * (x1 - x0)) ** 2) ** 0.5
+    return np.sum((p - x0) ** 2) ** 0.5 if t < 0 else np.sum((p - x1) ** 2) ** 0.5
+
+
+def edges_distance(edge_1, edge_2):
+    """energy.py:254-276."""
+    return min([point_to_edge_distance(q, edge_1) for q in edge_2] + [point_to_edge_distance(q, edge_2) for q in edge_1])
+
+
+def build_void_edge_distance(bond_connectivity):
+    """energy.py:283-330: (2 n_bonds,) distances between the block edges on either side of every ligament."""
+    bonds = np.asarray(bond_connectivity, dtype=np.int64).reshape(-1, 2)
+
+    def void_edge_distance(current_block_nodes):
+        nodes = np.asarray(current_block_nodes, dtype=float)
+        n = nodes.shape[1]
+        b1, k1, b2, k2 = bonds[:, 0] // n, bonds[:, 0] % n, bonds[:, 1] // n, bonds[:, 1] % n
+        p1, p1p, p1n = nodes[b1, k1], nodes[b1, (k1 - 1) % n], nodes[b1, (k1 + 1) % n]
+        p2, p2p, p2n = nodes[b2, k2], nodes[b2, (k2 - 1) % n], nodes[b2, (k2 + 1) % n]
+        d1 = [edges_distance((a, an), (b, bp)) for a, an, b, bp in zip(p1, p1n, p2, p2p)]
+        d2 = [edges_distance((a, ap), (b, bn)) for a, ap, b, bn in zip(p1, p1p, p2, p2n)]
+        return np.array(d1 + d2)
+    return void_edge_distance
+
+
 def build_contact_energy(bond_connectivity, angle_based=True):
-    """energy.py:364-407 (angle-based model; the distance-based variant has no caller in problems/)."""
-    if not angle_based:
-        raise NotImplementedError("distance-based contact is not part of the accelerated path")
+    """energy.py:364-407: angle-based (default) or distance-based (``angle_based=False``: the penalty of energy.py:333-361 on the
+    void-edge distances of energy.py:283-330, ``contact_params`` then being lengths, utils.py:101)."""
+    distance_fn = (lambda nodes: void_angles(nodes, bond_connectivity)) if angle_based else build_void_edge_distance(bond_connectivity)
 
     def host(block_displacement, control_params):
         gp = control_params.geometrical_params
         nd = block_to_node_kinematics(block_displacement, gp.centroid_node_vectors)[:, :, :2]
         nodes = np.asarray(gp.block_centroids)[:, None] + np.asarray(gp.centroid_node_vectors) + nd
         cp = control_params.mechanical_params.contact_params
-        return np.sum(contact_energy(void_angles(nodes, bond_connectivity), **cp._asdict()))
-    return _EnergyFn(EnergySpec(bond_connectivity, None, True), host)
+        return np.sum(contact_energy(distance_fn(nodes), **cp._asdict()))
+    return _EnergyFn(EnergySpec(bond_connectivity, None, 1 if angle_based else 2), host)
 
 
 def combine_block_energies(*energy_fns):

@@ -490,7 +490,7 @@ class MultiInputTargetKineticEnergy:
             if "void_angle0" in sums:
                 cnv_bar += void_angles0_vjp(cnv, bonds, sums["void_angle0"][m])
             cnv_bar += compute_inertia_vjp(cnv, fw0.density, sums["inertia"][m])[0]
-            grads.append(geo.vjp(d, cnv_bar, None))
+            grads.append(geo.vjp(d, cnv_bar, sums["block_centroids"][m] if "block_centroids" in sums else None))
         if many:
             return list(value), grads
         return float(value[0]), grads[0]

@@ -40,7 +40,9 @@ enum { DFX_BOND_LINEARIZED = 0, DFX_BOND_NONLINEAR = 1,         /* energy.py:99 
        DFX_BOND_SIMPLE_SPRING = 2,                              /* energy.py:30-48: k_stretch (|dU + l0| - |l0|)^2 / 2; k_bond[1..2] ignored */
        DFX_BOND_STRETCH_TORSION = 3 };                          /* energy.py:51-67: zero-length spring, k_stretch |dU|^2/2 + k_rot dtheta^2/2;
                                                                    k_bond[1] and reference_vector ignored (pass any non-zero vector) */
-enum { DFX_CONTACT_NONE = 0, DFX_CONTACT_ANGLE = 1 };           /* energy.py:364 (angle_based)  */
+enum { DFX_CONTACT_NONE = 0, DFX_CONTACT_ANGLE = 1,            /* energy.py:364 (angle_based)  */
+       DFX_CONTACT_DISTANCE = 2 };                              /* energy.py:222-330 (angle_based=False): void-edge distances;
+                                                                   `contact` = (min, cutoff, k) are lengths, needs block_centroids */
 enum { DFX_TABLEAU_DOPRI5 = 0, DFX_TABLEAU_RK4 = 1 };
 /* time-function library; parameters p[] in this order */
 enum {
@@ -93,6 +95,7 @@ typedef struct dfx_params {
   const double* void_angle0;              /* (batch, n_bonds, 2) undeformed void angles or NULL  */
   const double* contact;                  /* (batch, 3) min_angle, cutoff_angle, k_contact / NULL */
   const double* fn_params;                /* (batch, n_fns, DFX_FN_PARAMS)                       */
+  const double* block_centroids;          /* (batch, n_blocks, 2): DFX_CONTACT_DISTANCE only, else NULL */
 } dfx_params;
 
 /* Gradient of  L = sum(fields_bar * fields)  with respect to everything in dfx_params and the
@@ -107,6 +110,7 @@ typedef struct dfx_grads {
   double* contact;                        /* (batch, 3)                                          */
   double* fn_params;                      /* (batch, n_fns, DFX_FN_PARAMS)                       */
   double* state0;                         /* (batch, 2, n_blocks, 3)                             */
+  double* block_centroids;                /* (batch, n_blocks, 2): non-zero with DFX_CONTACT_DISTANCE only */
 } dfx_grads;
 
 typedef struct dfx_stats {

@@ -39,14 +39,15 @@ struct dfx_handle {
   std::vector<std::vector<double>> acc_times;  // end times of the accepted steps per member (adaptive)
   std::vector<double> t_steps;       // caller-chosen step boundaries (empty: equal steps)
   bool have_traj = false;
-  std::vector<double> view_store[9];  // dfx_kinetic_value_and_grad: arrays behind the returned views
+  std::vector<double> view_store[10];  // dfx_kinetic_value_and_grad: arrays behind the returned views
   std::vector<double> zero_state;
 };
 
 static Tables member_tables(const dfx_handle* h, int m) {
   const Plan& pl = h->pl;
   Tables tb;
-  tb.n_blocks = pl.n_blocks; tb.n_fns = pl.n_fns; tb.model = pl.model; tb.contact = pl.contact;
+  tb.n_blocks = pl.n_blocks; tb.n_fns = pl.n_fns; tb.model = pl.model; tb.contact = pl.contact; tb.n_npb = pl.n_npb;
+  tb.centroid = h->pp.centroid.data() + (size_t)m * pl.n_blocks * 2;
   tb.slot_info = pl.slot_info.data();
   tb.block_special = pl.block_special.data();
   tb.special = pl.special.data();
@@ -77,7 +78,7 @@ static void fwd_stage_t(const Tables& tb, const Tableau& T, const FwdStage& st, 
 }
 
 static void fwd_stage(const Tables& tb, const Tableau& T, const FwdStage& st, double* energy = nullptr) {
-#define CASE(M) case M: if (tb.contact) fwd_stage_t<M, 1>(tb, T, st, energy); else fwd_stage_t<M, 0>(tb, T, st, energy); break;
+#define CASE(M) case M: if (tb.contact == 2) fwd_stage_t<M, 2>(tb, T, st, energy); else if (tb.contact) fwd_stage_t<M, 1>(tb, T, st, energy); else fwd_stage_t<M, 0>(tb, T, st, energy); break;
   switch (tb.model) { CASE(kNonlinear) CASE(kLinearized) CASE(kSimpleSpring) CASE(kStretchTorsion) }
 #undef CASE
 }
@@ -97,7 +98,7 @@ static void adj_stage_t(const Tables& tb, const Tableau& T, const AdjStage& st, 
 }
 
 static void adj_stage(const Tables& tb, const Tableau& T, const AdjStage& st, const GradAcc& acc) {
-#define CASE(M) case M: if (tb.contact) adj_stage_t<M, 1>(tb, T, st, acc); else adj_stage_t<M, 0>(tb, T, st, acc); break;
+#define CASE(M) case M: if (tb.contact == 2) adj_stage_t<M, 2>(tb, T, st, acc); else if (tb.contact) adj_stage_t<M, 1>(tb, T, st, acc); else adj_stage_t<M, 0>(tb, T, st, acc); break;
   switch (tb.model) { CASE(kNonlinear) CASE(kLinearized) CASE(kSimpleSpring) CASE(kStretchTorsion) }
 #undef CASE
 }
@@ -375,13 +376,13 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
   auto t_begin = std::chrono::steady_clock::now();
   const int nsp = pl.n_special > 0 ? pl.n_special : 1;
   std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
-      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0);
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0);
   std::vector<double> Sst((size_t)T.s * rec), A((size_t)T.s * nb * 3), YB((size_t)T.s * nb * 6), LAM((size_t)nb * 6),
       W(2 * (size_t)nb * 3), KQ(2 * (size_t)nb * 3);
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
     GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
-                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS};
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2};
     const double* tr = h->traj.data() + (size_t)m * (N + 1) * rec;
     const double* G = Gall.data() + (size_t)m * Tn * nb * 6;
     int cur = 0;
@@ -434,6 +435,7 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
         }
   }
   if (grads) unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, grads);
+  if (grads && grads->block_centroids) memcpy(grads->block_centroids, cen_g.data(), sizeof(double) * cen_g.size());
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->steps = N; stats->rhs_evals = N * T.s;
@@ -521,12 +523,12 @@ int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int3
   // same contract as the HIP engine: results in handle-owned memory, valid until the next call on the handle
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, nbd = pl.n_bonds;
-  const size_t sizes[9] = {B * nb * pl.n_npb * 2, B * nbd * 2, B * nbd * 3, B * nb * 3, B * nb * 3, B * nbd * 2, B * 3,
-                           B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS, B * nb * 6};
+  const size_t sizes[10] = {B * nb * pl.n_npb * 2, B * nbd * 2, B * nbd * 3, B * nb * 3, B * nb * 3, B * nbd * 2, B * 3,
+                            B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS, B * nb * 6, B * nb * 2};
   dfx_grads g;
   double** gp = reinterpret_cast<double**>(&g);
   double* const* wp = reinterpret_cast<double* const*>(want);
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < 10; ++i) {
     gp[i] = nullptr;
     if (want && wp[i]) { h->view_store[i].assign(sizes[i], 0.0); gp[i] = h->view_store[i].data(); }
   }
@@ -602,12 +604,12 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   const int nb = pl.n_blocks, B = pl.batch;
   const int nsp = pl.n_special > 0 ? pl.n_special : 1;
   std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
-      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0);
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0);
   std::vector<double> S((size_t)nb * kRec), A((size_t)pl.tab.s * nb * 3), W((size_t)nb * 3);
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
     GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
-                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS};
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2};
     for (int b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) init_dof(tb, y + (size_t)m * nb * 6, t, S.data(), b, d);
     FwdStage st;
@@ -625,7 +627,7 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
       double hs[3] = {0, 0, 0};
       for (int k = 0; k < kSlots; ++k) {
         double hx = 0.0, hy = 0.0, hth = 0.0;
-#define CASE(M) case M: if (tb.contact) adj_slot<M, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<M, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); break;
+#define CASE(M) case M: if (tb.contact == 2) adj_slot<M, 2>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else if (tb.contact) adj_slot<M, 1>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); else adj_slot<M, 0>(tb, S.data(), W.data(), b * kSlots + k, acc, hx, hy, hth); break;
         switch (tb.model) { CASE(kNonlinear) CASE(kLinearized) CASE(kSimpleSpring) CASE(kStretchTorsion) }
 #undef CASE
         hs[0] += hx; hs[1] += hy; hs[2] += hth;
@@ -642,6 +644,7 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
     dfx_grads g = *grads;
     g.state0 = nullptr;
     unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g);
+    if (g.block_centroids) memcpy(g.block_centroids, cen_g.data(), sizeof(double) * cen_g.size());
   }
   return 0;
 }

@@ -180,10 +180,54 @@ def contact_energy(current_void_angles, min_angle=0.0, cutoff_angle=2.0 * math.p
     return torch.where(a < min_angle, zero, torch.where(a < cutoff_angle, inner, zero))
 
 
+def point_to_edge_distance(point, edge):
+    """energy.py:222-251, batched over a leading axis: point (n, 2), edge (n, 2, 2).  The reference's nested ``jnp.where``
+    evaluates all three branches; here the value of every branch is the reference's formula and the branch is picked by the
+    same conditions -- the unselected square roots are guarded (the usual double-where) so that autograd does not turn an
+    unselected sqrt(0) into NaN * 0."""
+    x0, x1 = edge[:, 0], edge[:, 1]
+    t = torch.sum((point - x0) * (x1 - x0), -1) / torch.sum((x1 - x0) * (x1 - x0), -1)
+    inside = (t >= 0) & (t <= 1)
+    arg_in = torch.sum((point - x0) ** 2 - (t[:, None] * (x1 - x0)) ** 2, -1)
+    d_in = torch.where(inside, arg_in, torch.ones_like(arg_in)) ** 0.5
+    arg0 = torch.sum((point - x0) ** 2, -1)
+    d0 = torch.where(t < 0, arg0, torch.ones_like(arg0)) ** 0.5
+    arg1 = torch.sum((point - x1) ** 2, -1)
+    d1 = torch.where(~inside & ~(t < 0), arg1, torch.ones_like(arg1)) ** 0.5
+    return torch.where(inside, d_in, torch.where(t < 0, d0, d1))
+
+
+def edges_distance_mapped(edge_1, edge_2):
+    """energy.py:254-280: min over the four point-to-other-edge distances, edges (n, 2, 2)."""
+    e2_onto_e1 = torch.stack([point_to_edge_distance(edge_2[:, k], edge_1) for k in range(2)], -1)
+    e1_onto_e2 = torch.stack([point_to_edge_distance(edge_1[:, k], edge_2) for k in range(2)], -1)
+    return torch.min(torch.cat([e2_onto_e1, e1_onto_e2], -1), dim=-1).values
+
+
+def build_void_edge_distance(bond_connectivity):
+    """energy.py:283-330."""
+    bonds = torch.as_tensor(np.asarray(bond_connectivity), dtype=torch.long)
+
+    def void_edge_distance(current_block_nodes):
+        n = current_block_nodes.shape[1]
+        n1, n2 = bonds[:, 0], bonds[:, 1]
+        pts1 = current_block_nodes[n1 // n, n1 % n]
+        pts1_prev = current_block_nodes[n1 // n, (n1 - 1) % n]
+        pts1_next = current_block_nodes[n1 // n, (n1 + 1) % n]
+        pts2 = current_block_nodes[n2 // n, n2 % n]
+        pts2_prev = current_block_nodes[n2 // n, (n2 - 1) % n]
+        pts2_next = current_block_nodes[n2 // n, (n2 + 1) % n]
+        d1 = edges_distance_mapped(torch.stack([pts1, pts1_next], 1), torch.stack([pts2, pts2_prev], 1))
+        d2 = edges_distance_mapped(torch.stack([pts1, pts1_prev], 1), torch.stack([pts2, pts2_next], 1))
+        return torch.cat([d1, d2])
+
+    return void_edge_distance
+
+
 def build_contact_energy(bond_connectivity, angle_based=True):
-    """energy.py:364-407 (angle-based model only; the distance-based one has no caller in problems/)."""
-    if not angle_based:
-        raise NotImplementedError("distance-based contact is outside the hot path (SURVEY 8(f)-3)")
+    """energy.py:364-407: the penalty of energy.py:333-361 on the void angles (default) or on the void-edge distances."""
+    void_edge_distance_fn = build_void_edge_distance(bond_connectivity)
+    distance_fn = (lambda nodes: void_angles(nodes, bond_connectivity)) if angle_based else void_edge_distance_fn
 
     def contact_energy_fn(block_displacement, control_params):
         c = control_params.geometrical_params.block_centroids
@@ -191,7 +235,7 @@ def build_contact_energy(bond_connectivity, angle_based=True):
         cp = control_params.mechanical_params.contact_params
         nd = block_to_node_kinematics(block_displacement, cnv)[:, :, :2]
         nodes = c[:, None] + cnv + nd
-        return torch.sum(contact_energy(void_angles(nodes, bond_connectivity), **cp._asdict()))
+        return torch.sum(contact_energy(distance_fn(nodes), **cp._asdict()))
 
     return contact_energy_fn
 
