@@ -4,14 +4,14 @@ independent optimisations, sharded over GPUs.
 
     python examples/multi_input_ensemble.py --members 32 --iterations 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        examples/multi_input_ensemble.py --members 256 --iterations 20
+        examples/multi_input_ensemble.py --members 256 --iterations 20      # any launcher that exports RANK / LOCAL_RANK / WORLD_SIZE
 
 24x16 quads, three inputs (left / right / bottom edge, input shifts 0 / -2 / -4), one objective per design = weighted sum
 of the three target kinetic energies; every member starts from its own perturbed design (seeds 1000, 1001, ...) and runs
 the reference's loop (method of moving asymptotes under the angle / edge-length constraints).  One rank = one GPU = one
 contiguous chunk of members integrated side by side (grid.y of every launch); members advance in lock-step so each round
-is three batched forward + reverse sweeps; no data-path collective, the final objectives are combined with one
-all_gather (difflexmm_amd/ensemble.py).
+is three batched forward + reverse sweeps; no data-path collective, the final objectives are combined with one RCCL
+all-gather inside libdfx (difflexmm_amd/ensemble.py: RcclComm -> dfx_gather_objectives).  No PyTorch in the ranks.
 """
 import argparse
 import math
@@ -32,21 +32,15 @@ def main():
     ap.add_argument("--n2", type=int, default=16)
     ap.add_argument("--steps-per-interval", type=int, default=100)
     ap.add_argument("--timepoints", type=int, default=41)
-    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--backend", default="rccl", help="rccl (inside libdfx) | socket (plain TCP: rehearsals without one GPU per rank)")
     ap.add_argument("--cpu-port", action="store_true", help="use the oracle's CPU port instead of libdfx (rehearsal without a GPU)")
     args = ap.parse_args()
 
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
     from difflexmm_amd import problems as P
+    from difflexmm_amd import ensemble
     from difflexmm_amd.ensemble import gather_objectives, shard_bounds
+    comm = ensemble.init_from_env(args.backend, device=local_rank) if world > 1 else ensemble.SerialComm()
     lib = None
     if args.cpu_port:
         from oracle.cpu import load
@@ -93,6 +87,8 @@ def main():
               f"-> packed arrays, gradient maps back to the design, the MMA sub-problems")
         print("objective, first evaluation :", np.array2string(first, precision=3, max_line_width=160))
         print("objective, best feasible    :", np.array2string(final, precision=3, max_line_width=160))
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -126,8 +126,7 @@ def arbitrary_python_callables_are_rejected(lib):
         setup_dynamic_solver(g, en, constrained_block_DOF_pairs=np.array([[0, 0]]), constrained_DOFs_fn=lambda t: 0.1 * t, _lib=lib)
     with pytest.raises(TypeError):
         setup_dynamic_solver(g, lambda u, cp: 0.0, _lib=lib)
-    with pytest.raises(NotImplementedError):
-        E.build_contact_energy(g.bond_connectivity(), angle_based=False)
+    assert E.build_contact_energy(g.bond_connectivity(), angle_based=False).spec.contact == 2       # distance-based: built in round 2
 
 
 @case
