@@ -30,7 +30,7 @@ class dfx_problem(C.Structure):
                 ("bond_model", C.c_int32), ("contact", C.c_int32), ("n_special", C.c_int32),
                 ("special", C.POINTER(dfx_special)), ("n_fns", C.c_int32), ("fn_type", C.c_int32 * DFX_MAX_FNS),
                 ("batch", C.c_int32), ("tableau", C.c_int32), ("device", C.c_int32),
-                ("fn_table_n", C.c_int32 * DFX_MAX_FNS), ("fn_table", _dp * DFX_MAX_FNS)]
+                ("fn_table_n", C.c_int32 * DFX_MAX_FNS), ("fn_table", _dp * DFX_MAX_FNS), ("streams", C.c_int32)]
 
 
 _PARAM_FIELDS = ["centroid_node_vectors", "reference_vector", "k_bond", "inertia", "damping", "void_angle0",
@@ -154,7 +154,7 @@ class Engine:
     """One ``dfx_handle``: a lattice + boundary-condition pattern, ``batch`` members wide."""
 
     def __init__(self, n_blocks, n_npb, bonds, bond_model, contact, special, fn_types, batch=1,
-                 tableau="dopri5", device=0, lib=None, fn_tables=None):
+                 tableau="dopri5", device=0, lib=None, fn_tables=None, streams=0):
         self.lib = lib if lib is not None else load_library()
         self.n_blocks, self.n_npb, self.batch = int(n_blocks), int(n_npb), int(batch)
         self.bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
@@ -178,6 +178,7 @@ class Engine:
         for f in range(DFX_MAX_FNS):
             prob.fn_type[f] = int(self.fn_types[f]) if f < self.n_fns else 0
         prob.batch, prob.tableau, prob.device = self.batch, TABLEAU[tableau], int(device)
+        prob.streams = int(streams or 0)
         tables = []                                   # (times, values) of FN_TABLE functions: static data, copied by dfx_create
         for f in range(DFX_MAX_FNS):
             tab = fn_tables[f] if fn_tables is not None and f < len(fn_tables) else None

@@ -681,7 +681,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     // members), 1 group below that (24x16 x 32 members: 4.8 s vs 8.4 s with 4 groups)
     const char* e = getenv("DFX_STREAMS");
     const long long waves = (long long)h->pl.batch * ((h->pl.n_slots + 63) / 64);
-    int want = e ? atoi(e) : (waves >= 2048 ? 2 : 1);
+    int want = e ? atoi(e) : (problem->streams > 0 ? problem->streams : (waves >= 2048 ? 2 : 1));
     int ng = std::max(1, std::min({want, h->pl.batch, kMaxGroups}));
     (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming);

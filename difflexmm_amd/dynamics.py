@@ -37,7 +37,7 @@ class DynamicSolver:
     """Callable returned by :func:`setup_dynamic_solver`."""
 
     def __init__(self, geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
-                 constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, lib):
+                 constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, lib, streams=0):
         if not isinstance(energy_fn, _EnergyFn) or energy_fn.spec.bond_model is None:
             raise TypeError("energy_fn must be built with difflexmm_amd.energy.build_strain_energy "
                             "(optionally combined with build_contact_energy)")
@@ -85,7 +85,7 @@ class DynamicSolver:
         self.engine = _b.Engine(self.n_blocks, self.n_npb, self.bonds, self.spec.bond_model,
                                 int(self.spec.contact or 0), self._special, fn_types,
                                 batch=self.batch, tableau=integrator, device=device, lib=lib,
-                                fn_tables=[getattr(f, "table", None) for f in self.con_terms + self.load_terms])
+                                fn_tables=[getattr(f, "table", None) for f in self.con_terms + self.load_terms], streams=streams)
         self._last = None
         self.solve_count = 0          # forward solves run so far (what the engine's resident history belongs to)
 
@@ -341,7 +341,7 @@ def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loadi
                          constrained_block_DOF_pairs=np.array([]), constrained_DOFs_fn=zero,
                          damped_blocks=None, rtol: float = 1e-8, atol: float = 1e-8, *,
                          integrator: str = "dopri5", steps_per_interval: Optional[int] = None,
-                         batch: int = 1, device: int = 0, _lib=None):
+                         batch: int = 1, device: int = 0, streams: int = 0, _lib=None):
     """Same positional/keyword arguments as ``difflexmm.dynamics.setup_dynamic_solver`` (dynamics.py:60-69)."""
     return DynamicSolver(geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
-                         constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, _lib)
+                         constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, _lib, streams)

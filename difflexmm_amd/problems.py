@@ -147,6 +147,7 @@ class QuadsFocusingForward:
     integrator: str = "dopri5"
     batch: int = 1
     device: int = 0
+    streams: int = 0          # member groups on their own HIP streams (0: the engine chooses); multi-input objectives set 1
     name: str = "quads_focusing"
     _lib: Any = None
 
@@ -164,7 +165,7 @@ class QuadsFocusingForward:
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=L.Pulse(vec),
             damped_blocks=np.arange(g.n_blocks), integrator=self.integrator,
-            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, _lib=self._lib)
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
         self.signed_amplitude = self.amplitude if self.loaded_side in ("left", "bottom") else -self.amplitude
@@ -299,6 +300,7 @@ class KagomeFocusingForward:
     integrator: str = "dopri5"
     batch: int = 1
     device: int = 0
+    streams: int = 0
     name: str = "kagome_focusing"
     _lib: Any = None
 
@@ -319,7 +321,7 @@ class KagomeFocusingForward:
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=L.Pulse(vec),
             damped_blocks=np.arange(g.n_blocks), integrator=self.integrator,
-            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, _lib=self._lib)
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
         self.signed_amplitude = self.amplitude
@@ -428,6 +430,12 @@ class MultiInputTargetKineticEnergy:
     (loaded side / input shift), so each owns a solver; the design gradient is the weighted sum."""
 
     def __init__(self, forward_problems, target_size, target_shift, weights):
+        # Several engines are driven at once (one host thread per input): measured on 24x16 x 96 members x 3 inputs, one stream
+        # per engine + three threads 0.91 s per evaluation against 1.4 s with two member groups per engine (profiles/
+        # r02_multi_engine_streams.txt) -- the concurrency comes from the engines, not from groups inside one.
+        for fp in forward_problems:
+            if len(forward_problems) > 1 and not getattr(fp, "is_setup", False) and not fp.streams:
+                fp.streams = 1
         self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
         self.target_size, self.target_shift = tuple(target_size), tuple(target_shift)
         self.concurrent_inputs = True

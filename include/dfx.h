@@ -83,6 +83,8 @@ typedef struct dfx_problem {
   int32_t device;                         /* HIP device ordinal (ignored by the CPU port)        */
   int32_t fn_table_n[DFX_MAX_FNS];        /* DFX_FN_TABLE: number of breakpoints (>= 2), else 0   */
   const double* fn_table[DFX_MAX_FNS];    /* DFX_FN_TABLE: fn_table_n increasing times, then fn_table_n values */
+  int32_t streams;                        /* member groups advanced on their own HIP streams; 0 = choose (2 when the launches fill the
+                                             chip, else 1).  Several engines driven concurrently (multi-input problems) run best with 1 */
 } dfx_problem;
 
 /* ControlParams, flattened (utils.py:48-163).  Leading axis of every array = batch. */
