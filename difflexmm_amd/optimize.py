@@ -112,11 +112,24 @@ def mma_steps(x0, lower=None, upper=None, constraints=(), maxeval=100, ftol_rel=
                 for _pass in range(20):
                     idx = np.flatnonzero(active)
                     if idx.size:
+                        # the dual is evaluated ~100 times per solve: rows of the working set sliced and transposed ONCE (CSR both
+                        # ways) -- the full (m, n) products and the transposed-matrix objects SciPy builds per `J.T @ y` call
+                        # were two thirds of the host time of the config-5 ensemble (profiles/r02_c5_host_profile.txt)
+                        Ji, Jai = J[idx].tocsr(), Jabs[idx].tocsr()
+                        JiT, JaiT = Ji.T.tocsr(), Jai.T.tocsr()
+                        fci, rci, gabs = fc[idx], rhoc[idx], np.abs(g)
+
                         def neg_dual(ya):
-                            yv = np.zeros(m); yv[idx] = ya
-                            d = primal(yv)
-                            gc = approx_constraints(d)[idx]
-                            val = f + approx(d, g, rho) + ya @ gc
+                            u = s2 * (g + JiT @ ya)
+                            v = sigma * (gabs + JaiT @ ya) + 0.5 * (rho + rci @ ya)
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                d = np.where(np.abs(u) < 1e-3 * (v + 1e-300), -0.5 * u / np.maximum(v, 1e-300),
+                                             (s2 / u) * (-v + np.sqrt(np.maximum(v * v - u * u / s2, 0.0))))
+                            d = np.clip(np.where(np.isfinite(d), d, 0.0), lo, hi)
+                            den = s2 - d * d
+                            w, w2 = d / den, d * d / den
+                            gc = fci + Ji @ (s2 * w) + Jai @ (sigma * w2) + 0.5 * rci * np.sum(w2)
+                            val = f + np.sum((g * s2 * d + (gabs * sigma + 0.5 * rho) * d * d) / den) + ya @ gc
                             return -val, -gc
                         res = scipy.optimize.minimize(neg_dual, y[idx], jac=True, method="L-BFGS-B",
                                                       bounds=scipy.optimize.Bounds(np.zeros(idx.size), np.full(idx.size, np.inf)),

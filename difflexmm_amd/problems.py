@@ -430,12 +430,16 @@ class MultiInputTargetKineticEnergy:
     (loaded side / input shift), so each owns a solver; the design gradient is the weighted sum."""
 
     def __init__(self, forward_problems, target_size, target_shift, weights):
-        # Several engines are driven at once (one host thread per input): measured on 24x16 x 96 members x 3 inputs, one stream
-        # per engine + three threads 0.91 s per evaluation against 1.4 s with two member groups per engine (profiles/
-        # r02_multi_engine_streams.txt) -- the concurrency comes from the engines, not from groups inside one.
+        # Several engines can be driven at once (one host thread per input).  That pays while ONE engine does not fill the chip:
+        # 24x16 x 96 members x 3 inputs, one stream per engine + three threads 0.91 s per evaluation against 1.4 s with two member
+        # groups per engine run one after the other (profiles/r02_multi_engine_streams.txt).  With 256 members each engine fills the
+        # chip alone and three threads issuing eager launches only contend for the runtime (forward 0.70 s vs 0.31 s per call,
+        # profiles/r02_c5_host_profile.txt): those keep the engine's own choice and run the inputs one after the other.
         for fp in forward_problems:
             if len(forward_problems) > 1 and not getattr(fp, "is_setup", False) and not fp.streams:
-                fp.streams = 1
+                n_units = (fp.n1_blocks * fp.n2_blocks) if hasattr(fp, "n1_blocks") else 2 * fp.n1_cells * fp.n2_cells
+                if fp.batch * n_units * 4 // 64 < 4096:      # waves per launch: below two rounds of the chip
+                    fp.streams = 1
         self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
         self.target_size, self.target_shift = tuple(target_size), tuple(target_shift)
         self.concurrent_inputs = True

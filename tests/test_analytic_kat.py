@@ -168,3 +168,106 @@ def test_prescribed_dof_outputs_closed_form_on_oracle():
     for (blk, d), w in zip(con, vec):
         assert np.abs(fields[:, 0, blk, d] - w * np.where(on, A * 0.5 * (1 - np.cos(2 * math.pi * f * tau)), 0.0)).max() < 1e-13 * A
         assert np.abs(fields[:, 1, blk, d] - w * np.where(on, A * math.pi * f * np.sin(2 * math.pi * f * tau), 0.0)).max() < 1e-10 * A * math.pi * f
+
+
+# ---- 3. distance-based contact (energy.py:222-330): the reference's formulas typed in literally, plain Python floats ------------------
+
+def _ref_point_to_edge(p, x0, x1):
+    """energy.py:234-251, the three branches exactly as written there."""
+    t = ((p[0] - x0[0]) * (x1[0] - x0[0]) + (p[1] - x0[1]) * (x1[1] - x0[1])) / ((x1[0] - x0[0]) ** 2 + (x1[1] - x0[1]) ** 2)
+    if 0 <= t <= 1:
+        return ((p[0] - x0[0]) ** 2 - (t * (x1[0] - x0[0])) ** 2 + (p[1] - x0[1]) ** 2 - (t * (x1[1] - x0[1])) ** 2) ** 0.5
+    if t < 0:
+        return ((p[0] - x0[0]) ** 2 + (p[1] - x0[1]) ** 2) ** 0.5
+    return ((p[0] - x1[0]) ** 2 + (p[1] - x1[1]) ** 2) ** 0.5
+
+
+def _ref_edges_distance(e1, e2):
+    """energy.py:266-276."""
+    return min([_ref_point_to_edge(q, *e1) for q in e2] + [_ref_point_to_edge(q, *e2) for q in e1])
+
+
+def closed_form_distance_contact(u, cnv, cen, dmin, dcut, k):
+    """Energy of the one-ligament hinge under block displacements u (2, 3): node positions c + u_xy + R(theta) r
+    (energy.py:397-404), the two void-edge distances of energy.py:301-326, the penalty of energy.py:349-360."""
+    X = []
+    for b in range(2):
+        c, s = math.cos(u[b][2]), math.sin(u[b][2])
+        X.append([(cen[b][0] + u[b][0] + c * r[0] - s * r[1], cen[b][1] + u[b][1] + s * r[0] + c * r[1]) for r in cnv[b]])
+    p1, p1n, p1p = X[0][0], X[0][1], X[0][3]            # node 0 of block 0, its next (1) and previous (3) node
+    p2, p2n, p2p = X[1][2], X[1][3], X[1][1]            # node 2 of block 1, next (3), previous (1)
+    ds = [_ref_edges_distance((p1, p1n), (p2, p2p)), _ref_edges_distance((p1, p1p), (p2, p2n))]
+    D = dcut - dmin
+    E = 0.0
+    for d in ds:
+        if dmin <= d < dcut:
+            x = (d - dcut) / D
+            E += k / 4 * D * D * (1 / (x + 1) - 1 / (x - 1) - 2)
+    return E, ds
+
+
+def _hinge_u(kappa, shift):
+    return [[0.3, -0.2, 0.1], [-0.4 + shift, 0.25, 0.1 + kappa]]
+
+
+@pytest.mark.parametrize("kappa,shift", [(-0.3, 0.1), (0.0, 0.5), (0.25, 0.9), (0.4, 1.3)])
+def test_distance_contact_energy_closed_form_vs_oracle(kappa, shift):
+    cnv, cen, bonds = hinge()
+    dmin, dcut, k = 0.2, 2.2, 0.9
+    u = _hinge_u(kappa, shift)
+    E, ds = closed_form_distance_contact(u, cnv, cen, dmin, dcut, k)
+    assert E > 0 and all(d > dmin for d in ds)
+    cp = OE.ControlParams(OE.GeometricalParams(torch.as_tensor(cen), torch.as_tensor(cnv)),
+                          OE.MechanicalParams(None, None, None, None, OE.ContactParams(*(torch.tensor(v, dtype=torch.float64) for v in (dmin, dcut, k)))))
+    ut = torch.tensor(u, dtype=torch.float64, requires_grad=True)
+    e = OE.build_contact_energy(bonds, angle_based=False)(ut, cp)
+    assert abs(e.item() - E) < 1e-12 * E
+    (g,) = torch.autograd.grad(e, ut)
+    for b in range(2):                       # gradient vs central differences of the literal formula
+        for d in range(3):
+            h = 1e-6
+            up, um = [list(r) for r in u], [list(r) for r in u]
+            up[b][d] += h
+            um[b][d] -= h
+            fd = (closed_form_distance_contact(up, cnv, cen, dmin, dcut, k)[0] - closed_form_distance_contact(um, cnv, cen, dmin, dcut, k)[0]) / (2 * h)
+            assert abs(g[b, d].item() - fd) < 2e-7 * max(1.0, abs(fd)), (b, d)
+
+
+def check_engine_distance_contact(lib):
+    cnv, cen, bonds = hinge()
+    dmin, dcut, k = 0.2, 2.2, 0.9
+
+    class G:
+        n_blocks, n_npb = 2, 4
+    energy = en_mod.combine_block_energies(en_mod.build_strain_energy(bonds, en_mod.ligament_energy),
+                                           en_mod.build_contact_energy(bonds, angle_based=False))
+    s = setup_dynamic_solver(G(), energy, _lib=lib)
+    cp = dm.ControlParams(dm.GeometricalParams(cen, cnv),
+                          dm.MechanicalParams(dm.LigamentParams(0.0, 0.0, 0.0, np.array([[1.0, 0.0]])), None, np.ones((2, 3)), 0.0,
+                                              dm.ContactParams(dmin, dcut, k)))
+    flat = s._flatten(cp)
+    s.engine.set_params(**{key: v[None] for key, v in flat.items()})
+    for kappa, shift in ((-0.3, 0.1), (0.0, 0.5), (0.25, 0.9), (0.4, 1.3)):
+        u = _hinge_u(kappa, shift)
+        E, _ = closed_form_distance_contact(u, cnv, cen, dmin, dcut, k)
+        y = np.zeros((1, 2, 2, 3))
+        y[0, 0] = u
+        assert abs(s.engine.energy(y[:, 0])[0] - E) < 1e-12 * E
+        dy = s.engine.rhs(y, 0.0)[0]                    # unit inertia, no ligament stiffness: acceleration = -dE/du
+        for b in range(2):
+            for d in range(3):
+                h = 1e-6
+                up, um = [list(r) for r in u], [list(r) for r in u]
+                up[b][d] += h
+                um[b][d] -= h
+                fd = (closed_form_distance_contact(up, cnv, cen, dmin, dcut, k)[0] - closed_form_distance_contact(um, cnv, cen, dmin, dcut, k)[0]) / (2 * h)
+                assert abs(dy[1, b, d] + fd) < 2e-7 * max(1.0, abs(fd)), (b, d)
+
+
+def test_distance_contact_closed_form_vs_cpu_port(cpu_lib):
+    check_engine_distance_contact(cpu_lib)
+
+
+@pytest.mark.gpu
+def test_distance_contact_closed_form_vs_hip(hip_lib):
+    check_engine_distance_contact(None)
