@@ -104,7 +104,7 @@ def execute(fw, obj, adjoint=True, spi=SPI):
             obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
         out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
-        out["checkpoint"] = "records" if st_a.get("checkpoint_records", 0) else ("stages" if st_a.get("stage_checkpoint", 0) else "state")
+        out["checkpoint"] = {1: "records", 2: "segments"}.get(st_a.get("checkpoint_records", 0)) or ("stages" if st_a.get("stage_checkpoint", 0) else "state")
         out["grads"] = grads
     return out
 
@@ -291,23 +291,25 @@ def main():
     prob = dict(input_delay=args.input_delay, target_shift=args.target_shift)
     reserve_steps = max(K, W, ROOFLINE_LEG_STEPS)
     if adjoint:
-        # the reverse sweep reads a checkpoint of every step: 72 B per unit per step per member
+        # What the forward pass keeps for the reverse sweep (the engine takes the richest level that fits; decide here, by the same
+        # rule, so that every leg below runs the same kernels): records 432 B per unit and step (reverse launches read their stage
+        # record directly), stages 72 + 120 B (records rebuilt elementwise), state 72 B (records recomputed), segments: nothing but
+        # the outputs -- the reverse sweep re-runs one output interval at a time; memory independent of the horizon, so the full
+        # 50 000 steps keep all 16 members.
         free_b, total_b = B.mem_info(local_rank)
-        per_member = 72.0 * args.size * args.size * (max(K, W) + 1) + 64e6
-        args.members = max(1, min(args.members, int(0.85 * free_b / per_member)))
-        args.members = int(comm.all_reduce([float(args.members)], "min")[0])     # same work on every rank (weak scaling)
-        if args.members < args.streams:
-            args.streams = args.members
-            os.environ["DFX_STREAMS"] = str(args.streams)
-        # What the forward pass keeps for the reverse sweep (the engine takes the richest level that fits; decide here, by the
-        # same rule, so that every leg below runs the same kernels): records 432 B per unit and step (reverse launches read
-        # their stage record directly), stages 72 + 120 B (records rebuilt elementwise), state 72 B (records recomputed).
         if "DFX_CHECKPOINT" not in os.environ and "DFX_STAGE_CHECKPOINT" not in os.environ:
             n_ck = max(K, W, ROOFLINE_LEG_STEPS)
             units = args.size * args.size * args.members
             room = free_b - 0.05 * total_b - 2e9
-            os.environ["DFX_CHECKPOINT"] = ("records" if 432.0 * (n_ck + 1) * units < room else
-                                            "stages" if (72.0 * (n_ck + 1) + 120.0 * n_ck) * units < room else "state")
+            level = ("records" if 432.0 * (n_ck + 1) * units < room else
+                     "stages" if (72.0 * (n_ck + 1) + 120.0 * n_ck) * units < room else
+                     "state" if 72.0 * (n_ck + 1) * units < room else "segments")
+            level = ["records", "stages", "state", "segments"][int(comm.all_reduce(
+                [float(["records", "stages", "state", "segments"].index(level))], "max")[0])]      # same kernels on every rank
+            os.environ["DFX_CHECKPOINT"] = level
+        if args.members < args.streams:
+            args.streams = args.members
+            os.environ["DFX_STREAMS"] = str(args.streams)
 
     def sync():
         B.device_synchronize(local_rank)
@@ -320,6 +322,9 @@ def main():
     rr = None
     if rank == 0 and not args.no_roofline_leg:
         os.environ["DFX_STREAMS"] = "1"
+        timed_level = os.environ.get("DFX_CHECKPOINT")
+        if timed_level == "segments":          # the segments level runs the records kernels inside every output interval
+            os.environ["DFX_CHECKPOINT"] = "records"
         fwr, objr, desr = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank, **prob)
         os.environ["DFX_STREAMS"] = str(args.streams)
         Kr = ROOFLINE_LEG_STEPS
@@ -330,6 +335,8 @@ def main():
         rr.pop("grads", None)
         fwr.solve_dynamics.engine.close()
         del fwr, objr
+        if timed_level is not None:
+            os.environ["DFX_CHECKPOINT"] = timed_level
     single = None
     if rank == 0 and world == 1 and args.members > 1 and adjoint and not args.no_single:
         # the same config with ONE design per GPU (launch-bound: one wave per SIMD), for reference
@@ -391,6 +398,9 @@ def main():
             a_us = None
             if r["adj_launches"] and r.get("checkpoint") in ("records", "stages"):
                 a_us = 1e3 * r["adj_ms"] / (r["adj_launches"] / n_streams)     # reverse stages only (no recompute launches)
+            elif r["adj_launches"] and r.get("checkpoint") == "segments":
+                n_adj = r["adj_launches"] / 2.0 / n_streams           # per reverse step: 6 re-run forward stages + 6 reverse stages
+                a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * f_us) / n_adj)
             elif r["adj_launches"]:
                 n_adj = r["adj_launches"] * 6.0 / 11.0 / n_streams   # per reverse step: 5 recomputed forward stages + 6 reverse stages
                 a_us = max(1e-9, (1e3 * r["adj_ms"] - n_adj * (5.0 / 6.0) * f_us) / n_adj)

@@ -126,6 +126,8 @@ struct dfx_handle {
   DevBuf<double> d_acc_times, d_tsteps;
   DevBuf<double> d_AD;             // stage checkpoint (stage accelerations of every step)
   bool dense = false;              // the last fixed-grid forward kept the stage checkpoint (stage accelerations of every step)
+  bool segments = false;           // ... or nothing but the outputs: the reverse sweep re-runs one output interval at a time (records level inside it)
+  std::vector<int> seg_first, seg_last;   // first / last segment of every output interval
   bool records = false;            // ... or the records checkpoint (every stage record of every step): no rebuild, no recompute
   std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps)
   std::vector<long long> accepted_per_member;
@@ -169,8 +171,8 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.t_steps = (!h->adaptive && !h->t_steps.empty()) ? h->d_tsteps.p : nullptr;
   c.rtol = h->rtol; c.atol = h->atol;
   c.traj = h->have_traj ? h->d_traj.p : nullptr;
-  c.rps = (h->have_traj && h->records) ? pl.tab.s : 1;
-  c.AD = (h->have_traj && h->dense && !h->records) ? h->d_AD.p : nullptr;
+  c.rps = (h->have_traj && (h->records || h->segments)) ? pl.tab.s : 1;
+  c.AD = (h->have_traj && h->dense && !h->records && !h->segments) ? h->d_AD.p : nullptr;
   c.ad_stride = pl.batch ? (long long)(h->d_AD.n / pl.batch) : 0;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
@@ -322,7 +324,7 @@ static bool solve_is_eager(const dfx_handle* h) {
   return waves >= 2048 || h->n_total <= 128;
 }
 
-static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int kind) {
+static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int kind, int seg_index = -1) {
   const int s = h->pl.tab.s, ng = (int)h->groups.size();
   if (kind == 1 && !cbase.AD && cbase.rps == 1) {      // recompute chains (events per group): group by group
     for (int gi = 0; gi < ng; ++gi) enqueue_segment(h, cbase, gi, n_steps, kind);
@@ -331,7 +333,8 @@ static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps,
   std::vector<DevCtx> cg(ng, cbase);
   for (int gi = 0; gi < ng; ++gi) {
     cg[gi] = group_ctx(h, cbase, gi);
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->groups[gi].stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
+    if (seg_index >= 0) hipLaunchKernelGGL(k_set_seg, dim3(1), dim3(1), 0, h->groups[gi].stream, (const Seg*)h->d_segs.p, seg_index, h->d_cur.p + gi);
+    else hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->groups[gi].stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
     h->launches++;
   }
   if (kind == 0) {
@@ -409,19 +412,25 @@ static int join_groups(dfx_handle* h) {
 //            pass writes its records there instead of into the ping-pong buffers, i.e. no extra forward traffic;
 //   stages   the step states + the first s-1 stage accelerations of every step (72 + 24 (s-1) B): s launches per step, each
 //            reverse launch rebuilds the record its successor reads (elementwise);
-//   state    the step states only (72 B): 2s - 1 launches per step (s - 1 forward launches recompute the records).
+//   state    the step states only (72 B): 2s - 1 launches per step (s - 1 forward launches recompute the records);
+//   segments nothing but the outputs the solve keeps anyway: the reverse sweep visits the output intervals backwards, re-runs the
+//            forward pass of ONE interval from its (resident) output row with the records checkpoint for that interval only, then
+//            reverses it: 3s launches per step in all, memory independent of the horizon -- taken when not even the step states fit
+//            (the full 50 000-step C3 then runs 16 members per GPU instead of 4).
 // DFX_CHECKPOINT=records|stages|state overrides (DFX_STAGE_CHECKPOINT=1/0 = stages / state, kept for older scripts).
-enum { kCkState = 0, kCkStages = 1, kCkRecords = 2 };
+enum { kCkState = 0, kCkStages = 1, kCkRecords = 2, kCkSegments = 3 };
 
-static int choose_checkpoint(dfx_handle* h, long long n_steps) {
+static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_steps) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, rec = (size_t)pl.n_blocks * kStep, N = (size_t)std::max<long long>(n_steps, 1);
   const size_t want_rec = B * (N * pl.tab.s + 1) * rec;
   const size_t want_state = B * (N + 1) * rec;
   const size_t want_ad = B * N * (pl.tab.s - 1) * pl.n_blocks * 3;
   int forced = -1;
-  if (const char* e = getenv("DFX_CHECKPOINT")) forced = e[0] == 'r' ? kCkRecords : (e[0] == 's' && e[2] == 'a' && e[3] == 'g' ? kCkStages : kCkState);
+  if (const char* e = getenv("DFX_CHECKPOINT"))
+    forced = e[0] == 'r' ? kCkRecords : (e[0] == 's' && e[1] == 'e' ? kCkSegments : (e[0] == 's' && e[2] == 'a' && e[3] == 'g' ? kCkStages : kCkState));
   else if (const char* e2 = getenv("DFX_STAGE_CHECKPOINT")) forced = e2[0] != '0' ? kCkStages : kCkState;
+  const size_t want_seg = B * ((size_t)std::max<long long>(max_interval_steps, 1) * pl.tab.s + 1) * rec;
   size_t free_b = 0, total_b = 0;
   const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
   auto fits = [&](size_t grow_elems) { return have_info && grow_elems * sizeof(double) + total_b / 20 <= free_b; };   // leave 5 % of the device
@@ -431,7 +440,12 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps) {
   if (mode < 0) {
     if (fits(grow(want_rec, have_t))) mode = kCkRecords;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
-    else mode = kCkState;
+    else if (fits(grow(want_state, have_t))) mode = kCkState;
+    else mode = kCkSegments;
+  }
+  if (mode == kCkSegments) {
+    if (h->d_traj.ensure(want_seg) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return mode;
   }
   // allocate; a failed allocation falls back one level (forced modes included: the solve still runs)
   if (mode == kCkRecords && h->d_traj.ensure(want_rec) != hipSuccess) { (void)hipGetLastError(); mode = kCkStages; }
@@ -801,7 +815,7 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
   HIP_OK(h->d_target.ensure(nb));
   HIP_OK(h->d_obj.ensure(B));
   HIP_OK(h->d_segs.ensure((size_t)max_timepoints * (2 + (size_t)(max_steps / std::max(1, max_timepoints - 1)) / kMaxGraphSteps)));
-  if (keep_trajectory && choose_checkpoint(h, max_steps) < 0) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
+  if (keep_trajectory && choose_checkpoint(h, max_steps, std::max<long long>(1, max_steps / std::max(1, max_timepoints - 1))) < 0) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
   (void)rec;
   return 0;
 }
@@ -845,7 +859,9 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
   h->have_traj = false;
   if (keep_trajectory) {
-    const int mode = choose_checkpoint(h, h->n_total);
+    long long max_spi = 1;
+    for (int v : h->spis) max_spi = std::max<long long>(max_spi, v);
+    const int mode = choose_checkpoint(h, h->n_total, max_spi);
     if (mode < 0) {
       h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string((B * (h->n_total + 1) * rec * 8) >> 20) + " MiB)";
       return 2;
@@ -853,8 +869,12 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     h->have_traj = true;
     h->records = mode == kCkRecords;
     h->dense = mode == kCkStages;
+    h->segments = mode == kCkSegments;
   }
   build_segments(h);
+  h->seg_first.assign(std::max(0, Tn - 1), 0); h->seg_last.assign(std::max(0, Tn - 1), -1);
+  for (int si = (int)h->segs.size() - 1; si >= 0; --si) h->seg_first[h->segs[si].interval] = si;
+  for (int si = 0; si < (int)h->segs.size(); ++si) h->seg_last[h->segs[si].interval] = si;
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
@@ -869,15 +889,16 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     HIP_OK(hipMemsetAsync(h->d_state0.p, 0, sizeof(double) * B * nb * 6, h->stream));
   }
   DevCtx c = make_ctx(h);
+  if (h->segments) { c.traj = nullptr; c.rps = 1; }        // segments level: the forward pass keeps nothing but its outputs
   h->launches = 0;
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
-  const bool eager = solve_is_eager(h);
+  const bool eager = solve_is_eager(h) || h->segments;
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
     if (eager) enqueue_interleaved(h, c, sg.n_steps, 0);
@@ -915,7 +936,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
-    stats->checkpoint_records = c.rps > 1 ? 1 : 0;
+    stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
   }
   return 0;
 }
@@ -966,7 +987,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   DevCtx c = make_ctx(h);
   h->launches = 0;
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
   std::vector<double> A((size_t)B * 7 * nd), V0(B * 7 * nd);
@@ -1119,6 +1140,25 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   }
   if (fork_groups(h)) return 2;
   const bool eager = solve_is_eager(h);
+  if (h->segments) {
+    // output intervals backwards: records of interval k rebuilt by re-running its forward pass from the resident output row k
+    // (bit-identical to the first pass: same state, same arithmetic), then its reverse stages read them
+    const size_t nb6 = (size_t)pl.n_blocks * 6;
+    for (int k = Tn - 2; k >= 0; --k) {
+      c.traj_step0 = h->step0[k];
+      for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
+        const Group& gr = h->groups[gi];
+        const DevCtx cg = group_ctx(h, c, gi);
+        hipLaunchKernelGGL(k_init, slot_grid(h, gr), dim3(kThreads), 0, gr.stream, cg, (const double*)(h->d_fields.p + (size_t)k * nb6), h->ts[k], 0,
+                           (long long)((size_t)Tn * nb6));
+        hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)(((size_t)pl.n_blocks * kStep + kThreads - 1) / kThreads), (unsigned)gr.nm), dim3(kThreads), 0,
+                           gr.stream, cg);
+        h->launches += 2;
+      }
+      for (int si = h->seg_first[k]; si <= h->seg_last[k]; ++si) enqueue_interleaved(h, c, h->segs[si].n_steps, 0, si);
+      for (int si = h->seg_last[k]; si >= h->seg_first[k]; --si) enqueue_interleaved(h, c, h->segs[si].n_steps, 1, si);
+    }
+  } else
   for (int si = nseg - 1; si >= 0; --si) {
     if (eager) { enqueue_interleaved(h, c, h->segs[si].n_steps, 1); continue; }
     for (int gi = 0; gi < (int)h->groups.size(); ++gi)
@@ -1142,7 +1182,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     stats->streams = (int64_t)h->groups.size();
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
-    stats->checkpoint_records = c.rps > 1 ? 1 : 0;
+    stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
   }
   return 0;
 }
@@ -1299,7 +1339,7 @@ static int hook_prepare(dfx_handle* h, const double* y, double t) {
   HIP_OK(hipMemcpyAsync(h->d_cur.p, &sg, sizeof(Seg), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, y, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, t, 0);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, t, 0, 0LL);
   return 0;
 }
 

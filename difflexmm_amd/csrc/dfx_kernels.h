@@ -83,6 +83,7 @@ struct DevCtx {
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
+  long long traj_step0;   // global index of the step whose records sit at the start of traj (segments checkpoint: one output interval at a time)
   int rps, pad_rps;       // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   const int32_t* slot_info;
   const int32_t* block_special;
@@ -163,7 +164,7 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 // buf >= 0: stage buffer `buf`;  buf < 0: record (-1 - buf) of step n in the trajectory checkpoint (record 0 = the step state;
 // records 1 .. s-1 exist in the records checkpoint only; record s of step n IS record 0 of step n + 1)
 __device__ __forceinline__ double* traj_rec(const DevCtx& c, int m, int buf, long long n) {
-  return c.traj + (size_t)m * c.traj_stride + ((size_t)n * c.rps + (size_t)(-1 - buf)) * ((size_t)c.n_blocks * kStep);
+  return c.traj + (size_t)m * c.traj_stride + ((size_t)(n - c.traj_step0) * c.rps + (size_t)(-1 - buf)) * ((size_t)c.n_blocks * kStep);
 }
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
   if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
@@ -179,6 +180,8 @@ __global__ void k_tick(const Seg* segs, int* seg_idx, int delta, Seg* cur) {
   *seg_idx = i;
   *cur = segs[i];
 }
+// the same without a cursor: segment i, chosen by the host (segments checkpoint: intervals are revisited out of order)
+__global__ void k_set_seg(const Seg* segs, int i, Seg* cur) { *cur = segs[i]; }
 
 struct TimeVals { double g, gt; };
 
@@ -197,14 +200,15 @@ __device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, co
 }
 
 // records of a full (2, n_blocks, 3) state at time t0 -> stage buffer `buf`  (constrained DOFs follow c(t0), c'(t0))
-__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf) {
+//   stride: elements between members in state0 (0: packed (batch, 2, n, 3); a row of the resident (batch, T, 2, n, 3) history otherwise)
+__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf, long long stride) {
   const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;
   if (d == 3) return;
-  const size_t nd = (size_t)c.n_blocks * 3;
-  double q = state0[(size_t)m * 2 * nd + b * 3 + d], v = state0[(size_t)m * 2 * nd + nd + b * 3 + d];
+  const size_t nd = (size_t)c.n_blocks * 3, ms = stride ? (size_t)stride : 2 * nd;
+  double q = state0[(size_t)m * ms + b * 3 + d], v = state0[(size_t)m * ms + nd + b * 3 + d];
   const int sidx = c.block_special[b];
   if (sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1)) {
     TimeVals tv = constrained_value(c, m, c.special[sidx], d, t0);

@@ -245,22 +245,47 @@ def test_reverse_sweep_reading_the_records_checkpoint(hip_lib, monkeypatch, latt
     assert abs(c.solver.adjoint_stats["launches"] / 600.0 - s_launch) < 0.2
 
 
-def test_three_checkpoint_levels_give_the_same_gradient(hip_lib, monkeypatch):
-    """records / stages / state on one problem: same forward fields bit for bit (the same arithmetic, only the place the records
-    are kept differs), gradients equal to rounding."""
+def test_four_checkpoint_levels_give_the_same_gradient(hip_lib, monkeypatch):
+    """records / stages / state / segments on one problem: same forward fields bit for bit (the same arithmetic, only what is kept
+    for the reverse sweep differs), gradients equal to rounding."""
     outs = {}
-    for level in ("records", "stages", "state"):
+    for level in ("records", "stages", "state", "segments"):
         monkeypatch.setenv("DFX_CHECKPOINT", level)
         c = Case("quads", 7, True, True, seed=12, lib=None, cutoff_deg=42.0, batch=2)
         cps = [c.cp._replace(constraint_params=dict(amplitude=a, loading_rate=3000.0, input_delay=1e-5)) for a in (7.5, -3.0)]
         ts = np.linspace(0, 3e-4, 4)
         f = c.solver(c.random_state(0.05, 0.02, 5.0), ts, cps, keep_trajectory=True, steps_per_interval=9)
-        assert (c.solver.stats["checkpoint_records"], c.solver.stats["stage_checkpoint"]) == {"records": (1, 0), "stages": (0, 1), "state": (0, 0)}[level]
+        assert (c.solver.stats["checkpoint_records"], c.solver.stats["stage_checkpoint"]) == \
+            {"records": (1, 0), "stages": (0, 1), "state": (0, 0), "segments": (2, 0)}[level]
         trees, s0 = c.solver.vjp(np.random.default_rng(3).normal(size=f.shape))
         outs[level] = (f, np.stack([t.geometrical_params.centroid_node_vectors for t in trees]), s0)
-    for level in ("stages", "state"):
+    for level in ("stages", "state", "segments"):
         assert np.array_equal(outs[level][0], outs["records"][0])
         assert relerr(outs[level][1], outs["records"][1]) < 1e-12 and relerr(outs[level][2], outs["records"][2]) < 1e-12
+
+
+@pytest.mark.parametrize("lattice,n,integrator", [("quads", 5, "dopri5"), ("kagome", 3, "rk4")])
+def test_reverse_sweep_recomputing_one_output_interval_at_a_time(hip_lib, cpu_lib, monkeypatch, lattice, n, integrator):
+    """Fourth level ("segments"): the forward pass keeps only its outputs; the reverse sweep re-runs the forward pass of one output
+    interval at a time (from the resident output row, with the records checkpoint for that interval) and reverses it.  Memory is
+    independent of the horizon.  Against the oracle on a grid with its own step boundaries, and against the CPU port over intervals
+    that span several launch segments, 3 members in 2 groups."""
+    monkeypatch.setenv("DFX_CHECKPOINT", "segments")
+    monkeypatch.setenv("DFX_STREAMS", "2")
+    parity.check_trajectory_and_adjoint(None, lattice, n, integrator, spi=np.array([3, 7, 2, 5]), own_step_times=True)
+    res = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case(lattice, n, True, True, seed=2, lib=lib, cutoff_deg=125.0 if lattice == "kagome" else 42.0, integrator=integrator, batch=3)
+        ts = np.linspace(0, 3e-4, 4)
+        y0 = c.random_state(0.05, 0.02, 5.0)
+        f = c.solver(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=np.array([300, 40, 270]))
+        if lib is None:
+            assert c.solver.stats["checkpoint_records"] == 2
+        fb = np.random.default_rng(4).normal(size=f.shape)
+        trees, s0 = c.solver.vjp(fb)
+        res[name] = (f, np.stack([t.geometrical_params.centroid_node_vectors for t in trees]), s0)
+    assert relerr(res["hip"][0], res["cpu"][0]) < 1e-10
+    assert relerr(res["hip"][1], res["cpu"][1]) < 1e-8 and relerr(res["hip"][2], res["cpu"][2]) < 1e-8
 
 
 @pytest.mark.parametrize("stage_checkpoint", ["0", "1"])
