@@ -893,7 +893,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   h->launches = 0;
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
   if (c.traj)
-    hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c);
+    hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
@@ -1145,14 +1145,16 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     // (bit-identical to the first pass: same state, same arithmetic), then its reverse stages read them
     const size_t nb6 = (size_t)pl.n_blocks * 6;
     for (int k = Tn - 2; k >= 0; --k) {
-      c.traj_step0 = h->step0[k];
+      // the buffer holds the records of THIS interval only: shift the base so that the kernels keep indexing by the global step
+      // (a per-interval offset inside the kernels cost the forward kernel two hot-path spills: profiles/r02_fwd_spill_regression.txt)
+      c.traj = h->d_traj.p - (size_t)h->step0[k] * (size_t)c.rps * ((size_t)pl.n_blocks * kStep);
       for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
         const Group& gr = h->groups[gi];
         const DevCtx cg = group_ctx(h, c, gi);
         hipLaunchKernelGGL(k_init, slot_grid(h, gr), dim3(kThreads), 0, gr.stream, cg, (const double*)(h->d_fields.p + (size_t)k * nb6), h->ts[k], 0,
                            (long long)((size_t)Tn * nb6));
         hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)(((size_t)pl.n_blocks * kStep + kThreads - 1) / kThreads), (unsigned)gr.nm), dim3(kThreads), 0,
-                           gr.stream, cg);
+                           gr.stream, cg, (long long)h->step0[k]);
         h->launches += 2;
       }
       for (int si = h->seg_first[k]; si <= h->seg_last[k]; ++si) enqueue_interleaved(h, c, h->segs[si].n_steps, 0, si);

@@ -83,7 +83,6 @@ struct DevCtx {
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
-  long long traj_step0;   // global index of the step whose records sit at the start of traj (segments checkpoint: one output interval at a time)
   int rps, pad_rps;       // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   const int32_t* slot_info;
   const int32_t* block_special;
@@ -164,7 +163,7 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 // buf >= 0: stage buffer `buf`;  buf < 0: record (-1 - buf) of step n in the trajectory checkpoint (record 0 = the step state;
 // records 1 .. s-1 exist in the records checkpoint only; record s of step n IS record 0 of step n + 1)
 __device__ __forceinline__ double* traj_rec(const DevCtx& c, int m, int buf, long long n) {
-  return c.traj + (size_t)m * c.traj_stride + ((size_t)(n - c.traj_step0) * c.rps + (size_t)(-1 - buf)) * ((size_t)c.n_blocks * kStep);
+  return c.traj + (size_t)m * c.traj_stride + ((size_t)n * c.rps + (size_t)(-1 - buf)) * ((size_t)c.n_blocks * kStep);
 }
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
   if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
@@ -238,12 +237,12 @@ __global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields,
   if (!isfinite(q) || !isfinite(v)) *bad = k + 1;   // any writer wins: only "some output row is not finite" matters
 }
 
-// copy stage buffer 0 into checkpoint slot n (only for the initial state)
-__global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c) {
+// copy stage buffer 0 into record 0 of step n of the checkpoint (the initial state; the start of an interval in the segments level)
+__global__ __launch_bounds__(kThreads) void k_checkpoint0(DevCtx c, long long n) {
   const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * kStep) return;
-  double* t = c.traj + (size_t)m * c.traj_stride;
+  double* t = traj_rec(c, m, -1, n);
   if (tid < c.n_blocks * kPos) t[tid] = c.POS[(size_t)m * c.nbuf * c.n_blocks * kPos + tid];
   else t[tid] = c.VEL[(size_t)m * c.nbuf * c.n_blocks * 3 + (tid - c.n_blocks * kPos)];
 }

@@ -1,0 +1,44 @@
+"""Build-time guard on the two stage kernels (no GPU needed: hipcc cross-compiles gfx950).  Round 2 lost 11 % of the forward kernel
+to an innocent-looking edit that made the register allocator move two spills out of the rare time-function path into the hot path
+(same VGPR count, same scratch size -- only the ISA shows it; profiles/r02_fwd_spill_regression.txt).  This test reads the ISA."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _function(txt, name):
+    i = txt.index("\n" + name + ":")
+    body = txt[i:txt.index(".Lfunc_end", i)].split("\n")
+    return [l.strip() for l in body if l.strip() and not l.strip().startswith((";", ".", "_")) and not l.strip().endswith(":")]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
+    out = tmp_path / "dfx.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(ROOT, "difflexmm_amd", "csrc", "dfx_engine.hip")], stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+    adj = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
+    # forward: 5 waves per SIMD are bought with ~100 B/lane of scratch, all of it inside the time-function path that only the lanes of
+    # driven blocks execute -- the ligament + contact evaluation (the first ~1000 instructions) must stay free of scratch traffic
+    first_spill = next((n for n, x in enumerate(fwd) if x.startswith("scratch_")), len(fwd))
+    assert first_spill > 1000, f"k_fwd_stage<nonlinear,contact>: scratch access at instruction {first_spill} of {len(fwd)} (hot path)"
+    # reverse (records level): no scratch at all
+    assert not any(x.startswith("scratch_") for x in adj), "k_adj_stage<nonlinear,contact,0,0> spills"
+    # the single batch of loads: the first wait on vector memory comes after at least 20 global loads have been issued (forward)
+    n_loads = 0
+    for x in fwd:
+        if x.startswith("global_load"):
+            n_loads += 1
+        if x.startswith("s_waitcnt") and "vmcnt" in x:
+            break
+    assert n_loads >= 20, f"k_fwd_stage: first vmcnt wait after only {n_loads} loads"
+    meta = re.search(r"\.name:\s+_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii.*?\.vgpr_count:\s+(\d+)", txt, re.S)
+    assert meta and int(meta.group(1)) <= 102, "k_fwd_stage<nonlinear,contact> no longer fits 5 waves per SIMD"
