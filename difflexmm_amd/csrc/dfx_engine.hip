@@ -438,7 +438,10 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
   auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
   int mode = forced;
   if (mode < 0) {
-    if (fits(grow(want_rec, have_t))) mode = kCkRecords;
+    // records pay on large lattices; with many small members (24x16 x 256) every launch touches one far-apart record per member
+    // (member-major checkpoint, 664 MB apart) and measured 3.6 s per evaluation against 2.65 s at the stages level
+    // (profiles/r02_config5_checkpoint_levels.txt): small lattices keep their records in the cache-resident ping-pong buffers
+    if (pl.n_blocks >= 4096 && fits(grow(want_rec, have_t))) mode = kCkRecords;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
     else if (fits(grow(want_state, have_t))) mode = kCkState;
     else mode = kCkSegments;
