@@ -47,7 +47,7 @@ BYTES_ADJ_STAGE = 272 + 96 + 256    # stage data + lambda / Ybar read-write + pa
 ROOFLINE_LEG_STEPS = 250            # length of the per-launch measurement (1 stream, all members per launch), whatever K is
 
 
-def c3_problem(size, seed, members, lib=None, device=0, input_delay=0.0, target_shift=None):
+def c3_problem(size, seed, members, lib=None, device=0, input_delay=0.0, target_shift=None, contact_cutoff_deg=-10.0, contact_min_deg=-15.0):
     from difflexmm_amd.problems import QuadsFocusingForward, TargetKineticEnergy
     spacing, bond = 15.0, 2.25
     rho, ksh, kr = 6.18e-9, 1.19, 1.5
@@ -58,7 +58,8 @@ def c3_problem(size, seed, members, lib=None, device=0, input_delay=0.0, target_
         n1_blocks=size, n2_blocks=size, spacing=spacing, bond_length=bond, k_stretch=120.0, k_shear=ksh, k_rot=kr,
         density=rho, damping=damping, amplitude=7.5, loading_rate=FREQ, input_delay=input_delay, n_excited_blocks=2,
         loaded_side="left", input_shift=0, simulation_time=2.0 / FREQ, n_timepoints=201, use_contact=True,
-        k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180, steps_per_interval=SPI,
+        k_contact=1.5, min_angle=contact_min_deg * math.pi / 180, cutoff_angle=contact_cutoff_deg * math.pi / 180,
+        steps_per_interval=SPI,
         batch=members, device=device, _lib=lib)
     fw.setup()
     if target_shift is None:
@@ -263,6 +264,10 @@ def main():
     ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx) | socket (rehearsal on one GPU)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     ap.add_argument("--input-delay", type=float, default=0.0, help="pulse delay in s (C3 text: 0.1/f = 3.33e-3)")
+    ap.add_argument("--contact-cutoff-deg", type=float, default=-10.0,
+                    help="void angle below which the contact penalty engages (C3: -10, never reached; 60 with --contact-min-deg 30 "
+                         "engages every narrow void of the 25-degree design: contact branches and their gradient traffic everywhere)")
+    ap.add_argument("--contact-min-deg", type=float, default=-15.0, help="void angle at which the penalty diverges (C3: -15)")
     ap.add_argument("--target-shift", type=int, nargs=2, default=None, help="target placement (C3 text: 21 25); default: next to the drive")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -288,7 +293,8 @@ def main():
     W = max(0, args.warmup)
     adjoint = not args.forward_only
     requested_members = args.members
-    prob = dict(input_delay=args.input_delay, target_shift=args.target_shift)
+    prob = dict(input_delay=args.input_delay, target_shift=args.target_shift, contact_cutoff_deg=args.contact_cutoff_deg,
+                contact_min_deg=args.contact_min_deg)
     reserve_steps = max(K, W, ROOFLINE_LEG_STEPS)
     if adjoint:
         # What the forward pass keeps for the reverse sweep (the engine takes the richest level that fits; decide here, by the same
@@ -433,7 +439,7 @@ def main():
                                    f"{'forward + adjoint wrt 66048 geometry params' if adjoint else 'forward only'}",
                        "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams,
                        "checkpoint": res.get("checkpoint"), "integrator": "dopri5-fixed",
-                       "steps_per_output": SPI, "input_delay_s": args.input_delay,
+                       "steps_per_output": SPI, "input_delay_s": args.input_delay, "contact_deg": [args.contact_min_deg, args.contact_cutoff_deg],
                        "target_blocks": [int(b) for b in obj.target_blocks], "collective": collective},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},

@@ -786,7 +786,7 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   double* LAMm = c.LAM + (size_t)m * nd6;
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
   if (!local_only) {
-    lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24);
+    if (i == 0 || ac.col[c.s] != 0.0) { lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24); }   // b_i = 0: lambda not needed (Dopri5 stage 1)
     double yq[kMaxStages], yv[kMaxStages];
 #pragma unroll
     for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
@@ -869,7 +869,10 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   double* bmm = c.blk_m + (size_t)m * nd;
   double* bcm = c.blk_c + (size_t)m * nd;
   const double2 r_old = ldg<double2>(grm, (u32)slot * 16);
-  const double p_old = CONTACT == 1 ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
+  // the void-angle accumulator moves only where a contact is engaged in this stage (d_phi is an exact zero elsewhere, and contacts
+  // are rare: 64 B/unit of the launch's traffic otherwise)
+  const bool phi_on = CONTACT == 1 && d_phi != 0.0;
+  const double p_old = phi_on ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
   const double bm_old = ldg<double>(bmm, o_dof);
   const double bc_old = c.blk_c ? ldg<double>(bcm, o_dof) : 0.0;
   hx = quad_sum(hx);
@@ -880,8 +883,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   eth = quad_sum(eth);
   if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
     stg<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
-    if (CONTACT == 1) stg<double>(gpm, (u32)slot * 8, p_old - d_phi);
   }
+  if (phi_on) stg<double>(gpm, (u32)slot * 8, p_old - d_phi);
   // ---- DOF epilogue
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
   if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }

@@ -35,7 +35,10 @@ WORKING_SET_GROWTH = 256
 
 
 class MMAResult(dict):
-    __getattr__ = dict.get
+    def __getattr__(self, name):
+        if name.startswith("__"):            # pickle / copy probe for optional protocol methods
+            raise AttributeError(name)
+        return self.get(name)
 
 
 def _abs(J):
@@ -224,38 +227,185 @@ def mma_minimize(fun, x0, **kw):
     return _drive(mma_steps(x0, **kw), fun)
 
 
-def mma_minimize_ensemble(batch_fun, x0s, per_member_kw=None, **kw):
-    """Independent minimisations advancing in lock-step: ``batch_fun(list of x) -> list of (value, gradient)`` is called
-    once per round with the pending point of EVERY member (members that have finished resubmit their last point so the
-    batch keeps its size: the engine integrates a fixed number of members side by side).  Each member's sequence of
-    iterates is exactly what :func:`mma_minimize` would produce for it alone."""
-    n = len(x0s)
-    gens = [mma_steps(x0, **dict(kw, **(per_member_kw[i] if per_member_kw else {}))) for i, x0 in enumerate(x0s)]
-    pending = [next(g) for g in gens]
+def maximizing(gen):
+    """A minimising coroutine turned into a maximising one: values and gradients are negated on the way in, the result on the
+    way out (``opt.set_max_objective``)."""
+    x = next(gen)
+    try:
+        while True:
+            f, g = yield x
+            x = gen.send((-f, -np.asarray(g)))
+    except StopIteration as stop:
+        res = stop.value
+        res["fun"] = -res["fun"]
+        res["history"] = [-h for h in res["history"]]
+        return res
+
+
+def _worker_main(conn):
+    """One host process of :class:`MemberWorkers`: owns the coroutines of some members and advances them on request."""
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+    gens = {}
+
+    def advance(idx, value):
+        try:
+            return idx, False, (next(gens[idx]) if value is None else gens[idx].send(value))
+        except StopIteration as stop:
+            del gens[idx]
+            return idx, True, stop.value
+
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            return
+        if msg[0] == "close":
+            return
+        try:
+            if msg[0] == "new":
+                out = []
+                for idx, factory, args, kwargs in msg[1]:
+                    gens[idx] = factory(*args, **kwargs)
+                    out.append(advance(idx, None))
+            else:                                   # "send": [(idx, (value, gradient)), ...]
+                out = [advance(idx, value) for idx, value in msg[1]]
+            conn.send(("ok", out))
+        except Exception as e:                      # the parent re-raises: a failing member must not hang the ensemble
+            import traceback
+            conn.send(("error", f"{e!r}\n{traceback.format_exc()}"))
+
+
+class MemberWorkers:
+    """Host processes for the per-member work of a lock-step ensemble (constraint evaluations, MMA sub-problems: a few
+    milliseconds of NumPy / L-BFGS-B per member and round, 15 of the 28 s of a 256-member x 4-evaluation run of config 5 when
+    done in the engine's process: profiles/r02_c5_host_profile_v2.txt).  Members are dealt to the workers once; per round each
+    worker receives the (value, gradient) of its members and returns their next points.
+
+    Create the workers BEFORE the process touches the GPU (``fork`` start method: a forked child of a process with a live HIP
+    runtime must never call into it, and nothing here does, but forking first keeps the children free of its state)."""
+
+    def __init__(self, n_workers):
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")
+        self._conns, self._procs = [], []
+        for _ in range(max(1, int(n_workers))):
+            parent, child = ctx.Pipe()
+            proc = ctx.Process(target=_worker_main, args=(child,), daemon=True)
+            proc.start()
+            child.close()
+            self._conns.append(parent)
+            self._procs.append(proc)
+        self._owner = {}
+
+    def __len__(self):
+        return len(self._procs)
+
+    def _collect(self, used):
+        out = {}
+        for w in used:
+            status, payload = self._conns[w].recv()
+            if status != "ok":
+                raise RuntimeError(f"ensemble worker {w} failed: {payload}")
+            for idx, done, value in payload:
+                out[idx] = (done, value)
+        return out
+
+    def start(self, specs):
+        """specs[i] = (factory, args, kwargs), picklable; returns {i: (done, first point or result)}."""
+        per = {}
+        for idx, spec in enumerate(specs):
+            w = idx % len(self._conns)
+            self._owner[idx] = w
+            per.setdefault(w, []).append((idx,) + tuple(spec))
+        for w, items in per.items():
+            self._conns[w].send(("new", items))
+        return self._collect(per)
+
+    def send(self, values):
+        """values: {i: (value, gradient)} of the members still running; returns {i: (done, next point or result)}."""
+        per = {}
+        for idx, v in values.items():
+            per.setdefault(self._owner[idx], []).append((idx, v))
+        for w, items in per.items():
+            self._conns[w].send(("send", items))
+        return self._collect(per)
+
+    def close(self):
+        for c in self._conns:
+            try:
+                c.send(("close",))
+                c.close()
+            except (OSError, BrokenPipeError):
+                pass
+        for p in self._procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        self._conns, self._procs = [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def drive_ensemble(batch_fun, specs, workers=None):
+    """Independent optimisations advancing in lock-step.  ``specs[i] = (factory, args, kwargs)``: ``factory(*args, **kwargs)``
+    is member i's coroutine (``yield x`` asks for ``(value, gradient)`` at x, its return value is the member's result).
+    ``batch_fun(list of x) -> list of (value, gradient)`` is called once per round with the pending point of EVERY member
+    (members that have finished resubmit their last point so the batch keeps its size: the engine integrates a fixed number of
+    members side by side).  With ``workers`` (:class:`MemberWorkers`) the coroutines live in host processes; the sequence of
+    iterates of every member is the same either way, and the same as if it ran alone."""
+    n = len(specs)
     results = [None] * n
+    pending = [None] * n
+
+    def absorb(replies):
+        for i, (done, value) in replies.items():
+            if done:
+                results[i] = value
+            else:
+                pending[i] = value
+
+    if workers is None:
+        gens = [f(*a, **k) for f, a, k in specs]
+
+        def advance(i, value):
+            try:
+                return False, (next(gens[i]) if value is None else gens[i].send(value))
+            except StopIteration as stop:
+                return True, stop.value
+        absorb({i: advance(i, None) for i in range(n)})
+    else:
+        absorb(workers.start(specs))
     while any(r is None for r in results):
         values = batch_fun(pending)
-        for i, g in enumerate(gens):
-            if results[i] is not None:
-                continue
-            try:
-                pending[i] = g.send(values[i])
-            except StopIteration as stop:
-                results[i] = stop.value
+        live = {i: values[i] for i in range(n) if results[i] is None}
+        absorb({i: advance(i, v) for i, v in live.items()} if workers is None else workers.send(live))
     return results
 
 
+def _mma_member(x0, maximize, kw):
+    gen = mma_steps(x0, **kw)
+    return maximizing(gen) if maximize else gen
+
+
+def mma_minimize_ensemble(batch_fun, x0s, per_member_kw=None, workers=None, _maximize=False, **kw):
+    """:func:`mma_minimize` for many members in lock-step (:func:`drive_ensemble`).  With ``workers`` the keyword arguments
+    (constraint callables included) must be picklable."""
+    specs = [(_mma_member, (x0, _maximize, dict(kw, **(per_member_kw[i] if per_member_kw else {}))), {}) for i, x0 in enumerate(x0s)]
+    return drive_ensemble(batch_fun, specs, workers)
+
+
 def mma_maximize_ensemble(batch_fun, x0s, **kw):
-    res = mma_minimize_ensemble(lambda xs: [tuple(-np.asarray(a) for a in vg) for vg in batch_fun(xs)], x0s, **kw)
-    for r in res:
-        r["fun"] = -r["fun"]
-        r["history"] = [-h for h in r["history"]]
-    return res
+    return mma_minimize_ensemble(batch_fun, x0s, _maximize=True, **kw)
 
 
 def mma_maximize(fun, x0, **kw):
     """maximise: fun(x) -> (value, gradient); same options as :func:`mma_minimize` (``opt.set_max_objective``)."""
-    res = mma_minimize(lambda z: tuple(-np.asarray(a) for a in fun(z)), x0, **kw)
-    res["fun"] = -res["fun"]
-    res["history"] = [-h for h in res["history"]]
-    return res
+    return _drive(maximizing(mma_steps(x0, **kw)), fun)

@@ -508,20 +508,45 @@ class MultiInputTargetKineticEnergy:
         return float(value[0]), grads[0]
 
 
+def _ensemble_member(g, x0, n_iterations, lower_bound, upper_bound, min_void_angle, min_block_angle, min_edge_length):
+    """One member of :func:`run_ensemble_optimization` as a coroutine (``yield x`` asks for the objective and its gradient at x):
+    the reference's loop for ONE design.  A module-level function of picklable arguments, so that it can live in a host worker
+    process (``optimize.MemberWorkers``); the constraint history travels back inside the result."""
+    from .optimize import maximizing, mma_steps
+    violation = {"angles": [], "edge_lengths": []}
+    cons = []
+    if min_void_angle is not None and min_block_angle is not None:
+        def ca(x):
+            r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
+            violation["angles"].append(float(r.max()))
+            return r
+        cons.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
+    if min_edge_length is not None:
+        def ce(x):
+            r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
+            violation["edge_lengths"].append(float(r.max()))
+            return r
+        cons.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
+    res = yield from maximizing(mma_steps(x0, lower=lower_bound, upper=upper_bound, constraints=cons, maxeval=n_iterations,
+                                          constraint_tol=1e-8))
+    res["constraints_violation"] = violation
+    return res
+
+
 def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bound=None, upper_bound=None,
-                              min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=False):
+                              min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=False, workers=None):
     """``len(initial_guesses)`` independent design optimisations (BASELINE config 5: an ensemble of multi-input focusing
     designs) advancing in lock-step: every round the pending design of EVERY member is evaluated in one batched call of
     the objective (``objective.value_and_grad(list of designs)`` -- the forward problems were built with
     ``batch=len(initial_guesses)``), i.e. one forward + reverse sweep of the engine integrates all members side by side.
     Each member runs the reference's loop (method of moving asymptotes under the angle / edge-length constraints,
-    problems/quads_focusing.py:546-652) exactly as it would alone.
+    problems/quads_focusing.py:546-652) exactly as it would alone.  ``workers`` (``optimize.MemberWorkers``, created before the
+    first GPU call): host processes that run the members' constraint evaluations and MMA sub-problems side by side.
     Returns (best designs, list of per-member dicts with objective_values / constraints_violation / mma result)."""
-    from .optimize import mma_maximize_ensemble
+    from .optimize import drive_ensemble
     g = objective.forward.geometry
     n = len(initial_guesses)
-    logs = [dict(objective_values=[], constraints_violation={"angles": [], "edge_lengths": []}) for _ in range(n)]
-    finished = [False] * n
+    logs = [dict(objective_values=[]) for _ in range(n)]
 
     def batch_fun(xs):
         designs = [_unflatten_design(g, x) for x in xs]
@@ -533,25 +558,11 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
             print(f"round: objectives = {np.array2string(np.asarray(vals), precision=4)}")
         return [(float(v), _flatten_design(gr)) for v, gr in zip(vals, grads)]
 
-    per_member = []
-    for i in range(n):
-        cons = []
-        if min_void_angle is not None and min_block_angle is not None:
-            def ca(x, i=i):
-                r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
-                logs[i]["constraints_violation"]["angles"].append(float(r.max()))
-                return r
-            cons.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
-        if min_edge_length is not None:
-            def ce(x, i=i):
-                r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
-                logs[i]["constraints_violation"]["edge_lengths"].append(float(r.max()))
-                return r
-            cons.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
-        per_member.append(dict(constraints=cons))
-    res = mma_maximize_ensemble(batch_fun, [_flatten_design(d) for d in initial_guesses], per_member_kw=per_member,
-                                lower=lower_bound, upper=upper_bound, maxeval=n_iterations, constraint_tol=1e-8)
+    specs = [(_ensemble_member, (g, _flatten_design(d), n_iterations, lower_bound, upper_bound, min_void_angle, min_block_angle,
+                                 min_edge_length), {}) for d in initial_guesses]
+    res = drive_ensemble(batch_fun, specs, workers)
     for log, r in zip(logs, res):
+        log["constraints_violation"] = r.pop("constraints_violation")
         log["mma"] = r
     return [_unflatten_design(g, r.x) for r in res], logs
 

@@ -33,12 +33,19 @@ def main():
     ap.add_argument("--steps-per-interval", type=int, default=100)
     ap.add_argument("--timepoints", type=int, default=41)
     ap.add_argument("--backend", default="rccl", help="rccl (inside libdfx) | socket (plain TCP: rehearsals without one GPU per rank)")
+    ap.add_argument("--host-workers", type=int, default=-1,
+                    help="host processes for the members' constraint evaluations and MMA sub-problems (0: in this process; "
+                         "-1: min(32, CPUs of this rank - 1))")
     ap.add_argument("--cpu-port", action="store_true", help="use the oracle's CPU port instead of libdfx (rehearsal without a GPU)")
     args = ap.parse_args()
 
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     from difflexmm_amd import problems as P
     from difflexmm_amd import ensemble
+    from difflexmm_amd.optimize import MemberWorkers
+    # the host workers are forked FIRST: before RCCL / the engines initialise the GPU in this process
+    n_workers = args.host_workers if args.host_workers >= 0 else min(32, max(1, len(os.sched_getaffinity(0)) // max(1, world) - 1))
+    workers = MemberWorkers(n_workers) if n_workers > 0 else None
     from difflexmm_amd.ensemble import gather_objectives, shard_bounds
     comm = ensemble.init_from_env(args.backend, device=local_rank) if world > 1 else ensemble.SerialComm()
     lib = None
@@ -72,7 +79,7 @@ def main():
     t0 = time.perf_counter()
     best, logs = P.run_ensemble_optimization(objective, x0s, args.iterations, lower_bound=-0.3 * spacing, upper_bound=0.3 * spacing,
                                              min_void_angle=amin, min_block_angle=amin, min_edge_length=0.1 * spacing,
-                                             verbose=(rank == 0))
+                                             verbose=(rank == 0), workers=workers)
     wall = time.perf_counter() - t0
     first = gather_objectives([l["objective_values"][0] for l in logs], args.members)
     final = gather_objectives([l["mma"].fun for l in logs], args.members)
@@ -84,9 +91,11 @@ def main():
         dev = sum(getattr(o, "device_ms", 0.0) for o in objective.objectives) * 1e-3
         print(f"device time of the forward + reverse sweeps, summed over the three engines: {dev:.1f} s (wall {wall:.1f} s; the engines of "
               f"the three inputs overlap when each runs a single stream); the rest is host work per round: design -> ControlParams "
-              f"-> packed arrays, gradient maps back to the design, the MMA sub-problems")
+              f"-> packed arrays, gradient maps back to the design, the MMA sub-problems ({n_workers} host worker processes)")
         print("objective, first evaluation :", np.array2string(first, precision=3, max_line_width=160))
         print("objective, best feasible    :", np.array2string(final, precision=3, max_line_width=160))
+    if workers is not None:
+        workers.close()
     comm.barrier()
     comm.close()
 

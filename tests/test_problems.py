@@ -288,6 +288,26 @@ def test_ensemble_optimisation_in_lock_step_equals_members_alone(cpu_lib):
         assert np.allclose(opt.objective_values, logs[m]["objective_values"], rtol=1e-9)
         assert all(np.allclose(a, b, rtol=0, atol=1e-10) for a, b in zip(x, best[m]))
     assert all(l["mma"].fun >= l["objective_values"][0] for l in logs)
+    # the members' host work (constraints, MMA sub-problems) in two worker processes: same iterates, same histories
+    from difflexmm_amd.optimize import MemberWorkers
+    with MemberWorkers(2) as workers:
+        best_w, logs_w = P.run_ensemble_optimization(obj3, x0s, 5, workers=workers, **kw)
+    for m in range(3):
+        assert logs_w[m]["objective_values"] == logs[m]["objective_values"]
+        assert logs_w[m]["constraints_violation"] == logs[m]["constraints_violation"] and logs[m]["constraints_violation"]["angles"]
+        assert all(np.array_equal(a, b) for a, b in zip(best_w[m], best[m])) and logs_w[m]["mma"].n_eval == logs[m]["mma"].n_eval
+
+
+def test_member_workers_report_a_failing_member():
+    from difflexmm_amd.optimize import MemberWorkers, drive_ensemble
+    with MemberWorkers(2) as workers:
+        with pytest.raises(RuntimeError, match="ensemble worker"):
+            drive_ensemble(lambda xs: [(0.0, np.zeros(1))] * len(xs), [(_failing_member, (), {}), (_failing_member, (), {})], workers)
+
+
+def _failing_member():
+    yield np.zeros(1)
+    raise ValueError("boom")
 
 
 def test_bench_host_path_on_cpu_port(cpu_lib):
