@@ -123,7 +123,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfx.so")
+    """``DFX_LIBRARY`` (a path) selects another build of the same HIP engine: kernel experiments side by side on one box."""
+    return os.environ.get("DFX_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfx.so")
 
 
 def load_library():
