@@ -41,6 +41,7 @@ SPI = 250                     # steps between outputs: 50 000 steps / 200 output
 FREQ = 30.0
 DT = (2.0 / FREQ) / 50000.0
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md, chip-level parameters
+FP64_VALU_PEAK_TFLOPS = 78.6  # vector fp64: 256 CUs x 64 FMA lanes per clock x 2 flops x 2.4 GHz (AMD: 78.6); no matrix cores on this path
 # ALGORITHMIC bytes per rigid unit per launch
 BYTES_FWD_STAGE = 272 + 72          # one RHS evaluation (quads + contact) + its share of the stage combine (432 / 6)
 BYTES_ADJ_STAGE = 272 + 96 + 256    # stage data + lambda / Ybar read-write + parameter-gradient read-modify-write = 624
@@ -445,6 +446,9 @@ def main():
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
             "host_prepare_ms": host_prepare_ms, "value_with_host_prepare": total_units_steps / (wall + 1e-3 * host_prepare_ms),
             "launches": {"forward": res["fwd_launches"], "adjoint": res["adj_launches"]},
+            # RHS evaluations per second (whole-lattice evaluations of every member; the reverse sweep adds one
+            # Hessian-vector product per forward evaluation, counted as one more each)
+            "rhs_evals_per_s": (12 if adjoint else 6) * K * args.members * world / wall,
             "objective": [float(x) for x in np.atleast_1d(objective)][:8], "grad_norm": gnorm,
         }
         if adj_us:
@@ -461,6 +465,19 @@ def main():
             line["roofline"] = roof("k_fwd_stage<nonlinear,contact>", BYTES_FWD_STAGE, fwd_us,
                                     {"traffic": None if traffic is None else traffic.get("k_fwd_stage_bytes_per_member_launch", 0) * mpl or None,
                                      "traffic_source": None if traffic is None else traffic.get("source")})
+        # SURVEY 8(d), caveat H5: the fp64 VALU rate beside the byte rate (instruction counts per launch from the committed SQ
+        # counter passes, 64 lanes per wave instruction, FMA = 2 flops; launch time measured in this run)
+        if traffic is not None and "counters" in traffic:
+            def valu(which, us):
+                c = traffic["counters"].get(which, {})
+                if not c or not us:
+                    return None
+                flop = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
+                               + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0))
+                flop *= mpl / float(traffic.get("members", mpl))
+                return {"fp64_flop_per_launch": flop, "achieved_tflops": flop / (us * 1e-6) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                        "frac": flop / (us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+            line["fp64_valu"] = {"k_fwd_stage": valu("fwd", fwd_us), "k_adj_stage": valu("adj", adj_us)}
         if streams > 1:
             # (2) the timed job itself: `streams` member groups overlap on the chip; aggregate algorithmic bytes / region time
             f_eff, a_eff = per_launch(res, streams)
