@@ -436,10 +436,13 @@ class MultiInputTargetKineticEnergy:
         # chip alone and three threads issuing eager launches only contend for the runtime (forward 0.70 s vs 0.31 s per call,
         # profiles/r02_c5_host_profile.txt): those keep the engine's own choice and run the inputs one after the other.
         for fp in forward_problems:
-            if len(forward_problems) > 1 and not getattr(fp, "is_setup", False) and not fp.streams:
+            if len(forward_problems) > 1 and not fp.streams:
                 n_units = (fp.n1_blocks * fp.n2_blocks) if hasattr(fp, "n1_blocks") else 2 * fp.n1_cells * fp.n2_cells
                 if fp.batch * n_units * 4 // 64 < 4096:      # waves per launch: below two rounds of the chip
                     fp.streams = 1
+                    if getattr(fp, "is_setup", False):       # already built with the engine's own choice: build it again
+                        fp.solve_dynamics.engine.close()
+                        fp.setup()
         self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
         self.target_size, self.target_shift = tuple(target_size), tuple(target_shift)
         self.concurrent_inputs = True
