@@ -1,8 +1,8 @@
 // dfx_engine.hip -- libdfx: the MI355X (gfx950) engine behind include/dfx.h (host side; kernels in dfx_kernels.h).
 //
 // Execution model
-//   * one lane per (block, node slot): 4 lanes = one rigid unit, 16 units per 64-wide wavefront, 256-thread workgroups,
-//     grid = (ceil(4*n_blocks/256), members of the group).  Every ligament is evaluated by both of its end lanes
+//   * one lane per (block, node slot): 4 lanes = one rigid unit, 16 units per 64-wide wavefront, 128-thread workgroups,
+//     grid = (ceil(4*n_blocks/128), members of the group).  Every ligament is evaluated by both of its end lanes
 //     ("gather form"); the 4 slot contributions of a unit are summed with DPP quad moves; lanes 0..2 of the quad own DOF
 //     x, y, theta in the integrator epilogue.  No LDS; atomics only for the (rare) time-function parameter gradients that
 //     several DOFs of one block share: results are reproducible run to run.
@@ -966,7 +966,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   const int n_partials = (pl.n_slots + 63) / 64;
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
   HIP_OK(h->d_clock.ensure(B));
-  HIP_OK(h->d_err_partial.ensure(B * n_wg * 4));
+  HIP_OK(h->d_err_partial.ensure(B * n_wg * kWavesPerWg));
   h->n_counts = std::max(0, Tn - 1);
   HIP_OK(h->d_step_counts.ensure(std::max<size_t>(1, B * h->n_counts)));
   HIP_OK(hipMemsetAsync(h->d_step_counts.p, 0, sizeof(int) * std::max<size_t>(1, B * h->n_counts), h->stream));

@@ -34,7 +34,11 @@ namespace {
 // checkpoint and the cotangent table keep 64-bit offsets.
 typedef unsigned u32;
 
-constexpr int kThreads = 256;
+#ifndef DFX_THREADS
+#define DFX_THREADS 128
+#endif
+constexpr int kThreads = DFX_THREADS;          // workgroup size of every kernel (128 / 512 measured: profiles/r02_workgroup_size.txt)
+constexpr int kWavesPerWg = kThreads / 64;
 constexpr int kAccCap = 1 << 20;   // accepted step times recorded per member (adaptive)
 constexpr int kMaxGraphSteps = 256;
 constexpr int kMaxGroups = 64;   // member groups (one stream each): size of the cursor tables and stride of the graph-cache key
@@ -102,7 +106,7 @@ struct DevCtx {
   const TimeFn* fns;
   const Seg* cur;         // the segment being replayed
   Clock* clock;           // per-member clocks (adaptive mode) or null
-  double* err_partial;    // batch * n_wg*4 per-wave partial sums of the squared error ratio
+  double* err_partial;    // batch * n_wg * kWavesPerWg per-wave partial sums of the squared error ratio
   int* step_counts;       // batch * (n_timepoints-1) accepted steps per output interval (adaptive)
   double* acc_times;      // batch * acc_cap end times of the accepted steps (adaptive)
   int acc_cap;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
     // per-wave sum of the squared error ratios (fixed order -> deterministic); lane 0 of each wave stores it
     double r2 = (k < 3 && valid) ? qnext : 0.0;
     for (int off = 32; off > 0; off >>= 1) r2 += __shfl_down(r2, off, 64);
-    if ((threadIdx.x & 63) == 0) c.err_partial[((u32)m * c.n_wg + lwg) * 4 + (threadIdx.x >> 6)] = r2;
+    if ((threadIdx.x & 63) == 0) c.err_partial[((u32)m * c.n_wg + lwg) * kWavesPerWg + (threadIdx.x >> 6)] = r2;
     return;
   }
   if (out_buf == -1) return;
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, 
   const int m = blockIdx.x;
   __shared__ double red[kThreads];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n_partials; i += kThreads) acc += c.err_partial[(size_t)m * c.n_wg * 4 + i];
+  for (int i = threadIdx.x; i < n_partials; i += kThreads) acc += c.err_partial[(size_t)m * c.n_wg * kWavesPerWg + i];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = kThreads / 2; s > 0; s >>= 1) {
