@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[2], SURVEY 8(d) "C3"): 128x128 quad lattice (16 384 rigid units), nonlinear
 ligaments + viscous damping + angle-based contact, raised-cosine displacement pulse on 2 left-edge blocks,
 clamped corners, Dormand-Prince tableau on a fixed grid with dt = (2/f)/50 000, one output every 250 steps,
-objective = kinetic energy of 2x2 target blocks, gradient w.r.t. the 66 048 geometry parameters.
+objective = kinetic energy of 2x2 target blocks, ControlParams-shaped gradient (node vectors, void angles, inertia of every design).
 One "step" = one RK step (6 RHS evaluations) of every member, forward AND reverse.  `--steps K` times exactly K
 steps (output intervals of 250 steps and, if K is not a multiple of 250, one shorter last interval); the full config is
 K = 50 000.  16 independent designs per GPU while the state checkpoint AND the stage checkpoint (72 + 120 B per unit and
@@ -437,7 +437,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C3: {args.size}x{args.size} quads, nonlinear ligaments + damping + angle contact, "
                                    f"pulse drive, fixed-step Dopri5 dt={DT:.3e}s, {K} of 50000 steps, "
-                                   f"{'forward + adjoint wrt 66048 geometry params' if adjoint else 'forward only'}",
+                                   f"{'forward + adjoint: ControlParams-shaped gradient per design (node vectors, undeformed void angles, inertia: 245760 values; the 66048 design shifts follow by a linear host-side map outside the solver boundary)' if adjoint else 'forward only'}",
                        "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams,
                        "checkpoint": res.get("checkpoint"), "integrator": "dopri5-fixed",
                        "steps_per_output": SPI, "input_delay_s": args.input_delay, "contact_deg": [args.contact_min_deg, args.contact_cutoff_deg],
