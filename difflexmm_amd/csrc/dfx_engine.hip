@@ -138,6 +138,9 @@ struct dfx_handle {
   // reads and writes (segment table, cursors) -- any of them changing (a buffer re-allocated by a larger solve) drops the graphs
   struct GraphKey { DevCtx ctx; const void* segs; const void* seg_idx; const void* cur; } graph_key;
   bool graph_ctx_valid = false;
+  // the adaptive controller's graph of 32 attempts (small lattices only), valid for the arguments it was captured with
+  hipGraphExec_t adaptive_exec = nullptr;
+  struct AdaptiveKey { DevCtx ctx; int n_timepoints; int n_partials; double two_n_free; } adaptive_key;
   long long launches = 0;
 };
 
@@ -145,6 +148,7 @@ static void drop_graphs(dfx_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   h->graphs.clear();
   h->graph_ctx_valid = false;
+  if (h->adaptive_exec) { (void)hipGraphExecDestroy(h->adaptive_exec); h->adaptive_exec = nullptr; }
 }
 
 static DevCtx make_ctx(dfx_handle* h) {
@@ -993,13 +997,15 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
-  std::vector<double> A((size_t)B * 7 * nd), V0(B * 7 * nd);
-  HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
+  // only the evaluation just made comes back (row 0 / row 1 of every member's seven stage accelerations), not all of d_A
+  std::vector<double> A0((size_t)B * nd), A1((size_t)B * nd);
+  HIP_OK(hipMemcpy2DAsync(A0.data(), sizeof(double) * nd, h->d_A.p, sizeof(double) * 7 * nd, sizeof(double) * nd, B,
+                          hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   // initial step size (Hairer II.4 as restated by jax, order 4), per member
   std::vector<double> y1(B * 2 * nd), tm(B), h0(B), d1v(B);
   for (size_t m = 0; m < B; ++m) {
-    const double* q = state0 + m * 2 * nd; const double* v = q + nd; const double* a = A.data() + m * 7 * nd;
+    const double* q = state0 + m * 2 * nd; const double* v = q + nd; const double* a = A0.data() + m * nd;
     double d0 = 0, d1 = 0;
     for (size_t i = 0; i < nd; ++i) if (!con[i]) {
       const double sq = atol + fabs(q[i]) * rtol, sv = atol + fabs(v[i]) * rtol;
@@ -1020,12 +1026,13 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   HIP_OK(hipMemcpyAsync(d_tm.p, tm.data(), sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_init_tm, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_tmp.p, (const double*)d_tm.p, 1);
   launch_fwd(h, c, 1, 0, 1, -1, 0, 0);                      // A_1 = f(y0 + h0 f0, t0 + h0)
-  HIP_OK(hipMemcpyAsync(A.data(), h->d_A.p, sizeof(double) * A.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpy2DAsync(A1.data(), sizeof(double) * nd, h->d_A.p + nd, sizeof(double) * 7 * nd, sizeof(double) * nd, B,
+                          hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   d_tm.release();
   for (size_t m = 0; m < B; ++m) {
     const double* q = state0 + m * 2 * nd; const double* v = q + nd;
-    const double* a0 = A.data() + m * 7 * nd; const double* a1 = a0 + nd; const double* v1 = y1.data() + m * 2 * nd + nd;
+    const double* a0 = A0.data() + m * nd; const double* a1 = A1.data() + m * nd; const double* v1 = y1.data() + m * 2 * nd + nd;
     double d2 = 0;
     for (size_t i = 0; i < nd; ++i) if (!con[i]) {
       const double sq = atol + fabs(q[i]) * rtol, sv = atol + fabs(v[i]) * rtol;
@@ -1064,15 +1071,32 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   const int kAttemptsPerGraph = 32;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  if (h->use_graph) {
-    const long long before = h->launches;
-    HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int a = 0; a < kAttemptsPerGraph; ++a) enqueue_attempt();
-    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-    h->launches = before;
-    if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (graph) (void)hipGraphDestroy(graph);
-    if (ce != hipSuccess) { h->err = std::string("graph capture / instantiate: ") + hipGetErrorString(ce); h->adaptive = false; return 2; }
+  // Same rule as the fixed grid (solve_is_eager): launches that fill the chip are issued eagerly -- instantiating the 256-node graph
+  // cost 5-10 ms per call, more than a short solve runs (profiles/r02_adaptive_fixed_cost.txt); small lattices replay a graph,
+  // kept in the handle while the arguments baked into it stay the same.
+  const long long waves = (long long)pl.batch * ((pl.n_slots + 63) / 64);
+  if (h->use_graph && waves < 2048) {
+    dfx_handle::AdaptiveKey key;
+    memset(&key, 0, sizeof(key));
+    key.ctx = c; key.n_timepoints = Tn; key.n_partials = n_partials; key.two_n_free = 2.0 * (double)n_free;
+    if (h->adaptive_exec && memcmp(&key, &h->adaptive_key, sizeof(key)) != 0) {
+      (void)hipGraphExecDestroy(h->adaptive_exec); h->adaptive_exec = nullptr;
+    }
+    if (!h->adaptive_exec) {
+      const long long before = h->launches;
+      HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      for (int a = 0; a < kAttemptsPerGraph; ++a) enqueue_attempt();
+      hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+      h->launches = before;
+      if (ce == hipSuccess) ce = hipGraphInstantiate(&h->adaptive_exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (ce != hipSuccess) {
+        h->adaptive_exec = nullptr;
+        h->err = std::string("graph capture / instantiate: ") + hipGetErrorString(ce); h->adaptive = false; return 2;
+      }
+      memcpy(&h->adaptive_key, &key, sizeof(key));
+    }
+    exec = h->adaptive_exec;
   }
   long long attempts_issued = 0;
   int rc = 0;
@@ -1092,7 +1116,6 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     if (attempts_issued >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; rc = 4; break; }
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
-  if (exec) (void)hipGraphExecDestroy(exec);
   if (rc) { h->adaptive = false; return rc; }
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));

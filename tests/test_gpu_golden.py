@@ -82,3 +82,23 @@ def test_adaptive_members_control_their_own_step(hip_lib):
     assert singles[0][1] != singles[1][1]          # the two members really take different numbers of steps
     for m in range(2):
         assert np.array_equal(fb[m], singles[m][0])
+
+
+def test_adaptive_graph_of_attempts_is_reused_and_rebuilt(hip_lib):
+    """Small lattices replay a graph of 32 adaptive attempts kept in the handle: a second call with the same arguments reuses it, a
+    call with another number of timepoints or another tolerance (both baked into the graph's kernel arguments) rebuilds it -- every
+    result must equal the one of a fresh handle bit for bit."""
+    def fresh(ts, tol):
+        c = Case("quads", 5, True, True, seed=31, lib=None, cutoff_deg=42.0)
+        c.solver.rtol = c.solver.atol = tol
+        cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=900.0, input_delay=1e-5))
+        return c, cp, c.solver(np.zeros((2, 25, 3)), ts, cp)
+    ts5, ts3 = np.linspace(0.0, 2e-3, 5), np.linspace(0.0, 1e-3, 3)
+    c, cp, f5 = fresh(ts5, 1e-9)
+    assert np.array_equal(c.solver(np.zeros((2, 25, 3)), ts5, cp), f5)            # reused
+    f3 = c.solver(np.zeros((2, 25, 3)), ts3, cp)                                  # other T: rebuilt
+    assert np.array_equal(f3, fresh(ts3, 1e-9)[2])
+    c.solver.rtol = c.solver.atol = 1e-7                                          # other tolerance: rebuilt
+    assert np.array_equal(c.solver(np.zeros((2, 25, 3)), ts5, cp), fresh(ts5, 1e-7)[2])
+    c.solver.rtol = c.solver.atol = 1e-9
+    assert np.array_equal(c.solver(np.zeros((2, 25, 3)), ts5, cp), f5)
