@@ -407,3 +407,22 @@ def test_optimization_problem_round_trips_through_a_dict_and_resumes(cpu_lib, tm
     md = P.OptimizationProblem(mi).to_dict()
     mb = P.OptimizationProblem.from_dict(md, _lib=cpu_lib)
     assert [o.forward.loaded_side for o in mb.objective.objectives] == ["left", "bottom"] and list(mb.objective.weights) == [1.0, 0.5]
+
+
+@pytest.mark.parametrize("n", [3, 4, 5])
+def test_closed_form_polygon_cotangents_match_the_complex_step_jacobians(n):
+    """geometry.polygon_props_vjp (closed form, used by the design loop) against polygon_props_jac (complex step through
+    polygon_props itself), for counter-clockwise polygons (the lattices) and clockwise ones (where polygon_props, like the reference,
+    divides by |S| and the reference point is not the centroid)."""
+    from difflexmm_amd import geometry as G
+    rng = np.random.default_rng(n)
+    th = np.sort(rng.uniform(0, 2 * np.pi, (40, n)), axis=1)
+    r = rng.uniform(0.5, 1.5, (40, n))
+    v = np.stack([r * np.cos(th) + rng.normal(size=(40, 1)), r * np.sin(th) + rng.normal(size=(40, 1))], -1)
+    for vv in (v, v[:, ::-1].copy()):
+        dA, dC, dI = G.polygon_props_jac(vv)
+        ab, cb, ib = rng.normal(size=40), rng.normal(size=(40, 2)), rng.normal(size=40)
+        ref = ab[:, None, None] * dA + np.einsum("bc,bcnk->bnk", cb, dC) + ib[:, None, None] * dI
+        got = G.polygon_props_vjp(vv, ab, cb, ib)
+        assert (np.abs(got - ref).reshape(40, -1).max(1) / np.abs(ref).reshape(40, -1).max(1)).max() < 1e-11
+        assert np.allclose(G.polygon_props_vjp(vv, area_bar=ab), ab[:, None, None] * dA, rtol=0, atol=1e-13)
