@@ -334,6 +334,22 @@ class KagomeFocusingForward:
     from_dict = classmethod(_forward_from_dict)
 
 
+def design_gradients(fw, designs, raw):
+    """The engine's raw gradients (batch-leading arrays for centroid_node_vectors, void_angle0, inertia[, block_centroids]) mapped
+    back to the designs: void-angle and inertia chain rules, then the lattice map (all linear in the cotangent)."""
+    from .geometry import compute_inertia_vjp, void_angles0_vjp
+    geo, bonds = fw.geometry, fw.solve_dynamics.bonds
+    grads = []
+    for m, d in enumerate(designs):
+        _, cnv = geometry_from_design_cached(geo, d)
+        cnv_bar = np.array(raw["centroid_node_vectors"][m], dtype=float)
+        if "void_angle0" in raw:
+            cnv_bar += void_angles0_vjp(cnv, bonds, raw["void_angle0"][m])
+        cnv_bar += compute_inertia_vjp(cnv, fw.density, raw["inertia"][m])[0]
+        grads.append(geo.vjp(d, cnv_bar, raw["block_centroids"][m] if "block_centroids" in raw else None))
+    return grads
+
+
 class TargetKineticEnergy:
     """objective(design) = sum_t sum_{b in target} m v^2/2 and its gradient w.r.t. the design
     (problems/quads_focusing.py:432-471 + jit(value_and_grad(.)) at :565; kagome_focusing.py:388-424)."""
@@ -354,17 +370,20 @@ class TargetKineticEnergy:
         return vals if isinstance(sol, list) else vals[0]
 
     def value_and_grad(self, design):
+        """Only the parameter groups a design reaches are differentiated on the device (node vectors, undeformed void angles,
+        inertia, block centroids for the distance-based contact): asking the engine for every ControlParams leaf switches the
+        reverse stage to its variant that also accumulates per-ligament stiffness / reference-vector / contact-constant / damping
+        gradients -- twice the time per launch on the 64x64 kagome of config 4 (profiles/r02_c4_design_gradient_subset.txt)."""
         fw = self.forward
         fw.solve(design, keep_trajectory=True, want_fields=False)
-        obj, trees, _ = fw.solve_dynamics.kinetic_energy_value_and_vjp(self.target_blocks)
+        obj, raw = fw.solve_dynamics.kinetic_energy_value_and_raw(self.target_blocks)
         # device time of this evaluation (forward + reverse sweep), for throughput reports
         self.device_ms = getattr(self, "device_ms", 0.0) + fw.solve_dynamics.stats["kernel_ms"] + fw.solve_dynamics.adjoint_stats["kernel_ms"]
         many = isinstance(design, list)
         designs = design if many else [design]
-        trees = trees if many else [trees]
-        grads = [fw.geometry.vjp(d, t.geometrical_params.centroid_node_vectors, t.geometrical_params.block_centroids)
-                 for d, t in zip(designs, trees)]
-        return (obj, grads) if many else (obj, grads[0])
+        grads = design_gradients(fw, designs, raw)
+        obj = np.asarray(obj, dtype=float)
+        return (obj, grads) if many else (float(obj[0]), grads[0])
 
 
 class TargetAngularMomentum:
@@ -496,16 +515,7 @@ class MultiInputTargetKineticEnergy:
                     sums[k] += w * a
         self.last_individual = np.array(vals) if many else np.array(vals)[:, 0]
         value = self.weights @ np.array(vals)
-        fw0 = self.objectives[0].forward
-        geo, bonds = fw0.geometry, fw0.solve_dynamics.bonds
-        grads = []
-        for m, d in enumerate(designs):
-            _, cnv = geometry_from_design_cached(geo, d)
-            cnv_bar = sums["centroid_node_vectors"][m].copy()
-            if "void_angle0" in sums:
-                cnv_bar += void_angles0_vjp(cnv, bonds, sums["void_angle0"][m])
-            cnv_bar += compute_inertia_vjp(cnv, fw0.density, sums["inertia"][m])[0]
-            grads.append(geo.vjp(d, cnv_bar, sums["block_centroids"][m] if "block_centroids" in sums else None))
+        grads = design_gradients(self.objectives[0].forward, designs, sums)
         if many:
             return list(value), grads
         return float(value[0]), grads[0]
