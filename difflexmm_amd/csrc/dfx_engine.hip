@@ -1415,8 +1415,8 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) {
-        y_bar[m * nb * 6 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + d];
-        y_bar[m * nb * 6 + nb * 3 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + 3 + d];
+        y_bar[m * nb * 6 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + 2 * d];          // device layout: (q, v) of one DOF side by side
+        y_bar[m * nb * 6 + nb * 3 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + 2 * d + 1];
       }
   return 0;
 }
