@@ -181,6 +181,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
   c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
+  c.lam_pairs = (c.g_b || c.AD) ? 0 : 1;      // the REBUILD builds of the reverse stage (launch_adj_t) keep the scalar layout
   c.blk_m = h->d_blk_m.p; c.blk_c = h->want_damping_grads ? h->d_blk_c.p : nullptr;
   c.fn_g = h->want_fn_grads ? h->d_fn_g.p : nullptr;
   return c;
@@ -1415,8 +1416,8 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   for (size_t m = 0; m < B; ++m)
     for (size_t b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) {
-        y_bar[m * nb * 6 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + 2 * d];          // device layout: (q, v) of one DOF side by side
-        y_bar[m * nb * 6 + nb * 3 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + 2 * d + 1];
+        y_bar[m * nb * 6 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + (c.lam_pairs ? 2 * d : d)];          // DevCtx::lam_pairs
+        y_bar[m * nb * 6 + nb * 3 + b * 3 + d] = YB[m * pl.tab.s * nb * 6 + b * 6 + (c.lam_pairs ? 2 * d + 1 : 3 + d)];
       }
   return 0;
 }

@@ -87,7 +87,10 @@ struct DevCtx {
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
   long long traj_stride;  // elements between members in traj
-  int rps, pad_rps;       // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
+  int rps;                // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
+  int lam_pairs;          // layout of LAM / YB: 1 = (q, v) of one DOF side by side (b*6 + 2d, + 1), one 16-B access per lane; 0 = (q0 q1 q2 v0 v1 v2)
+                          // -- the REBUILD builds of the reverse stage (stage checkpoint, per-ligament gradients) sit at their register limit
+                          // and lose the fourth wave per SIMD with 16-B accesses (profiles/r02_wide_per_dof_accesses.txt)
   const int32_t* slot_info;
   const int32_t* block_special;
   const dfx_special* special;
@@ -775,13 +778,15 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   LaneRaw R;
   issue_lane<CONTACT>(c, B, slot, POSin, R);
   const int dof = b * 3 + kd;
-  // per-lane byte offsets shared by the per-DOF arrays; lambda and Ybar keep (q, v) of one DOF side by side: one 16-B access per lane
-  const u32 o_dof = (u32)dof * 8, o_b6 = ((u32)b * 6 + 2 * kd) * 8;
+  // per-lane byte offsets shared by the per-DOF arrays; lambda and Ybar: see DevCtx::lam_pairs (= !REBUILD)
+  const u32 o_dof = (u32)dof * 8, o_b6 = REBUILD ? ((u32)b * 6 + kd) * 8 : ((u32)b * 6 + 2 * kd) * 8;
   const double* Win = c.W + ((size_t)m * 2 + win) * nd;
   const double w_d = ldg<double>(Win, o_dof);
   // partner's w from the guessed slot (same batch as everything else)
   double wpx, wpy, wpth;
-  { const u32 gb = (u32)(R.guess >> 2) * 24; const double2 wxy = ldg<double2>(Win, gb); wpx = wxy.x; wpy = wxy.y; wpth = ldg<double>(Win, gb + 16); }
+  { const u32 gb = (u32)(R.guess >> 2) * 24;
+    if (!REBUILD) { const double2 wxy = ldg<double2>(Win, gb); wpx = wxy.x; wpy = wxy.y; } else { wpx = ldg<double>(Win, gb); wpy = ldg<double>(Win, gb + 8); }
+    wpth = ldg<double>(Win, gb + 16); }
   const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
   const double kq_in = ldg<double>(c.KQ + ((size_t)m * 2 + win) * nd, o_dof);
   const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
@@ -791,25 +796,46 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
   double* LAMm = c.LAM + (size_t)m * nd6;
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
   if (!local_only) {
-    if (i == 0 || ac.col[c.s] != 0.0) { const double2 l2 = ldg<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b_i = 0: lambda not needed (Dopri5 stage 1)
-    double2 yb[kMaxStages];
+    if (!REBUILD) {
+      if (i == 0 || ac.col[c.s] != 0.0) { const double2 l2 = ldg<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b_i = 0: lambda not needed (Dopri5 stage 1)
+      double2 yb[kMaxStages];
 #pragma unroll
-    for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
-      const bool on = jj > i && jj < c.s;
-      yb[jj] = on ? ldg<double2>(YBm + (size_t)jj * nd6, o_b6) : make_double2(0.0, 0.0);
-    }
+      for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
+        const bool on = jj > i && jj < c.s;
+        yb[jj] = on ? ldg<double2>(YBm + (size_t)jj * nd6, o_b6) : make_double2(0.0, 0.0);
+      }
 #pragma unroll
-    for (int jj = 1; jj < kMaxStages; ++jj) {
-      const double cf = i > 0 ? ac.col[jj] : 1.0;
-      sq += cf * yb[jj].x;
-      sv += cf * yb[jj].y;
+      for (int jj = 1; jj < kMaxStages; ++jj) {
+        const double cf = i > 0 ? ac.col[jj] : 1.0;
+        sq += cf * yb[jj].x;
+        sv += cf * yb[jj].y;
+      }
+    } else {
+      if (i == 0 || ac.col[c.s] != 0.0) { lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24); }
+      double yq[kMaxStages], yv[kMaxStages];
+#pragma unroll
+      for (int jj = 1; jj < kMaxStages; ++jj) {
+        const bool on = jj > i && jj < c.s;
+        yq[jj] = on ? ldg<double>(YBm + (size_t)jj * nd6, o_b6) : 0.0;
+        yv[jj] = on ? ldg<double>(YBm + (size_t)jj * nd6, o_b6 + 24) : 0.0;
+      }
+#pragma unroll
+      for (int jj = 1; jj < kMaxStages; ++jj) {
+        const double cf = i > 0 ? ac.col[jj] : 1.0;
+        sq += cf * yq[jj];
+        sv += cf * yv[jj];
+      }
     }
   }
   LaneIn L;
   resolve_lane<CONTACT>(c, B, POSin, R, L);
   DistIn D;
   if (CONTACT == 2) load_dist(c, B, slot, L, D);
-  if (L.pslot != L.guess) { const u32 pb = (u32)(L.pslot >> 2) * 24; const double2 wxy = ldg<double2>(Win, pb); wpx = wxy.x; wpy = wxy.y; wpth = ldg<double>(Win, pb + 16); }
+  if (L.pslot != L.guess) {
+    const u32 pb = (u32)(L.pslot >> 2) * 24;
+    if (!REBUILD) { const double2 wxy = ldg<double2>(Win, pb); wpx = wxy.x; wpy = wxy.y; } else { wpx = ldg<double>(Win, pb); wpy = ldg<double>(Win, pb + 8); }
+    wpth = ldg<double>(Win, pb + 16);
+  }
   const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
@@ -924,7 +950,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
       stg<double>(bmm, o_dof, bm_old - w_d * a_i);
       if (c.blk_c) stg<double>(bcm, o_dof, bc_old - w_d * v_i);
     }
-    stg<double2>(YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
+    if (!REBUILD) stg<double2>(YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
+    else { stg<double>(YBm + (size_t)i * nd6, o_b6, ybq); stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
     if (!local_only) {
       double kq, kv;
       if (i > 0) {
@@ -939,7 +966,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
           lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
         }
         if (constrained) { lq = 0.0; lv = 0.0; }
-        stg<double2>(LAMm, o_b6, make_double2(lq, lv));
+        if (!REBUILD) stg<double2>(LAMm, o_b6, make_double2(lq, lv));
+        else { stg<double>(LAMm, o_b6, lq); stg<double>(LAMm, o_b6 + 24, lv); }
         kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
@@ -965,8 +993,8 @@ __global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last,
   const bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
   const double* G = c.G + ((size_t)(c.n_timepoints - 1) * c.batch + m) * nd6;
   const double lq = con ? 0.0 : G[b * 6 + d], lv = con ? 0.0 : G[b * 6 + 3 + d];
-  c.LAM[(size_t)m * nd6 + b * 6 + 2 * d] = lq;
-  c.LAM[(size_t)m * nd6 + b * 6 + 2 * d + 1] = lv;
+  c.LAM[(size_t)m * nd6 + b * 6 + (c.lam_pairs ? 2 * d : d)] = lq;
+  c.LAM[(size_t)m * nd6 + b * 6 + (c.lam_pairs ? 2 * d + 1 : 3 + d)] = lv;
   c.KQ[((size_t)m * 2 + buf) * nd + b * 3 + d] = h_last * b_last * lq;
   c.W[((size_t)m * 2 + buf) * nd + b * 3 + d] = con ? 0.0 : h_last * b_last * lv * c.inv_m[(size_t)m * nd + b * 3 + d];
 }
@@ -1019,8 +1047,8 @@ __global__ __launch_bounds__(kThreads) void k_pack_grads(DevCtx c, const int32_t
   }
   if (out_lam && k < 3) {
     const size_t nd = (size_t)c.n_blocks * 3, o = (size_t)m * c.n_blocks * 6;
-    out_lam[o + (size_t)b * 3 + k] = c.LAM[o + (size_t)b * 6 + 2 * k];
-    out_lam[o + nd + (size_t)b * 3 + k] = c.LAM[o + (size_t)b * 6 + 2 * k + 1];
+    out_lam[o + (size_t)b * 3 + k] = c.LAM[o + (size_t)b * 6 + (c.lam_pairs ? 2 * k : k)];
+    out_lam[o + nd + (size_t)b * 3 + k] = c.LAM[o + (size_t)b * 6 + (c.lam_pairs ? 2 * k + 1 : 3 + k)];
   }
 }
 
