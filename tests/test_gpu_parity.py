@@ -348,3 +348,26 @@ def test_single_system_reverse_sweep_on_two_chains(hip_lib, cpu_lib, monkeypatch
         res[name] = (f, tree.geometrical_params.centroid_node_vectors, s0)
     for a, b, tol in zip(res["hip"], res["cpu"], (1e-10, 1e-8, 1e-8)):
         assert relerr(a, b) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["records", "state", "segments"])
+def test_design_subset_of_the_gradient_equals_the_full_set(hip_lib, monkeypatch, level):
+    """Asking only for what a design reaches (node vectors, void angles, inertia -- plus state0 here) runs the reverse stage in its
+    build without per-ligament gradients, which keeps lambda / Ybar as (q, v) pairs (DevCtx::lam_pairs); asking for every leaf runs
+    the other build with the scalar layout.  Same objective, same numbers for the common leaves, state0 (read back from lambda) included."""
+    monkeypatch.setenv("DFX_CHECKPOINT", level)
+    c = Case("quads", 7, True, True, seed=5, lib=None, cutoff_deg=42.0, batch=2)
+    cps = [c.cp._replace(constraint_params=dict(amplitude=a, loading_rate=3000.0, input_delay=1e-5)) for a in (7.5, -3.0)]
+    ts = np.linspace(0, 3e-4, 4)
+    target = np.array([16, 17, 23, 24], dtype=np.int32)
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    sub = ("centroid_node_vectors", "void_angle0", "inertia", "state0")
+    c.solver(y0, ts, cps, keep_trajectory=True, steps_per_interval=9, want_fields=False)
+    o1, g1, _ = c.solver.engine.kinetic_value_and_grad(target, which=sub)
+    g1 = {k: np.array(v) for k, v in g1.items()}
+    c.solver(y0, ts, cps, keep_trajectory=True, steps_per_interval=9, want_fields=False)
+    o2, g2, _ = c.solver.engine.kinetic_value_and_grad(target)
+    assert np.array_equal(o1, o2) and np.all(o1 > 0)
+    for k in sub:
+        assert np.abs(g1[k]).max() > 0 and relerr(g1[k], np.array(g2[k])) < 1e-12, k
