@@ -1434,7 +1434,7 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
     for (size_t b = 0; b < nb; ++b) {
       double* r = S.data() + m * (2 * pl.tab.s) * nb * kPos + b * kPos;
       for (int d = 0; d < 3; ++d) r[d] = u[m * nb * 3 + b * 3 + d];
-      r[3] = cos(0.5 * r[2]); r[4] = sin(0.5 * r[2]);
+      r[3] = sin(0.5 * r[2]);
     }
   HIP_OK(hipMemcpyAsync(h->d_POS.p, S.data(), sizeof(double) * S.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_tmp.ensure(B * pl.n_slots));

@@ -42,8 +42,8 @@ constexpr int kWavesPerWg = kThreads / 64;
 constexpr int kAccCap = 1 << 20;   // accepted step times recorded per member (adaptive)
 constexpr int kMaxGraphSteps = 256;
 constexpr int kMaxGroups = 64;   // member groups (one stream each): size of the cursor tables and stride of the graph-cache key
-constexpr int kPos = 6;   // doubles per unit position record: x y th cos(th/2) sin(th/2) pad   (three 16-byte chunks)
-constexpr int kStep = 9;  // doubles per unit in a trajectory checkpoint: position record + velocity (3)
+constexpr int kPos = 4;   // doubles per unit position record: x y th sin(th/2)   (two 16-byte chunks; cos(th/2) is derived: half_cos)
+constexpr int kStep = kPos + 3;  // doubles per unit in a trajectory checkpoint: position record + velocity (3)
 
 struct Seg {            // one graph replay worth of steps
   double t_interval;    // timepoints[k]
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
   if (d == 2) {
     double sn, cs;
     fast_sincos(0.5 * q, &sn, &cs);
-    pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
+    pr[3] = sn;
   }
 }
 
@@ -288,8 +288,8 @@ struct LaneIn {
 };
 
 struct Partner {
-  double2 b0, b1, rp;
-  double b2, phi;
+  double2 b0, b1, rp;      // (x, y), (theta, sin(theta/2)), node vector
+  double phi;
 };
 
 template <int CONTACT>
@@ -297,7 +297,6 @@ __device__ __forceinline__ void load_partner(const MemberBases& B, int pslot, co
   const u32 rec = (u32)(pslot >> 2) * (kPos * 8);
   P.b0 = ldg<double2>(POSin, rec);
   P.b1 = ldg<double2>(POSin, rec + 16);
-  P.b2 = ldg<double>(POSin, rec + 32);
   P.rp = ldg<double2>(B.p_r, (u32)pslot * 16);
   P.phi = CONTACT == 1 ? ldg<double>(B.p_phi, (u32)pslot * 8) : 0.0;
 }
@@ -321,7 +320,7 @@ template <int CONTACT>
 __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B, int slot, const double* POSin, LaneRaw& R) {
   const int b = slot >> 2, k = slot & 3;
   R.info = ldg<int>(c.slot_info, (u32)slot * 4);
-  R.pc = k < 3 ? ldg<double2>(POSin, ((u32)b * kPos + 2 * k) * 8) : make_double2(0.0, 0.0);
+  R.pc = k < 2 ? ldg<double2>(POSin, ((u32)b * kPos + 2 * k) * 8) : make_double2(0.0, 0.0);
   R.ro = ldg<double2>(B.p_r, (u32)slot * 16);
   // branch-free (a branch here would end the batch of loads): the unused one of the two reads one shared valid address
   R.lidx = (int)ldg<uint8_t>(c.l_dict_on ? (const void*)B.p_lidx : (const void*)B.cst, c.l_dict_on ? (u32)slot : 0u);
@@ -355,9 +354,10 @@ __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases&
   }
   if (CONTACT) { L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2]; }
   L.o.x = quad_bcast<0>(R.pc.x); L.o.y = quad_bcast<0>(R.pc.y);
-  L.o.th = quad_bcast<1>(R.pc.x); L.o.ch = quad_bcast<1>(R.pc.y);
-  L.o.sh = quad_bcast<2>(R.pc.x);
-  L.p.x = R.P.b0.x; L.p.y = R.P.b0.y; L.p.th = R.P.b1.x; L.p.ch = R.P.b1.y; L.p.sh = R.P.b2;
+  L.o.th = quad_bcast<1>(R.pc.x); L.o.sh = quad_bcast<1>(R.pc.y);
+  L.o.ch = half_cos(L.o.th, L.o.sh);
+  L.p.x = R.P.b0.x; L.p.y = R.P.b0.y; L.p.th = R.P.b1.x; L.p.sh = R.P.b1.y;
+  L.p.ch = half_cos(L.p.th, L.p.sh);
   L.rox = R.ro.x; L.roy = R.ro.y; L.rpx = R.P.rp.x; L.rpy = R.P.rp.y;
   L.lx = lv.x; L.ly = lv.y;
   if (c.l_dict_on) { L.l0 = ln.x; L.il0 = ln.y; }
@@ -537,22 +537,22 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
     return;
   }
   if (out_buf == -1) return;
-  // ---- publish the next stage record: lanes 0..2 each store one aligned 16-byte chunk (x,y) (th,ch) (sh,0)
+  // ---- publish the next stage record: lanes 0 and 1 each store one aligned 16-byte chunk (x, y) (th, sin th/2)
   const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
   double sn, cs;
   fast_sincos(0.5 * th2, &sn, &cs);
-  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
+  const double2 chunk = k == 0 ? make_double2(qnext, y1) : make_double2(th2, sn);
   if (k < 3 && !(c.ablate & 2)) {
     const u32 o_chunk = ((u32)b * kPos + 2 * k) * 8;
     if (out_buf >= 0) {
-      stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
+      if (k < 2) stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
       stg<double>(c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
     }
     if (write_traj || out_buf < -1) {
       // state checkpoint: the new step state, once more; records checkpoint (out_buf < -1): the record goes ONLY there, the
       // next launch reads it from there and so does the reverse sweep
       double* tr = out_buf < -1 ? traj_rec(c, m, out_buf, n) : traj_rec(c, m, -1, n + 1);
-      stg<double2>(tr, o_chunk, chunk);
+      if (k < 2) stg<double2>(tr, o_chunk, chunk);
       stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
     }
   }
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
     }
     // commit
     if (k < 3) {
-      *reinterpret_cast<double2*>(POS0 + 2 * k) = *reinterpret_cast<const double2*>(POS3 + 2 * k);
+      if (k < 2) *reinterpret_cast<double2*>(POS0 + 2 * k) = *reinterpret_cast<const double2*>(POS3 + 2 * k);
       VEL0[dof] = v1;
       Am[dof] = a6;
     }
@@ -648,9 +648,9 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
   const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
   double sn, cs;
   fast_sincos(0.5 * th2, &sn, &cs);
-  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
+  const double2 chunk = k == 0 ? make_double2(qnext, y1) : make_double2(th2, sn);
   if (k < 3) {
-    *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
+    if (k < 2) *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
     c.VEL[((size_t)m * c.nbuf + 1) * nd + dof] = vnext;
   }
 }
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kThreads) void k_init_tm(DevCtx c, const double* st
   if (d == 2) {
     double sn, cs;
     fast_sincos(0.5 * q, &sn, &cs);
-    pr[3] = cs; pr[4] = sn; pr[5] = 0.0;
+    pr[3] = sn;
   }
 }
 
@@ -737,9 +737,9 @@ __device__ __forceinline__ void rebuild_record(const DevCtx& c, int m, int b, in
   const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
   double sn, cs;
   fast_sincos(0.5 * th2, &sn, &cs);
-  const double2 chunk = k == 0 ? make_double2(qnext, y1) : (k == 1 ? make_double2(th2, cs) : make_double2(sn, 0.0));
+  const double2 chunk = k == 0 ? make_double2(qnext, y1) : make_double2(th2, sn);
   if (k < 3) {
-    stg<double2>(c.POS + ((size_t)m * c.nbuf + r) * (u32)c.n_blocks * kPos, ((u32)b * kPos + 2 * k) * 8, chunk);
+    if (k < 2) stg<double2>(c.POS + ((size_t)m * c.nbuf + r) * (u32)c.n_blocks * kPos, ((u32)b * kPos + 2 * k) * 8, chunk);
     stg<double>(c.VEL + ((size_t)m * c.nbuf + r) * nd, o_dof, vnext);
   }
 }

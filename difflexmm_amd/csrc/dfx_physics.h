@@ -154,6 +154,15 @@ DFX_HD void fast_sincos(double x, double* sn, double* cs) {
     sincos(x, sn, cs);
   }
 }
+// cos(th/2) from th and sh = sin(th/2): the stage records keep the sine only (32-byte records, two gathers per partner instead of
+// three); |cos| = sqrt(1 - sh^2) is exact to rounding for the moderate rotations a lattice takes and loses digits only within a
+// fraction of a degree of |th| = pi (absolute error ~1e-16 / |cos|); the sign follows the quadrant of th/2.
+DFX_HD double half_cos(double th, double sh) {
+  const double t = th * 0.07957747154594767280;                 // th / (4 pi): cos(th/2) = cos(2 pi t)
+  const double f = t - rint(t);
+  const double c = sqrt(fmax(0.0, fma(-sh, sh, 1.0)));
+  return fabs(f) <= 0.25 ? c : -c;
+}
 // wrap an angle into [-pi, pi] (value only; derivative 1)
 DFX_HD double twrap(double a) { return a - kTwoPi * rint(a * (1.0 / kTwoPi)); }
 DFX_HD Dual twrap(Dual a) { return Dual(twrap(a.v), a.e); }
