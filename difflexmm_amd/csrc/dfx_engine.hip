@@ -240,7 +240,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   const int rb = (c.AD && !local_only) ? (i >= 2 ? i - 1 : (i == 0 ? s - 1 : 0)) : 0;
   const StageCoef rc = stage_coef(h->pl.tab, rb > 0 ? rb - 1 : 0);
   if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
-  else if (c.AD) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  else if (c.AD) hipLaunchKernelGGL((k_adj_stage_rb<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {

@@ -26,6 +26,9 @@ using namespace dfx;
 #ifndef DFX_ADJ_OCC
 #define DFX_ADJ_OCC
 #endif
+#ifndef DFX_ADJ_RB_OCC
+#define DFX_ADJ_RB_OCC __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 
 namespace {
 
@@ -761,8 +764,8 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
-__global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
-                                                        int local_only, StageCoef rc, int rb) {
+__device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& ac, int i, int j, int in_buf, int wbuf_static,
+                                               int local_only, const StageCoef& rc, int rb) {
   const int m = blockIdx.y + c.m0;
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
@@ -979,6 +982,19 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, Ad
     if (i > 0) rebuild_record(c, m, b, k, rc, rb, n, h, t_n);
     else if (n > 0) rebuild_record(c, m, b, k, rc, rb, n - 1, h_before, c.t_steps ? c.t_steps[n - 1] : t_n - h_before);
   }
+}
+
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD>
+__global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
+                                                        int local_only, StageCoef rc, int rb) {
+  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
+}
+// The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry
+// point, so that its occupancy can be pinned (DFX_ADJ_RB_OCC) without touching the others.
+template <int MODEL, int CONTACT>
+__global__ __launch_bounds__(kThreads) DFX_ADJ_RB_OCC void k_adj_stage_rb(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
+                                                           int local_only, StageCoef rc, int rb) {
+  adj_stage_body<MODEL, CONTACT, 0, 1>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 
 // start of the reverse sweep: lambda_N = G_last; kbar_{s-1} of the last step into buffer `buf`
