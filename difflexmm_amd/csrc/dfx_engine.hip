@@ -215,6 +215,8 @@ static AdjCoef adj_coef(const Tableau& T, int i) {
   } else {
     ac.col[T.s] = T.a[T.s][T.s - 1];
   }
+  for (int j = i + 1; j < T.s; ++j) ac.cur[j] = T.a[j][i];
+  ac.cur[T.s] = T.a[T.s][i];
   ac.c_i = T.c[i];
   return ac;
 }

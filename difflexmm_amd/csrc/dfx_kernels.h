@@ -81,6 +81,8 @@ struct StageCoef {
 // reverse-stage coefficients: kbar_{i-1} = h (b_{i-1} lambda + sum_{j>=i} a[j][i-1] Ybar_j)
 struct AdjCoef {
   double col[kMaxStages + 1];  // col[j] = a[j][i-1] for j in i..s-1, col[s] = b_{i-1};  at i == 0: col[s] = b_{s-1}
+  double cur[kMaxStages + 1];  // cur[j] = a[j][i] for j in i+1..s-1, cur[s] = b_i: Kbar_q of THIS stage is recomputed from lambda and the
+                               // later stages' Ybar (already loaded for the next stage's Kbar) instead of being stored and re-read
   double c_i;
 };
 
@@ -791,16 +793,19 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     if (!REBUILD) { const double2 wxy = ldg<double2>(Win, gb); wpx = wxy.x; wpy = wxy.y; } else { wpx = ldg<double>(Win, gb); wpy = ldg<double>(Win, gb + 8); }
     wpth = ldg<double>(Win, gb + 16); }
   const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
-  const double kq_in = ldg<double>(c.KQ + ((size_t)m * 2 + win) * nd, o_dof);
+  // Kbar_q of this stage: recomputed in the epilogue from lambda and the later stages' Ybar (already loaded for the next stage's
+  // Kbar) in the records build -- 48 B/unit less than storing and re-reading it; the REBUILD builds (at their register limit, the
+  // second coefficient column costs them scalar-register spills: 42 -> 46.6 us) and the single-RHS VJP hook read the stored / seeded one
+  double kq_in = (REBUILD || local_only) ? ldg<double>(c.KQ + ((size_t)m * 2 + win) * nd, o_dof) : 0.0;
   const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
   const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
   double* YBm = c.YB + (size_t)m * (u32)c.s * nd6;
   double* LAMm = c.LAM + (size_t)m * nd6;
-  double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0;
+  double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0, sqc = 0.0;
   if (!local_only) {
     if (!REBUILD) {
-      if (i == 0 || ac.col[c.s] != 0.0) { const double2 l2 = ldg<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b_i = 0: lambda not needed (Dopri5 stage 1)
+      if (i == 0 || ac.col[c.s] != 0.0 || ac.cur[c.s] != 0.0) { const double2 l2 = ldg<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b = 0: lambda not needed
       double2 yb[kMaxStages];
 #pragma unroll
       for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
@@ -812,6 +817,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
         const double cf = i > 0 ? ac.col[jj] : 1.0;
         sq += cf * yb[jj].x;
         sv += cf * yb[jj].y;
+        sqc += ac.cur[jj] * yb[jj].x;
       }
     } else {
       if (i == 0 || ac.col[c.s] != 0.0) { lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24); }
@@ -947,6 +953,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     }
     const double a_i = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
     double ybq = 0.0, ybv = 0.0;
+    if (!REBUILD && !local_only) kq_in = h * (ac.cur[c.s] * lq + sqc);      // (zero on constrained DOFs: their lambda and Ybar are)
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
@@ -956,9 +963,9 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     if (!REBUILD) stg<double2>(YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
     else { stg<double>(YBm + (size_t)i * nd6, o_b6, ybq); stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
     if (!local_only) {
-      double kq, kv;
+      double kq = 0.0, kv;       // Kbar of the next stage to run (records build: its Kbar_q is recomputed there)
       if (i > 0) {
-        kq = h * (ac.col[c.s] * lq + ac.col[i] * ybq + sq);
+        if (REBUILD) kq = h * (ac.col[c.s] * lq + ac.col[i] * ybq + sq);
         kv = h * (ac.col[c.s] * lv + ac.col[i] * ybv + sv);
       } else {
         lq += ybq + sq;
@@ -971,10 +978,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
         if (constrained) { lq = 0.0; lv = 0.0; }
         if (!REBUILD) stg<double2>(LAMm, o_b6, make_double2(lq, lv));
         else { stg<double>(LAMm, o_b6, lq); stg<double>(LAMm, o_b6 + 24, lv); }
-        kq = h_before * ac.col[c.s] * lq;
+        if (REBUILD) kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
-      stg<double>(c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
+      if (REBUILD) stg<double>(c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
       stg<double>(c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
     }
   }
