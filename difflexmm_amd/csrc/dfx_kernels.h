@@ -303,7 +303,7 @@ __device__ __forceinline__ void load_partner(const MemberBases& B, int pslot, co
   P.b0 = ldg<double2>(POSin, rec);
   P.b1 = ldg<double2>(POSin, rec + 16);
   P.rp = ldg<double2>(B.p_r, (u32)pslot * 16);
-  P.phi = CONTACT == 1 ? ldg<double>(B.p_phi, (u32)pslot * 8) : 0.0;
+  P.phi = 0.0;      // angle contact: the void angles are loaded by resolve_lane, and only where the contact can engage
 }
 
 // Everything a lane needs for its ligament, in two phases so that every load that does not depend on another
@@ -318,12 +318,13 @@ struct LaneRaw {
   Partner P;
   double2 pc, ro, lv;
   double ks, ksh, kr, phi;
-  int info, guess, lidx;
+  int info, guess, lidx, slot;
 };
 
 template <int CONTACT>
 __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B, int slot, const double* POSin, LaneRaw& R) {
   const int b = slot >> 2, k = slot & 3;
+  R.slot = slot;
   R.info = ldg<int>(c.slot_info, (u32)slot * 4);
   R.pc = k < 2 ? ldg<double2>(POSin, ((u32)b * kPos + 2 * k) * 8) : make_double2(0.0, 0.0);
   R.ro = ldg<double2>(B.p_r, (u32)slot * 16);
@@ -332,7 +333,7 @@ __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B
   R.lv = ldg<double2>(c.l_dict_on ? B.cst : B.p_l, c.l_dict_on ? 0u : (u32)slot * 16);
   R.ks = R.ksh = R.kr = 0.0;
   if (!c.k_uniform) { R.ks = ldg<double>(B.p_k, (u32)slot * 32); R.ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); R.kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
-  R.phi = CONTACT == 1 ? ldg<double>(B.p_phi, (u32)slot * 8) : 0.0;
+  R.phi = 0.0;
   const int delta = k == 0 ? c.pred[0] : (k == 1 ? c.pred[1] : (k == 2 ? c.pred[2] : c.pred[3]));   // selects: a dynamic index would be a memory load
   R.guess = min(max(slot + delta, 0), c.n_slots - 1);
   load_partner<CONTACT>(B, R.guess, POSin, R.P);
@@ -353,16 +354,24 @@ __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases&
   const double* cst = B.cst;
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
-  if (CONTACT == 1) {
-    L.phi1 = (info & 1) ? R.P.phi : R.phi;
-    L.phi2 = (info & 1) ? R.phi : R.P.phi;
-  }
   if (CONTACT) { L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2]; }
   L.o.x = quad_bcast<0>(R.pc.x); L.o.y = quad_bcast<0>(R.pc.y);
   L.o.th = quad_bcast<1>(R.pc.x); L.o.sh = quad_bcast<1>(R.pc.y);
   L.o.ch = half_cos(L.o.th, L.o.sh);
   L.p.x = R.P.b0.x; L.p.y = R.P.b0.y; L.p.th = R.P.b1.x; L.p.sh = R.P.b1.y;
   L.p.ch = half_cos(L.p.th, L.p.sh);
+  if (CONTACT == 1) {
+    // culling bound of pack_params (cst[9], cst[10]): a ligament whose ends have turned against each other by less than kappa_safe
+    // cannot touch whatever its undeformed void angles are -- they are not loaded (32 B/unit and one gather), the member's smallest
+    // one stands in and yields exact zeros; the others (rare) fetch theirs now, a second round trip for those lanes only
+    double ph_o = cst[10], ph_p = cst[10];
+    if (info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) {
+      ph_o = ldg<double>(B.p_phi, (u32)R.slot * 8);
+      ph_p = ldg<double>(B.p_phi, (u32)pslot * 8);
+    }
+    L.phi1 = (info & 1) ? ph_p : ph_o;
+    L.phi2 = (info & 1) ? ph_o : ph_p;
+  }
   L.rox = R.ro.x; L.roy = R.ro.y; L.rpx = R.P.rp.x; L.rpy = R.P.rp.y;
   L.lx = lv.x; L.ly = lv.y;
   if (c.l_dict_on) { L.l0 = ln.x; L.il0 = ln.y; }

@@ -193,6 +193,18 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       }
     }
     if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + i] = q->contact[m * 3 + i];
+    if (q->contact && pl.contact == 1) {
+      // Angle contact, culling bound: with phi in [phi_lo, phi_hi] over the member's ligament ends, a relative rotation |kappa| <= kappa_safe
+      // = min(phi_lo - cutoff, pi - phi_hi) leaves both void angles wrap(phi -+ kappa) in [cutoff, pi]: the penalty and all its
+      // derivatives are exactly zero whatever phi is, so the kernels do not load phi for such ligaments (cst[9] = kappa_safe with a
+      // rounding margin, <= 0: never skip; cst[10] = phi_lo, the stand-in value).
+      double lo = 1e300, hi = -1e300;
+      for (int s_ = 0; s_ < NS; ++s_) if (pl.slot_info[s_] >= 0) { const double v = out.p_phi[(size_t)m * NS + s_]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+      double safe = -1.0;
+      if (lo <= hi) { const double a = lo - q->contact[m * 3 + 1], b2 = 3.14159265358979323846 - hi; safe = (a < b2 ? a : b2) * (1.0 - 1e-12) - 1e-12; }
+      out.cst[(size_t)m * 16 + 9] = safe;
+      out.cst[(size_t)m * 16 + 10] = lo <= hi ? lo : 0.0;
+    }
     if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + 3 + i] = kb[i];
     {  // dictionary of reference vectors
       int n_dict = 0;
