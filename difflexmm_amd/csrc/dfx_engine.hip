@@ -1176,7 +1176,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     for (int k = Tn - 2; k >= 0; --k) {
       // the buffer holds the records of THIS interval only: shift the base so that the kernels keep indexing by the global step
       // (a per-interval offset inside the kernels cost the forward kernel two hot-path spills: profiles/r02_fwd_spill_regression.txt)
-      c.traj = h->d_traj.p - (size_t)h->step0[k] * (size_t)c.rps * ((size_t)pl.n_blocks * kStep);
+      c.traj = h->d_traj.p - (size_t)h->step0[k] * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
       for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
         const Group& gr = h->groups[gi];
         const DevCtx cg = group_ctx(h, c, gi);

@@ -91,7 +91,7 @@ struct DevCtx {
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
-  long long traj_stride;  // elements between members in traj
+  long long traj_stride;  // unused (the checkpoint is record-major: see traj_rec)
   int rps;                // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   int lam_pairs;          // layout of LAM / YB: 1 = (q, v) of one DOF side by side (b*6 + 2d, + 1), one 16-B access per lane; 0 = (q0 q1 q2 v0 v1 v2)
                           // -- the REBUILD builds of the reverse stage (stage checkpoint, per-ligament gradients) sit at their register limit
@@ -125,7 +125,8 @@ struct DevCtx {
   double* fields_dev;     // batch * T * n_blocks*6 (adaptive mode writes its dense output here)
   double rtol, atol;
   // state: nbuf = 2s stage buffers per member (two sets for the two-chain reverse sweep); buffer 0 = current step state
-  double* traj;           // batch * traj_stride   checkpoints: per step [POS n_blocks*6 | VEL n_blocks*3]
+  double* traj;           // checkpoints, record-major: [record ordinal][member][POS n_blocks*kPos | VEL n_blocks*3] -- all members' records of
+                          // one (step, stage) are contiguous: a launch streams ONE region however many small members it integrates
   double* POS;            // batch * nbuf * n_blocks*kPos
   double* VEL;            // batch * nbuf * n_blocks*3
   double* A;              // batch * s * n_blocks*3
@@ -175,7 +176,7 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 // buf >= 0: stage buffer `buf`;  buf < 0: record (-1 - buf) of step n in the trajectory checkpoint (record 0 = the step state;
 // records 1 .. s-1 exist in the records checkpoint only; record s of step n IS record 0 of step n + 1)
 __device__ __forceinline__ double* traj_rec(const DevCtx& c, int m, int buf, long long n) {
-  return c.traj + (size_t)m * c.traj_stride + ((size_t)n * c.rps + (size_t)(-1 - buf)) * ((size_t)c.n_blocks * kStep);
+  return c.traj + (((size_t)n * c.rps + (size_t)(-1 - buf)) * (u32)c.batch + (u32)m) * ((size_t)c.n_blocks * kStep);
 }
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
   if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
@@ -731,7 +732,7 @@ __device__ __forceinline__ void rebuild_record(const DevCtx& c, int m, int b, in
   const int kd = k < 3 ? k : 2;
   const u32 nd = (u32)c.n_blocks * 3;
   const u32 o_dof = ((u32)b * 3 + kd) * 8;
-  const double* tr = c.traj + (size_t)m * c.traj_stride + (size_t)nr * c.n_blocks * kStep;
+  const double* tr = c.traj + ((size_t)nr * (u32)c.batch + (u32)m) * ((size_t)c.n_blocks * kStep);      // step states only here (rps == 1)
   const double qn = ldg<double>(tr, ((u32)b * kPos + kd) * 8);
   const double vn = ldg<double>(tr + (size_t)c.n_blocks * kPos, o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
