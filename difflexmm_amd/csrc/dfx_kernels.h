@@ -796,7 +796,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   // per-lane byte offsets shared by the per-DOF arrays; lambda and Ybar: see DevCtx::lam_pairs (= !REBUILD)
   const u32 o_dof = (u32)dof * 8, o_b6 = REBUILD ? ((u32)b * 6 + kd) * 8 : ((u32)b * 6 + 2 * kd) * 8;
   const double* Win = c.W + ((size_t)m * 2 + win) * nd;
-  const double w_d = ldg<double>(Win, o_dof);
+  double w_d = (REBUILD || local_only) ? ldg<double>(Win, o_dof) : 0.0;    // records build: own w recomputed below (like Kbar_q)
   // partner's w from the guessed slot (same batch as everything else)
   double wpx, wpy, wpth;
   { const u32 gb = (u32)(R.guess >> 2) * 24;
@@ -812,7 +812,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
   double* YBm = c.YB + (size_t)m * (u32)c.s * nd6;
   double* LAMm = c.LAM + (size_t)m * nd6;
-  double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0, sqc = 0.0;
+  double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0, sqc = 0.0, svc = 0.0;
   if (!local_only) {
     if (!REBUILD) {
       if (i == 0 || ac.col[c.s] != 0.0 || ac.cur[c.s] != 0.0) { const double2 l2 = ldg<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b = 0: lambda not needed
@@ -828,7 +828,11 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
         sq += cf * yb[jj].x;
         sv += cf * yb[jj].y;
         sqc += ac.cur[jj] * yb[jj].x;
+        svc += ac.cur[jj] * yb[jj].y;
       }
+      // own w = Kbar_v / m of this stage, from the same values (zero on constrained DOFs by itself: their lambda and Ybar are stored
+      // as zeros); the neighbours read the copy the previous launch stored -- equal to rounding
+      w_d = ((c.t_steps ? c.t_steps[n + 1] - c.t_steps[n] : sg.h) * (ac.cur[c.s] * lv + svc)) * invm;
     } else {
       if (i == 0 || ac.col[c.s] != 0.0) { lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24); }
       double yq[kMaxStages], yv[kMaxStages];
