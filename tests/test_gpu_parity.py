@@ -371,3 +371,12 @@ def test_design_subset_of_the_gradient_equals_the_full_set(hip_lib, monkeypatch,
     assert np.array_equal(o1, o2) and np.all(o1 > 0)
     for k in sub:
         assert np.abs(g1[k]).max() > 0 and relerr(g1[k], np.array(g2[k])) < 1e-12, k
+
+
+@pytest.mark.parametrize("lattice,n", [("quads", 9), ("kagome", 5)])
+def test_rhs_and_vjp_with_rotations_in_every_quadrant(hip_lib, lattice, n):
+    """The stage records keep sin(theta/2) only; cos(theta/2) = +-sqrt(1 - sin^2) with the sign from the quadrant of theta/2
+    (dfx_physics.h: half_cos).  Block rotations drawn with a standard deviation of 3 rad put theta/2 in all four quadrants and beyond
+    one turn: one RHS and every VJP against autograd through the oracle (digits are lost only within a fraction of a degree of
+    |theta| = pi, hence 1e-10 instead of 1e-12)."""
+    parity.check_rhs_and_vjp(None, lattice, n, True, False, seed=11, scale_th=3.0, rtol=1e-10)
