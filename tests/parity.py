@@ -17,8 +17,8 @@ def T64(x, grad=False):
     return torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=grad)
 
 
-def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=True, scale_th=0.15, rtol=None):
-    cut = (125.0 if lattice == "kagome" else 42.0)
+def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=True, scale_th=0.15, rtol=None, cutoff_deg=None):
+    cut = cutoff_deg if cutoff_deg is not None else (125.0 if lattice == "kagome" else 42.0)
     c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, per_bond_k=per_bond_k)
     s = c.solver
     flat = s._flatten(c.cp)

@@ -380,3 +380,17 @@ def test_rhs_and_vjp_with_rotations_in_every_quadrant(hip_lib, lattice, n):
     one turn: one RHS and every VJP against autograd through the oracle (digits are lost only within a fraction of a degree of
     |theta| = pi, hence 1e-10 instead of 1e-12)."""
     parity.check_rhs_and_vjp(None, lattice, n, True, False, seed=11, scale_th=3.0, rtol=1e-10)
+
+
+def test_contact_culling_bound_with_some_ligaments_beyond_it(hip_lib):
+    """Angle contact with the cutoff a little below the smallest undeformed void angle: the per-member culling bound
+    (pack_params: kappa_safe = min(phi_lo - cutoff, pi - phi_hi)) is then a few degrees, the random rotations put some ligaments
+    beyond it (they load their void angles and may touch) and leave the others culled (exact zeros without loading them).
+    RHS, y_bar and every parameter gradient, the contact constants included, against autograd through the oracle."""
+    from difflexmm_amd import geometry as geo
+    from .common import Case
+    c = Case("quads", 9, True, True, seed=3, lib=None, cutoff_deg=42.0)
+    phi = geo.void_angles0(c.cnv, c.bonds)
+    lo = float(np.min(phi)) * 180 / np.pi
+    errs = parity.check_rhs_and_vjp(None, "quads", 9, True, True, seed=3, scale_th=0.06, cutoff_deg=lo - 2.0)
+    assert errs["contact"] < 1e-12
