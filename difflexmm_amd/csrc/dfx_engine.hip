@@ -445,9 +445,10 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
   auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
   int mode = forced;
   if (mode < 0) {
-    // records pay on large lattices; with many small members (24x16 x 256) every launch touches one far-apart record per member
-    // (member-major checkpoint, 664 MB apart) and measured 3.6 s per evaluation against 2.65 s at the stages level
-    // (profiles/r02_config5_checkpoint_levels.txt): small lattices keep their records in the cache-resident ping-pong buffers
+    // records pay on large lattices (reverse launch 32 us against 42 us at the stages level).  With many small members (24x16 x 256,
+    // three engines side by side) they gain 5 % of device time at twice the checkpoint memory, and the engines then compete for the
+    // HBM (profiles/r02_config5_checkpoint_levels.txt; with the member-major checkpoint of mid-round 2 they LOST 35 %: one far-apart
+    // record per member and launch; the checkpoint is record-major since): small lattices stay at the stages level
     if (pl.n_blocks >= 4096 && fits(grow(want_rec, have_t))) mode = kCkRecords;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
     else if (fits(grow(want_state, have_t))) mode = kCkState;
