@@ -169,3 +169,31 @@ def test_second_solve_with_a_larger_segment_table_on_one_handle(hip_lib, cpu_lib
             out.append((f, tree.geometrical_params.centroid_node_vectors, s0))
         assert relerr(out[0][0], out[1][0]) < 1e-10
         assert relerr(out[0][1], out[1][1]) < 1e-8 and relerr(out[0][2], out[1][2]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_c3_design_gradient_matches_finite_differences_of_the_objective(hip_lib):
+    """No oracle involved: C3 at full size (128x128 quads, contact, damping, pulse), 2 designs, 300 Dopri5 steps -- the design
+    gradient of the target kinetic energy (reverse sweep + host-side design maps) against central differences of the objective along
+    a random direction of the 66 048 design shifts (tools/fd_check_fullsize.py runs the same check over 1 000 steps)."""
+    import bench
+    from difflexmm_amd.problems import design_gradients
+    K, eps = 300, 1e-5
+    fw, obj, designs = bench.c3_problem(128, 3, 2)
+    rng = np.random.default_rng(7)
+    direction = [tuple(rng.normal(size=a.shape) for a in d) for d in designs]
+    bench.prepare(fw, designs, K)
+    res = bench.execute(fw, obj, adjoint=True)
+    grads = design_gradients(fw, designs, {k: np.array(v) for k, v in res["grads"].items()})
+    an = np.array([sum(float((g * d).sum()) for g, d in zip(gm, dm)) for gm, dm in zip(grads, direction)])
+
+    def objective(ds):
+        bench.prepare(fw, ds, K)
+        eng = fw.solve_dynamics.engine
+        eng.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=True, want_fields=False)
+        return np.array(eng.kinetic_value_and_grad(obj.target_blocks, which=("inertia",))[0])
+    plus = [tuple(a + eps * d for a, d in zip(dm, dd)) for dm, dd in zip(designs, direction)]
+    minus = [tuple(a - eps * d for a, d in zip(dm, dd)) for dm, dd in zip(designs, direction)]
+    fd = (objective(plus) - objective(minus)) / (2 * eps)
+    fw.solve_dynamics.engine.close()
+    assert np.all(np.abs(fd) > 0) and np.all(np.abs(an - fd) < 1e-5 * np.abs(fd)), (an, fd)
