@@ -253,6 +253,22 @@ class DynamicSolver:
                     term.scatter_grad(g5, tree.constraint_params)
         return trees, s0
 
+    def vjp_raw(self, fields_bar, which=("centroid_node_vectors", "void_angle0", "inertia")):
+        """Reverse sweep for a cotangent of the fields, returning the engine's raw gradient arrays (batch-leading) of the requested
+        parameter groups only -- by default what a design reaches.  Asking for every ControlParams leaf (``vjp``) runs the reverse
+        stage in its build that also accumulates per-ligament and damping gradients, at up to twice the time per launch."""
+        if self._last is None:
+            raise RuntimeError("vjp_raw: call the solver with keep_trajectory=True first")
+        fb = np.asarray(fields_bar, dtype=float)
+        if fb.ndim == 4:
+            fb = fb[None]
+        which = tuple(w for w in which if not (w == "void_angle0" and self.spec.contact != _b.CONTACT_ANGLE))
+        if self.spec.contact == _b.CONTACT_DISTANCE and "block_centroids" not in which:
+            which = which + ("block_centroids",)
+        grads, stats = self.engine.adjoint(fb, which=which)
+        self.adjoint_stats = stats
+        return grads
+
     def kinetic_energy_value_and_vjp(self, target_blocks):
         """objective = sum_t sum_{b in target} m v^2/2 (energy.py:494-499 over problems/quads_focusing.py:461-467),
         evaluated and differentiated on the device (one engine call: the objective rides along with the reverse sweep)."""

@@ -429,18 +429,17 @@ class TargetAngularMomentum:
         fb[:, 1, tb, 0] = -pos[..., 1] * inertia[:, 0]
         fb[:, 1, tb, 1] = pos[..., 0] * inertia[:, 1]
         fb[:, 1, tb, 2] = inertia[:, 2]
-        tree, _ = fw.solve_dynamics.vjp(fb)
-        cnv_bar = tree.geometrical_params.centroid_node_vectors.copy()
-        cen_bar = np.array(tree.geometrical_params.block_centroids, dtype=float, copy=True)
+        # only the parameter groups a design reaches are differentiated on the device (TargetKineticEnergy.value_and_grad)
+        raw = {k: np.array(v, dtype=float) for k, v in fw.solve_dynamics.vjp_raw(fb).items()}
         # explicit terms: positions contain the block centroids; the inertia of the target blocks
-        cen_bar[tb, 0] += (vel[..., 1] * inertia[:, 1]).sum(0)
-        cen_bar[tb, 1] += (-vel[..., 0] * inertia[:, 0]).sum(0)
-        ib = np.zeros((fw.geometry.n_blocks, 3))
-        ib[tb, 0] = (-pos[..., 1] * vel[..., 0]).sum(0)
-        ib[tb, 1] = (pos[..., 0] * vel[..., 1]).sum(0)
-        ib[tb, 2] = vel[..., 2].sum(0)
-        cnv_bar += compute_inertia_vjp(sol.centroid_node_vectors, fw.density, ib)[0]
-        return val, fw.geometry.vjp(design, cnv_bar, cen_bar)
+        cen_bar = raw["block_centroids"] if "block_centroids" in raw else np.zeros((1, fw.geometry.n_blocks, 2))
+        cen_bar[0, tb, 0] += (vel[..., 1] * inertia[:, 1]).sum(0)
+        cen_bar[0, tb, 1] += (-vel[..., 0] * inertia[:, 0]).sum(0)
+        raw["block_centroids"] = cen_bar
+        raw["inertia"][0, tb, 0] += (-pos[..., 1] * vel[..., 0]).sum(0)
+        raw["inertia"][0, tb, 1] += (pos[..., 0] * vel[..., 1]).sum(0)
+        raw["inertia"][0, tb, 2] += vel[..., 2].sum(0)
+        return val, design_gradients(fw, [design], raw)[0]
 
 
 class MultiInputTargetKineticEnergy:
