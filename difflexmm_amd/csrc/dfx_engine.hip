@@ -449,7 +449,9 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
     // three engines side by side) they gain 5 % of device time at twice the checkpoint memory, and the engines then compete for the
     // HBM (profiles/r02_config5_checkpoint_levels.txt; with the member-major checkpoint of mid-round 2 they LOST 35 %: one far-apart
     // record per member and launch; the checkpoint is record-major since): small lattices stay at the stages level
-    if (pl.n_blocks >= 4096 && fits(grow(want_rec, have_t))) mode = kCkRecords;
+    // ... unless their records checkpoint is small (config 5's share of one of 8 GPUs, 32 designs per input: 16 GB; 13 % less device
+    // time, 9 % less wall: profiles/r02_config5_checkpoint_levels.txt)
+    if ((pl.n_blocks >= 4096 || want_rec * sizeof(double) <= ((size_t)24 << 30)) && fits(grow(want_rec, have_t))) mode = kCkRecords;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
     else if (fits(grow(want_state, have_t))) mode = kCkState;
     else mode = kCkSegments;
