@@ -1060,17 +1060,21 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   memset(&sc_err, 0, sizeof(sc_err));
   for (int l = 0; l < 7; ++l) { sc_err.cv[l] = D.e[l]; sc_err.cq[l] = D.ee[l]; }
   sc_err.c_i = 1.0; sc_err.c_next = 1.0;
-  auto enqueue_attempt = [&]() {
-    // evaluations at S_1..S_5, candidate y1 into buffer 3, then the FSAL evaluation with the error estimate
+  // one of the eight launches of an attempt (p = 0..4: evaluations at S_1..S_5, the last one leaves the candidate y1 in buffer 3;
+  // 5: the FSAL evaluation with the error estimate; 6: controller; 7: dense output / commit / next stage-1 record) for the members of
+  // one context (the whole batch, or one member group on its own stream)
+  auto launch_phase = [&](int p, const DevCtx& cc, hipStream_t st, dim3 grid, unsigned nm) {
     static const int inb[6] = {0, 1, 2, 1, 2, 1}, outb[6] = {0, 2, 1, 2, 1, 3};
-    for (int i = 1; i <= 5; ++i) launch_fwd(h, c, i, 0, inb[i], outb[i], 0, 0);
-#define DFX_ERR_CASE(M) case M: if (pl.contact == 2) hipLaunchKernelGGL((k_fwd_stage<M, 2>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); else if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); else hipLaunchKernelGGL((k_fwd_stage<M, 0>), slot_grid(h), dim3(kThreads), 0, h->stream, c, sc_err, 6, 0, 3, -1, 0, 2); break;
-    switch (pl.model) { DFX_ERR_CASE(kNonlinear) DFX_ERR_CASE(kLinearized) DFX_ERR_CASE(kSimpleSpring) DFX_ERR_CASE(kStretchTorsion) }
+    if (p < 5) { launch_fwd(h, cc, st, grid, p + 1, 0, inb[p + 1], outb[p + 1], 0, 0); return; }
+    if (p == 5) {
+#define DFX_ERR_CASE(M) case M: if (pl.contact == 2) hipLaunchKernelGGL((k_fwd_stage<M, 2>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, 3, -1, 0, 2); else if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, 3, -1, 0, 2); else hipLaunchKernelGGL((k_fwd_stage<M, 0>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, 3, -1, 0, 2); break;
+      switch (pl.model) { DFX_ERR_CASE(kNonlinear) DFX_ERR_CASE(kLinearized) DFX_ERR_CASE(kSimpleSpring) DFX_ERR_CASE(kStretchTorsion) }
 #undef DFX_ERR_CASE
-    hipLaunchKernelGGL(k_control, dim3((unsigned)B), dim3(kThreads), 0, h->stream, c, n_partials, 2.0 * (double)n_free, Tn);
-    hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn);
-    h->launches += 3;
+    } else if (p == 6) hipLaunchKernelGGL(k_control, dim3(nm), dim3(kThreads), 0, st, cc, n_partials, 2.0 * (double)n_free, Tn);
+    else hipLaunchKernelGGL(k_prepare, grid, dim3(kThreads), 0, st, cc, dc, Tn);
+    h->launches++;
   };
+  auto enqueue_attempt = [&]() { for (int p = 0; p < 8; ++p) launch_phase(p, c, h->stream, slot_grid(h), (unsigned)B); };
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   // stage-1 record of the first attempt (accept = 0: nothing to commit)
   hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn);
@@ -1108,6 +1112,19 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   int rc = 0;
   while (true) {
     if (exec) { HIP_OK(hipGraphLaunch(exec, h->stream)); h->launches += 8LL * kAttemptsPerGraph; }
+    else if (h->groups.size() > 1) {
+      // eager launches that fill the chip: the member groups advance on their own streams, interleaved launch by launch like the
+      // fixed grid (every member carries its own clock, so the groups are independent); the main stream waits for all of them
+      // before the clocks are read
+      if (int rc2 = fork_groups(h)) return rc2;
+      for (int a = 0; a < kAttemptsPerGraph; ++a)
+        for (int p = 0; p < 8; ++p)
+          for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
+            const Group& gr = h->groups[gi];
+            launch_phase(p, group_ctx(h, c, gi), gr.stream, slot_grid(h, gr), (unsigned)gr.nm);
+          }
+      if (int rc2 = join_groups(h)) return rc2;
+    }
     else for (int a = 0; a < kAttemptsPerGraph; ++a) enqueue_attempt();
     attempts_issued += kAttemptsPerGraph;
     HIP_OK(hipMemcpyAsync(clk.data(), h->d_clock.p, sizeof(Clock) * B, hipMemcpyDeviceToHost, h->stream));
@@ -1141,7 +1158,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     stats->rhs_evals = 6 * att + 2;
     stats->launches = h->launches;
     stats->kernel_ms = ms;
-    stats->streams = 1;
+    stats->streams = (!exec && h->groups.size() > 1) ? (int64_t)h->groups.size() : 1;
     stats->stage_kernel_us = att ? 1e3 * ms / (double)(att * 8) : 0.0;
   }
   return 0;

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
 // ---- adaptive step control (jax.experimental.ode semantics) --------------------------------------
 // one workgroup per member: reduce the per-wave partials in a fixed order, decide, advance the clock
 __global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, double two_n_free, int n_timepoints) {
-  const int m = blockIdx.x;
+  const int m = blockIdx.x + c.m0;
   __shared__ double red[kThreads];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n_partials; i += kThreads) acc += c.err_partial[(size_t)m * c.n_wg * kWavesPerWg + i];

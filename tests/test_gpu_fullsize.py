@@ -197,3 +197,21 @@ def test_c3_design_gradient_matches_finite_differences_of_the_objective(hip_lib)
     fd = (objective(plus) - objective(minus)) / (2 * eps)
     fw.solve_dynamics.engine.close()
     assert np.all(np.abs(fd) > 0) and np.all(np.abs(an - fd) < 1e-5 * np.abs(fd)), (an, fd)
+
+
+@pytest.mark.gpu
+def test_adaptive_solve_on_member_group_streams_equals_one_stream(hip_lib, monkeypatch):
+    """The adaptive controller at a size whose launches fill the chip (2 x 128x128: eager attempts, no graph): two member groups on
+    their own streams against all members on one stream -- every member carries its own clock, the fields must agree bit for bit."""
+    import bench
+    out = {}
+    for streams in ("1", "2"):
+        monkeypatch.setenv("DFX_STREAMS", streams)
+        fw, obj, designs = bench.c3_problem(128, 3, 2)
+        bench.prepare(fw, designs, 2 * bench.SPI)
+        eng = fw.solve_dynamics.engine
+        f, st = eng.forward_adaptive(np.zeros((2, 2, 128 * 128, 3)), np.asarray(fw.timepoints), 1e-8, 1e-8)
+        out[streams] = (f, st["streams"], st["steps"], eng.adaptive_step_counts())
+        eng.close()
+    assert out["1"][1] == 1 and out["2"][1] == 2 and out["1"][2] == out["2"][2] > 10
+    assert np.array_equal(out["1"][3], out["2"][3]) and np.array_equal(out["1"][0], out["2"][0]) and np.abs(out["1"][0]).max() > 0
