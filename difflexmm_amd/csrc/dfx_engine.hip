@@ -90,7 +90,7 @@ struct dfx_handle {
   std::vector<Group> groups;
   bool dual_chain = true;
   hipEvent_t ev_fork2 = nullptr;
-  PinnedBuf stage, obj_stage;
+  PinnedBuf stage, obj_stage, zero_phi;   // zero_phi: an all-zero void-angle gradient handed out when the sweep never touched the accumulator
   hipEvent_t ev_fork = nullptr;
   PackedParams pp;
   std::string err;
@@ -100,7 +100,7 @@ struct dfx_handle {
   bool have_params = false, have_traj = false, have_fields = false;
   bool use_graph = true;
   bool want_bond_grads = true, want_fn_grads = true, want_damping_grads = true;
-  DevBuf<int32_t> d_slot_info, d_block_special, d_slot_bond;
+  DevBuf<int32_t> d_slot_info, d_block_special, d_slot_bond, d_touch;
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<double> d_resp;                           // dfx_response_data outputs
   DevBuf<dfx_special> d_special;
@@ -181,6 +181,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
   c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
+  c.touch = h->d_touch.p;
   c.lam_pairs = (c.g_b || c.AD) ? 0 : 1;      // the REBUILD builds of the reverse stage (launch_adj_t) keep the scalar layout
   c.blk_m = h->d_blk_m.p; c.blk_c = h->want_damping_grads ? h->d_blk_c.p : nullptr;
   c.fn_g = h->want_fn_grads ? h->d_fn_g.p : nullptr;
@@ -527,6 +528,7 @@ static int zero_grad_accumulators(dfx_handle* h) {
   const size_t nsp = std::max(1, pl.n_special);
   HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
   HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_touch.p, 0, sizeof(int32_t) * 4, h->stream));
   if (h->want_bond_grads) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
   HIP_OK(hipMemsetAsync(h->d_blk_m.p, 0, sizeof(double) * B * nb * 3, h->stream));
   if (pl.contact == DFX_CONTACT_DISTANCE) HIP_OK(hipMemsetAsync(h->d_g_c.p, 0, sizeof(double) * B * nb * 2, h->stream));
@@ -552,7 +554,22 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
     HIP_OK(hipGetLastError());
     return 0;
   }
-  const bool w_r = want->centroid_node_vectors, w_phi = want->void_angle0 && pl.contact == DFX_CONTACT_ANGLE;
+  const bool w_r = want->centroid_node_vectors;
+  bool w_phi = want->void_angle0 && pl.contact == DFX_CONTACT_ANGLE;
+  // contacts are rare: when no lane of the sweep added to the void-angle accumulator (one flag, known after the sweep) its gradient
+  // is identically zero -- neither re-laid-out nor downloaded (8 MB of the 31 MB that leave the device for 16 x 128x128), the caller
+  // gets a view of a zero buffer that is never written
+  bool phi_zero = false;
+  if (w_phi) {
+    int32_t touched = 1;
+    HIP_OK(hipMemcpyAsync(&touched, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    if (!touched) {
+      const size_t bytes = sizeof(double) * B * nbd * 2;
+      if (h->zero_phi.n < bytes || !h->zero_phi.p) { HIP_OK(h->zero_phi.ensure(bytes)); memset(h->zero_phi.p, 0, h->zero_phi.n); }
+      phi_zero = true; w_phi = false;
+    }
+  }
   const bool w_cen = want->block_centroids && pl.contact == DFX_CONTACT_DISTANCE;
   const bool w_b = h->want_bond_grads && (want->reference_vector || want->k_bond || want->contact);
   const bool w_m = want->inertia, w_c = want->damping && h->want_damping_grads, w_fn = want->fn_params && h->want_fn_grads;
@@ -563,7 +580,7 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   // small host-side results (bond parameters, time-function parameters) live behind the DMA area
   const size_t n_small = (want->reference_vector ? B * nbd * 2 : 0) + (want->k_bond ? B * nbd * 3 : 0) + (want->contact ? B * 3 : 0) +
                          (want->fn_params ? B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS : 0) + (want->damping && !w_c ? B * nb * 3 : 0) +
-                         (want->void_angle0 && !w_phi ? B * nbd * 2 : 0) + (want->block_centroids && !w_cen ? B * nb * 2 : 0);
+                         (want->void_angle0 && !w_phi && !phi_zero ? B * nbd * 2 : 0) + (want->block_centroids && !w_cen ? B * nb * 2 : 0);
   HIP_OK(h->stage.ensure((n_r + n_phi + n_b + n_m + n_c + n_fn + n_lam + n_cen + n_small + 8) * sizeof(double)));
   double* g_r = reinterpret_cast<double*>(h->stage.p);
   double* g_phi = g_r + n_r;
@@ -602,12 +619,13 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   memset(&v, 0, sizeof(v));
   if (w_r) v.centroid_node_vectors = g_r;
   if (w_phi) v.void_angle0 = g_phi;
+  if (phi_zero) v.void_angle0 = reinterpret_cast<double*>(h->zero_phi.p);
   if (w_m) v.inertia = g_m;
   if (w_c) v.damping = g_c;
   if (w_lam) v.state0 = lam;
   if (w_cen) v.block_centroids = cen;
   auto take = [&](size_t n) { double* q = small; small += n; memset(q, 0, sizeof(double) * n); return q; };
-  if (want->void_angle0 && !w_phi) v.void_angle0 = take(B * nbd * 2);
+  if (want->void_angle0 && !w_phi && !phi_zero) v.void_angle0 = take(B * nbd * 2);
   if (want->damping && !w_c) v.damping = take(B * nb * 3);
   if (want->block_centroids && !w_cen) v.block_centroids = take(B * nb * 2);
   if (want->reference_vector) v.reference_vector = take(B * nbd * 2);
@@ -729,7 +747,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   }
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
-            h->d_slot_bond.ensure(pl.n_slots) == hipSuccess &&
+            h->d_slot_bond.ensure(pl.n_slots) == hipSuccess && h->d_touch.ensure(4) == hipSuccess &&
             h->d_special.ensure(std::max(1, pl.n_special)) == hipSuccess && h->d_seg_idx.ensure(2 + kMaxGroups) == hipSuccess &&
             h->d_cur.ensure(kMaxGroups) == hipSuccess;
   if (!ok) { h->err = "hipMalloc (static tables) failed"; return fail(2); }
@@ -747,7 +765,7 @@ int dfx_destroy(dfx_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
-  h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release();
+  h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release(); h->d_touch.release(); h->zero_phi.release();
   h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release(); h->d_resp.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release(); h->d_p_c.release(); h->d_g_c.release();

@@ -139,6 +139,7 @@ struct DevCtx {
   double* g_r;            // batch * n_slots*2     d/d(own node vector)
   double* g_phi;          // batch * n_slots       d/d(void angle): phi1 on the end-0 slot of a ligament, phi2 on its end-1 slot
   double* g_b;            // batch * n_slots*8     d/d(l0(2), k(3), contact(3)) (end-1 slots) or null
+  int* touch;             // touch[0] = 1 once any lane of the sweep has added to the void-angle accumulator (else its download is skipped)
   double* blk_m;          // batch * n_blocks*3    d/d(inertia)
   double* g_c;            // batch * n_blocks*2    d/d(block_centroids) (distance-based contact only)
   int n_npb, pad_npb;     // nodes per block (3 or 4)
@@ -937,7 +938,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
     stg<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
   }
-  if (phi_on) stg<double>(gpm, (u32)slot * 8, p_old - d_phi);
+  if (phi_on) { stg<double>(gpm, (u32)slot * 8, p_old - d_phi); c.touch[0] = 1; }
   // ---- DOF epilogue
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
   if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
