@@ -42,3 +42,17 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     assert n_loads >= 20, f"k_fwd_stage: first vmcnt wait after only {n_loads} loads"
     meta = re.search(r"\.name:\s+_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii.*?\.vgpr_count:\s+(\d+)", txt, re.S)
     assert meta and int(meta.group(1)) <= 102, "k_fwd_stage<nonlinear,contact> no longer fits 5 waves per SIMD"
+    # reverse: both builds must keep four waves per SIMD (<= 128 VGPRs); the stage-checkpoint build, pinned to that occupancy, may
+    # spill a little (12 B/lane when this was written) but not more
+    def meta_of(mangled_prefix):
+        m = re.search(r"\.name:\s+(" + mangled_prefix + r"\S*).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", txt, re.S)
+        if m is None:
+            m2 = re.search(r"\.name:\s+(" + mangled_prefix + r"\S*)", txt)
+            assert m2, mangled_prefix
+            blk = txt[m2.start():m2.start() + 4000]
+            return int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)), int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        return int(m.group(2)), int(m.group(3))
+    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0EE")
+    assert vgprs <= 128 and scratch == 0, ("k_adj_stage<nonlinear,contact,0,0>", vgprs, scratch)
+    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_114k_adj_stage_rbILi1ELi1EE")
+    assert vgprs <= 128 and scratch <= 32, ("k_adj_stage_rb<nonlinear,contact>", vgprs, scratch)
