@@ -161,7 +161,6 @@ static DevCtx make_ctx(dfx_handle* h) {
   for (int k = 0; k < 4; ++k) c.pred[k] = pl.pred_delta[k];
   c.nbuf = 2 * pl.tab.s;
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
-  c.traj_stride = pl.batch ? (long long)(h->d_traj.n / pl.batch) : 0;
   c.slot_info = h->d_slot_info.p; c.block_special = h->d_block_special.p; c.special = h->d_special.p;
   c.p_lidx = h->d_l_idx.p; c.l_dict = h->d_l_dict.p; c.l_dict_on = h->pp.l_dict_ok ? 1 : 0; c.damping_uniform = h->pp.damping_uniform ? 1 : 0;
   c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;

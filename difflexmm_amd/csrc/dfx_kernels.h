@@ -91,7 +91,6 @@ struct DevCtx {
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
-  long long traj_stride;  // unused (the checkpoint is record-major: see traj_rec)
   int rps;                // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   int lam_pairs;          // layout of LAM / YB: 1 = (q, v) of one DOF side by side (b*6 + 2d, + 1), one 16-B access per lane; 0 = (q0 q1 q2 v0 v1 v2)
                           // -- the REBUILD builds of the reverse stage (stage checkpoint, per-ligament gradients) sit at their register limit
