@@ -560,14 +560,20 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
     n = len(initial_guesses)
     logs = [dict(objective_values=[]) for _ in range(n)]
 
+    round_times = []
+
     def batch_fun(xs):
+        import time
+        t0 = time.perf_counter()
         designs = [_unflatten_design(g, x) for x in xs]
         vals, grads = objective.value_and_grad(designs)
         for i, v in enumerate(vals):
             if len(logs[i]["objective_values"]) < n_iterations:
                 logs[i]["objective_values"].append(float(v))
+        round_times.append(time.perf_counter() - t0)
         if verbose:
-            print(f"round: objectives = {np.array2string(np.asarray(vals), precision=4)}")
+            print(f"round {len(round_times)}: evaluation of all members {round_times[-1]:.2f} s, objectives = "
+                  f"{np.array2string(np.asarray(vals), precision=4, threshold=8)}")
         return [(float(v), _flatten_design(gr)) for v, gr in zip(vals, grads)]
 
     specs = [(_ensemble_member, (g, _flatten_design(d), n_iterations, lower_bound, upper_bound, min_void_angle, min_block_angle,
@@ -576,6 +582,8 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
     for log, r in zip(logs, res):
         log["constraints_violation"] = r.pop("constraints_violation")
         log["mma"] = r
+        log["evaluation_seconds"] = list(round_times)      # wall time of every lock-step evaluation of the whole ensemble (the first one
+                                                           # includes the engines' device allocations)
     return [_unflatten_design(g, r.x) for r in res], logs
 
 

@@ -88,6 +88,9 @@ def main():
         steps = (args.timepoints - 1) * args.steps_per_interval
         print(f"{args.members} designs x 3 inputs x {args.iterations} evaluations on {world} rank(s): {wall:.1f} s, "
               f"{solves / wall:.1f} forward+adjoint solves/s, {solves * steps * nb / wall:.3e} timesteps*units/s")
+        ev = logs[0]["evaluation_seconds"]
+        print("evaluations of the whole ensemble (forward + reverse sweeps of the three inputs + design maps), s: "
+              + " ".join(f"{t:.2f}" for t in ev) + "   (the first allocates the engines' checkpoints)")
         dev = sum(getattr(o, "device_ms", 0.0) for o in objective.objectives) * 1e-3
         print(f"device time of the forward + reverse sweeps, summed over the three engines: {dev:.1f} s (wall {wall:.1f} s; the engines of "
               f"the three inputs overlap when each runs a single stream); the rest is host work per round: design -> ControlParams "
