@@ -14,7 +14,7 @@ DFX_FN_PARAMS = 5
 BOND_LINEARIZED, BOND_NONLINEAR, BOND_SIMPLE_SPRING, BOND_STRETCH_TORSION = 0, 1, 2, 3
 CONTACT_NONE, CONTACT_ANGLE, CONTACT_DISTANCE = 0, 1, 2
 TABLEAU = {"dopri5": 0, "rk4": 1}
-FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_PULSE, FN_TABLE = range(8)
+FN_ZERO, FN_PULSE, FN_HARMONIC, FN_RAMP, FN_SECH2TANH, FN_CONSTANT, FN_RAMP_CAP, FN_TABLE = range(8)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -32,6 +32,7 @@
 
 
 #include "dfx_kernels.h"
+#include "dfx_pair.h"
 
 // ================================================================================================
 // host side
@@ -136,12 +137,17 @@ struct dfx_handle {
   std::map<std::pair<int, int>, hipGraphExec_t> graphs;
   // what the cached graphs have baked in: every kernel argument (the DevCtx passed by value) and the addresses the tick node
   // reads and writes (segment table, cursors) -- any of them changing (a buffer re-allocated by a larger solve) drops the graphs
-  struct GraphKey { DevCtx ctx; const void* segs; const void* seg_idx; const void* cur; } graph_key;
+  struct GraphKey { DevCtx ctx; const void* segs; const void* seg_idx; const void* cur; int pair_fwd, pair_adj, pair_rows, pad; } graph_key;
   bool graph_ctx_valid = false;
   // the adaptive controller's graph of 32 attempts (small lattices only), valid for the arguments it was captured with
   hipGraphExec_t adaptive_exec = nullptr;
   struct AdaptiveKey { DevCtx ctx; int n_timepoints; int n_partials; double two_n_free; } adaptive_key;
   long long launches = 0;
+  // two stages per launch on lattice windows (dfx_pair.h): the row length found at create, or tiling_ok = false
+  TileCtx tile;
+  bool tiling_ok = false;
+  int pair_rows = 16;            // window rows = wavefronts per workgroup (16: 1024 threads, 8: 512)
+  bool pair_fwd = false, pair_adj = false;   // what the current solve launches (decided per solve: pair_plan)
 };
 
 static void drop_graphs(dfx_handle* h) {
@@ -221,6 +227,82 @@ static AdjCoef adj_coef(const Tableau& T, int i) {
   return ac;
 }
 
+// ---- lattice windows for the pair launches --------------------------------------------------------------------------------------
+// A row length R with block = row * R + col such that every ligament joins blocks at most one row and one column apart.  Candidates
+// come from the block offsets the bond list contains; any R that passes is valid (R only shapes the windows, correctness does not
+// depend on which one is taken).  Lattices of a single row, or connectivity that is not a grid in the caller's block order, keep the
+// one-stage launches.
+static bool find_tiling(const Plan& pl, int& R_out) {
+  std::map<int, int> deltas;
+  for (int s = 0; s < pl.n_slots; ++s)
+    if (pl.slot_info[s] >= 0) ++deltas[std::abs((pl.slot_info[s] >> 3) - (s >> 2))];
+  std::vector<int> cand;
+  for (auto& kv : deltas) if (kv.first > 1) { cand.push_back(kv.first - 1); cand.push_back(kv.first); cand.push_back(kv.first + 1); }
+  std::sort(cand.begin(), cand.end());
+  for (int R : cand) {
+    if (R < 2 || pl.n_blocks % R || pl.n_blocks / R < 2) continue;
+    bool ok = true;
+    for (int s = 0; s < pl.n_slots && ok; ++s) {
+      if (pl.slot_info[s] < 0) continue;
+      const int b = s >> 2, pb = pl.slot_info[s] >> 3;
+      ok = std::abs(b / R - pb / R) <= 1 && std::abs(b % R - pb % R) <= 1;
+    }
+    if (ok) { R_out = R; return true; }
+  }
+  return false;
+}
+static int tiles_along(int n, int w) { return n <= w ? 1 : 1 + (n - w + (w - 3)) / (w - 2); }
+static void setup_tiling(dfx_handle* h) {
+  memset(&h->tile, 0, sizeof(h->tile));
+  int R = 0;
+  h->tiling_ok = find_tiling(h->pl, R);
+  if (!h->tiling_ok) return;
+  h->tile.R = R; h->tile.n_rows = h->pl.n_blocks / R;
+  if (const char* e = getenv("DFX_PAIR_ROWS")) h->pair_rows = atoi(e) == 8 ? 8 : 16;
+  else h->pair_rows = h->tile.n_rows <= 8 ? 8 : 16;
+  h->tile.tiles_x = tiles_along(R, kWCols);
+  h->tile.tiles_y = tiles_along(h->tile.n_rows, h->pair_rows);
+  h->tile.n_tiles = h->tile.tiles_x * h->tile.tiles_y;
+}
+// which launches the next solve uses (the pair kernels cover: even stage count, no distance-based contact, fixed grid; reverse: the
+// records checkpoint without per-ligament gradients); DFX_PAIR=0 keeps the one-stage launches, DFX_PAIR=f / a only one direction
+static void pair_plan(dfx_handle* h, const DevCtx& c) {
+  const char* e = getenv("DFX_PAIR");
+  const bool base = h->tiling_ok && (h->pl.tab.s % 2 == 0) && h->pl.contact != DFX_CONTACT_DISTANCE && !h->adaptive && !(e && e[0] == '0');
+  h->pair_fwd = base && !(e && e[0] == 'a');
+  h->pair_adj = base && c.rps > 1 && !c.g_b && !(e && e[0] == 'f');
+}
+static TileCtx group_tile(const dfx_handle* h, int nm) { TileCtx t = h->tile; t.total_wg = t.n_tiles * nm; return t; }
+
+template <int MODEL, int CONTACT>
+static void launch_fwd_pair_t(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int i, int j, int in_buf, int mid_buf, int out_buf, int y_buf, int mode) {
+  const TileCtx tc = group_tile(h, nm);
+  const StageCoef s0 = stage_coef(h->pl.tab, i), s1 = stage_coef(h->pl.tab, i + 1);
+  if (h->pair_rows == 16) hipLaunchKernelGGL((k_fwd_pair<MODEL, CONTACT, 16>), dim3(tc.total_wg), dim3(1024), 0, st, c, tc, s0, s1, i, j, in_buf, mid_buf, out_buf, y_buf, mode);
+  else hipLaunchKernelGGL((k_fwd_pair<MODEL, CONTACT, 8>), dim3(tc.total_wg), dim3(512), 0, st, c, tc, s0, s1, i, j, in_buf, mid_buf, out_buf, y_buf, mode);
+}
+static void launch_fwd_pair(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int i, int j, int in_buf, int mid_buf, int out_buf, int y_buf, int mode) {
+  const Plan& pl = h->pl;
+#define DFX_FP_CASE(M) case M: if (pl.contact) launch_fwd_pair_t<M, 1>(h, c, st, nm, i, j, in_buf, mid_buf, out_buf, y_buf, mode); else launch_fwd_pair_t<M, 0>(h, c, st, nm, i, j, in_buf, mid_buf, out_buf, y_buf, mode); break;
+  switch (pl.model) { DFX_FP_CASE(kNonlinear) DFX_FP_CASE(kLinearized) DFX_FP_CASE(kSimpleSpring) DFX_FP_CASE(kStretchTorsion) }
+#undef DFX_FP_CASE
+  h->launches++;
+}
+template <int MODEL, int CONTACT>
+static void launch_adj_pair_t(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int i, int j) {
+  const TileCtx tc = group_tile(h, nm);
+  const AdjCoef a1 = adj_coef(h->pl.tab, i), a2 = adj_coef(h->pl.tab, i - 1);
+  if (h->pair_rows == 16) hipLaunchKernelGGL((k_adj_pair<MODEL, CONTACT, 16>), dim3(tc.total_wg), dim3(1024), 0, st, c, tc, a1, a2, i, j);
+  else hipLaunchKernelGGL((k_adj_pair<MODEL, CONTACT, 8>), dim3(tc.total_wg), dim3(512), 0, st, c, tc, a1, a2, i, j);
+}
+static void launch_adj_pair(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int i, int j) {
+  const Plan& pl = h->pl;
+#define DFX_AP_CASE(M) case M: if (pl.contact) launch_adj_pair_t<M, 1>(h, c, st, nm, i, j); else launch_adj_pair_t<M, 0>(h, c, st, nm, i, j); break;
+  switch (pl.model) { DFX_AP_CASE(kNonlinear) DFX_AP_CASE(kLinearized) DFX_AP_CASE(kSimpleSpring) DFX_AP_CASE(kStretchTorsion) }
+#undef DFX_AP_CASE
+  h->launches++;
+}
+
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
@@ -267,6 +349,22 @@ static void launch_fwd_step_stage(dfx_handle* h, const DevCtx& c, hipStream_t st
   else launch_fwd(h, c, st, grid, i, j, fin(i), fout(i, s), 0, (i == s - 1 && c.traj) ? 1 : 0);
 }
 static int adj_in_buf(const DevCtx& c, int i) { return c.rps > 1 ? -1 - i : (i == 0 ? -1 : i); }
+// A step is s one-stage launches or s / 2 pair launches ("units"); unit u of step j, forward / reverse:
+static int step_units(const dfx_handle* h, int kind) { return (kind == 0 ? h->pair_fwd : h->pair_adj) ? h->pl.tab.s / 2 : h->pl.tab.s; }
+static void launch_fwd_unit(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int u, int j) {
+  if (!h->pair_fwd) { launch_fwd_step_stage(h, c, st, grid, u, j); return; }
+  const int s = h->pl.tab.s, i = 2 * u, nm = (int)grid.y;
+  // records checkpoint: every record lives in the trajectory; otherwise the records ping-pong between stage buffers 1 and 2 and the
+  // step state between buffers 0 and 3 (k_fwd_pair resolves buffer 0 by the parity of the step)
+  if (c.rps > 1) launch_fwd_pair(h, c, st, nm, i, j, -1 - i, -1 - (i + 1), -1 - (i + 2), -1, 0);
+  else launch_fwd_pair(h, c, st, nm, i, j, u == 0 ? 0 : 1 + ((u - 1) & 1), -1, i + 2 == s ? 0 : 1 + (u & 1), 0, (i + 2 == s && c.traj) ? 1 : 0);
+}
+// reverse unit u counts from the END of the step (u = 0: the last stage / pair)
+static void launch_adj_unit(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int u, int j) {
+  const int s = h->pl.tab.s;
+  if (!h->pair_adj) { const int i = s - 1 - u; launch_adj(h, c, st, grid, i, j, adj_in_buf(c, i), -1, 0); return; }
+  launch_adj_pair(h, c, st, (int)grid.y, s - 1 - 2 * u, j);
+}
 
 // enqueue one segment (kind 0: forward steps; kind 1: reverse steps) of group gi on that group's stream
 static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_steps, int kind) {
@@ -278,11 +376,11 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   h->launches++;
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
-      for (int i = 0; i < s; ++i) launch_fwd_step_stage(h, c, g.stream, grid, i, j);
+      for (int u = 0; u < step_units(h, 0); ++u) launch_fwd_unit(h, c, g.stream, grid, u, j);
   } else if (c.AD || c.rps > 1) {
     // stage checkpoint: no recompute launches; every reverse launch also rebuilds the record its successor reads
     for (int j = n_steps - 1; j >= 0; --j)
-      for (int i = s - 1; i >= 0; --i) launch_adj(h, c, g.stream, grid, i, j, adj_in_buf(c, i), -1, 0);
+      for (int u = 0; u < step_units(h, 1); ++u) launch_adj_unit(h, c, g.stream, grid, u, j);
   } else if (!h->dual_chain) {
     for (int j = n_steps - 1; j >= 0; --j) {
       // recompute the stage records of step n from its checkpoint: stage i -> buffer i+1
@@ -332,7 +430,7 @@ static bool solve_is_eager(const dfx_handle* h) {
 }
 
 static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int kind, int seg_index = -1) {
-  const int s = h->pl.tab.s, ng = (int)h->groups.size();
+  const int ng = (int)h->groups.size();
   if (kind == 1 && !cbase.AD && cbase.rps == 1) {      // recompute chains (events per group): group by group
     for (int gi = 0; gi < ng; ++gi) enqueue_segment(h, cbase, gi, n_steps, kind);
     return;
@@ -346,14 +444,14 @@ static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps,
   }
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
-      for (int i = 0; i < s; ++i)
+      for (int u = 0; u < step_units(h, 0); ++u)
         for (int gi = 0; gi < ng; ++gi)
-          launch_fwd_step_stage(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j);
+          launch_fwd_unit(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), u, j);
   } else {
     for (int j = n_steps - 1; j >= 0; --j)
-      for (int i = s - 1; i >= 0; --i)
+      for (int u = 0; u < step_units(h, 1); ++u)
         for (int gi = 0; gi < ng; ++gi)
-          launch_adj(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), i, j, adj_in_buf(cg[gi], i), -1, 0);
+          launch_adj_unit(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), u, j);
   }
 }
 
@@ -364,6 +462,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
   memcpy(&gk.ctx, &c, sizeof(DevCtx));
   gk.ctx.n_timepoints = 0;  // not read by the stage kernels
   gk.segs = h->d_segs.p; gk.seg_idx = h->d_seg_idx.p; gk.cur = h->d_cur.p;
+  gk.pair_fwd = h->pair_fwd; gk.pair_adj = h->pair_adj; gk.pair_rows = h->pair_rows;
   if (!h->graph_ctx_valid || memcmp(&h->graph_key, &gk, sizeof(gk)) != 0) {
     drop_graphs(h);
     memcpy(&h->graph_key, &gk, sizeof(gk));
@@ -372,7 +471,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
   auto key = std::make_pair(n_steps, kind * kMaxGroups + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
-  const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD || c.rps > 1) ? s : 2 * s - 1);   // launches in the graph
+  const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD || c.rps > 1) ? step_units(h, kind) : 2 * s - 1);   // launches in the graph
   hipStream_t st = h->groups[gi].stream;
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -508,7 +607,7 @@ static int ensure_adjoint_buffers(dfx_handle* h) {
   const size_t B = pl.batch, nb = pl.n_blocks, s = pl.tab.s;
   const size_t nsp = std::max(1, pl.n_special);
   HIP_OK(h->d_YB.ensure(B * s * nb * 6));
-  HIP_OK(h->d_LAM.ensure(B * nb * 6));
+  HIP_OK(h->d_LAM.ensure(2 * B * nb * 6));      // x 2: the pair launches double-buffer lambda by step parity
   HIP_OK(h->d_W.ensure(B * 2 * nb * 3));
   HIP_OK(h->d_KQ.ensure(B * 2 * nb * 3));
   HIP_OK(h->d_g_r.ensure(B * pl.n_slots * 2));
@@ -744,6 +843,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
       h->groups.push_back(gr);
     }
   }
+  setup_tiling(h);
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
             h->d_slot_bond.ensure(pl.n_slots) == hipSuccess && h->d_touch.ensure(4) == hipSuccess &&
@@ -920,6 +1020,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   }
   DevCtx c = make_ctx(h);
   if (h->segments) { c.traj = nullptr; c.rps = 1; }        // segments level: the forward pass keeps nothing but its outputs
+  pair_plan(h, c);
   h->launches = 0;
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
   if (c.traj)
@@ -938,7 +1039,8 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
         const Group& gr = h->groups[gi];
         // end of the interval: the state is in buffer 0, or (records checkpoint) only in the trajectory
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
-                           h->d_seg_idx.p + 1, c.rps > 1 ? -1 : 0, (long long)h->step0[sg.interval + 1]);
+                           h->d_seg_idx.p + 1, c.rps > 1 ? -1 : (h->pair_fwd ? state_buf(h->step0[sg.interval + 1]) : 0),
+                           (long long)h->step0[sg.interval + 1]);
       }
     }
   }
@@ -1196,8 +1298,11 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   const double h_last = Tn > 1 ? (h->t_steps.empty() ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]
                                                      : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  const int wb = (int)((h->n_total * pl.tab.s - 1) & 1);
-  hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb);
+  pair_plan(h, c);
+  // the (w, Kbar_q) buffers alternate per launch, lambda (pair launches only) per step
+  const int wb = (int)((h->n_total * step_units(h, 1) - 1) & 1);
+  hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb,
+                     h->pair_adj ? (int)(h->n_total & 1) : 0);
   if (c.AD && h->n_total > 0) {     // stage checkpoint: the record the first reverse launch reads
     const long long nr = h->n_total - 1;
     const double t_nr = h->t_steps.empty() ? h->ts[Tn - 1] - h_last : h->t_steps[nr];

@@ -1019,7 +1019,8 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_RB_OCC void k_adj_stage_rb(DevCtx
 }
 
 // start of the reverse sweep: lambda_N = G_last; kbar_{s-1} of the last step into buffer `buf`
-__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf) {
+//   lam_par: which of the two lambda buffers (the pair launches double-buffer lambda by step parity; 0 otherwise)
+__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf, int lam_par) {
   const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
@@ -1030,8 +1031,9 @@ __global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last,
   const bool con = sidx >= 0 && ((c.special[sidx].con_mask >> d) & 1);
   const double* G = c.G + ((size_t)(c.n_timepoints - 1) * c.batch + m) * nd6;
   const double lq = con ? 0.0 : G[b * 6 + d], lv = con ? 0.0 : G[b * 6 + 3 + d];
-  c.LAM[(size_t)m * nd6 + b * 6 + (c.lam_pairs ? 2 * d : d)] = lq;
-  c.LAM[(size_t)m * nd6 + b * 6 + (c.lam_pairs ? 2 * d + 1 : 3 + d)] = lv;
+  double* LAMm = c.LAM + ((size_t)lam_par * c.batch + m) * nd6;
+  LAMm[b * 6 + (c.lam_pairs ? 2 * d : d)] = lq;
+  LAMm[b * 6 + (c.lam_pairs ? 2 * d + 1 : 3 + d)] = lv;
   c.KQ[((size_t)m * 2 + buf) * nd + b * 3 + d] = h_last * b_last * lq;
   c.W[((size_t)m * 2 + buf) * nd + b * 3 + d] = con ? 0.0 : h_last * b_last * lv * c.inv_m[(size_t)m * nd + b * 3 + d];
 }

@@ -449,7 +449,7 @@ enum TimeFnType {
   kFnRamp = 3,        // p = (A, r):       A * (t r  if t < 1/r else 1)
   kFnSech2Tanh = 4,   // p = (A, s):       2A/s^2 sech^2(t/s - 3) tanh(3 - t/s)
   kFnConstant = 5,    // p = (A)
-  kFnRampPulse = 6,   // p = (A, f, t_d, S, r): S*min(t r,1) + pulse(t - t_d; A, f)   (static tuning)
+  kFnRampCap = 6,     // p = (L, r, cap):  L * min(t r, cap)   (static compression: quads_kinetic_energy_static_tuning.py:176-182)
   kFnTable = 7        // p = (A, t_d): A * piecewise-linear table(t - t_d), end values held
 };
 constexpr int kMaxFnParams = 5;
@@ -468,8 +468,7 @@ DFX_HD void eval_time_fn(const TimeFn& f, double t, double& g, double& gt, doubl
   gt = 0.0;
   switch (f.type) {
     case kFnPulse:
-    case kFnHarmonic:
-    case kFnRampPulse: {
+    case kFnHarmonic: {
       double A = f.p[0], fr = f.p[1], tau = t - f.p[2];
       bool on = (tau > 0.0) && (f.type == kFnHarmonic || tau * fr < 1.0);
       if (on) {
@@ -481,11 +480,12 @@ DFX_HD void eval_time_fn(const TimeFn& f, double t, double& g, double& gt, doubl
         gp[1] = A * kPi * tau * s;
         gp[2] = -gt;
       }
-      if (f.type == kFnRampPulse) {
-        double S = f.p[3], r = f.p[4];
-        if (t * r < 1.0) { g += S * t * r; gt += S * r; gp[3] = t * r; gp[4] = S * t; }
-        else { g += S; gp[3] = 1.0; }
-      }
+    } break;
+    case kFnRampCap: {
+      // jnp.where(t < cap / r, t * r, cap) scaled by L: the ramp branch is taken where t r < cap
+      double Lf = f.p[0], r = f.p[1], cap = f.p[2];
+      if (t * r < cap) { g = Lf * t * r; gt = Lf * r; gp[0] = t * r; gp[1] = Lf * t; }
+      else { g = Lf * cap; gp[0] = cap; gp[2] = Lf; }
     } break;
     case kFnRamp: {
       double A = f.p[0], r = f.p[1];

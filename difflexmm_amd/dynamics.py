@@ -250,7 +250,7 @@ class DynamicSolver:
                             g5 += wq[k] * term.param_partials(float(t), p, "value")
                         if wv[k]:
                             g5 += wv[k] * term.param_partials(float(t), p, "rate")
-                    term.scatter_grad(g5, tree.constraint_params)
+                    term.scatter_grad(g5, tree.constraint_params, cp.constraint_params)
         return trees, s0
 
     def vjp_raw(self, fields_bar, which=("centroid_node_vectors", "void_angle0", "inertia")):
@@ -335,9 +335,9 @@ class DynamicSolver:
                 contact_bar = ContactParams(min_angle=c[0], cutoff_angle=c[1], k_contact=c[2])
             con_bar, load_bar = {}, {}
             for f, term in enumerate(self.con_terms):
-                term.scatter_grad(g["fn_params"][m][f], con_bar)
+                term.scatter_grad(g["fn_params"][m][f], con_bar, cp.constraint_params)
             for f, term in enumerate(self.load_terms):
-                term.scatter_grad(g["fn_params"][m][len(self.con_terms) + f], load_bar)
+                term.scatter_grad(g["fn_params"][m][len(self.con_terms) + f], load_bar, cp.loading_params)
             trees.append(ControlParams(
                 geometrical_params=GeometricalParams(
                     block_centroids=(np.array(g["block_centroids"][m]).reshape(np.shape(gp.block_centroids)) if "block_centroids" in g

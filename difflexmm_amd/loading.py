@@ -11,7 +11,7 @@ Every parameter is either a number (a constant baked into the solver) or a strin
 """
 import numpy as np
 
-from ._binding import (DFX_FN_PARAMS, FN_CONSTANT, FN_HARMONIC, FN_PULSE, FN_RAMP, FN_RAMP_PULSE,
+from ._binding import (DFX_FN_PARAMS, FN_CONSTANT, FN_HARMONIC, FN_PULSE, FN_RAMP, FN_RAMP_CAP,
                        FN_SECH2TANH, FN_TABLE, FN_ZERO)
 
 
@@ -40,8 +40,9 @@ class TimeFunction:
             out[i] = float(v)
         return out
 
-    def scatter_grad(self, grad5, out_dict):
-        """Add d/d(params) (5 numbers from the engine) to a dict keyed like the params dict."""
+    def scatter_grad(self, grad5, out_dict, params_dict=None):
+        """Add d/d(params) (5 numbers from the engine) to a dict keyed like the params dict (``params_dict``: the values the
+        solve was run with, for terms whose engine parameters are derived from several entries)."""
         for i, n in enumerate(self.param_names):
             v = self.params[n]
             if isinstance(v, str):
@@ -149,15 +150,55 @@ class Constant(TimeFunction):
         return p[0]
 
 
-class RampPulse(TimeFunction):
-    """static ramp + delayed pulse (problems/quads_kinetic_energy_static_tuning.py:176-196)."""
-    type_id = FN_RAMP_PULSE
-    param_names = ("amplitude", "loading_rate", "input_delay", "static", "static_rate")
+class CappedRamp(TimeFunction):
+    """length * min(t * rate, cap): the static compression of ``problems/quads_kinetic_energy_static_tuning.py:176-182``
+    (``length = (n2_blocks - 1) * spacing``, ``rate = compressive_strain_rate``, ``cap = compressive_strain``; the reference's
+    ``jnp.where(t < cap / rate, t * rate, cap)``)."""
+    type_id = FN_RAMP_CAP
+    param_names = ("length", "rate", "cap")
 
     def value(self, t, p):
-        tau = t - p[2]
-        pulse = p[0] * 0.5 * (1 - np.cos(2 * np.pi * p[1] * tau)) if (tau > 0 and tau * p[1] < 1) else 0.0
-        return pulse + p[3] * (t * p[4] if t * p[4] < 1 else 1.0)
+        return p[0] * (t * p[1] if t * p[1] < p[2] else p[2])
+
+
+class DelayedPulse(Pulse):
+    """The pulse of ``quads_kinetic_energy_static_tuning.py:184-186``: it starts once the static ramp has ended,
+    ``tau = t - strain / strain_rate - input_delay``.  The engine integrates a plain pulse with the derived delay
+    ``strain / strain_rate + input_delay``; its gradient w.r.t. that delay is chained back to all three on the host."""
+
+    def __init__(self, vector=1.0, strain="compressive_strain", strain_rate="compressive_strain_rate", **params):
+        super().__init__(vector, **params)
+        self.strain, self.strain_rate = strain, strain_rate
+
+    def _lookup(self, v, params_dict):
+        if isinstance(v, str):
+            if v not in params_dict:
+                raise KeyError(f"{type(self).__name__}: parameter '{v}' missing from the params dict")
+            return float(params_dict[v])
+        return float(v)
+
+    def resolve(self, params_dict):
+        out = super().resolve(params_dict)
+        out[2] += self._lookup(self.strain, params_dict) / self._lookup(self.strain_rate, params_dict)
+        return out
+
+    def scatter_grad(self, grad5, out_dict, params_dict=None):
+        super().scatter_grad(grad5, out_dict, params_dict)
+        if params_dict is None:
+            raise ValueError("DelayedPulse.scatter_grad needs the params dict the solve was run with")
+        eps, rate = self._lookup(self.strain, params_dict), self._lookup(self.strain_rate, params_dict)
+        if isinstance(self.strain, str):
+            out_dict[self.strain] = out_dict.get(self.strain, 0.0) + float(grad5[2]) / rate
+        if isinstance(self.strain_rate, str):
+            out_dict[self.strain_rate] = out_dict.get(self.strain_rate, 0.0) - float(grad5[2]) * eps / rate ** 2
+
+
+def static_tuning_drive(static_vector, dynamic_vector, length):
+    """``constrained_DOFs_fn`` of ``quads_kinetic_energy_static_tuning.py:176-186``: the static compression on
+    ``static_vector`` plus the pulse, delayed by the end of the ramp + ``input_delay``, on ``dynamic_vector``; parameters
+    ``amplitude, loading_rate, compressive_strain, compressive_strain_rate, input_delay`` of ``constraint_params``."""
+    return (CappedRamp(static_vector, length=float(length), rate="compressive_strain_rate", cap="compressive_strain")
+            + DelayedPulse(dynamic_vector))
 
 
 class Table(TimeFunction):
@@ -188,5 +229,5 @@ def as_time_function(fn, what):
     if isinstance(fn, TimeFunction):
         return fn
     raise TypeError(
-        f"{what} must be built from difflexmm_amd.loading (Pulse, Harmonic, Ramp, Sech2Tanh, Constant, RampPulse, Table, "
+        f"{what} must be built from difflexmm_amd.loading (Pulse, Harmonic, Ramp, Sech2Tanh, Constant, CappedRamp, DelayedPulse, Table, "
         f"zero, or a sum of them): an arbitrary Python callable cannot be evaluated inside a HIP kernel")

@@ -150,6 +150,7 @@ class QuadsFocusingForward:
     streams: int = 0          # member groups on their own HIP streams (0: the engine chooses); multi-input objectives set 1
     name: str = "quads_focusing"
     _lib: Any = None
+    _drive_cls = L.Pulse          # problems/quads_focusing.py:211-222
 
     def setup(self):
         g = self.geometry = QuadGeometry(self.n1_blocks, self.n2_blocks, self.spacing, self.bond_length)
@@ -163,7 +164,7 @@ class QuadsFocusingForward:
                                        E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
         energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
         self.solve_dynamics = setup_dynamic_solver(
-            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=L.Pulse(vec),
+            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=self._drive_cls(vec),
             damped_blocks=np.arange(g.n_blocks), integrator=self.integrator,
             steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
@@ -271,6 +272,14 @@ QuadsFocusingForward.from_dict = classmethod(_forward_from_dict)
 
 
 @dataclass
+class QuadsSpinForward(QuadsFocusingForward):
+    """``problems/quads_spin.py:ForwardProblem``: the focusing problem's lattice and boundary conditions driven by the harmonic
+    signal of ``quads_spin.py:210-222`` (the raised cosine switched on at ``t > input_delay`` and never off)."""
+    name: str = "quads_spin"
+    _drive_cls = L.Harmonic
+
+
+@dataclass
 class KagomeFocusingForward:
     """NumPy counterpart of ``problems/kagome_focusing.py:ForwardProblem`` (fields with the same names; left-loaded)."""
     n1_cells: int
@@ -332,6 +341,241 @@ class KagomeFocusingForward:
     compute_response_data = _compute_response_data
     to_dict = _forward_to_dict
     from_dict = classmethod(_forward_from_dict)
+
+
+def static_tuning_constraints(geometry: QuadGeometry, n_excited_blocks: int, input_shift: int = 0):
+    """``problems/quads_kinetic_energy_static_tuning.py:124-170``: driven blocks centred on the left edge (x driven, y / theta
+    held), bottom and top rows clamped in (y, x, theta) order; the dynamic loading vector selects the driven x DOFs, the static
+    one the y DOFs of the bottom (+1/2) and top (-1/2) rows.  Returns (pairs, dynamic vector, static vector, driven ids,
+    clamped ids)."""
+    n1, n2, nb, ne = geometry.n1_blocks, geometry.n2_blocks, geometry.n_blocks, n_excited_blocks
+    driven = np.stack([np.tile(np.arange((n2 - ne) // 2 + input_shift, (n2 + ne) // 2 + input_shift) * n1, 3),
+                       np.array([0] * ne + [1] * ne + [2] * ne)], 1)
+    order = np.array([1] * n1 + [0] * n1 + [2] * n1)
+    bottom = np.stack([np.concatenate([np.arange(0, n1)] * 3), order], 1)
+    top = np.stack([np.concatenate([np.arange(nb - n1, nb)] * 3), order], 1)
+    pairs = np.concatenate([driven, bottom, top]).astype(np.int64)
+    dyn = np.zeros(len(pairs))
+    dyn[:ne] = 1
+    sta = np.zeros(len(pairs))
+    sta[3 * ne:3 * ne + n1] = 0.5
+    sta[3 * ne + 3 * n1:3 * ne + 4 * n1] = -0.5
+    clamped = np.unique(np.concatenate([bottom, top])[:, 0])
+    return pairs, dyn, sta, np.unique(driven[:, 0]), clamped
+
+
+@dataclass
+class ForwardInput:
+    """``quads_kinetic_energy_static_tuning.py:ForwardInput``: one entry per forward problem (the rows the reference maps over
+    devices with ``pmap``) in each of the four loading tuples."""
+    horizontal_shifts: Any
+    vertical_shifts: Any
+    amplitude: Tuple[Any, ...]
+    loading_rate: Tuple[Any, ...]
+    compressive_strain: Tuple[Any, ...]
+    compressive_strain_rate: Tuple[Any, ...]
+
+    def rows(self):
+        return np.array([self.amplitude, self.loading_rate, self.compressive_strain, self.compressive_strain_rate], dtype=float).T
+
+
+@dataclass
+class QuadsStaticTuningForward:
+    """NumPy counterpart of ``problems/quads_kinetic_energy_static_tuning.py:ForwardProblem`` (fields with the same names):
+    bottom and top edges clamped and slowly compressed (``compressive_strain`` at ``compressive_strain_rate``), one pulse on the
+    left edge once the compression has ended.
+
+    The reference maps the forward inputs over devices (``pmap``, ``:473-478``).  Here rows are ensemble members of one engine
+    call whenever they share their output times -- a member's time grid starts with the static phase ``[0, strain / strain_rate +
+    input_delay]``, so rows with different strains or rates have different grids and are integrated by calls of their own (on one
+    GPU one after the other; ``ensemble`` shards rows over ranks).  ``static_steps`` / ``steps_per_interval``: RK steps in the
+    static interval / between dynamic outputs (both None: the adaptive controller, and its frozen grid for gradients)."""
+    n1_blocks: int
+    n2_blocks: int
+    spacing: Any
+    bond_length: Any
+    k_stretch: Any
+    k_shear: Any
+    k_rot: Any
+    density: Any
+    damping: Any
+    n_excited_blocks: int
+    input_shift: int
+    simulation_time_dynamic: Any
+    n_timepoints: int
+    linearized_strains: bool = False
+    use_contact: bool = True
+    k_contact: Any = 1.
+    min_angle: Any = 0. * np.pi / 180
+    cutoff_angle: Any = 5. * np.pi / 180
+    name: str = "quads_kinetic_energy_static_tuning"
+    atol: float = 1e-8
+    rtol: float = 1e-8
+    steps_per_interval: Optional[int] = None
+    static_steps: Optional[int] = None
+    integrator: str = "dopri5"
+    device: int = 0
+    streams: int = 0
+    _lib: Any = None
+
+    def setup(self):
+        g = self.geometry = QuadGeometry(self.n1_blocks, self.n2_blocks, self.spacing, self.bond_length)
+        self.bond_connectivity = g.bond_connectivity()
+        self.reference_bond_vectors = g.reference_bond_vectors()
+        pairs, dyn, sta, self.driven_blocks_ids, self.clamped_blocks_ids = static_tuning_constraints(
+            g, self.n_excited_blocks, self.input_shift)
+        self.constrained_block_DOF_pairs = pairs
+        self.constrained_DOFs_loading_vector_dynamic, self.constrained_DOFs_loading_vector_static = dyn, sta
+        self.moving_blocks_ids = np.setdiff1d(np.arange(g.n_blocks), self.clamped_blocks_ids)
+        strain = E.build_strain_energy(self.bond_connectivity,
+                                       E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
+        self._energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
+        self._drive = L.static_tuning_drive(sta, dyn, (g.n2_blocks - 1) * self.spacing)       # :176-186
+        self._solvers = {}
+        self.state0 = np.zeros((2, g.n_blocks, 3))
+        self.solve_dynamics = self.solver(1)
+        self.is_setup = True
+
+    def solver(self, batch):
+        """The solver that integrates ``batch`` rows side by side (built on first use)."""
+        sd = self._solvers.get(batch)
+        if sd is None:
+            sd = self._solvers[batch] = setup_dynamic_solver(
+                self.geometry, self._energy, constrained_block_DOF_pairs=self.constrained_block_DOF_pairs,
+                constrained_DOFs_fn=self._drive, damped_blocks=np.arange(self.geometry.n_blocks), rtol=self.rtol, atol=self.atol,
+                integrator=self.integrator, batch=batch, device=self.device, streams=self.streams, _lib=self._lib)
+        return sd
+
+    def control_params(self, design, amplitude, loading_rate, compressive_strain, compressive_strain_rate):
+        centroids, cnv = geometry_from_design_cached(self.geometry, design)
+        return ControlParams(
+            geometrical_params=GeometricalParams(block_centroids=centroids, centroid_node_vectors=cnv),
+            mechanical_params=MechanicalParams(
+                bond_params=LigamentParams(self.k_stretch, self.k_shear, self.k_rot, self.reference_bond_vectors),
+                density=self.density, damping=self.damping,
+                contact_params=ContactParams(min_angle=self.min_angle, cutoff_angle=self.cutoff_angle, k_contact=self.k_contact)),
+            constraint_params=dict(amplitude=amplitude, loading_rate=loading_rate, compressive_strain=compressive_strain,
+                                   compressive_strain_rate=compressive_strain_rate, input_delay=0.1 / loading_rate))       # :213
+
+    def timepoints_of(self, loading_rate, compressive_strain, compressive_strain_rate, full_simulation_time=False, n_timepoints=None):
+        """``:246-259``."""
+        n = self.n_timepoints if n_timepoints is None else n_timepoints
+        t0 = compressive_strain / compressive_strain_rate + 0.1 / loading_rate
+        if full_simulation_time:
+            return np.linspace(0, self.simulation_time_dynamic + t0, n)
+        return np.concatenate([[0.], np.linspace(t0, t0 + self.simulation_time_dynamic, n)])
+
+    def step_counts(self, timepoints, full_simulation_time):
+        if self.steps_per_interval is None:
+            return None
+        counts = np.full(len(timepoints) - 1, int(self.steps_per_interval), dtype=np.int32)
+        if not full_simulation_time:
+            if self.static_steps is None:
+                raise ValueError("steps_per_interval needs static_steps (RK steps of the static interval) as well")
+            counts[0] = int(self.static_steps)
+        return counts
+
+    def solve_rows(self, design, rows, full_simulation_time=False, n_timepoints=None, keep_trajectory=False, want_fields=True,
+                   group_key=None, after_group=None):
+        """Integrate the forward inputs ``rows`` (R, 4) = (amplitude, loading_rate, compressive_strain, compressive_strain_rate) for
+        one design.  Rows with identical output times (and identical ``group_key(r)`` when given) share an engine call.  Returns the
+        list of SolutionData in row order (``want_fields``) and remembers the groups (``self.groups``: solver, row indices, params).
+        ``after_group(solver, row indices, params)`` runs right after a group's solve, while its trajectory is still the engine's
+        (groups of equal size share a solver: the next solve replaces it)."""
+        rows = np.asarray(rows, dtype=float).reshape(-1, 4)
+        tps = [self.timepoints_of(r[1], r[2], r[3], full_simulation_time, n_timepoints) for r in rows]
+        keys = {}
+        for i, tp in enumerate(tps):
+            keys.setdefault((tp.tobytes(), None if group_key is None else group_key(i)), []).append(i)
+        sols, self.groups = [None] * len(rows), []
+        for idx in keys.values():
+            sd = self.solver(len(idx))
+            cps = [self.control_params(design, *rows[i]) for i in idx]
+            tp = tps[idx[0]]
+            fields = sd(self.state0, tp, cps if len(idx) > 1 else cps[0], keep_trajectory=keep_trajectory,
+                        steps_per_interval=self.step_counts(tp, full_simulation_time), want_fields=want_fields)
+            self.groups.append((sd, idx, cps, tp))
+            if after_group is not None:
+                after_group(sd, idx, cps)
+            if fields is None:
+                continue
+            for m, i in enumerate(idx):
+                f = fields[m] if len(idx) > 1 else fields
+                gp = cps[m].geometrical_params
+                sols[i] = SolutionData(gp.block_centroids, gp.centroid_node_vectors, self.bond_connectivity,
+                                       tp if full_simulation_time else tp[1:] - tp[1], f if full_simulation_time else f[1:])    # :268-276
+        self._last_design = design
+        if want_fields:
+            self._last_solutions, self.solution_data = sols, sols[0]
+            self._last_solve_id = -1        # response data of a static-tuning solution: host formulas (rows may live in several engines)
+        return sols if want_fields else None
+
+    def solve(self, design, amplitude, loading_rate, compressive_strain, compressive_strain_rate, full_simulation_time=False,
+              n_timepoints=None):
+        """``forward(...)`` of ``:199-277`` for one forward input."""
+        return self.solve_rows(design, [[amplitude, loading_rate, compressive_strain, compressive_strain_rate]],
+                               full_simulation_time, n_timepoints)[0]
+
+    def solve_dynamic(self, design, amplitude, loading_rate, compressive_strain, compressive_strain_rate):
+        """``:280-281``: the dynamic step only (what the optimisation differentiates)."""
+        return self.solve(design, amplitude, loading_rate, compressive_strain, compressive_strain_rate, False, self.n_timepoints)
+
+    compute_response_data = _compute_response_data
+    to_dict = _forward_to_dict
+    from_dict = classmethod(_forward_from_dict)
+
+
+class StaticTuningKineticEnergy:
+    """``problems/quads_kinetic_energy_static_tuning.py:OptimizationProblem.setup_objective`` (``:430-480``):
+    ``weights @ [target kinetic energy of every forward input]`` for ONE design; negative weights "protect".  Every row has its own
+    target blocks (``target_sizes`` / ``target_shifts``).  ``value_and_grad`` also leaves the gradient w.r.t. the forward inputs in
+    ``self.last_input_grads`` (one dict per row; ``loading_rate`` includes the path through ``input_delay = 0.1 / loading_rate``;
+    output times are held fixed: the engine has no time-point cotangent and the reference's optimisation never asks for one)."""
+
+    def __init__(self, forward, forward_input, target_sizes, target_shifts, weights):
+        self.forward = forward
+        if not getattr(forward, "is_setup", False):
+            forward.setup()
+        self.forward_input = forward_input
+        self.rows = forward_input.rows()
+        self.weights = np.asarray(weights, dtype=float)
+        self.target_blocks = [quads_target_blocks(forward.geometry, ts, sh) for ts, sh in zip(target_sizes, target_shifts)]
+        if not (len(self.rows) == len(self.weights) == len(self.target_blocks)):
+            raise ValueError("forward inputs, weights and targets must have one entry per forward problem")
+
+    def individual(self, design):
+        fw = self.forward
+        sols = fw.solve_rows(design, self.rows)
+        return np.array([E.kinetic_energy(s.fields[:, 1, tb, :], compute_inertia(s.centroid_node_vectors, fw.density)[tb])
+                         for s, tb in zip(sols, self.target_blocks)])
+
+    def value(self, design):
+        return float(self.weights @ self.individual(design))
+
+    def value_and_grad(self, design):
+        fw = self.forward
+        vals = np.zeros(len(self.rows))
+        sums, self.last_input_grads = {}, [None] * len(self.rows)
+
+        def reverse(sd, idx, cps):
+            obj, raw = sd.kinetic_energy_value_and_raw(self.target_blocks[idx[0]],
+                                                       which=("centroid_node_vectors", "void_angle0", "inertia", "fn_params"))
+            for m, i in enumerate(idx):
+                vals[i] = obj[m]
+                bar = {}
+                for f, term in enumerate(sd.con_terms):
+                    term.scatter_grad(raw["fn_params"][m][f], bar, cps[m].constraint_params)
+                bar["loading_rate"] = bar.get("loading_rate", 0.0) - bar.pop("input_delay", 0.0) * 0.1 / self.rows[i][1] ** 2
+                self.last_input_grads[i] = bar
+                for k in raw:
+                    if k != "fn_params":
+                        sums[k] = sums.get(k, 0.0) + self.weights[i] * np.asarray(raw[k][m], dtype=float)
+
+        fw.solve_rows(design, self.rows, keep_trajectory=True, want_fields=False,
+                      group_key=lambda i: self.target_blocks[i].tobytes(), after_group=reverse)
+        self.last_individual = vals
+        grads = design_gradients(fw, [design], {k: a[None] for k, a in sums.items()})[0]
+        return float(self.weights @ vals), grads
 
 
 def design_gradients(fw, designs, raw):

@@ -52,7 +52,8 @@ enum {
   DFX_FN_RAMP = 3,         /* (A, r)        tests/test_difflexmm.py:85-86                        */
   DFX_FN_SECH2TANH = 4,    /* (A, s)        scripts/pulse_RS.py:49-50                            */
   DFX_FN_CONSTANT = 5,     /* (A)                                                                 */
-  DFX_FN_RAMP_PULSE = 6,   /* (A, f, t_d, S, r) problems/quads_kinetic_energy_static_tuning.py:176-196 */
+  DFX_FN_RAMP_CAP = 6,     /* (L, r, cap): L min(t r, cap)  static compression, problems/quads_kinetic_energy_static_tuning.py:176-182;
+                              the delayed pulse of :184-186 is DFX_FN_PULSE with t_d = cap / r + input_delay (host-side chain rule) */
   DFX_FN_TABLE = 7         /* (A, t_d): A * interp(t - t_d; table), piecewise linear, end values held (jnp.interp semantics):
                               a recorded input signal; the table itself is static data of dfx_problem             */
 };

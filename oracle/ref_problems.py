@@ -6,6 +6,8 @@ Follows, construct by construct (NumPy standing in for jax.numpy; same tile / ar
 * ``problems/quads_focusing.py:447-467``  target blocks and the target-kinetic-energy objective
 * ``problems/kagome_focusing.py:96-172``  the same for the kagome lattice (left-loaded only), ``:403-424`` targets
 * ``problems/quads_focusing_multi_input.py:43-86``  weighted sum over forward problems that share one design
+* ``problems/quads_kinetic_energy_static_tuning.py:124-283, 453-478``  static compression + delayed pulse, weighted objective
+* ``problems/quads_spin.py:210-222, 391-428`` with ``difflexmm/energy.py:502-519``  harmonic drive, target angular momentum
 
 The objective is evaluated through the oracle's own solver (``oracle.ref_dynamics``) and differentiated with
 ``torch.autograd`` where the reference calls ``jit(value_and_grad(objective))`` (``problems/quads_focusing.py:565``).
@@ -112,12 +114,18 @@ def pulse(t, amplitude, loading_rate):
                                    torch.zeros((), dtype=F64))
 
 
-def make_constrained_DOFs_fn(loading_vector):
-    """problems/quads_focusing.py:218-222."""
+def harmonic_signal(t, amplitude, loading_rate):
+    """problems/quads_spin.py:210-215."""
+    t = _t(t)
+    return amplitude * torch.where((t > 0.), (1 - torch.cos(2 * math.pi * loading_rate * t)) / 2, torch.zeros((), dtype=F64))
+
+
+def make_constrained_DOFs_fn(loading_vector, signal=pulse):
+    """problems/quads_focusing.py:218-222 (``signal=harmonic_signal``: quads_spin.py:217-222)."""
     vec = _t(loading_vector)
 
     def constrained_DOFs_fn(t, amplitude, loading_rate, input_delay):
-        return pulse(_t(t) - input_delay, amplitude, loading_rate) * vec
+        return signal(_t(t) - input_delay, amplitude, loading_rate) * vec
     return constrained_DOFs_fn
 
 
@@ -142,7 +150,7 @@ class ForwardProblem:
     def __init__(self, lattice, n1, n2, spacing, bond_length, k_stretch, k_shear, k_rot, density, damping, amplitude, loading_rate,
                  input_delay, n_excited_blocks, simulation_time, n_timepoints, loaded_side="left", input_shift=0,
                  linearized_strains=False, use_contact=True, k_contact=1.0, min_angle=0.0, cutoff_angle=5 * math.pi / 180,
-                 n_blocks_clamped_corner=2):
+                 n_blocks_clamped_corner=2, signal=pulse):
         self.lattice = lattice
         if lattice == "quads":
             self.geometry = OG.QuadGeometry(n1, n2, spacing, bond_length)
@@ -159,7 +167,7 @@ class ForwardProblem:
         energy = OE.combine_block_energies(strain, OE.build_contact_energy(self.bonds)) if use_contact else strain    # :229-237
         self.energy = energy
         self.solver_args = dict(constrained_block_DOF_pairs=self.constrained_block_DOF_pairs,
-                                constrained_DOFs_fn=make_constrained_DOFs_fn(self.constrained_DOFs_loading_vector),
+                                constrained_DOFs_fn=make_constrained_DOFs_fn(self.constrained_DOFs_loading_vector, signal),
                                 damped_blocks=np.arange(self.geometry.n_blocks))                               # :101, :239-248
         self.timepoints = np.linspace(0, simulation_time, n_timepoints)                                          # :251
         self.state0 = np.zeros((2, self.geometry.n_blocks, 3))                                                   # :254
@@ -199,7 +207,144 @@ def target_kinetic_energy(problem, design, target_blocks, steps_per_interval):
     return OE.kinetic_energy(vel, inertia)
 
 
+def angular_momentum(block_position, block_velocity, inertia, reference_point):
+    """difflexmm/energy.py:502-519."""
+    d = block_position[:, :2] - reference_point
+    mv = block_velocity[:, :2] * inertia[:, :2]
+    momentum_centroids = d[:, 0] * mv[:, 1] - d[:, 1] * mv[:, 0]
+    momentum_rotations = block_velocity[:, 2] * inertia[:, 2]
+    return momentum_centroids + momentum_rotations
+
+
+def target_angular_momentum(problem, design, target_blocks, spin_center, steps_per_interval):
+    """problems/quads_spin.py:404-428: angular momentum of the target blocks about ``spin_center`` summed over blocks and output
+    times; positions = block centroids of the design + displacements, inertia = compute_inertia of the target blocks' vertices."""
+    hist, solver = problem.velocity_history(design, steps_per_interval)
+    free = list(solver.free_DOF_ids)
+    cols = torch.as_tensor([[free.index(int(b) * 3 + d) for d in range(3)] for b in target_blocks], dtype=torch.long)
+    tb = torch.as_tensor(np.asarray(target_blocks), dtype=torch.long)
+    disp, vel = hist[:, 0][:, cols], hist[:, 1][:, cols]                       # (T, n_target, 3)
+    centroids = problem.geometry.block_centroids(*design)[tb]
+    inertia = OG.compute_inertia(problem.geometry.centroid_node_vectors(*design)[tb], _t(problem.p["density"]))
+    total = torch.zeros((), dtype=F64)
+    for k in range(hist.shape[0]):
+        total = total + angular_momentum(centroids + disp[k][:, :2], vel[k], inertia, _t(spin_center)).sum()
+    return total
+
+
 def multi_input_objective(problems, design, target_blocks, weights, steps_per_interval):
     """problems/quads_focusing_multi_input.py:64-82: weights @ [target kinetic energy of every forward problem]."""
     vals = torch.stack([target_kinetic_energy(p, design, target_blocks, steps_per_interval) for p in problems])
+    return (_t(weights) * vals).sum(), vals
+
+
+# ---- problems/quads_kinetic_energy_static_tuning.py -------------------------------------------------------------------------
+def static_tuning_constraints(n1_blocks, n2_blocks, n_excited_blocks, input_shift):
+    """problems/quads_kinetic_energy_static_tuning.py:124-170, construct by construct."""
+    n_blocks, ne = n1_blocks * n2_blocks, n_excited_blocks
+    driven = np.array([np.tile(np.arange((n2_blocks - ne) // 2 + input_shift, (n2_blocks + ne) // 2 + input_shift) * n1_blocks, 3),
+                       np.array([0] * ne + [1] * ne + [2] * ne)]).T                                             # :126-133
+    bottom = np.array([np.concatenate([np.arange(0, n1_blocks)] * 3),
+                       np.array([1] * n1_blocks + [0] * n1_blocks + [2] * n1_blocks)]).T                        # :135-139
+    top = np.array([np.concatenate([np.arange(n_blocks - n1_blocks, n_blocks)] * 3),
+                    np.array([1] * n1_blocks + [0] * n1_blocks + [2] * n1_blocks)]).T                           # :140-145
+    pairs = np.concatenate([driven, bottom, top])                                                               # :146-149
+    vec = np.zeros((len(pairs),))
+    dyn = vec.copy()
+    dyn[:ne] = 1                                                                                                # :153-154
+    sta = vec.copy()
+    sta[3 * ne:3 * ne + n1_blocks] = 0.5                                                                        # :155-156
+    sta[3 * ne + 3 * n1_blocks:3 * ne + 4 * n1_blocks] = -0.5                                                   # :157-158
+    clamped_ids = np.unique(np.concatenate([bottom, top])[:, 0])                                                # :160-164
+    moving_ids = np.setdiff1d(np.arange(n_blocks), clamped_ids)
+    driven_ids = np.unique(driven[:, 0])
+    return dict(constrained_block_DOF_pairs=pairs, constrained_DOFs_loading_vector_dynamic=dyn,
+                constrained_DOFs_loading_vector_static=sta, clamped_blocks_ids=clamped_ids, moving_blocks_ids=moving_ids,
+                driven_blocks_ids=driven_ids)
+
+
+def make_static_tuning_fn(n2_blocks, spacing, vec_dynamic, vec_static):
+    """problems/quads_kinetic_energy_static_tuning.py:172-196."""
+    vd, vs = _t(vec_dynamic), _t(vec_static)
+
+    def constrained_DOFs_fn_dynamic(t, amplitude, loading_rate):                                                # :176-181
+        return amplitude * torch.where((t > 0.) & (t < loading_rate ** -1), (1 - torch.cos(2 * math.pi * loading_rate * t)) / 2,
+                                       torch.zeros((), dtype=F64)) * vd
+
+    def constrained_DOFs_fn_static(t, compressive_strain, compressive_strain_rate):                             # :187-192
+        return (n2_blocks - 1) * spacing * torch.where(t < compressive_strain * compressive_strain_rate ** -1,
+                                                       t * compressive_strain_rate, compressive_strain * torch.ones((), dtype=F64)) * vs
+
+    def constrained_DOFs_fn(t, amplitude, loading_rate, compressive_strain, compressive_strain_rate, input_delay):   # :194-195
+        t = _t(t)
+        amplitude, loading_rate, compressive_strain, compressive_strain_rate, input_delay = (
+            _t(amplitude), _t(loading_rate), _t(compressive_strain), _t(compressive_strain_rate), _t(input_delay))
+        return constrained_DOFs_fn_static(t, compressive_strain, compressive_strain_rate) + constrained_DOFs_fn_dynamic(
+            t - compressive_strain * compressive_strain_rate ** -1 - input_delay, amplitude, loading_rate)
+    return constrained_DOFs_fn
+
+
+class StaticTuningForward:
+    """``ForwardProblem.setup`` / ``forward`` of problems/quads_kinetic_energy_static_tuning.py:102-283 on the oracle."""
+
+    def __init__(self, n1, n2, spacing, bond_length, k_stretch, k_shear, k_rot, density, damping, n_excited_blocks, input_shift,
+                 simulation_time_dynamic, n_timepoints, linearized_strains=False, use_contact=True, k_contact=1.0, min_angle=0.0,
+                 cutoff_angle=5 * math.pi / 180):
+        self.geometry = OG.QuadGeometry(n1, n2, spacing, bond_length)
+        self.__dict__.update(static_tuning_constraints(n1, n2, n_excited_blocks, input_shift))
+        self.n1, self.n2 = n1, n2
+        self.bonds = self.geometry.bond_connectivity()
+        self.reference_bond_vectors = self.geometry.reference_bond_vectors()
+        strain = OE.build_strain_energy(self.bonds, OE.ligament_energy_linearized if linearized_strains else OE.ligament_energy)
+        self.energy = OE.combine_block_energies(strain, OE.build_contact_energy(self.bonds)) if use_contact else strain   # :198-205
+        self.constrained_DOFs_fn = make_static_tuning_fn(n2, spacing, self.constrained_DOFs_loading_vector_dynamic,
+                                                         self.constrained_DOFs_loading_vector_static)
+        self.solver_args = dict(constrained_block_DOF_pairs=self.constrained_block_DOF_pairs,
+                                constrained_DOFs_fn=self.constrained_DOFs_fn, damped_blocks=np.arange(self.geometry.n_blocks))
+        self.simulation_time_dynamic, self.n_timepoints = simulation_time_dynamic, n_timepoints
+        self.state0 = np.zeros((2, self.geometry.n_blocks, 3))                                                  # :118
+        self.p = dict(k_stretch=k_stretch, k_shear=k_shear, k_rot=k_rot, density=density, damping=damping, k_contact=k_contact,
+                      min_angle=min_angle, cutoff_angle=cutoff_angle)
+
+    def control_params(self, design, amplitude, loading_rate, compressive_strain, compressive_strain_rate):
+        """:228-256 (``input_delay = 0.1 / loading_rate``, :229)."""
+        p = self.p
+        input_delay = 0.1 * _t(loading_rate) ** -1
+        return OE.ControlParams(
+            OE.GeometricalParams(self.geometry.block_centroids(*design), self.geometry.centroid_node_vectors(*design)),
+            OE.MechanicalParams(OE.LigamentParams(_t(p["k_stretch"]), _t(p["k_shear"]), _t(p["k_rot"]), _t(self.reference_bond_vectors)),
+                                _t(p["density"]), None, _t(p["damping"]),
+                                OE.ContactParams(_t(p["min_angle"]), _t(p["cutoff_angle"]), _t(p["k_contact"]))),
+            constraint_params=dict(amplitude=_t(amplitude), loading_rate=_t(loading_rate), compressive_strain=_t(compressive_strain),
+                                   compressive_strain_rate=_t(compressive_strain_rate), input_delay=input_delay))
+
+    def timepoints(self, loading_rate, compressive_strain, compressive_strain_rate, full_simulation_time=False, n_timepoints=None):
+        """:258-272 (plain numbers: the output times are not differentiated)."""
+        n = self.n_timepoints if n_timepoints is None else n_timepoints
+        t0 = float(compressive_strain) / float(compressive_strain_rate) + 0.1 / float(loading_rate)
+        if full_simulation_time:
+            return np.linspace(0, self.simulation_time_dynamic + t0, n)
+        return np.concatenate([np.array([0.]), np.linspace(t0, t0 + self.simulation_time_dynamic, n)])
+
+    def velocity_history(self, design, row, step_counts, timepoints=None):
+        """Free-DOF history of the dynamic-step solve (:280) on a fixed grid, on the autograd tape.  ``row`` = (amplitude,
+        loading_rate, compressive_strain, compressive_strain_rate), tensors or numbers."""
+        solver = OD.setup_dynamic_solver(self.geometry, self.energy, integrator="fixed", steps_per_interval=step_counts, **self.solver_args)
+        ts = self.timepoints(*[float(x.detach()) if isinstance(x, torch.Tensor) else float(x) for x in row[1:]]) if timepoints is None else timepoints
+        hist, _ = OD.solve_fixed_differentiable(solver, self.geometry, _t(self.state0), ts, self.control_params(design, *row), step_counts)
+        return hist, solver
+
+
+def static_tuning_objective(problem, design, rows, target_blocks_list, weights, step_counts):
+    """problems/quads_kinetic_energy_static_tuning.py:453-478: weights @ [target kinetic energy of every forward input]; the
+    fields of the dynamic step drop the first output (``solution[1:]``, :276)."""
+    vals = []
+    for row, tb in zip(rows, target_blocks_list):
+        hist, solver = problem.velocity_history(design, row, step_counts)
+        free = list(solver.free_DOF_ids)
+        cols = torch.as_tensor([[free.index(int(b) * 3 + d) for d in range(3)] for b in tb], dtype=torch.long)
+        vel = hist[1:, 1][:, cols]
+        inertia = OG.compute_inertia(problem.geometry.centroid_node_vectors(*design), _t(problem.p["density"]))[torch.as_tensor(tb)]
+        vals.append(OE.kinetic_energy(vel, inertia))
+    vals = torch.stack(vals)
     return (_t(weights) * vals).sum(), vals

@@ -1,0 +1,113 @@
+"""Shared body of the static-tuning parity tests (problems/quads_kinetic_energy_static_tuning.py): the same checks run on the CPU
+port of the engine (no GPU) and, marked gpu, on the HIP engine."""
+import math
+
+import numpy as np
+import torch
+
+from difflexmm_amd import problems as P
+from oracle import ref_problems as RP
+
+N1, N2 = 6, 5
+ROWS = np.array([[3.0, 400.0, 0.004, 40.0], [3.0, 400.0, 0.012, 40.0]])      # amplitude, loading_rate, strain, strain_rate
+STATIC_STEPS, SPI, NT, TDYN = 24, 12, 4, 1.2e-3
+KW = dict(spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5, density=6.18e-9)
+CONTACT = dict(use_contact=True, k_contact=1.5, min_angle=5 * math.pi / 180, cutoff_angle=45 * math.pi / 180)   # narrow voids engaged
+
+
+def damping():
+    return 0.05 * np.array([2 * math.sqrt(0.36125 * 6.18e-9 * 225 * 1.19)] * 2 + [2 * math.sqrt(0.02175026 * 6.18e-9 * 15.0 ** 4 * 1.5)]) * np.ones((N1 * N2, 1))
+
+
+def forward(lib):
+    fw = P.QuadsStaticTuningForward(n1_blocks=N1, n2_blocks=N2, damping=damping(), n_excited_blocks=1, input_shift=0,
+                                    simulation_time_dynamic=TDYN, n_timepoints=NT, steps_per_interval=SPI, static_steps=STATIC_STEPS,
+                                    _lib=lib, **KW, **CONTACT)
+    fw.setup()
+    return fw
+
+
+def oracle_forward():
+    return RP.StaticTuningForward(N1, N2, KW["spacing"], KW["bond_length"], KW["k_stretch"], KW["k_shear"], KW["k_rot"], KW["density"],
+                                  damping(), 1, 0, TDYN, NT, use_contact=True, k_contact=1.5, min_angle=CONTACT["min_angle"],
+                                  cutoff_angle=CONTACT["cutoff_angle"])
+
+
+def design(fw, seed=5, amp=0.2):
+    rng = np.random.default_rng(seed)
+    base = fw.geometry.get_design_from_rotated_square(25 * math.pi / 180)
+    return tuple(b + rng.uniform(-amp, amp, b.shape) for b in base)
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max()))
+
+
+def check_boundary_conditions_equal_oracle(lib):
+    fw, ofw = forward(lib), oracle_forward()
+    assert np.array_equal(fw.constrained_block_DOF_pairs, ofw.constrained_block_DOF_pairs)
+    assert np.array_equal(fw.constrained_DOFs_loading_vector_dynamic, ofw.constrained_DOFs_loading_vector_dynamic)
+    assert np.array_equal(fw.constrained_DOFs_loading_vector_static, ofw.constrained_DOFs_loading_vector_static)
+    assert np.array_equal(fw.clamped_blocks_ids, ofw.clamped_blocks_ids) and np.array_equal(fw.driven_blocks_ids, ofw.driven_blocks_ids)
+    assert len(fw.constrained_block_DOF_pairs) == 3 * 1 + 6 * N1          # driven x, y, theta + two clamped rows
+    # the drive as a function of time: value of every constrained DOF against the reference's formula (oracle restatement)
+    row = ROWS[1]
+    cp = fw.control_params(design(fw), *row)
+    t_ramp = row[2] / row[3]
+    for t in (0.0, 0.3 * t_ramp, t_ramp, t_ramp + 0.1 / row[1] + 0.3 / row[1], t_ramp + 0.1 / row[1] + 1.5 / row[1]):
+        mine = fw._drive(t, **cp.constraint_params)
+        ref = ofw.constrained_DOFs_fn(t, **{k: torch.tensor(float(v), dtype=torch.float64) for k, v in cp.constraint_params.items()}).numpy()
+        assert np.allclose(mine, ref, rtol=1e-14, atol=1e-16), t
+
+
+def check_trajectory_and_gradients(lib, tol_traj=1e-10, tol_grad=1e-9):
+    """Dynamic-step solution of both forward inputs (two engine calls: their time grids differ) against the oracle's fixed-grid
+    solver; weighted objective and its gradient w.r.t. the design AND the forward inputs (amplitude, loading rate incl. the
+    input_delay = 0.1 / f path, compressive strain incl. the delay of the pulse, strain rate) against autograd through the
+    unrolled oracle."""
+    fw, ofw = forward(lib), oracle_forward()
+    x = design(fw)
+    finp = P.ForwardInput(x[0], x[1], tuple(ROWS[:, 0]), tuple(ROWS[:, 1]), tuple(ROWS[:, 2]), tuple(ROWS[:, 3]))
+    obj = P.StaticTuningKineticEnergy(fw, finp, ((2, 2), (1, 2)), ((1, 0), (1, 1)), weights=(0.75, -0.25))
+    counts = np.array([STATIC_STEPS] + [SPI] * (NT - 1))
+    # trajectories
+    sols = fw.solve_rows(x, ROWS)
+    assert len(fw.groups) == 2 and all(len(g[1]) == 1 for g in fw.groups)
+    import oracle.ref_dynamics as OD
+    for r, sol in zip(ROWS, sols):
+        osolver = OD.setup_dynamic_solver(ofw.geometry, ofw.energy, integrator="fixed", steps_per_interval=counts, **ofw.solver_args)
+        ts = ofw.timepoints(*r[1:])
+        oref = osolver(ofw.state0, ts, ofw.control_params(tuple(torch.tensor(a) for a in x), *r)).numpy()
+        assert np.allclose(sol.timepoints, ts[1:] - ts[1])
+        assert relerr(sol.fields, oref[1:]) < tol_traj
+        assert np.abs(sol.fields[:, 0, fw.clamped_blocks_ids[0], 1]).max() > 0          # the static compression is really applied
+    # objective + gradients
+    v, g = obj.value_and_grad(x)
+    xt = [torch.tensor(a, requires_grad=True) for a in x]
+    rt = [[torch.tensor(float(c), dtype=torch.float64, requires_grad=True) for c in r] for r in ROWS]
+    ov, ovals = RP.static_tuning_objective(ofw, xt, rt, obj.target_blocks, obj.weights, counts)
+    flat = [c for r in rt for c in r]
+    og = torch.autograd.grad(ov, xt + flat)
+    assert abs(v - ov.item()) < tol_grad * abs(ov.item())
+    assert relerr(obj.last_individual, ovals.detach().numpy()) < tol_grad
+    for a, b in zip(g, og[:2]):
+        assert relerr(a, b.numpy()) < tol_grad
+    og_in = np.array([float(t) for t in og[2:]]).reshape(len(ROWS), 4)
+    for i, w in enumerate(obj.weights):
+        bar = obj.last_input_grads[i]
+        mine = w * np.array([bar["amplitude"], bar["loading_rate"], bar["compressive_strain"], bar["compressive_strain_rate"]])
+        assert np.all(np.abs(mine) > 0)
+        assert np.abs(mine - og_in[i]).max() < 10 * tol_grad * np.abs(og_in[i]).max(), (i, mine, og_in[i])
+
+
+def check_rows_with_equal_grids_share_one_call(lib):
+    """Forward inputs whose output times coincide (same strain / rate / frequency, different amplitudes) are ensemble members of
+    ONE engine call and give what they give alone."""
+    fw = forward(lib)
+    x = design(fw)
+    rows = np.array([[3.0, 400.0, 0.008, 40.0], [1.5, 400.0, 0.008, 40.0], [2.0, 400.0, 0.008, 40.0]])
+    sols = fw.solve_rows(x, rows)
+    assert len(fw.groups) == 1 and fw.groups[0][0].batch == 3
+    alone = fw.solve_rows(x, rows[1:2])[0]
+    assert relerr(sols[1].fields, alone.fields) < 1e-13
+    assert relerr(sols[0].fields, sols[1].fields) > 1e-3
