@@ -127,8 +127,28 @@ def library_path():
     return os.environ.get("DFX_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfx.so")
 
 
+def is_hip_engine(lib):
+    """A build of the gfx950 engine says so in ``dfx_version()``; anything else with the same symbols (the CPU port of the oracle) is
+    test infrastructure and must never stand in for the product."""
+    try:
+        lib.dfx_version.restype = C.c_char_p
+        return b"gfx950" in lib.dfx_version()
+    except Exception:       # noqa: BLE001
+        return False
+
+
+def check_engine_library(lib):
+    """The product accepts only the HIP engine.  Test infrastructure hands over the CPU port by marking the handle it loaded
+    (``oracle.cpu.load()`` sets ``lib._dfx_test_only = True``): an explicit, test-only door -- no environment variable opens it."""
+    if is_hip_engine(lib) or getattr(lib, "_dfx_test_only", False) is True:
+        return lib
+    raise RuntimeError("difflexmm_amd: the library handed in is not the gfx950 engine (dfx_version() = %r): there is no CPU fallback"
+                       % (getattr(lib, "dfx_version", lambda: b"?")(),))
+
+
 def load_library():
-    """Load the HIP engine.  Fails loudly when it has not been built: there is no fallback."""
+    """Load the HIP engine.  Fails loudly when it has not been built, and when ``DFX_LIBRARY`` points at something that is not a
+    build of the gfx950 engine: there is no fallback."""
     global _LIB
     if _LIB is None:
         path = library_path()
@@ -136,7 +156,11 @@ def load_library():
             raise RuntimeError(
                 f"difflexmm_amd: {path} not found -- build the HIP engine first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C difflexmm_amd/csrc)")
-        _LIB = declare(C.CDLL(path))
+        lib = declare(C.CDLL(path))
+        if not is_hip_engine(lib):
+            raise RuntimeError(f"difflexmm_amd: {path} is not a build of the gfx950 engine (dfx_version() = {lib.dfx_version()!r}); "
+                               "DFX_LIBRARY selects between builds of the HIP engine only")
+        _LIB = lib
     return _LIB
 
 
@@ -156,7 +180,7 @@ class Engine:
 
     def __init__(self, n_blocks, n_npb, bonds, bond_model, contact, special, fn_types, batch=1,
                  tableau="dopri5", device=0, lib=None, fn_tables=None, streams=0):
-        self.lib = lib if lib is not None else load_library()
+        self.lib = check_engine_library(lib) if lib is not None else load_library()
         self.n_blocks, self.n_npb, self.batch = int(n_blocks), int(n_npb), int(batch)
         self.bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
         self.n_bonds = len(self.bonds)
@@ -271,7 +295,7 @@ class Engine:
     def forward_adaptive(self, state0, timepoints, rtol, atol, max_attempts=10_000_000):
         """Adaptive Dormand-Prince with the reference's odeint semantics (forward only)."""
         B, nb = self.batch, self.n_blocks
-        state0 = _f64(state0, (B, 2, nb, 3))
+        state0 = _f64(state0, (B, 2, nb, 3)) if state0 is not None else None        # None: every member starts at rest
         ts = _f64(timepoints)
         T = len(ts)
         fields = np.empty((B, T, 2, nb, 3))

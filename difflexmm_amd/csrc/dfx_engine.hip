@@ -47,6 +47,7 @@
   } while (0)
 
 static std::string g_create_error;
+static size_t dfx_test_free_bytes = 0;     // DFX_TEST_FREE_BYTES: pretend that only so much HBM is free (tests of the checkpoint choice)
 
 template <class T>
 struct DevBuf {
@@ -264,13 +265,23 @@ static void setup_tiling(dfx_handle* h) {
   h->tile.tiles_y = tiles_along(h->tile.n_rows, h->pair_rows);
   h->tile.n_tiles = h->tile.tiles_x * h->tile.tiles_y;
 }
-// which launches the next solve uses (the pair kernels cover: even stage count, no distance-based contact, fixed grid; reverse: the
-// records checkpoint without per-ligament gradients); DFX_PAIR=0 keeps the one-stage launches, DFX_PAIR=f / a only one direction
+// which launches the next solve uses.  The pair kernels cover: even stage count, no distance-based contact, fixed grid; reverse: the
+// records checkpoint without per-ligament gradients.  Measured (profiles/r03_pair_launches.txt): a pair launch is one 1024-thread
+// workgroup per compute unit whose 16 waves load, evaluate, meet at the barrier and evaluate again in lock step, so memory time and
+// arithmetic no longer overlap between workgroups, and the window's outer ring adds 27 % of arithmetic to kernels whose vector ALUs
+// are already busy half of the time: 16 x 128x128 forward pair 53 us against 2 x 19.4 us, reverse pair 98 - 138 us against 2 x 32.8 us.
+// They pay where the launches do not fill the chip anyway: the forward pass of ONE large lattice (128x128: 10.5 ms against 12.1 ms per
+// 250 steps).  Default: forward pairs for a single group of at most 1024 waves on lattices of >= 4096 blocks, reverse never;
+// DFX_PAIR=1 forces both where they apply, f / a one direction, 0 none.
 static void pair_plan(dfx_handle* h, const DevCtx& c) {
   const char* e = getenv("DFX_PAIR");
-  const bool base = h->tiling_ok && (h->pl.tab.s % 2 == 0) && h->pl.contact != DFX_CONTACT_DISTANCE && !h->adaptive && !(e && e[0] == '0');
-  h->pair_fwd = base && !(e && e[0] == 'a');
-  h->pair_adj = base && c.rps > 1 && !c.g_b && !(e && e[0] == 'f');
+  const bool can = h->tiling_ok && (h->pl.tab.s % 2 == 0) && h->pl.contact != DFX_CONTACT_DISTANCE && !h->adaptive;
+  const long long waves = (long long)h->pl.batch * ((h->pl.n_slots + 63) / 64);
+  const bool pays_fwd = waves <= 1024 && h->pl.n_blocks >= 4096;
+  const bool want_f = e ? (e[0] == '1' || e[0] == 'f') : pays_fwd;
+  const bool want_a = e ? (e[0] == '1' || e[0] == 'a') : false;
+  h->pair_fwd = can && want_f;
+  h->pair_adj = can && want_a && c.rps > 1 && !c.g_b;
 }
 static TileCtx group_tile(const dfx_handle* h, int nm) { TileCtx t = h->tile; t.total_wg = t.n_tiles * nm; return t; }
 
@@ -528,18 +539,30 @@ enum { kCkState = 0, kCkStages = 1, kCkRecords = 2, kCkSegments = 3 };
 
 static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_steps) {
   const Plan& pl = h->pl;
+  { const char* t = getenv("DFX_TEST_FREE_BYTES"); dfx_test_free_bytes = t ? (size_t)atoll(t) : 0; }
   const size_t B = pl.batch, rec = (size_t)pl.n_blocks * kStep, N = (size_t)std::max<long long>(n_steps, 1);
   const size_t want_rec = B * (N * pl.tab.s + 1) * rec;
   const size_t want_state = B * (N + 1) * rec;
   const size_t want_ad = B * N * (pl.tab.s - 1) * pl.n_blocks * 3;
   int forced = -1;
-  if (const char* e = getenv("DFX_CHECKPOINT"))
-    forced = e[0] == 'r' ? kCkRecords : (e[0] == 's' && e[1] == 'e' ? kCkSegments : (e[0] == 's' && e[2] == 'a' && e[3] == 'g' ? kCkStages : kCkState));
-  else if (const char* e2 = getenv("DFX_STAGE_CHECKPOINT")) forced = e2[0] != '0' ? kCkStages : kCkState;
+  if (const char* e = getenv("DFX_CHECKPOINT")) {
+    if (!strcmp(e, "records")) forced = kCkRecords;
+    else if (!strcmp(e, "stages")) forced = kCkStages;
+    else if (!strcmp(e, "state")) forced = kCkState;
+    else if (!strcmp(e, "segments")) forced = kCkSegments;
+    else {
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "[dfx] DFX_CHECKPOINT=%s is not one of records|stages|state|segments: ignored\n", e);
+      warned = true;
+    }
+  } else if (const char* e2 = getenv("DFX_STAGE_CHECKPOINT")) forced = e2[0] != '0' ? kCkStages : kCkState;
   const size_t want_seg = B * ((size_t)std::max<long long>(max_interval_steps, 1) * pl.tab.s + 1) * rec;
   size_t free_b = 0, total_b = 0;
   const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-  auto fits = [&](size_t grow_elems) { return have_info && grow_elems * sizeof(double) + total_b / 20 <= free_b; };   // leave 5 % of the device
+  // a level whose buffers already exist fits whatever else has been allocated since (adjoint work buffers, sibling engines of a
+  // multi-input objective, RCCL): only GROWTH is checked against the free memory, leaving 5 % of the device
+  const size_t free_now = dfx_test_free_bytes ? std::min<size_t>(free_b, dfx_test_free_bytes) : free_b;
+  auto fits = [&](size_t grow_elems) { return grow_elems == 0 || (have_info && grow_elems * sizeof(double) + total_b / 20 <= free_now); };
   const size_t have_t = h->d_traj.n, have_a = h->d_AD.n;
   auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
   int mode = forced;
@@ -1103,6 +1126,8 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   HIP_OK(h->d_ts.ensure(Tn));
   HIP_OK(h->d_tmp.ensure(std::max<size_t>(B * nb * 6, B)));
   HIP_OK(hipMemcpyAsync(h->d_ts.p, timepoints, sizeof(double) * Tn, hipMemcpyHostToDevice, h->stream));
+  std::vector<double> rest;
+  if (!state0) { rest.assign(B * nb * 6, 0.0); state0 = rest.data(); }      // NULL = every member starts at rest, as in dfx_forward
   HIP_OK(hipMemcpyAsync(h->d_state0.p, state0, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   // constrained flags and free-DOF count
   std::vector<char> con(nd, 0);

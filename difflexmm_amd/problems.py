@@ -5,7 +5,7 @@
 * kagome: ``problems/kagome_focusing.py:96-172``, ``:403-407``
 * objective ``target_kinetic_energy``: ``problems/quads_focusing.py:453-467`` with ``energy.py:494-499``
 """
-from dataclasses import dataclass
+from dataclasses import InitVar, dataclass
 from typing import Any, Optional, Tuple
 
 import numpy as np
@@ -143,13 +143,18 @@ class QuadsFocusingForward:
     min_angle: Any = 0. * np.pi / 180
     cutoff_angle: Any = 5. * np.pi / 180
     n_blocks_clamped_corner: int = 2
+    atol: float = 1e-8              # solver tolerances (problems/quads_focusing.py:73-74): the adaptive controller's, and those of
+    rtol: float = 1e-8              # the grid it freezes for gradients, when steps_per_interval is None
     steps_per_interval: Optional[int] = None
     integrator: str = "dopri5"
     batch: int = 1
     device: int = 0
     streams: int = 0          # member groups on their own HIP streams (0: the engine chooses); multi-input objectives set 1
     name: str = "quads_focusing"
-    _lib: Any = None
+    _lib: InitVar[Any] = None      # test infrastructure only (the CPU port of the oracle): not a field, never serialised
+
+    def __post_init__(self, _lib=None):
+        self._lib = _lib
     _drive_cls = L.Pulse          # problems/quads_focusing.py:211-222
 
     def setup(self):
@@ -165,7 +170,7 @@ class QuadsFocusingForward:
         energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=self._drive_cls(vec),
-            damped_blocks=np.arange(g.n_blocks), integrator=self.integrator,
+            damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
             steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
@@ -305,13 +310,18 @@ class KagomeFocusingForward:
     min_angle: Any = 0. * np.pi / 180
     cutoff_angle: Any = 5. * np.pi / 180
     n_blocks_clamped_corner: int = 2
+    atol: float = 1e-8              # solver tolerances (problems/quads_focusing.py:73-74): the adaptive controller's, and those of
+    rtol: float = 1e-8              # the grid it freezes for gradients, when steps_per_interval is None
     steps_per_interval: Optional[int] = None
     integrator: str = "dopri5"
     batch: int = 1
     device: int = 0
     streams: int = 0
     name: str = "kagome_focusing"
-    _lib: Any = None
+    _lib: InitVar[Any] = None      # test infrastructure only (the CPU port of the oracle): not a field, never serialised
+
+    def __post_init__(self, _lib=None):
+        self._lib = _lib
 
     def setup(self):
         if self.loaded_side != "left":
@@ -329,7 +339,7 @@ class KagomeFocusingForward:
         energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=L.Pulse(vec),
-            damped_blocks=np.arange(g.n_blocks), integrator=self.integrator,
+            damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
             steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
@@ -416,7 +426,10 @@ class QuadsStaticTuningForward:
     integrator: str = "dopri5"
     device: int = 0
     streams: int = 0
-    _lib: Any = None
+    _lib: InitVar[Any] = None      # test infrastructure only (the CPU port of the oracle): not a field, never serialised
+
+    def __post_init__(self, _lib=None):
+        self._lib = _lib
 
     def setup(self):
         g = self.geometry = QuadGeometry(self.n1_blocks, self.n2_blocks, self.spacing, self.bond_length)

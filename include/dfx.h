@@ -125,9 +125,11 @@ typedef struct dfx_stats {
   int64_t streams;                        /* member groups integrated concurrently (one HIP stream each) */
   int64_t stage_checkpoint;               /* 1: the forward pass also kept the stage accelerations of every step, so the
                                              reverse sweep runs without recompute launches (chosen when it fits in HBM) */
-  int64_t checkpoint_records;             /* 1: the forward pass kept EVERY stage record of every step (72 s B per unit and step): the
+  int64_t checkpoint_records;             /* 1: the forward pass kept EVERY stage record of every step (56 s B per unit and step): the
                                              reverse launches read them directly, nothing is rebuilt or recomputed (richest level,
-                                             taken when it fits; then stage_checkpoint = 0) */
+                                             taken when it fits; then stage_checkpoint = 0);
+                                             2: "segments": nothing but the outputs was kept, the reverse sweep re-runs one output
+                                             interval at a time with the records of that interval only */
 } dfx_stats;
 
 typedef struct dfx_handle dfx_handle;
@@ -162,6 +164,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
 
 /* The reference's own integrator semantics (jax.experimental.ode.odeint 0.4.8 called at dynamics.py:166): adaptive
  * Dormand-Prince 5(4), RMS error norm over the free (q, v) components with tolerance atol + rtol*max(|y0|,|y1|),
+ * (state0 == NULL: every member starts at rest, as in dfx_forward / dfx_forward_grid)
  * step factor min(10, max(0.9 ratio^-1/5, 1 | 0.2)) applied on accept and reject, Hairer initial step, quartic dense
  * output at `timepoints` (steps are not clipped to output times).  Every member controls its own step.  Forward only:
  * the reverse sweep needs the fixed grid of dfx_forward.  stats->steps = accepted steps (max over members),

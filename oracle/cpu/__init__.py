@@ -20,6 +20,7 @@ def load():
     if _LIB is None:
         from difflexmm_amd._binding import declare
         _LIB = declare(ctypes.CDLL(build()))
+        _LIB._dfx_test_only = True        # the product's Engine refuses any non-gfx950 library without this mark
         # hosts report hundreds of logical CPUs but may grant only a few: a spinning 256-thread OpenMP team on small
         # lattices is pathologically slow, so cap the team unless the user asked for something else
         if "OMP_NUM_THREADS" not in os.environ:

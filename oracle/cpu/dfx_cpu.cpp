@@ -252,6 +252,7 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
   const Plan& pl = h->pl;
   const int nb = pl.n_blocks, nd = nb * 3, B = pl.batch, Tn = n_timepoints;
   const Dopri D = make_dopri();
+  if (!state0) { h->zero_state.assign((size_t)B * nb * 6, 0.0); state0 = h->zero_state.data(); }   // NULL: at rest
   h->ts.assign(timepoints, timepoints + Tn);
   h->have_traj = false;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);

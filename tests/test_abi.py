@@ -66,3 +66,29 @@ def test_product_never_imports_the_oracle():
             elif f.endswith((".h", ".hip", ".cpp")):
                 src = open(path).read()
                 assert not re.search(r'#include\s+"[^"]*oracle/', src), path
+
+
+def test_dfx_library_cannot_point_at_the_cpu_port(cpu_lib, monkeypatch):
+    """DFX_LIBRARY selects between builds of the gfx950 engine; pointing it at the CPU port of the oracle (same symbols) must fail
+    loudly, and so must handing an unmarked non-gfx950 library to Engine / the problem classes."""
+    import ctypes
+    import numpy as np
+    from difflexmm_amd import _binding as b
+    cpu_so = os.path.join(ROOT, "oracle", "cpu", "libdfx_cpu.so")
+    monkeypatch.setenv("DFX_LIBRARY", cpu_so)
+    monkeypatch.setattr(b, "_LIB", None)
+    with pytest.raises(RuntimeError, match="not a build of the gfx950 engine"):
+        b.load_library()
+    monkeypatch.delenv("DFX_LIBRARY")
+    monkeypatch.setattr(b, "_LIB", None)
+    raw = b.declare(ctypes.CDLL(cpu_so))                   # the same library WITHOUT the test-only mark oracle.cpu.load() sets
+    with pytest.raises(RuntimeError, match="not the gfx950 engine"):
+        b.Engine(4, 4, np.array([[0, 6]]), 1, 0, [], [], lib=raw)
+    assert getattr(cpu_lib, "_dfx_test_only", False) is True
+
+
+def test_test_library_hook_is_not_a_dataclass_field():
+    import dataclasses
+    from difflexmm_amd import problems as P
+    for cls in (P.QuadsFocusingForward, P.KagomeFocusingForward, P.QuadsStaticTuningForward, P.QuadsSpinForward):
+        assert "_lib" not in [f.name for f in dataclasses.fields(cls)]

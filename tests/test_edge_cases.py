@@ -155,6 +155,20 @@ def invalid_problems_are_refused(lib):
         solver.engine.adjoint(np.zeros((1, 2, 2, g.n_blocks, 3)))
 
 
+@case
+def adaptive_solve_from_rest_without_a_state(lib):
+    """state0 == NULL means "at rest" for the adaptive forward too (include/dfx.h; round-2 advice: only the fixed-grid entry
+    points handled it)."""
+    c = Case("quads", 4, True, False, lib=lib)
+    c.cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+    flat = c.solver._flatten(c.cp)
+    c.solver.engine.set_params(**{k: v[None] for k, v in flat.items()})
+    ts = np.linspace(0.0, 2e-4, 3)
+    f0, st0 = c.solver.engine.forward_adaptive(None, ts, 1e-8, 1e-8)
+    f1, st1 = c.solver.engine.forward_adaptive(np.zeros((1, 2, 16, 3)), ts, 1e-8, 1e-8)
+    assert st0["steps"] == st1["steps"] > 0 and np.array_equal(f0, f1) and np.abs(f0).max() > 0
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_edge_case_cpu_port(cpu_lib, name):
     CASES[name](cpu_lib)

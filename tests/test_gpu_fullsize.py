@@ -215,3 +215,21 @@ def test_adaptive_solve_on_member_group_streams_equals_one_stream(hip_lib, monke
         eng.close()
     assert out["1"][1] == 1 and out["2"][1] == 2 and out["1"][2] == out["2"][2] > 10
     assert np.array_equal(out["1"][3], out["2"][3]) and np.array_equal(out["1"][0], out["2"][0]) and np.abs(out["1"][0]).max() > 0
+
+
+def test_checkpoint_level_survives_low_free_memory_once_allocated(hip_lib, monkeypatch):
+    """Round-2 advice: choose_checkpoint ran its 5 %-of-HBM-free test even for buffers that already existed, so the second solve of a
+    loop that nearly fills the device silently dropped from records to segments (3 s launches per step instead of s).  A level whose
+    buffers exist must fit; only growth is checked.  DFX_TEST_FREE_BYTES makes the engine believe the device is almost full."""
+    c = Case("quads", 16, True, True, seed=2, cutoff_deg=42.0)
+    c.cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+    ts = np.linspace(0.0, 2e-4, 3)
+    y0 = np.zeros((2, 256, 3))
+    monkeypatch.delenv("DFX_CHECKPOINT", raising=False)
+    c.solver(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=10)
+    assert c.solver.stats["checkpoint_records"] == 1                       # records level, buffers now allocated
+    monkeypatch.setenv("DFX_TEST_FREE_BYTES", "1024")                     # "nothing is free any more"
+    c.solver(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=10)
+    assert c.solver.stats["checkpoint_records"] == 1                       # same level: nothing had to grow
+    c.solver(y0, np.linspace(0.0, 4e-4, 5), c.cp, keep_trajectory=True, steps_per_interval=10)
+    assert c.solver.stats["checkpoint_records"] == 2                       # a longer solve must grow: with no memory left -> segments
