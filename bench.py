@@ -74,19 +74,19 @@ def c3_problem(size, seed, members, lib=None, device=0, input_delay=0.0, target_
     return fw, obj, designs
 
 
-def step_grid(n_steps, spi=SPI):
+def step_grid(n_steps, spi=SPI, t_start=0.0):
     """EXACTLY n_steps RK steps of size DT: full output intervals of `spi` steps and, when n_steps is not a multiple of
     spi, one shorter last interval.  Returns (timepoints, steps per interval)."""
     full, rest = divmod(int(n_steps), spi)
     counts = [spi] * full + ([rest] if rest else [])
-    ts = np.concatenate([[0.0], np.cumsum(counts) * DT])
+    ts = t_start + np.concatenate([[0.0], np.cumsum(counts) * DT])
     return ts, (spi if not rest else np.array(counts, dtype=np.int32))
 
 
-def prepare(fw, designs, n_steps, spi=SPI):
+def prepare(fw, designs, n_steps, spi=SPI, t_start=0.0):
     """Host side of a solve: design -> ControlParams -> flattened arrays -> device (dfx_set_params).  After this call the
     inputs are resident in HBM; it is NOT part of the timed region."""
-    fw.timepoints, fw.step_counts = step_grid(n_steps, spi)
+    fw.timepoints, fw.step_counts = step_grid(n_steps, spi, t_start)
     sd = fw.solve_dynamics
     cps = [fw.control_params(d) for d in designs]
     flats = [sd._flatten(cp) for cp in cps]
@@ -129,6 +129,133 @@ def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
     if fw.solve_dynamics.engine.lib.dfx_device_count() > 0 and spi == SPI:
         spin_up(fw, spi=spi)
     return execute(fw, obj, adjoint, spi)
+
+
+def c3_as_written_leg(args, device, sync, steps=2500):
+    """C3 as BASELINE.json / SURVEY 8(d) write it, at the only checkpoint level its 50 000-step horizon can use.  The headline times
+    K steps at the records level with the pulse at t = 0 and the target next to the drive; a user of C3 gets: pulse delayed by
+    0.1/f, 2x2 target shifted by (N//6, N//5) = (21, 25), and -- 4.4 TB of stage records do not fit -- the SEGMENTS level (the reverse
+    sweep re-runs one output interval at a time: 3 s launches per step instead of 2 s).  Timed here: `steps` steps of that solve,
+    the window that starts when the pulse does (t0 = 0.1/f: the lattice is exactly at rest until then, so the window is steps
+    2 500 .. 2 500 + `steps` of the 50 000), all members, forward + adjoint."""
+    t_d = 0.1 / FREQ
+    keep = os.environ.get("DFX_CHECKPOINT")
+    os.environ["DFX_CHECKPOINT"] = "segments"
+    os.environ["DFX_STREAMS"] = str(args.streams)
+    try:
+        fw, obj, designs = c3_problem(args.size, 3, args.members, device=device, input_delay=t_d,
+                                      target_shift=(args.size // 6, args.size // 5))
+        eng = fw.solve_dynamics.engine
+        eng.reserve(steps, steps // SPI + 2, keep_trajectory=True)
+        prepare(fw, designs, 2 * SPI, t_start=t_d)
+        execute(fw, obj)                                         # warm-up: two output intervals, same kernels
+        prepare(fw, designs, steps, t_start=t_d)
+        spin_up(fw)
+        sync()
+        t0 = time.perf_counter()
+        res = execute(fw, obj)
+        sync()
+        wall = time.perf_counter() - t0
+        gnorm = grad_norm(res)
+        eng.close()
+    finally:
+        if keep is None:
+            os.environ.pop("DFX_CHECKPOINT", None)
+        else:
+            os.environ["DFX_CHECKPOINT"] = keep
+    n_units = args.size * args.size
+    streams = res["streams"]
+    # per reverse step and stream: 6 re-run forward stages + 6 reverse stages
+    f_us = 1e3 * res["fwd_ms"] / max(1.0, res["fwd_launches"] / streams)
+    n_adj = res["adj_launches"] / 2.0 / streams
+    a_us = max(1e-9, (1e3 * res["adj_ms"] - n_adj * f_us) / n_adj)
+    per_step_bytes = 6 * BYTES_FWD_STAGE + 48 + 6 * BYTES_ADJ_STAGE          # SURVEY 8(d): what ONE forward + ONE reverse pass need
+    total = steps * n_units * args.members
+    return {"value": total / wall, "unit": "timesteps*units/s", "steps": steps, "window": f"steps 2500..{2500 + steps} of 50000 (t0 = 0.1/f)",
+            "members_per_gpu": args.members, "checkpoint": res.get("checkpoint"), "input_delay_s": t_d,
+            "target_shift": [args.size // 6, args.size // 5], "target_blocks": [int(b) for b in obj.target_blocks],
+            "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
+            "adjoint_over_forward": res["adj_ms"] / res["fwd_ms"], "launches": {"forward": res["fwd_launches"], "adjoint": res["adj_launches"]},
+            "objective": [float(x) for x in np.atleast_1d(res["objective"])][:4], "grad_norm": gnorm,
+            "end_to_end_frac_of_hbm_peak": per_step_bytes * total / wall / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_adj_stage<nonlinear,contact>", "regime": f"{streams} member groups on concurrent streams",
+                         "launch_period_us": a_us, "achieved": BYTES_ADJ_STAGE * n_units * args.members / (a_us * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": BYTES_ADJ_STAGE * n_units * args.members / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "forward_launch_period_us": f_us,
+                         "forward_frac": BYTES_FWD_STAGE * n_units * args.members / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+
+
+C4_DESIGNS = 64                 # BASELINE config 4: 64 designs in all, seeds 100 .. 163
+
+
+def c4_problem(members, steps, device=0, lib=None):
+    """BASELINE config 4 (SURVEY 8(d) "C4"): 64x64-cell kagome (8 192 triangles), notebook constants of
+    kagome_focusing_3dp_pla_shims.ipynb cell 7, contact + damping, pulse on the left edge, 3/f horizon, target kinetic energy,
+    through the caller the reference uses (problems/kagome_focusing.py restated in difflexmm_amd/problems.py)."""
+    from difflexmm_amd.problems import KagomeFocusingForward, TargetKineticEnergy
+    n1 = n2 = 64
+    rho, ksh, kr, cell = 6.18e-9, 1.19, 1.5, 20.0
+    damping = 0.0186 * np.array([2 * math.sqrt(0.070175913225 * rho * cell ** 2 * ksh)] * 2 +
+                                [2 * math.sqrt(0.0009477510275 * rho * cell ** 4 * kr)]) * np.ones((2 * n1 * n2, 1))
+    n_out = 40
+    spi = max(1, steps // n_out)
+    fw = KagomeFocusingForward(n1_cells=n1, n2_cells=n2, cell_size=cell, bond_length=2.25, k_stretch=120.0, k_shear=ksh, k_rot=kr,
+                               density=rho, damping=damping, amplitude=0.5 * cell, loading_rate=FREQ, input_delay=0.1 / FREQ,
+                               n_excited_blocks=2, simulation_time=spi * n_out * DT,      # the full config: 75 000 steps of DT = 3/f
+                               n_timepoints=n_out + 1, use_contact=True, k_contact=kr, min_angle=-15 * math.pi / 180,
+                               cutoff_angle=-10 * math.pi / 180, steps_per_interval=spi, batch=members, device=device, _lib=lib)
+    obj = TargetKineticEnergy(fw, (2, 2), (n1 // 6, n2 // 5))
+    return fw, obj, spi * n_out
+
+
+def run_c4(args, comm, comm_info, world, rank, local_rank):
+    """`--workload c4 --gpus N`: the 64 designs are dealt to the ranks in contiguous equal chunks (strong scaling: the total is
+    fixed), every rank evaluates objective + design gradient of its chunk as ONE batch through the problem layer (host-side design
+    maps included, as a user of problems/kagome_focusing.py pays them), objectives are combined with ONE all-gather."""
+    from difflexmm_amd import _binding as B
+    from difflexmm_amd import ensemble
+    if C4_DESIGNS % world:
+        sys.exit(f"bench.py --workload c4: {C4_DESIGNS} designs do not split evenly over {world} ranks")
+    members = C4_DESIGNS // world
+    K = max(40, args.steps - args.steps % 40)
+    fw, obj, K = c4_problem(members, K, device=local_rank)
+    lo, hi = ensemble.shard_bounds(C4_DESIGNS, rank, world)
+    designs = []
+    for seed in range(100 + lo, 100 + hi):
+        rng = np.random.default_rng(seed)
+        designs.append(tuple(rng.uniform(-0.3, 0.3, sh) for sh in fw.geometry.design_shapes()))
+    for _ in range(1 if args.warmup else 0):
+        obj.value_and_grad(designs)                 # allocations, graphs, clocks
+    B.device_synchronize(local_rank); comm.barrier(); B.device_synchronize(local_rank)
+    t0 = time.perf_counter()
+    vals, grads = obj.value_and_grad(designs)
+    B.device_synchronize(local_rank); comm.barrier(); B.device_synchronize(local_rank)
+    wall = float(comm.all_reduce([time.perf_counter() - t0], "max")[0])
+    allv = ensemble.gather_objectives(vals, C4_DESIGNS, comm)
+    sd = fw.solve_dynamics
+    dev_ms = comm.all_reduce([sd.stats["kernel_ms"], sd.adjoint_stats["kernel_ms"]], "max")
+    if rank == 0:
+        n_units = fw.geometry.n_blocks
+        gn = float(np.sqrt(sum(float(np.vdot(a, a)) for g in grads for a in g)))
+        line = {"metric": "timesteps*rigid-units/s (forward + design gradient)", "value": K * n_units * C4_DESIGNS / wall,
+                "unit": "timesteps*units/s", "n_gpus": world, "steps": K, "warmup": 1 if args.warmup else 0, "ms_per_step": 1e3 * wall / K,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"C4: 64x64-cell kagome ({n_units} units), nonlinear ligaments + damping + angle contact, pulse drive, "
+                                       f"fixed-step Dopri5, {K} steps over {fw.simulation_time:.3e} s, {C4_DESIGNS} designs in all "
+                                       f"(seeds 100..163), forward + gradient w.r.t. the three shift fields through KagomeFocusingForward / "
+                                       "TargetKineticEnergy (host-side design maps inside the timed region)",
+                           "designs_total": C4_DESIGNS, "members_per_gpu": members, "collective": comm_info["collective"],
+                           "ranks_seen": comm_info.get("ranks_seen"), "rccl_version": comm_info.get("rccl_runtime"),
+                           "checkpoint": {1: "records", 2: "segments"}.get(sd.adjoint_stats.get("checkpoint_records", 0))
+                           or ("stages" if sd.adjoint_stats.get("stage_checkpoint") else "state"),
+                           "concurrent_streams": int(sd.adjoint_stats.get("streams", 1))},
+                "device_ms": {"forward": float(dev_ms[0]), "adjoint": float(dev_ms[1]), "wall": 1e3 * wall},
+                "device_only_value": K * n_units * C4_DESIGNS / (1e-3 * float(dev_ms[0] + dev_ms[1])),
+                "objective": [float(x) for x in allv[:8]], "objectives_gathered": int(len(allv)), "grad_norm_rank0": gn}
+        print(json.dumps(line), flush=True)
+    comm.barrier()
+    comm.close()
+    sd.engine.close()
 
 
 def usable_cpus():
@@ -224,28 +351,31 @@ def launch_ranks(n, argv):
 
 
 def make_comm(args, world, rank, local_rank):
-    """Communicator of the N > 1 run.  RCCL (inside libdfx) is the collective; a TCP control channel comes first so that the
-    ranks agree on whether it came up -- if it did not on any rank, all of them say so in the JSON line and gather the
-    objectives over the control channel instead of hanging."""
+    """Communicator of the N > 1 run + what it really is.  RCCL (inside libdfx) is the collective; a TCP control channel comes first:
+    the unique id travels over it and the ranks agree on go / no-go BEFORE anyone enters ncclCommInitRank.  `--backend rccl` (the
+    default) is strict: if RCCL does not come up on N distinct devices every rank exits non-zero -- no silent TCP stand-in;
+    `--backend socket` is the explicit rehearsal (several ranks on one GPU)."""
     from difflexmm_amd import ensemble
     if world == 1:
-        return ensemble.SerialComm(), "none (1 rank)"
+        return ensemble.SerialComm(), {"collective": "none (1 rank)", "ranks_seen": 1}
     ctrl = ensemble.SocketComm(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                int(os.environ.get("DFX_SOCKET_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 11)))
     if args.backend == "socket":
-        return ctrl, "socket (rehearsal)"
-    err = ""
-    comm = None
+        return ctrl, {"collective": "socket (rehearsal)", "ranks_seen": ctrl.world}
+    err, comm = "", None
     try:
-        comm = ensemble.init_from_env("rccl", device=local_rank)
+        comm = ensemble.init_from_env("rccl", device=local_rank, ctrl=ctrl)
     except Exception as e:            # noqa: BLE001 -- reported, not swallowed
         err = f"{type(e).__name__}: {e}"
     ok = ctrl.all_reduce([0.0 if err else 1.0], "min")[0] > 0
-    if ok:
-        return comm, "rccl"
-    if rank == 0:
-        print(f"bench: RCCL did not come up ({err or 'on another rank'}); objectives gathered over TCP", file=sys.stderr)
-    return ctrl, f"socket-fallback ({err or 'rccl failed on another rank'})"
+    if not ok:
+        if rank == 0 or err:
+            print(f"bench: rank {rank}: RCCL did not come up ({err or 'on another rank'}); --backend rccl does not fall back", file=sys.stderr)
+        ctrl.close()
+        sys.exit(3)
+    info = dict(comm.info(), collective="rccl")
+    ctrl.close()
+    return comm, info
 
 
 def main():
@@ -262,7 +392,14 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="member groups advanced concurrently, one HIP stream each")
     ap.add_argument("--no-single", action="store_true", help="skip the extra 1-member reference measurement")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the separate 1-stream per-launch measurement")
-    ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx) | socket (rehearsal on one GPU)")
+    ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx; strict: exits non-zero if it "
+                                                      "does not come up on N distinct GPUs) | socket (rehearsal on one GPU)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3: 128x128 quads, fixed designs per GPU (weak scaling; the headline).  c4: BASELINE config 4 -- 64 kagome "
+                         "designs (64x64 cells) in all, sharded over the ranks, forward + design gradient through the problem layer, "
+                         "one all-gather of objectives (strong scaling)")
+    ap.add_argument("--no-as-written", action="store_true", help="skip the extra C3-as-written leg (segments checkpoint, paper's pulse "
+                                                                 "delay and target placement, 2500 steps)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     ap.add_argument("--input-delay", type=float, default=0.0, help="pulse delay in s (C3 text: 0.1/f = 3.33e-3)")
     ap.add_argument("--contact-cutoff-deg", type=float, default=-10.0,
@@ -288,7 +425,10 @@ def main():
     from difflexmm_amd import _binding as B
     if args.all_ranks_device >= 0:
         local_rank = args.all_ranks_device
-    comm, collective = make_comm(args, world, rank, local_rank)
+    comm, comm_info = make_comm(args, world, rank, local_rank)
+    collective = comm_info["collective"]
+    if args.workload == "c4":
+        return run_c4(args, comm, comm_info, world, rank, local_rank)
     os.environ["DFX_STREAMS"] = str(args.streams)
     K = max(1, args.steps)                      # EXACTLY K steps are timed
     W = max(0, args.warmup)
@@ -358,9 +498,17 @@ def main():
         r1 = execute(fw1, obj1)
         sync()
         w1 = time.perf_counter() - t1
+        f1_us, a1_us = 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]), 1e3 * r1["adj_ms"] / max(1, r1["adj_launches"])
+        n1u = args.size * args.size
+        stages_per_fwd_launch = 6.0 * K1 / max(1, r1["fwd_launches"] - K1 // SPI - 2)      # 2 when the forward pass runs pair launches
         single = {"members_per_gpu": 1, "steps": K1, "value": K1 * args.size * args.size / w1,
                   "forward_only_value": K1 * args.size * args.size / (r1["fwd_ms"] * 1e-3),
-                  "fwd_launch_us": 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]),
+                  "fwd_launch_us": f1_us, "adj_launch_us": a1_us,
+                  "roofline": {"bound": "hbm", "kernel": "k_adj_stage<nonlinear,contact>", "launch_us": a1_us,
+                               "achieved": BYTES_ADJ_STAGE * n1u / (a1_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": BYTES_ADJ_STAGE * n1u / (a1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "forward_frac": round(stages_per_fwd_launch) * BYTES_FWD_STAGE * n1u / (f1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "forward_stages_per_launch": round(stages_per_fwd_launch)},
                   "checkpoint": r1.get("checkpoint"),
                   "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
         fw1.solve_dynamics.engine.close()
@@ -441,7 +589,8 @@ def main():
                        "members_per_gpu": args.members, "members_requested": requested_members, "concurrent_streams": streams,
                        "checkpoint": res.get("checkpoint"), "integrator": "dopri5-fixed",
                        "steps_per_output": SPI, "input_delay_s": args.input_delay, "contact_deg": [args.contact_min_deg, args.contact_cutoff_deg],
-                       "target_blocks": [int(b) for b in obj.target_blocks], "collective": collective},
+                       "target_blocks": [int(b) for b in obj.target_blocks], "collective": collective,
+                       "ranks_seen": comm_info.get("ranks_seen"), "rccl_version": comm_info.get("rccl_runtime")},
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
             "host_prepare_ms": host_prepare_ms, "value_with_host_prepare": total_units_steps / (wall + 1e-3 * host_prepare_ms),
@@ -494,6 +643,8 @@ def main():
         line["end_to_end_frac_of_hbm_peak"] = per_step_bytes * total_units_steps / wall / 1e9 / HBM_PEAK_GBS
         if single is not None:
             line["single_system"] = single
+        if world == 1 and adjoint and not args.no_as_written and args.size == 128:
+            line["c3_as_written"] = c3_as_written_leg(args, local_rank, sync)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.size, 3)
         print(json.dumps(line), flush=True)

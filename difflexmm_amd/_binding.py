@@ -56,7 +56,7 @@ EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
-COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rank", "dfx_comm_size",
+COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
                 "dfx_mem_info", "dfx_device_synchronize"]
 EXPORTS = EXPORTS + COMM_EXPORTS
@@ -94,6 +94,7 @@ def declare(lib):
         lib.dfx_comm_init.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(H)]
         for n in ("dfx_comm_destroy", "dfx_comm_rank", "dfx_comm_size", "dfx_comm_barrier"):
             getattr(lib, n).argtypes = [H]
+        lib.dfx_comm_rccl_version.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.dfx_gather_objectives.argtypes = [H, _dp, C.c_int32, _dp]
         lib.dfx_reduce_grads.argtypes = [H, _dp, C.c_int64]
         lib.dfx_comm_allreduce.argtypes = [H, _dp, C.c_int64, C.c_int32]

@@ -67,6 +67,11 @@ int dfx_comm_init(int32_t rank, int32_t nranks, const char* uid128, int32_t devi
   auto fail = [&](int rc) { delete c; return rc; };
   if (hipSetDevice(device) != hipSuccess) { g_comm_error = "comm_init: hipSetDevice failed"; return fail(2); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_comm_error = "comm_init: hipStreamCreate failed"; return fail(2); }
+  { int rt = 0;      // the headers this file was compiled with and the library it runs must agree on the major version
+    if (ncclGetVersion(&rt) != ncclSuccess || rt / 10000 != NCCL_VERSION_CODE / 10000) {
+      g_comm_error = "comm_init: RCCL runtime " + std::to_string(rt) + " does not match the headers (" + std::to_string(NCCL_VERSION_CODE) + ")";
+      (void)hipStreamDestroy(c->stream); return fail(3);
+    } }
   ncclUniqueId id;
   memcpy(&id, uid128, sizeof(id));
   ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
@@ -84,6 +89,16 @@ int dfx_comm_destroy(dfx_comm* c) {
   if (c->h_buf) (void)hipHostFree(c->h_buf);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return 0;
+}
+
+// RCCL the process actually runs (another library with the same SONAME may have been loaded first, e.g. the one bundled with a
+// Python package) and the one the engine was compiled against: major * 10000 + minor * 100 + patch
+int dfx_comm_rccl_version(int32_t* runtime, int32_t* compiled) {
+  int v = 0;
+  COMM_NCCL(ncclGetVersion(&v));
+  if (runtime) *runtime = v;
+  if (compiled) *compiled = NCCL_VERSION_CODE;
   return 0;
 }
 

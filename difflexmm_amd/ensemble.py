@@ -43,14 +43,39 @@ class SerialComm:
 
 
 class RcclComm:
-    """RCCL over xGMI through libdfx (one rank per GPU)."""
+    """RCCL over xGMI through libdfx (one rank per GPU).
 
-    def __init__(self, rank, world, device, uid_file, lib=None, timeout=300.0):
+    Bring-up is agreed on BEFORE any rank enters ``ncclCommInitRank`` (a rank that fails alone would leave the others blocked inside
+    it): with a control channel ``ctrl`` (any communicator with ``all_gather`` / ``all_reduce``; ``init_from_env`` opens a
+    ``SocketComm``) rank 0 sends the unique id over it, every rank sets its device, and all ranks exchange a go / no-go -- one failed
+    preflight and every rank raises.  Ranks must sit on distinct devices.  Without a control channel the id travels through
+    ``uid_file`` (rank 0 removes a stale file first and publishes atomically)."""
+
+    def __init__(self, rank, world, device, uid_file=None, lib=None, timeout=300.0, ctrl=None):
         from ._binding import load_library
         self.lib = lib if lib is not None else load_library()
-        self.rank, self.world = int(rank), int(world)
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
         uid = C.create_string_buffer(128)
-        if self.rank == 0:
+        err = ""
+        if ctrl is not None:
+            if self.rank == 0 and self.lib.dfx_comm_unique_id(uid) != 0:
+                err = "dfx_comm_unique_id: " + self.lib.dfx_comm_last_error().decode()
+            sent = ctrl.all_gather(np.frombuffer(uid.raw, dtype=np.uint8).astype(np.float64))     # rank 0's row is the id
+            uid = C.create_string_buffer(bytes(np.asarray(sent[0], dtype=np.uint8)), 128)
+            f, t = C.c_int64(0), C.c_int64(0)
+            if not err and self.lib.dfx_mem_info(self.device, C.byref(f), C.byref(t)) != 0:       # sets the device: the preflight
+                err = f"device {self.device}: " + self.lib.dfx_comm_last_error().decode()
+            devices = ctrl.all_gather(np.array([float(self.device)])).ravel()
+            if not err and len(set(devices.tolist())) != self.world and os.environ.get("DFX_ALLOW_SHARED_DEVICE") != "1":
+                err = f"ranks share a device ({devices.astype(int).tolist()}): RCCL needs one GPU per rank"
+            ok = ctrl.all_reduce([0.0 if err else 1.0], "min")[0] > 0
+            if not ok:
+                raise RuntimeError("RcclComm: bring-up refused before ncclCommInitRank (" + (err or "preflight failed on another rank") + ")")
+        elif self.rank == 0:
+            try:
+                os.remove(uid_file)                      # a crashed launch with the same name may have left one behind
+            except OSError:
+                pass
             self._check(self.lib.dfx_comm_unique_id(uid), "dfx_comm_unique_id")
             tmp = f"{uid_file}.tmp{os.getpid()}"
             with open(tmp, "wb") as f:
@@ -65,13 +90,19 @@ class RcclComm:
             with open(uid_file, "rb") as f:
                 uid = C.create_string_buffer(f.read(), 128)
         self._c = C.c_void_p()
-        self._check(self.lib.dfx_comm_init(self.rank, self.world, uid, int(device), C.byref(self._c)), "dfx_comm_init")
+        self._check(self.lib.dfx_comm_init(self.rank, self.world, uid, self.device, C.byref(self._c)), "dfx_comm_init")
         self.barrier()
-        if self.rank == 0:
+        if ctrl is None and self.rank == 0:
             try:
                 os.remove(uid_file)
             except OSError:
                 pass
+
+    def info(self):
+        """What the collective really is: ranks RCCL sees, RCCL version running / compiled against."""
+        rt, cp = C.c_int32(0), C.c_int32(0)
+        self.lib.dfx_comm_rccl_version(C.byref(rt), C.byref(cp))
+        return {"ranks_seen": int(self.lib.dfx_comm_size(self._c)), "rccl_runtime": int(rt.value), "rccl_compiled": int(cp.value)}
 
     def _check(self, rc, what):
         if rc != 0:
@@ -189,9 +220,10 @@ class SocketComm:
         self._peers = []
 
 
-def init_from_env(backend="rccl", device=None, lib=None):
+def init_from_env(backend="rccl", device=None, lib=None, ctrl=None):
     """Communicator of this process from the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT --
-    what ``torch.distributed.run`` and ``bench.py``'s own launcher export) and make it the module default."""
+    what ``torch.distributed.run`` and ``bench.py``'s own launcher export) and make it the module default.  ``backend="rccl"``
+    opens a TCP control channel first (or uses ``ctrl``): the RCCL bring-up is agreed on over it."""
     global _DEFAULT
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -199,11 +231,15 @@ def init_from_env(backend="rccl", device=None, lib=None):
     if world_size == 1:
         _DEFAULT = SerialComm()
     elif backend == "rccl":
-        port = os.environ.get("MASTER_PORT", "29500")
-        # all ranks of one launch share the launcher process: its pid tells two launches on the same port apart
-        uid_file = os.environ.get("DFX_UID_FILE") or os.path.join(
-            os.environ.get("TMPDIR", "/tmp"), f"dfx_uid_{port}_{os.getppid()}")
-        _DEFAULT = RcclComm(rank, world_size, local_rank if device is None else device, uid_file, lib=lib)
+        own = ctrl is None
+        if own:
+            ctrl = SocketComm(rank, world_size, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                              int(os.environ.get("DFX_SOCKET_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 11)))
+        try:
+            _DEFAULT = RcclComm(rank, world_size, local_rank if device is None else device, lib=lib, ctrl=ctrl)
+        finally:
+            if own:
+                ctrl.close()
     elif backend == "socket":
         _DEFAULT = SocketComm(rank, world_size, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                               int(os.environ.get("DFX_SOCKET_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 11)))

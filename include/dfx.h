@@ -228,6 +228,8 @@ typedef struct dfx_comm dfx_comm;
 int dfx_comm_unique_id(char* uid128);
 int dfx_comm_init(int32_t rank, int32_t nranks, const char* uid128, int32_t device, dfx_comm** out);
 int dfx_comm_destroy(dfx_comm* c);
+/* RCCL version the process runs / the engine was compiled against (major*10000 + minor*100 + patch) */
+int dfx_comm_rccl_version(int32_t* runtime, int32_t* compiled);
 int dfx_comm_rank(const dfx_comm* c);
 int dfx_comm_size(const dfx_comm* c);
 /* all[r * n_local + i] = local[i] of rank r, on every rank (one ncclAllGather) */

@@ -102,3 +102,99 @@ def test_shard_bounds_cover_everything():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+
+
+class _FakeRccl:
+    """Stands in for libdfx's comm entry points in the bring-up test below (no GPU here): records whether ncclCommInitRank would
+    have been entered and with which unique id."""
+
+    def __init__(self, rank, world, out_dir, fail_rank):
+        self.rank, self.world, self.out_dir, self.fail_rank = rank, world, out_dir, fail_rank
+
+    def dfx_comm_unique_id(self, buf):
+        buf.raw = bytes((7 * i + 3) % 251 for i in range(128))
+        return 0
+
+    def dfx_mem_info(self, device, f, t):
+        return 2 if self.rank == self.fail_rank else 0
+
+    def dfx_comm_last_error(self):
+        return b"no such HIP device (fake)"
+
+    def dfx_comm_init(self, rank, world, uid, device, out):
+        with open(os.path.join(self.out_dir, f"entered{rank}"), "wb") as f:
+            f.write(uid.raw)
+        return 0
+
+    def dfx_comm_barrier(self, c):
+        return 0
+
+    def dfx_comm_size(self, c):
+        return self.world
+
+    def dfx_comm_rccl_version(self, rt, cp):
+        rt._obj.value, cp._obj.value = 22606, 22707
+        return 0
+
+    def dfx_comm_destroy(self, c):
+        return 0
+
+
+def _bringup_worker(rank, world_size, port, out_dir, fail_rank, same_device):
+    sys.path.insert(0, ROOT)
+    from difflexmm_amd import ensemble
+    ctrl = ensemble.SocketComm(rank, world_size, "127.0.0.1", port)
+    res = "ok"
+    try:
+        comm = ensemble.RcclComm(rank, world_size, 0 if same_device else rank, lib=_FakeRccl(rank, world_size, out_dir, fail_rank), ctrl=ctrl)
+        res = "ok " + repr(comm.info())
+    except RuntimeError as e:
+        res = "refused: " + str(e)
+    with open(os.path.join(out_dir, f"result{rank}"), "w") as f:
+        f.write(res)
+    ctrl.barrier()
+    ctrl.close()
+
+
+@pytest.mark.parametrize("mode", ["ok", "one rank fails its preflight", "ranks share a device"])
+def test_rccl_bringup_is_agreed_on_before_any_rank_enters_init(tmp_path, mode):
+    """Round-2 advice: a rank that failed before ncclCommInitRank left the others blocked inside it.  Now the unique id travels
+    over the control channel and all ranks exchange go / no-go first: one failed preflight (or two ranks on one device) and EVERY
+    rank raises without entering the init call; otherwise all enter it with rank 0's id."""
+    import torch.multiprocessing as mp
+    port = 31000 + (os.getpid() % 2000) + {"ok": 0, "one rank fails its preflight": 1, "ranks share a device": 2}[mode]
+    mp.spawn(_bringup_worker, args=(2, port, str(tmp_path), 1 if mode.startswith("one") else -1, mode.startswith("ranks")), nprocs=2, join=True)
+    results = [open(tmp_path / f"result{r}").read() for r in range(2)]
+    if mode == "ok":
+        assert all(r.startswith("ok") and "'ranks_seen': 2" in r and "22606" in r for r in results), results
+        ids = [open(tmp_path / f"entered{r}", "rb").read() for r in range(2)]
+        assert ids[0] == ids[1] == bytes((7 * i + 3) % 251 for i in range(128))
+    else:
+        assert all(r.startswith("refused: RcclComm: bring-up refused before ncclCommInitRank") for r in results), results
+        assert not any((tmp_path / f"entered{r}").exists() for r in range(2))
+        assert ("no such HIP device" in results[1]) if mode.startswith("one") else ("share a device" in results[0])
+
+
+def _bench_comm_worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    import argparse
+    import json
+    import bench
+    comm, info = bench.make_comm(argparse.Namespace(backend="socket"), world_size, rank, rank)
+    gathered = comm.all_gather([float(rank)])
+    with open(os.path.join(out_dir, f"info{rank}.json"), "w") as f:
+        json.dump(dict(info, gathered=gathered.ravel().tolist()), f)
+    comm.barrier()
+    comm.close()
+
+
+def test_bench_reports_what_the_collective_really_is(tmp_path):
+    """bench.py --gpus N puts the collective and the number of ranks it saw into the JSON line (`config.collective`, `ranks_seen`)."""
+    import json
+    import torch.multiprocessing as mp
+    port = 33000 + (os.getpid() % 2000)
+    mp.spawn(_bench_comm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        info = json.load(open(tmp_path / f"info{r}.json"))
+        assert info["collective"] == "socket (rehearsal)" and info["ranks_seen"] == 2 and info["gathered"] == [0.0, 1.0]
