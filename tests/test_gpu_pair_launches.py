@@ -17,7 +17,8 @@ def _solve(c, ts, spi, target, env):
     try:
         fields = c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=spi)
         obj, raw = c.solver.kinetic_energy_value_and_raw(target)
-        return fields.copy(), float(np.atleast_1d(obj)[0]), {k: np.array(v) for k, v in raw.items()}, dict(c.solver.adjoint_stats)
+        return (fields.copy(), float(np.atleast_1d(obj)[0]), {k: np.array(v) for k, v in raw.items()}, dict(c.solver.adjoint_stats),
+                c.solver.stats["launches"])
     finally:
         for k, v in old.items():
             if v is None:
@@ -39,7 +40,9 @@ def test_pair_launches_equal_stage_launches(hip_lib, lattice, n, rows):
     ref = _solve(c, ts, 7, target, {"DFX_PAIR": "0"})
     for level in ("records", "segments"):
         out = _solve(c, ts, 7, target, {"DFX_PAIR": "1", "DFX_PAIR_ROWS": rows, "DFX_CHECKPOINT": level})
-        assert out[3]["launches"] < ref[3]["launches"]                      # the pair launches really ran
+        assert c.solver.stats["launches"] < 0.6 * ref[4]                    # the pair launches really ran: half the forward launches
+        if level == "records":
+            assert out[3]["launches"] < 0.6 * ref[3]["launches"]            # ... and half the reverse launches
         assert relerr(out[0], ref[0]) < 1e-12 and abs(out[1] - ref[1]) < 1e-12 * abs(ref[1])
         for k in ref[2]:
             assert relerr(out[2][k], ref[2][k]) < 1e-10, (level, k)
