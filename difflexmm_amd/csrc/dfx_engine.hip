@@ -165,6 +165,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.n_blocks = pl.n_blocks; c.n_slots = pl.n_slots; c.n_fns = pl.n_fns; c.batch = pl.batch; c.s = pl.tab.s;
   { const char* a = getenv("DFX_ABLATE"); c.ablate = a ? atoi(a) : 0; }
   c.n_wg = (pl.n_slots + kThreads - 1) / kThreads;
+  c.n_wg3 = (pl.n_blocks + (kThreads / 16) * 5 - 1) / ((kThreads / 16) * 5);
   for (int k = 0; k < 4; ++k) c.pred[k] = pl.pred_delta[k];
   c.nbuf = 2 * pl.tab.s;
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
@@ -314,8 +315,20 @@ static void launch_adj_pair(dfx_handle* h, const DevCtx& c, hipStream_t st, int 
   h->launches++;
 }
 
+// 3-node blocks: the two stage kernels pack five triangles per 16 lanes (lane_pos<3>) instead of leaving every fourth lane idle --
+// 20 blocks per wave instead of 16.  Fixed grid only (the adaptive controller's error reduction keeps the quad mapping), not with the
+// distance-based contact; reverse: the records build.  DFX_PACK3=0 keeps the quad mapping (A/B measurements).
+static bool pack3(const dfx_handle* h) {
+  const char* e = getenv("DFX_PACK3");
+  return h->pl.n_npb == 3 && !h->adaptive && !(e && e[0] == '0');
+}
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
+  if (CONTACT != 2 && pack3(h) && !(mode & 2)) {
+    if constexpr (CONTACT != 2)
+      hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 3>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+    return;
+  }
   hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
 }
 static void launch_fwd(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
@@ -336,6 +349,10 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   const StageCoef rc = stage_coef(h->pl.tab, rb > 0 ? rb - 1 : 0);
   if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else if (c.AD) hipLaunchKernelGGL((k_adj_stage_rb<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  else if (CONTACT != 2 && pack3(h)) {
+    if constexpr (CONTACT != 2)
+      hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 3>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  }
   else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
 }
 static void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only) {

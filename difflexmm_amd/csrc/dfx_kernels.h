@@ -91,6 +91,7 @@ struct DevCtx {
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
   int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
+  int n_wg3;              // ... of the launches that pack 3-node blocks densely (lane_pos<3>: 40 blocks per 128-thread workgroup)
   int rps;                // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   int lam_pairs;          // layout of LAM / YB: 1 = (q, v) of one DOF side by side (b*6 + 2d, + 1), one 16-B access per lane; 0 = (q0 q1 q2 v0 v1 v2)
                           // -- the REBUILD builds of the reverse stage (stage checkpoint, per-ligament gradients) sit at their register limit
@@ -165,6 +166,50 @@ __device__ __forceinline__ void acc_add(double* p, double v) { (void)unsafeAtomi
 
 template <int J>
 __device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<J | (J << 2) | (J << 4) | (J << 6)>(v); }
+
+// ---- lanes of one block.  NPB = 4: a quad (quads; 3-node blocks with their fourth lane idle).  NPB = 3: 3-node blocks packed
+// densely -- five triangles in the 15 low lanes of every 16-lane DPP row, the sixteenth lane plays the padding slot of the row's last
+// triangle (no ligament, no DOF: it never stores) -- 20 blocks per wave instead of 16.  Memory keeps 4 slots per block either way, so
+// kernels of both mappings read and write the same arrays.  Lane moves inside a row: row_shl:n (lane i reads lane i + n), row_shr:n
+// (lane i reads lane i - n); what a lane reads from outside its triangle is never selected.
+struct LanePos { int slot, b, k; bool valid; };
+template <int NPB>
+__device__ __forceinline__ LanePos lane_pos(int lwg, int n_blocks) {
+  LanePos p;
+  const int gtid = lwg * kThreads + (int)threadIdx.x;
+  if (NPB == 4) { p.slot = gtid; p.b = gtid >> 2; p.k = gtid & 3; p.valid = p.b < n_blocks; return p; }
+  const int j = gtid & 15;
+  const int tri = min((j * 11) >> 5, 4);            // j / 3 for j < 15; lane 15 joins triangle 4 as its padding lane (k = 3)
+  p.k = j - 3 * tri;
+  p.b = (gtid >> 4) * 5 + tri;
+  p.valid = p.b < n_blocks;
+  p.slot = p.b * 4 + p.k;
+  return p;
+}
+// value held by lane J of the own block
+template <int NPB, int J>
+__device__ __forceinline__ double blk_bcast(double v, int k) {
+  if (NPB == 4) return quad_bcast<J>(v);
+  if (J == 0) { const double m1 = dpp_mov<0x111>(v), m2 = dpp_mov<0x112>(v); return k == 0 ? v : (k == 1 ? m1 : m2); }
+  if (J == 1) { const double p1 = dpp_mov<0x101>(v), m1 = dpp_mov<0x111>(v); return k == 0 ? p1 : (k == 1 ? v : m1); }
+  const double p2 = dpp_mov<0x102>(v), p1 = dpp_mov<0x101>(v);
+  return k == 0 ? p2 : (k == 1 ? p1 : v);
+}
+// lane k of a block receives the block's sum of component k: (a0, a1, a2) = this lane's contributions to (x, y, theta)
+template <int NPB>
+__device__ __forceinline__ double blk_reduce3(double a0, double a1, double a2, int k) {
+  if (NPB == 4) {
+    a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2);
+    return k == 0 ? a0 : (k == 1 ? a1 : a2);
+  }
+  // transposed: every lane hands component (k+1)%3 to the next lane of its triangle and (k+2)%3 to the one after (cyclic)
+  const double own = k == 0 ? a0 : (k == 1 ? a1 : a2);
+  const double u = k == 0 ? a1 : (k == 1 ? a2 : a0);     // for lane k+1
+  const double w = k == 0 ? a2 : (k == 1 ? a0 : a1);     // for lane k+2
+  const double u_m1 = dpp_mov<0x111>(u), u_p2 = dpp_mov<0x102>(u);   // from lane k-1 = i - 1 (k >= 1) / i + 2 (k == 0)
+  const double w_p1 = dpp_mov<0x101>(w), w_m2 = dpp_mov<0x112>(w);   // from lane k+1 = i + 1 (k <= 1) / i - 2 (k == 2)
+  return own + (k == 0 ? u_p2 : u_m1) + (k == 2 ? w_m2 : w_p1);
+}
 
 // XCD-aware workgroup order: hardware deals workgroups round-robin over the 8 XCDs (id % 8 share an L2);
 // give every XCD one contiguous band of the lattice so neighbour gathers mostly hit that XCD's own L2.
@@ -324,7 +369,7 @@ struct LaneRaw {
 
 template <int CONTACT>
 __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B, int slot, const double* POSin, LaneRaw& R) {
-  const int b = slot >> 2, k = slot & 3;
+  const int b = slot >> 2, k = slot & 3;      // memory keeps 4 slots per block whatever the lane mapping is
   R.slot = slot;
   R.info = ldg<int>(c.slot_info, (u32)slot * 4);
   R.pc = k < 2 ? ldg<double2>(POSin, ((u32)b * kPos + 2 * k) * 8) : make_double2(0.0, 0.0);
@@ -340,8 +385,9 @@ __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B
   load_partner<CONTACT>(B, R.guess, POSin, R.P);
 }
 
-template <int CONTACT>
+template <int CONTACT, int NPB = 4>
 __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases& B, const double* POSin, LaneRaw& R, LaneIn& L) {
+  const int k_ = R.slot & 3;
   const int info = R.info;
   L.info = info;
   double2 lv = R.lv, ln = make_double2(0.0, 0.0);
@@ -356,8 +402,8 @@ __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases&
   if (c.k_uniform) { L.ks = cst[3]; L.ksh = cst[4]; L.kr = cst[5]; }
   else { L.ks = R.ks; L.ksh = R.ksh; L.kr = R.kr; }
   if (CONTACT) { L.am = cst[0]; L.ac = cst[1]; L.kc = cst[2]; }
-  L.o.x = quad_bcast<0>(R.pc.x); L.o.y = quad_bcast<0>(R.pc.y);
-  L.o.th = quad_bcast<1>(R.pc.x); L.o.sh = quad_bcast<1>(R.pc.y);
+  L.o.x = blk_bcast<NPB, 0>(R.pc.x, k_); L.o.y = blk_bcast<NPB, 0>(R.pc.y, k_);
+  L.o.th = blk_bcast<NPB, 1>(R.pc.x, k_); L.o.sh = blk_bcast<NPB, 1>(R.pc.y, k_);
   L.o.ch = half_cos(L.o.th, L.o.sh);
   L.p.x = R.P.b0.x; L.p.y = R.P.b0.y; L.p.th = R.P.b1.x; L.p.sh = R.P.b1.y;
   L.p.ch = half_cos(L.p.th, L.p.sh);
@@ -425,14 +471,18 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   out_buf : buffer for the next stage's records (-1: none)
 //   y_buf   : 0: step base state (q_n, v_n) in buffer 0;  -1: in the checkpoint of step n
 //   write_traj: also store the new record into the checkpoint of step n+1 (last stage, keep_trajectory)
-template <int MODEL, int CONTACT>
+//   NPB: lanes per block (lane_pos); the packed mapping serves 3-node blocks on the fixed grid (not the adaptive controller's error
+//   reduction, not the distance-based contact, whose node rotations are quad moves)
+template <int MODEL, int CONTACT, int NPB = 4>
 __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
+  static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
   const int m = blockIdx.y + c.m0;
-  const int lwg = logical_wg(blockIdx.x, c.n_wg);
-  int slot = lwg * kThreads + threadIdx.x;
-  const int write_traj = mode & 1, err_mode = mode & 2;
-  const bool valid = slot < c.n_slots;
+  const int lwg = logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3);
+  const LanePos lp = lane_pos<NPB>(lwg, c.n_blocks);
+  int slot = lp.slot;
+  const int write_traj = mode & 1, err_mode = NPB == 4 ? (mode & 2) : 0;
+  const bool valid = lp.valid;
   if (!valid) {
     if (!err_mode) return;
     slot = c.n_slots - 4 + (threadIdx.x & 3);   // keep the wave whole for the reduction: redo the last unit, contribute 0
@@ -469,7 +519,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
 #pragma unroll
   for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? ldg<double>(Am + (size_t)l * nd, o_dof) : 0.0;
   LaneIn L;
-  resolve_lane<CONTACT>(c, B, POSin, R, L);
+  resolve_lane<CONTACT, NPB>(c, B, POSin, R, L);
   DistIn D;
   if (CONTACT == 2) load_dist(c, B, slot, L, D);
   double sv = 0.0, sq = 0.0;
@@ -498,15 +548,12 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       fx += dg.fx; fy += dg.fy; fth += dg.fth;
     }
   }
-  fx = quad_sum(fx);
-  fy = quad_sum(fy);
-  fth = quad_sum(fth);
+  const double dE = blk_reduce3<NPB>(fx, fy, fth, k);
   // ---- DOF epilogue on lanes 0..2
   double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
   if (c.t_steps && !c.clock) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
   double qnext = 0.0, vnext = 0.0;
   if (k < 3) {
-    const double dE = k == 0 ? fx : (k == 1 ? fy : fth);
     bool constrained = false;
     double fload = 0.0;
     if (sidx >= 0) {
@@ -553,7 +600,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   }
   if (out_buf == -1) return;
   // ---- publish the next stage record: lanes 0 and 1 each store one aligned 16-byte chunk (x, y) (th, sin th/2)
-  const double y1 = quad_bcast<1>(qnext), th2 = quad_bcast<2>(qnext);
+  const double y1 = blk_bcast<NPB, 1>(qnext, k), th2 = blk_bcast<NPB, 2>(qnext, k);
   double sn, cs;
   fast_sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : make_double2(th2, sn);
@@ -773,14 +820,17 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
+//   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
 __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& ac, int i, int j, int in_buf, int wbuf_static,
                                                int local_only, const StageCoef& rc, int rb) {
+  static_assert(NPB == 4 || (CONTACT != 2 && !REBUILD && !BOND_GRADS), "the packed mapping serves the records build without distance contact");
   const int m = blockIdx.y + c.m0;
-  const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
-  if (slot >= c.n_slots) return;
+  const LanePos lp = lane_pos<NPB>(logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3), c.n_blocks);
+  const int slot = lp.slot;
+  if (!lp.valid) return;
   const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
   const Seg sg = *c.cur;
   const long long n = sg.base_step + j;
@@ -851,7 +901,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     }
   }
   LaneIn L;
-  resolve_lane<CONTACT>(c, B, POSin, R, L);
+  resolve_lane<CONTACT, NPB>(c, B, POSin, R, L);
   DistIn D;
   if (CONTACT == 2) load_dist(c, B, slot, L, D);
   if (L.pslot != L.guess) {
@@ -859,7 +909,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     if (!REBUILD) { const double2 wxy = ldg<double2>(Win, pb); wpx = wxy.x; wpy = wxy.y; } else { wpx = ldg<double>(Win, pb); wpy = ldg<double>(Win, pb + 8); }
     wpth = ldg<double>(Win, pb + 16);
   }
-  const double wox = quad_bcast<0>(w_d), woy = quad_bcast<1>(w_d), woth = quad_bcast<2>(w_d);
+  const double wox = blk_bcast<NPB, 0>(w_d, k), woy = blk_bcast<NPB, 1>(w_d, k), woth = blk_bcast<NPB, 2>(w_d, k);
   // ---- Hessian-vector product + mixed parameter derivatives of this slot
   double hx = 0.0, hy = 0.0, hth = 0.0;
   double ex = 0.0, ey = 0.0, eth = 0.0;   // dE/du of this slot (value parts): gives the stage acceleration without re-reading it
@@ -928,12 +978,8 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   const double p_old = phi_on ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
   const double bm_old = ldg<double>(bmm, o_dof);
   const double bc_old = c.blk_c ? ldg<double>(bcm, o_dof) : 0.0;
-  hx = quad_sum(hx);
-  hy = quad_sum(hy);
-  hth = quad_sum(hth);
-  ex = quad_sum(ex);
-  ey = quad_sum(ey);
-  eth = quad_sum(eth);
+  const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
+  const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
   if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
     stg<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
   }
@@ -942,8 +988,6 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
   if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
   if (k < 3) {
-    const double hw = k == 0 ? hx : (k == 1 ? hy : hth);
-    const double dE = k == 0 ? ex : (k == 1 ? ey : eth);
     bool constrained = false;
     double fload = 0.0;
     if (sidx >= 0) {
@@ -1005,10 +1049,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   }
 }
 
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
-  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
+  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 // The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry
 // point, so that its occupancy can be pinned (DFX_ADJ_RB_OCC) without touching the others.

@@ -481,16 +481,13 @@ DFX_HD void eval_time_fn(const TimeFn& f, double t, double& g, double& gt, doubl
         gp[2] = -gt;
       }
     } break;
+    case kFnRamp:
     case kFnRampCap: {
-      // jnp.where(t < cap / r, t * r, cap) scaled by L: the ramp branch is taken where t r < cap
-      double Lf = f.p[0], r = f.p[1], cap = f.p[2];
-      if (t * r < cap) { g = Lf * t * r; gt = Lf * r; gp[0] = t * r; gp[1] = Lf * t; }
-      else { g = Lf * cap; gp[0] = cap; gp[2] = Lf; }
-    } break;
-    case kFnRamp: {
-      double A = f.p[0], r = f.p[1];
-      if (t * r < 1.0) { g = A * t * r; gt = A * r; gp[0] = t * r; gp[1] = A * t; }
-      else { g = A; gp[0] = 1.0; }
+      // A min(t r, cap): the plain ramp has cap = 1; the capped one is the reference's jnp.where(t < cap / r, t * r, cap) scaled by
+      // L = A (static compression) -- the ramp branch is taken where t r < cap
+      const double A = f.p[0], r = f.p[1], cap = f.type == kFnRampCap ? f.p[2] : 1.0;
+      if (t * r < cap) { g = A * t * r; gt = A * r; gp[0] = t * r; gp[1] = A * t; }
+      else { g = A * cap; gp[0] = cap; if (f.type == kFnRampCap) gp[2] = A; }
     } break;
     case kFnSech2Tanh: {
       double A = f.p[0], s = f.p[1];

@@ -68,3 +68,22 @@ def test_pair_launches_match_the_oracle(hip_lib):
     lv = dict(loading_rate=torch.tensor(3000.0, dtype=torch.float64), input_delay=torch.tensor(1e-5, dtype=torch.float64))
     osol = c.oracle_solver(integrator="fixed", steps_per_interval=12)
     assert relerr(fields, osol(np.zeros((2, 400, 3)), ts, c.oracle_cp(lv)).numpy()) < 1e-10
+
+
+@pytest.mark.parametrize("n", [7, 21])
+def test_packed_triangles_equal_the_quad_mapping(hip_lib, n):
+    """3-node blocks: five triangles per 16 lanes (lane_pos<3>, DPP row moves) against one triangle per quad (the mapping of rounds
+    1-2, DFX_PACK3=0): fields, objective, every gradient the records build accumulates.  n = 7: 98 blocks = two and a half
+    workgroups with a ragged last row; n = 21: 882 blocks."""
+    c = Case("kagome", n, True, True, seed=8, cutoff_deg=125.0)
+    c.cp = c.cp._replace(constraint_params=FAST)
+    ts = np.linspace(0.0, 3e-4, 4)
+    mid = c.geo.n_blocks // 2
+    target = np.array([mid + 1, mid + 2], dtype=np.int32)
+    ref = _solve(c, ts, 7, target, {"DFX_PACK3": "0", "DFX_CHECKPOINT": "records"})
+    for level in ("records", "state"):
+        out = _solve(c, ts, 7, target, {"DFX_PACK3": "1", "DFX_CHECKPOINT": level})
+        assert relerr(out[0], ref[0]) < 1e-12 and abs(out[1] - ref[1]) < 1e-12 * abs(ref[1])
+        for k in ref[2]:
+            assert relerr(out[2][k], ref[2][k]) < 1e-10, (level, k)
+    assert np.abs(ref[2]["centroid_node_vectors"]).max() > 0 and ref[1] > 0
