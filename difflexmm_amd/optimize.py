@@ -325,14 +325,24 @@ class MemberWorkers:
             self._conns[w].send(("new", items))
         return self._collect(per)
 
-    def send(self, values):
-        """values: {i: (value, gradient)} of the members still running; returns {i: (done, next point or result)}."""
+    def post(self, values):
+        """Hand {i: (value, gradient)} to the workers that own those members and return at once (a ticket for :meth:`collect`):
+        the workers run the members' next MMA steps while the caller does something else -- integrate the other half of the
+        ensemble on the device."""
         per = {}
         for idx, v in values.items():
             per.setdefault(self._owner[idx], []).append((idx, v))
         for w, items in per.items():
             self._conns[w].send(("send", items))
-        return self._collect(per)
+        return per
+
+    def collect(self, ticket):
+        """{i: (done, next point or result)} of the members of a :meth:`post`."""
+        return self._collect(ticket)
+
+    def send(self, values):
+        """values: {i: (value, gradient)} of the members still running; returns {i: (done, next point or result)}."""
+        return self.collect(self.post(values))
 
     def close(self):
         for c in self._conns:
@@ -354,16 +364,25 @@ class MemberWorkers:
         self.close()
 
 
-def drive_ensemble(batch_fun, specs, workers=None):
+def drive_ensemble(batch_fun, specs, workers=None, groups=1):
     """Independent optimisations advancing in lock-step.  ``specs[i] = (factory, args, kwargs)``: ``factory(*args, **kwargs)``
     is member i's coroutine (``yield x`` asks for ``(value, gradient)`` at x, its return value is the member's result).
     ``batch_fun(list of x) -> list of (value, gradient)`` is called once per round with the pending point of EVERY member
     (members that have finished resubmit their last point so the batch keeps its size: the engine integrates a fixed number of
     members side by side).  With ``workers`` (:class:`MemberWorkers`) the coroutines live in host processes; the sequence of
-    iterates of every member is the same either way, and the same as if it ran alone."""
+    iterates of every member is the same either way, and the same as if it ran alone.
+
+    ``groups=2`` (needs ``workers``): the members are split into two halves that take turns on the device -- while one half is
+    integrated (``batch_fun`` is then called with that half's points only), the workers run the MMA steps of the other half, so the
+    host work of a round hides behind the device work of the next.  Every member still sees exactly its own sequence of
+    evaluations: results are identical to ``groups=1``."""
     n = len(specs)
     results = [None] * n
     pending = [None] * n
+    if groups > 1:
+        if workers is None or groups != 2 or n % 2:
+            raise ValueError("drive_ensemble: groups=2 needs host workers and an even number of members")
+        return _drive_two_groups(batch_fun, specs, workers, results, pending)
 
     def absorb(replies):
         for i, (done, value) in replies.items():
@@ -387,6 +406,36 @@ def drive_ensemble(batch_fun, specs, workers=None):
         values = batch_fun(pending)
         live = {i: values[i] for i in range(n) if results[i] is None}
         absorb({i: advance(i, v) for i, v in live.items()} if workers is None else workers.send(live))
+    return results
+
+
+def _drive_two_groups(batch_fun, specs, workers, results, pending):
+    n = len(specs)
+    halves = [list(range(0, n // 2)), list(range(n // 2, n))]
+
+    def absorb(replies):
+        for i, (done, value) in replies.items():
+            if done:
+                results[i] = value
+            else:
+                pending[i] = value
+
+    absorb(workers.start(specs))
+    ticket = [None, None]
+    g = 0
+    while any(r is None for r in results):
+        if ticket[g] is not None:                       # this half's next points: computed while the other half was on the device
+            absorb(workers.collect(ticket[g]))
+            ticket[g] = None
+        ids = halves[g]
+        if any(results[i] is None for i in ids):
+            values = batch_fun([pending[i] for i in ids], ids)
+            live = {i: values[k] for k, i in enumerate(ids) if results[i] is None}
+            ticket[g] = workers.post(live)
+        g ^= 1
+    for t in ticket:
+        if t is not None:
+            absorb(workers.collect(t))
     return results
 
 

@@ -803,7 +803,8 @@ def _ensemble_member(g, x0, n_iterations, lower_bound, upper_bound, min_void_ang
 
 
 def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bound=None, upper_bound=None,
-                              min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=False, workers=None):
+                              min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=False, workers=None,
+                              pipeline=False):
     """``len(initial_guesses)`` independent design optimisations (BASELINE config 5: an ensemble of multi-input focusing
     designs) advancing in lock-step: every round the pending design of EVERY member is evaluated in one batched call of
     the objective (``objective.value_and_grad(list of designs)`` -- the forward problems were built with
@@ -811,20 +812,26 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
     Each member runs the reference's loop (method of moving asymptotes under the angle / edge-length constraints,
     problems/quads_focusing.py:546-652) exactly as it would alone.  ``workers`` (``optimize.MemberWorkers``, created before the
     first GPU call): host processes that run the members' constraint evaluations and MMA sub-problems side by side.
+    ``pipeline=True`` (needs ``workers``; the forward problems built with ``batch = len(initial_guesses) // 2``): the two halves of
+    the ensemble take turns on the device, the host work of one half (MMA sub-problems, constraint Jacobians) runs while the other
+    half is integrated -- same iterates, less wall time.
     Returns (best designs, list of per-member dicts with objective_values / constraints_violation / mma result)."""
     from .optimize import drive_ensemble
     g = objective.forward.geometry
     n = len(initial_guesses)
     logs = [dict(objective_values=[]) for _ in range(n)]
+    if pipeline and getattr(objective.forward, "batch", n // 2) != n // 2:
+        raise ValueError(f"pipeline=True evaluates half of the ensemble per engine call: build the forward problems with batch={n // 2}")
 
     round_times = []
 
-    def batch_fun(xs):
+    def batch_fun(xs, ids=None):
         import time
         t0 = time.perf_counter()
         designs = [_unflatten_design(g, x) for x in xs]
         vals, grads = objective.value_and_grad(designs)
-        for i, v in enumerate(vals):
+        for k, v in enumerate(vals):
+            i = k if ids is None else ids[k]                       # pipelined: one half of the ensemble per call
             if len(logs[i]["objective_values"]) < n_iterations:
                 logs[i]["objective_values"].append(float(v))
         round_times.append(time.perf_counter() - t0)
@@ -835,7 +842,7 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
 
     specs = [(_ensemble_member, (g, _flatten_design(d), n_iterations, lower_bound, upper_bound, min_void_angle, min_block_angle,
                                  min_edge_length), {}) for d in initial_guesses]
-    res = drive_ensemble(batch_fun, specs, workers)
+    res = drive_ensemble(batch_fun, specs, workers, groups=2 if pipeline else 1)
     for log, r in zip(logs, res):
         log["constraints_violation"] = r.pop("constraints_violation")
         log["mma"] = r

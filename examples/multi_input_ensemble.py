@@ -37,6 +37,9 @@ def main():
                     help="host processes for the members' constraint evaluations and MMA sub-problems (0: in this process; "
                          "-1: min(32, CPUs of this rank - 1))")
     ap.add_argument("--cpu-port", action="store_true", help="use the oracle's CPU port instead of libdfx (rehearsal without a GPU)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="evaluate the whole chunk of members in one engine call per input and round (default with host workers: the two "
+                         "halves of the chunk take turns on the device, the workers run one half's MMA steps while the other half is integrated)")
     args = ap.parse_args()
 
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -55,6 +58,8 @@ def main():
 
     lo, hi = shard_bounds(args.members, rank, world)
     mine = hi - lo
+    pipeline = workers is not None and not args.no_pipeline and mine >= 2 and mine % 2 == 0
+    per_call = mine // 2 if pipeline else mine
     spacing, bond, rho, ksh, kr, freq = 15.0, 2.25, 6.18e-9, 1.19, 1.5, 30.0
     nb = args.n1 * args.n2
     damping = 0.0186 * np.array([2 * math.sqrt(0.36125 * rho * spacing ** 2 * ksh)] * 2
@@ -66,7 +71,7 @@ def main():
             density=rho, damping=damping, amplitude=7.5, loading_rate=freq, input_delay=0.1 / freq, n_excited_blocks=2,
             loaded_side=side, input_shift=shift, simulation_time=2.0 / freq, n_timepoints=args.timepoints,
             use_contact=True, k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180,
-            steps_per_interval=args.steps_per_interval, batch=mine, device=local_rank, _lib=lib)
+            steps_per_interval=args.steps_per_interval, batch=per_call, device=local_rank, _lib=lib)
         fw.setup()
         forwards.append(fw)
     objective = P.MultiInputTargetKineticEnergy(forwards, (2, 2), (args.n1 // 6, args.n2 // 5), weights=[1.0, 1.0, 1.0])
@@ -79,14 +84,14 @@ def main():
     t0 = time.perf_counter()
     best, logs = P.run_ensemble_optimization(objective, x0s, args.iterations, lower_bound=-0.3 * spacing, upper_bound=0.3 * spacing,
                                              min_void_angle=amin, min_block_angle=amin, min_edge_length=0.1 * spacing,
-                                             verbose=(rank == 0), workers=workers)
+                                             verbose=(rank == 0), workers=workers, pipeline=pipeline)
     wall = time.perf_counter() - t0
     first = gather_objectives([l["objective_values"][0] for l in logs], args.members)
     final = gather_objectives([l["mma"].fun for l in logs], args.members)
     if rank == 0:
         solves = 3 * args.members * args.iterations
         steps = (args.timepoints - 1) * args.steps_per_interval
-        print(f"{args.members} designs x 3 inputs x {args.iterations} evaluations on {world} rank(s): {wall:.1f} s, "
+        print(f"{args.members} designs x 3 inputs x {args.iterations} evaluations on {world} rank(s){' (two halves pipelined)' if pipeline else ''}: {wall:.1f} s, "
               f"{solves / wall:.1f} forward+adjoint solves/s, {solves * steps * nb / wall:.3e} timesteps*units/s")
         ev = logs[0]["evaluation_seconds"]
         print("evaluations of the whole ensemble (forward + reverse sweeps of the three inputs + design maps), s: "

@@ -292,6 +292,18 @@ def test_ensemble_optimisation_in_lock_step_equals_members_alone(cpu_lib):
     from difflexmm_amd.optimize import MemberWorkers
     with MemberWorkers(2) as workers:
         best_w, logs_w = P.run_ensemble_optimization(obj3, x0s, 5, workers=workers, **kw)
+    # pipelined: the two halves of a 4-member ensemble take turns on the engine (batch 2), the workers run one half's MMA steps
+    # while the other half is integrated -- the same iterates as the members alone
+    obj2, _ = objective(2)
+    x0s4 = x0s + [_design(fw, seed=7, amp=0.05)]
+    with MemberWorkers(2) as workers:
+        best_p, logs_p = P.run_ensemble_optimization(obj2, x0s4, 5, workers=workers, pipeline=True, **kw)
+    for m in range(3):
+        assert logs_p[m]["objective_values"] == logs[m]["objective_values"]
+        assert all(np.array_equal(a, b) for a, b in zip(best_p[m], best[m]))
+    assert len(logs_p[3]["objective_values"]) == 5
+    with pytest.raises(ValueError, match="batch=2"):
+        P.run_ensemble_optimization(obj3, x0s4, 5, workers=None, pipeline=True, **kw)
     for m in range(3):
         assert logs_w[m]["objective_values"] == logs[m]["objective_values"]
         assert logs_w[m]["constraints_violation"] == logs[m]["constraints_violation"] and logs[m]["constraints_violation"]["angles"]
