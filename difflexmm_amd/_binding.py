@@ -54,7 +54,7 @@ class dfx_stats(C.Structure):
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid",
            "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
-           "dfx_device_count", "dfx_version"]
+           "dfx_device_count", "dfx_version", "dfx_share_checkpoint"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
@@ -67,6 +67,8 @@ def declare(lib):
     H = C.c_void_p
     lib.dfx_create.argtypes = [C.POINTER(dfx_problem), C.POINTER(H)]
     lib.dfx_destroy.argtypes = [H]
+    if hasattr(lib, "dfx_share_checkpoint"):
+        lib.dfx_share_checkpoint.argtypes = [H, H]
     lib.dfx_last_error.argtypes = [H]
     lib.dfx_last_error.restype = C.c_char_p
     lib.dfx_set_params.argtypes = [H, C.POINTER(dfx_params)]
@@ -255,6 +257,10 @@ class Engine:
             keep.append(a)
             setattr(p, name, _ptr(a))
         self._check(self.lib.dfx_set_params(self._h, C.byref(p)), "dfx_set_params")
+
+    def share_checkpoint(self, other):
+        """Keep this engine's trajectory checkpoint in ``other``'s buffers (engines whose solves never overlap in time)."""
+        self._check(self.lib.dfx_share_checkpoint(self._h, other._h), "dfx_share_checkpoint")
 
     def reserve(self, max_steps, max_timepoints, keep_trajectory=True):
         self._check(self.lib.dfx_reserve(self._h, int(max_steps), int(max_timepoints), int(bool(keep_trajectory))), "dfx_reserve")

@@ -87,7 +87,18 @@ struct Group {            // members [m0, m0+nm) advance on their own stream so 
   int m0 = 0, nm = 0;
 };
 
+// The trajectory checkpoint (and the stage accelerations of the "stages" level) is by far the largest allocation of a handle.  Handles
+// whose solves never overlap in time -- the engines of a multi-input objective, evaluated one input after the other, forward + reverse
+// each -- can share ONE (dfx_share_checkpoint): a third of the memory, a third of the allocation time, and room for a richer level.
+// `writer` is the handle whose forward pass filled it last: a reverse sweep of any other handle refuses to run on it.
+struct CheckpointPool {
+  DevBuf<double> traj, AD;
+  int users = 1;
+  const void* writer = nullptr;
+};
+
 struct dfx_handle {
+  CheckpointPool* ck = new CheckpointPool();
   Plan pl;
   std::vector<Group> groups;
   bool dual_chain = true;
@@ -117,7 +128,7 @@ struct dfx_handle {
   bool adaptive = false;
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
-  DevBuf<double> d_traj, d_POS, d_VEL, d_A, d_state0, d_fields;
+  DevBuf<double> d_POS, d_VEL, d_A, d_state0, d_fields;
   DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_m, d_blk_c, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
@@ -126,7 +137,6 @@ struct dfx_handle {
   DevBuf<int> d_step_counts;
   int n_counts = 0;
   DevBuf<double> d_acc_times, d_tsteps;
-  DevBuf<double> d_AD;             // stage checkpoint (stage accelerations of every step)
   bool dense = false;              // the last fixed-grid forward kept the stage checkpoint (stage accelerations of every step)
   bool segments = false;           // ... or nothing but the outputs: the reverse sweep re-runs one output interval at a time (records level inside it)
   std::vector<int> seg_first, seg_last;   // first / last segment of every output interval
@@ -181,10 +191,10 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.acc_times = h->adaptive ? h->d_acc_times.p : nullptr; c.acc_cap = kAccCap;
   c.t_steps = (!h->adaptive && !h->t_steps.empty()) ? h->d_tsteps.p : nullptr;
   c.rtol = h->rtol; c.atol = h->atol;
-  c.traj = h->have_traj ? h->d_traj.p : nullptr;
+  c.traj = h->have_traj ? h->ck->traj.p : nullptr;
   c.rps = (h->have_traj && (h->records || h->segments)) ? pl.tab.s : 1;
-  c.AD = (h->have_traj && h->dense && !h->records && !h->segments) ? h->d_AD.p : nullptr;
-  c.ad_stride = pl.batch ? (long long)(h->d_AD.n / pl.batch) : 0;
+  c.AD = (h->have_traj && h->dense && !h->records && !h->segments) ? h->ck->AD.p : nullptr;
+  c.ad_stride = pl.batch ? (long long)(h->ck->AD.n / pl.batch) : 0;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
   c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
@@ -580,7 +590,7 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
   // multi-input objective, RCCL): only GROWTH is checked against the free memory, leaving 5 % of the device
   const size_t free_now = dfx_test_free_bytes ? std::min<size_t>(free_b, dfx_test_free_bytes) : free_b;
   auto fits = [&](size_t grow_elems) { return grow_elems == 0 || (have_info && grow_elems * sizeof(double) + total_b / 20 <= free_now); };
-  const size_t have_t = h->d_traj.n, have_a = h->d_AD.n;
+  const size_t have_t = h->ck->traj.n, have_a = h->ck->AD.n;
   auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
   int mode = forced;
   if (mode < 0) {
@@ -590,19 +600,20 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
     // record per member and launch; the checkpoint is record-major since): small lattices stay at the stages level
     // ... unless their records checkpoint is small (config 5's share of one of 8 GPUs, 32 designs per input: 16 GB; 13 % less device
     // time, 9 % less wall: profiles/r02_config5_checkpoint_levels.txt)
-    if ((pl.n_blocks >= 4096 || want_rec * sizeof(double) <= ((size_t)24 << 30)) && fits(grow(want_rec, have_t))) mode = kCkRecords;
+    // ... or the checkpoint is shared between the engines of a multi-input objective (ONE allocation instead of three)
+    if ((pl.n_blocks >= 4096 || h->ck->users > 1 || want_rec * sizeof(double) <= ((size_t)24 << 30)) && fits(grow(want_rec, have_t))) mode = kCkRecords;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
     else if (fits(grow(want_state, have_t))) mode = kCkState;
     else mode = kCkSegments;
   }
   if (mode == kCkSegments) {
-    if (h->d_traj.ensure(want_seg) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (h->ck->traj.ensure(want_seg) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return mode;
   }
   // allocate; a failed allocation falls back one level (forced modes included: the solve still runs)
-  if (mode == kCkRecords && h->d_traj.ensure(want_rec) != hipSuccess) { (void)hipGetLastError(); mode = kCkStages; }
-  if (mode != kCkRecords && h->d_traj.ensure(want_state) != hipSuccess) { (void)hipGetLastError(); return -1; }
-  if (mode == kCkStages && h->d_AD.ensure(want_ad) != hipSuccess) { (void)hipGetLastError(); mode = kCkState; }
+  if (mode == kCkRecords && h->ck->traj.ensure(want_rec) != hipSuccess) { (void)hipGetLastError(); mode = kCkStages; }
+  if (mode != kCkRecords && h->ck->traj.ensure(want_state) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (mode == kCkStages && h->ck->AD.ensure(want_ad) != hipSuccess) { (void)hipGetLastError(); mode = kCkState; }
   return mode;
 }
 
@@ -909,8 +920,9 @@ int dfx_destroy(dfx_handle* h) {
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
   h->d_inv_m.release(); h->d_damping.release(); h->d_fns.release(); h->d_p_c.release(); h->d_g_c.release();
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
-  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release(); h->d_AD.release();
-  h->d_traj.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
+  h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release(); 
+  if (--h->ck->users == 0) { h->ck->traj.release(); h->ck->AD.release(); delete h->ck; }
+  h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
   h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release();
@@ -990,6 +1002,20 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
   return 0;
 }
 
+int dfx_share_checkpoint(dfx_handle* h, dfx_handle* with) {
+  if (!h || !with) return 1;
+  if (h->device != with->device) { h->err = "share_checkpoint: the handles live on different devices"; return 1; }
+  if (h->ck == with->ck) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  drop_graphs(h);                                          // cached graphs hold the old buffer's address
+  if (--h->ck->users == 0) { h->ck->traj.release(); h->ck->AD.release(); delete h->ck; }
+  h->ck = with->ck;
+  h->ck->users++;
+  h->have_traj = false;
+  return 0;
+}
+
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                 int32_t steps_per_interval, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
   if (n_timepoints < 1 || steps_per_interval < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
@@ -1037,6 +1063,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
       return 2;
     }
     h->have_traj = true;
+    h->ck->writer = h;
     h->records = mode == kCkRecords;
     h->dense = mode == kCkStages;
     h->segments = mode == kCkSegments;
@@ -1360,7 +1387,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     for (int k = Tn - 2; k >= 0; --k) {
       // the buffer holds the records of THIS interval only: shift the base so that the kernels keep indexing by the global step
       // (a per-interval offset inside the kernels cost the forward kernel two hot-path spills: profiles/r02_fwd_spill_regression.txt)
-      c.traj = h->d_traj.p - (size_t)h->step0[k] * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
+      c.traj = h->ck->traj.p - (size_t)h->step0[k] * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
       for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
         const Group& gr = h->groups[gi];
         const DevCtx cg = group_ctx(h, c, gi);
@@ -1427,9 +1454,12 @@ int dfx_adaptive_step_times(dfx_handle* h, int32_t member, double* times, int64_
   return 0;
 }
 
+static const char* kStaleCheckpoint = "the shared trajectory checkpoint was overwritten by a solve of another handle (dfx_share_checkpoint): run this handle's forward again";
+
 int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_traj) { h->err = "adjoint: run forward with keep_trajectory=1 first"; return 1; }
+  if (h->ck->writer != h) { h->err = std::string("adjoint: ") + kStaleCheckpoint; return 1; }
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   const int Tn = (int)h->ts.size();
@@ -1469,6 +1499,7 @@ static int adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t 
                            dfx_grads* grads, dfx_grads* views, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_traj || !h->have_fields) { h->err = "adjoint_kinetic: run forward with keep_trajectory=1 first"; return 1; }
+  if (h->ck->writer != h) { h->err = std::string("adjoint_kinetic: ") + kStaleCheckpoint; return 1; }
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   const int Tn = (int)h->ts.size();

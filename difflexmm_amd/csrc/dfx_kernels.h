@@ -317,6 +317,35 @@ template <class T>
 __device__ __forceinline__ void stg(void* base, u32 byte_off, T v) {
   *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// Streaming variants for data that is touched once per launch and next by a LATER launch (checkpoint records, Ybar, the accumulators'
+// read-modify-write): the non-temporal hint keeps them from displacing what the neighbour gathers hit in the L2.  Measured, not
+// assumed: DFX_NT is off unless a build defines it (profiles/r03_nontemporal_hint.txt).
+typedef double dfx_d2 __attribute__((ext_vector_type(2)));
+template <class T> struct NtType { typedef T type; };
+template <> struct NtType<double2> { typedef dfx_d2 type; };
+template <class T>
+__device__ __forceinline__ T ldg_s(const void* base, u32 byte_off) {
+#ifdef DFX_NT
+  typedef typename NtType<T>::type V;
+  const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off));
+  T out;
+  __builtin_memcpy(&out, &v, sizeof(T));
+  return out;
+#else
+  return ldg<T>(base, byte_off);
+#endif
+}
+template <class T>
+__device__ __forceinline__ void stg_s(void* base, u32 byte_off, T v) {
+#ifdef DFX_NT
+  typedef typename NtType<T>::type V;
+  V x;
+  __builtin_memcpy(&x, &v, sizeof(T));
+  __builtin_nontemporal_store(x, reinterpret_cast<V*>(reinterpret_cast<char*>(base) + byte_off));
+#else
+  stg<T>(base, byte_off, v);
+#endif
+}
 
 // uniform bases of member m's parameter arrays
 struct MemberBases {
@@ -614,8 +643,8 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       // state checkpoint: the new step state, once more; records checkpoint (out_buf < -1): the record goes ONLY there, the
       // next launch reads it from there and so does the reverse sweep
       double* tr = out_buf < -1 ? traj_rec(c, m, out_buf, n) : traj_rec(c, m, -1, n + 1);
-      if (k < 2) stg<double2>(tr, o_chunk, chunk);
-      stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
+      if (k < 2) stg_s<double2>(tr, o_chunk, chunk);
+      stg_s<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
     }
   }
 }
@@ -852,7 +881,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   { const u32 gb = (u32)(R.guess >> 2) * 24;
     if (!REBUILD) { const double2 wxy = ldg<double2>(Win, gb); wpx = wxy.x; wpy = wxy.y; } else { wpx = ldg<double>(Win, gb); wpy = ldg<double>(Win, gb + 8); }
     wpth = ldg<double>(Win, gb + 16); }
-  const double v_i = ldg<double>(vel_in(c, m, in_buf, n), o_dof);
+  const double v_i = ldg_s<double>(vel_in(c, m, in_buf, n), o_dof);
   // Kbar_q of this stage: recomputed in the epilogue from lambda and the later stages' Ybar (already loaded for the next stage's
   // Kbar) in the records build -- 48 B/unit less than storing and re-reading it; the REBUILD builds (at their register limit, the
   // second coefficient column costs them scalar-register spills: 42 -> 46.6 us) and the single-RHS VJP hook read the stored / seeded one
@@ -865,12 +894,12 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0, sqc = 0.0, svc = 0.0;
   if (!local_only) {
     if (!REBUILD) {
-      if (i == 0 || ac.col[c.s] != 0.0 || ac.cur[c.s] != 0.0) { const double2 l2 = ldg<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b = 0: lambda not needed
+      if (i == 0 || ac.col[c.s] != 0.0 || ac.cur[c.s] != 0.0) { const double2 l2 = ldg_s<double2>(LAMm, o_b6); lq = l2.x; lv = l2.y; }   // b = 0: lambda not needed
       double2 yb[kMaxStages];
 #pragma unroll
       for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
         const bool on = jj > i && jj < c.s;
-        yb[jj] = on ? ldg<double2>(YBm + (size_t)jj * nd6, o_b6) : make_double2(0.0, 0.0);
+        yb[jj] = on ? ldg_s<double2>(YBm + (size_t)jj * nd6, o_b6) : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int jj = 1; jj < kMaxStages; ++jj) {
@@ -971,17 +1000,17 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   double* gpm = c.g_phi + ms;
   double* bmm = c.blk_m + (size_t)m * nd;
   double* bcm = c.blk_c + (size_t)m * nd;
-  const double2 r_old = ldg<double2>(grm, (u32)slot * 16);
+  const double2 r_old = ldg_s<double2>(grm, (u32)slot * 16);
   // the void-angle accumulator moves only where a contact is engaged in this stage (d_phi is an exact zero elsewhere, and contacts
   // are rare: 64 B/unit of the launch's traffic otherwise)
   const bool phi_on = CONTACT == 1 && d_phi != 0.0;
   const double p_old = phi_on ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
-  const double bm_old = ldg<double>(bmm, o_dof);
+  const double bm_old = ldg_s<double>(bmm, o_dof);
   const double bc_old = c.blk_c ? ldg<double>(bcm, o_dof) : 0.0;
   const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
   const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
   if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
-    stg<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
+    stg_s<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
   }
   if (phi_on) { stg<double>(gpm, (u32)slot * 8, p_old - d_phi); c.touch[0] = 1; }
   // ---- DOF epilogue
@@ -1015,10 +1044,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
-      stg<double>(bmm, o_dof, bm_old - w_d * a_i);
+      stg_s<double>(bmm, o_dof, bm_old - w_d * a_i);
       if (c.blk_c) stg<double>(bcm, o_dof, bc_old - w_d * v_i);
     }
-    if (!REBUILD) stg<double2>(YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
+    if (!REBUILD) stg_s<double2>(YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
     else { stg<double>(YBm + (size_t)i * nd6, o_b6, ybq); stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
     if (!local_only) {
       double kq = 0.0, kv;       // Kbar of the next stage to run (records build: its Kbar_q is recomputed there)

@@ -721,6 +721,15 @@ class MultiInputTargetKineticEnergy:
         self.objectives = [TargetKineticEnergy(fp, target_size, target_shift) for fp in forward_problems]
         self.target_size, self.target_shift = tuple(target_size), tuple(target_shift)
         self.concurrent_inputs = True
+        # Inputs that run one after the other (forward + reverse sweep of one input before the next starts) keep their trajectory
+        # checkpoints in ONE set of buffers: a third of the memory and of the allocation time, and room for the records level where
+        # three separate checkpoints only fitted the stage accelerations (config 5: 256 designs x 3 inputs on one GPU).
+        if len(forward_problems) > 1 and not all(fp.streams == 1 for fp in forward_problems) \
+                and len({(fp.device, id(fp._lib)) for fp in forward_problems}) == 1:
+            first = forward_problems[0].solve_dynamics.engine
+            for fp in forward_problems[1:]:
+                fp.solve_dynamics.engine.share_checkpoint(first)
+            self.concurrent_inputs = False
         self.weights = np.asarray(weights, dtype=float)
         self.target_blocks = self.objectives[0].target_blocks
         self.forward = forward_problems[0]

@@ -37,9 +37,9 @@ def main():
                     help="host processes for the members' constraint evaluations and MMA sub-problems (0: in this process; "
                          "-1: min(32, CPUs of this rank - 1))")
     ap.add_argument("--cpu-port", action="store_true", help="use the oracle's CPU port instead of libdfx (rehearsal without a GPU)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="evaluate the whole chunk of members in one engine call per input and round (default with host workers: the two "
-                         "halves of the chunk take turns on the device, the workers run one half's MMA steps while the other half is integrated)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="the two halves of the chunk take turns on the device, the workers run one half's MMA steps while the other half is "
+                         "integrated (same iterates; measured on config 5: no gain, half batches run the device less efficiently)")
     args = ap.parse_args()
 
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -58,7 +58,7 @@ def main():
 
     lo, hi = shard_bounds(args.members, rank, world)
     mine = hi - lo
-    pipeline = workers is not None and not args.no_pipeline and mine >= 2 and mine % 2 == 0
+    pipeline = workers is not None and args.pipeline and mine >= 2 and mine % 2 == 0
     per_call = mine // 2 if pipeline else mine
     spacing, bond, rho, ksh, kr, freq = 15.0, 2.25, 6.18e-9, 1.19, 1.5, 30.0
     nb = args.n1 * args.n2

@@ -145,6 +145,12 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params);
  * calls neither allocate nor re-instantiate their hipGraphs. */
 int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_t keep_trajectory);
 
+/* Let `h` keep its trajectory checkpoint in the buffers of `with` (same device) instead of its own: for handles whose solves never
+ * overlap in time -- the engines of a multi-input objective (problems/quads_focusing_multi_input.py:66-86), each running forward +
+ * reverse before the next starts.  One allocation instead of one per input, and room for a richer checkpoint level.  A reverse sweep
+ * on a handle whose checkpoint has meanwhile been overwritten by another handle's forward pass fails with an error. */
+int dfx_share_checkpoint(dfx_handle* h, dfx_handle* with);
+
 /* Integrate from timepoints[0] with `steps_per_interval` equal RK steps between consecutive
  * timepoints.  state0: (batch, 2, n_blocks, 3), or NULL: every member starts at rest (the reference's problems all do,
  * problems/quads_focusing.py:300); fields: (batch, T, 2, n_blocks, 3) or NULL (they stay on the device), row 0 is the

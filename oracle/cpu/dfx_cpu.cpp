@@ -132,6 +132,7 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
 }
 
 int dfx_reserve(dfx_handle*, int64_t, int32_t, int32_t) { return 0; }
+int dfx_share_checkpoint(dfx_handle*, dfx_handle*) { return 0; }      // host memory: every handle keeps its own trajectory
 
 int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                      const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,

@@ -86,3 +86,33 @@ def test_response_data_reduced_on_the_device(hip_lib, batch):
     (k_response), against the oracle's strains and the host formulas."""
     from .test_problems import check_response_data
     check_response_data(None, batch)
+
+
+def test_inputs_evaluated_in_turn_share_one_checkpoint(hip_lib):
+    """Engines of a multi-input objective whose inputs run one after the other keep their trajectory checkpoints in ONE set of
+    buffers (dfx_share_checkpoint): same objective and gradient as engines with checkpoints of their own, and a reverse sweep on a
+    handle whose checkpoint another handle has overwritten meanwhile is refused."""
+    def build(streams):
+        fws = []
+        for side, shift in (("left", 0), ("right", -2)):
+            fw = P.QuadsFocusingForward(
+                n1_blocks=24, n2_blocks=16, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5, density=6.18e-9,
+                damping=1e-4 * np.ones((384, 3)), amplitude=7.5, loading_rate=300.0, input_delay=1e-4, n_excited_blocks=2,
+                loaded_side=side, input_shift=shift, simulation_time=4e-3, n_timepoints=11, use_contact=True, k_contact=1.5,
+                min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180, steps_per_interval=40, batch=2, streams=streams)
+            fw.setup()
+            fws.append(fw)
+        return P.MultiInputTargetKineticEnergy(fws, (2, 2), (4, 3), weights=(1.0, 0.5)), fws
+    own, _ = build(1)                         # one stream each: concurrent inputs, every engine its own checkpoint
+    shared, fws = build(2)                    # two member groups each: inputs in turn, ONE checkpoint
+    assert own.concurrent_inputs and not shared.concurrent_inputs
+    designs = [_design(fws[0], 1000), _design(fws[0], 1001)]
+    v0, g0 = own.value_and_grad(designs)
+    v1, g1 = shared.value_and_grad(designs)
+    assert np.allclose(v0, v1, rtol=1e-12)
+    for a, b in zip(g0, g1):
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 1e-10 * np.abs(y).max()
+    # input 0's checkpoint has been overwritten by input 1's forward pass: its reverse sweep must refuse to run
+    with pytest.raises(RuntimeError, match="overwritten by a solve of another handle"):
+        fws[0].solve_dynamics.kinetic_energy_value_and_raw(shared.target_blocks)
