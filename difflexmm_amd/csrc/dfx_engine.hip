@@ -594,14 +594,12 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
   auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
   int mode = forced;
   if (mode < 0) {
-    // records pay on large lattices (reverse launch 32 us against 42 us at the stages level).  With many small members (24x16 x 256,
-    // three engines side by side) they gain 5 % of device time at twice the checkpoint memory, and the engines then compete for the
-    // HBM (profiles/r02_config5_checkpoint_levels.txt; with the member-major checkpoint of mid-round 2 they LOST 35 %: one far-apart
-    // record per member and launch; the checkpoint is record-major since): small lattices stay at the stages level
-    // ... unless their records checkpoint is small (config 5's share of one of 8 GPUs, 32 designs per input: 16 GB; 13 % less device
-    // time, 9 % less wall: profiles/r02_config5_checkpoint_levels.txt)
-    // ... or the checkpoint is shared between the engines of a multi-input objective (ONE allocation instead of three)
-    if ((pl.n_blocks >= 4096 || h->ck->users > 1 || want_rec * sizeof(double) <= ((size_t)24 << 30)) && fits(grow(want_rec, have_t))) mode = kCkRecords;
+    // records whenever they fit: the reverse launch reads the record it linearises about instead of rebuilding it (128x128 x 16:
+    // 32 us against 42 us; 24x16 x 256: forward + reverse 254 + 370 ms against 245 + 473 ms, profiles/r03_c5_shared_checkpoint.txt).
+    // Round 2 kept small lattices at the stages level because THREE engines of a multi-input objective each allocated a 50 - 130 GB
+    // checkpoint; engines whose inputs run in turn now share one (dfx_share_checkpoint), and a level that does not fit next to what
+    // other handles hold falls back by itself.
+    if (fits(grow(want_rec, have_t))) mode = kCkRecords;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
     else if (fits(grow(want_state, have_t))) mode = kCkState;
     else mode = kCkSegments;
@@ -1051,13 +1049,21 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
     HIP_OK(h->d_tsteps.ensure(h->t_steps.size()));
     HIP_OK(hipMemcpyAsync(h->d_tsteps.p, h->t_steps.data(), sizeof(double) * h->t_steps.size(), hipMemcpyHostToDevice, h->stream));
   }
+  const auto tw0 = std::chrono::steady_clock::now();
   if (ensure_work_buffers(h)) return 2;
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
+  if (getenv("DFX_TIMING"))
+    fprintf(stderr, "[dfx] forward: work buffers %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
   h->have_traj = false;
   if (keep_trajectory) {
     long long max_spi = 1;
     for (int v : h->spis) max_spi = std::max<long long>(max_spi, v);
+    const auto tc0 = std::chrono::steady_clock::now();
     const int mode = choose_checkpoint(h, h->n_total, max_spi);
+    if (getenv("DFX_TIMING"))
+      fprintf(stderr, "[dfx] choose_checkpoint: level %d, %.1f ms (traj %.1f GB, AD %.1f GB, shared by %d)\n", mode,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(),
+              h->ck->traj.n * 8e-9, h->ck->AD.n * 8e-9, h->ck->users);
     if (mode < 0) {
       h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string((B * (h->n_total + 1) * rec * 8) >> 20) + " MiB)";
       return 2;
