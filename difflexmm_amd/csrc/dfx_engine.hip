@@ -128,7 +128,7 @@ struct dfx_handle {
   bool adaptive = false;
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
-  DevBuf<double> d_POS, d_VEL, d_A, d_state0, d_fields;
+  DevBuf<double> d_POS, d_VEL, d_A, d_state0, d_fields, d_fn_tab;
   DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_m, d_blk_c, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
@@ -185,6 +185,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.fns = h->d_fns.p;
   c.p_c = h->d_p_c.p; c.g_c = h->d_g_c.p; c.n_npb = pl.n_npb;
   c.cur = h->d_cur.p;
+  c.fn_tab = nullptr;          // fixed-grid solves switch it on (use_fn_table): the table is refreshed per segment
   c.clock = h->adaptive ? h->d_clock.p : nullptr;
   c.err_partial = h->d_err_partial.p; c.ts_dev = h->d_ts.p; c.fields_dev = h->d_fields.p;
   c.step_counts = h->adaptive ? h->d_step_counts.p : nullptr;
@@ -404,6 +405,21 @@ static void launch_adj_unit(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3
   launch_adj_pair(h, c, st, (int)grid.y, s - 1 - 2 * u, j);
 }
 
+// the time functions of the segment the group's cursor now points at, for every step and stage time (k_fn_table); DFX_FN_TABLE=0:
+// the lanes of driven / loaded blocks evaluate them themselves, as in rounds 1-2
+static bool use_fn_table(const dfx_handle* h) {
+  const char* e = getenv("DFX_FN_TABLE");
+  return h->pl.n_fns > 0 && !h->adaptive && h->d_fn_tab.p && !(e && e[0] == '0');
+}
+static void launch_fn_table(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) {
+  if (!c.fn_tab) return;
+  StageTimes tms;
+  for (int r = 0; r < kFnRows; ++r) tms.c[r] = r <= h->pl.tab.s ? h->pl.tab.c[r] : 0.0;
+  const int total = n_steps * (h->pl.tab.s + 1) * h->pl.n_fns;
+  hipLaunchKernelGGL(k_fn_table, dim3((total + 63) / 64, nm), dim3(64), 0, st, c, tms, n_steps, h->d_fn_tab.p);
+  h->launches++;
+}
+
 // enqueue one segment (kind 0: forward steps; kind 1: reverse steps) of group gi on that group's stream
 static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_steps, int kind) {
   const int s = h->pl.tab.s;
@@ -412,6 +428,7 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   const dim3 grid = slot_grid(h, g);
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, g.stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
   h->launches++;
+  launch_fn_table(h, c, g.stream, g.nm, n_steps);
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
       for (int u = 0; u < step_units(h, 0); ++u) launch_fwd_unit(h, c, g.stream, grid, u, j);
@@ -479,6 +496,7 @@ static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps,
     if (seg_index >= 0) hipLaunchKernelGGL(k_set_seg, dim3(1), dim3(1), 0, h->groups[gi].stream, (const Seg*)h->d_segs.p, seg_index, h->d_cur.p + gi);
     else hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->groups[gi].stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
     h->launches++;
+    launch_fn_table(h, cg[gi], h->groups[gi].stream, h->groups[gi].nm, n_steps);
   }
   if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
@@ -509,7 +527,7 @@ static int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int 
   auto key = std::make_pair(n_steps, kind * kMaxGroups + gi);
   auto it = h->graphs.find(key);
   const int s = h->pl.tab.s;
-  const long long per = 1 + (long long)n_steps * ((kind == 0 || c.AD || c.rps > 1) ? step_units(h, kind) : 2 * s - 1);   // launches in the graph
+  const long long per = 1 + (c.fn_tab ? 1 : 0) + (long long)n_steps * ((kind == 0 || c.AD || c.rps > 1) ? step_units(h, kind) : 2 * s - 1);   // launches in the graph
   hipStream_t st = h->groups[gi].stream;
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -648,6 +666,7 @@ static int ensure_work_buffers(dfx_handle* h) {
   HIP_OK(h->d_A.ensure(B * (s + 1) * nb * 3));
   HIP_OK(h->d_state0.ensure(B * nb * 6));
   HIP_OK(h->d_cur.ensure(kMaxGroups));
+  if (pl.n_fns > 0) HIP_OK(h->d_fn_tab.ensure(B * (size_t)kMaxGraphSteps * kFnRows * DFX_MAX_FNS * kFnEntry));
   return 0;
 }
 
@@ -920,7 +939,7 @@ int dfx_destroy(dfx_handle* h) {
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release(); 
   if (--h->ck->users == 0) { h->ck->traj.release(); h->ck->AD.release(); delete h->ck; }
-  h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
+  h->d_fn_tab.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
   h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release();
@@ -1093,6 +1112,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   }
   DevCtx c = make_ctx(h);
   if (h->segments) { c.traj = nullptr; c.rps = 1; }        // segments level: the forward pass keeps nothing but its outputs
+  if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   pair_plan(h, c);
   h->launches = 0;
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
@@ -1374,6 +1394,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
                                                      : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   pair_plan(h, c);
+  if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   // the (w, Kbar_q) buffers alternate per launch, lambda (pair launches only) per step
   const int wb = (int)((h->n_total * step_units(h, 1) - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb,

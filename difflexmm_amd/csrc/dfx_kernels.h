@@ -112,6 +112,8 @@ struct DevCtx {
   const double* inv_m;    // n_blocks*3
   const double* damping;  // n_blocks*3
   const TimeFn* fns;
+  const double* fn_tab;   // values of the time functions at every stage time of the segment being replayed (k_fn_table), or null: the
+                          // lanes of driven / loaded blocks evaluate them themselves (adaptive steps, test hooks)
   const Seg* cur;         // the segment being replayed
   Clock* clock;           // per-member clocks (adaptive mode) or null
   double* err_partial;    // batch * n_wg * kWavesPerWg per-wave partial sums of the squared error ratio
@@ -254,6 +256,36 @@ __device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, co
       r.gt += sp.con_coef[d][f] * gt;
     }
   return r;
+}
+
+// ---- time functions, tabulated per segment ------------------------------------------------------------------------------------
+// Every lane of a driven or loaded block needs g_f(t) at the stage time of its launch (and, constrained DOFs, at the next stage
+// time for the record it publishes): a dependent load of the function's parameters, a sin / cos pair in software, a second
+// evaluation -- a few hundred instructions and three memory round trips on a handful of lanes.  Invisible when launches fill the
+// chip; 2.8 of the 7.1 us of a launch-bound forward stage (one 128x128 system: profiles/r03_time_function_table.txt), because a
+// launch ends with its slowest workgroup.  All those lanes ask for the same numbers, so one small launch per segment computes them
+// for every (step, stage time, function, member) and the stage kernels read them with scalar loads issued at the top of the kernel.
+//   entry (m, j, r, f): 8 doubles = g, dg/dt, dg/dp[0..4], pad;  r = 0 .. s: stage times t_n + c_r h with c_s = 1
+constexpr int kFnEntry = 8;
+constexpr int kFnRows = kMaxStages + 1;
+__device__ __forceinline__ const double* fn_tab_row(const DevCtx& c, int m, int j, int r) {
+  return c.fn_tab + (((size_t)m * kMaxGraphSteps + j) * kFnRows + r) * (DFX_MAX_FNS * kFnEntry);
+}
+struct StageTimes { double c[kFnRows]; };
+__global__ __launch_bounds__(64) void k_fn_table(DevCtx c, StageTimes st, int n_steps, double* tab) {
+  const int m = blockIdx.y + c.m0;
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= n_steps * (c.s + 1) * c.n_fns) return;
+  const int f = idx % c.n_fns, r = (idx / c.n_fns) % (c.s + 1), j = idx / (c.n_fns * (c.s + 1));
+  const Seg sg = *c.cur;
+  const long long n = sg.base_step + j;
+  double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
+  if (c.t_steps) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
+  double g, gt, gp[kMaxFnParams];
+  eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + st.c[r] * h, g, gt, gp);
+  double* e = tab + ((((size_t)m * kMaxGraphSteps + j) * kFnRows + r) * DFX_MAX_FNS + f) * kFnEntry;
+  e[0] = g; e[1] = gt;
+  for (int i = 0; i < kMaxFnParams; ++i) e[2 + i] = gp[i];
 }
 
 // records of a full (2, n_blocks, 3) state at time t0 -> stage buffer `buf`  (constrained DOFs follow c(t0), c'(t0))
@@ -526,6 +558,11 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   }
   const long long n = sg.base_step + j;
   const u32 nd = (u32)c.n_blocks * 3;
+  // time functions at this stage's time and at the next one: uniform addresses (scalar loads), or evaluated by the few lanes that
+  // need them when there is no table
+  const bool use_tab = c.fn_tab != nullptr && !c.clock;
+  const double* ft_i = use_tab ? fn_tab_row(c, m, j, i) : nullptr;
+  const double* ft_n = use_tab ? fn_tab_row(c, m, j, i + 1) : nullptr;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
   const MemberBases B = member_bases(c, m);
@@ -589,13 +626,17 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       const dfx_special& sp = c.special[sidx];
       constrained = (sp.con_mask >> k) & 1;
       if (!constrained) {
-        double gp[kMaxFnParams];
-        for (int f = 0; f < c.n_fns; ++f)
-          if (sp.load_coef[k][f] != 0.0) {
-            double g, gt;
-            eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + sc.c_i * h, g, gt, gp);
-            fload += sp.load_coef[k][f] * g;
-          }
+        if (use_tab) {
+          for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * ft_i[f * kFnEntry];
+        } else {
+          double gp[kMaxFnParams];
+          for (int f = 0; f < c.n_fns; ++f)
+            if (sp.load_coef[k][f] != 0.0) {
+              double g, gt;
+              eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + sc.c_i * h, g, gt, gp);
+              fload += sp.load_coef[k][f] * g;
+            }
+        }
       }
     }
     const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
@@ -616,8 +657,14 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       qnext = r2;
     }
     if (constrained && out_buf != -1) {
-      TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
-      qnext = tv.g; vnext = tv.gt;
+      if (use_tab) {
+        const dfx_special& sp = c.special[sidx];
+        qnext = 0.0; vnext = 0.0;
+        for (int f = 0; f < c.n_fns; ++f) { qnext += sp.con_coef[k][f] * ft_n[f * kFnEntry]; vnext += sp.con_coef[k][f] * ft_n[f * kFnEntry + 1]; }
+      } else {
+        TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
+        qnext = tv.g; vnext = tv.gt;
+      }
     }
   }
   if (err_mode) {
@@ -1023,13 +1070,17 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
       const dfx_special& sp = c.special[sidx];
       constrained = (sp.con_mask >> k) & 1;
       const double t_i = t_n + ac.c_i * h;
+      const double* ft = (c.fn_tab != nullptr && !local_only) ? fn_tab_row(c, m, j, i) : nullptr;     // tabulated per segment: k_fn_table
       double gp[kMaxFnParams];
       for (int f = 0; f < c.n_fns; ++f) {
         const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
         const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
         if ((coef != 0.0 && c.fn_g) || loaded) {
           double g, gt;
-          eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
+          if (ft) {
+            g = ft[f * kFnEntry];
+            if (coef != 0.0 && c.fn_g) for (int kk = 0; kk < kMaxFnParams; ++kk) gp[kk] = ft[f * kFnEntry + 2 + kk];
+          } else eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
           if (loaded) fload += sp.load_coef[k][f] * g;
           if (coef != 0.0 && c.fn_g) {
             double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
