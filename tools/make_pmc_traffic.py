@@ -6,8 +6,13 @@ src, tag, members, ck = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 p = json.load(open(src))
 out = {"source": f"tools/profile_round.sh {tag} {members} on MI355X: rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT TCC_MISS | 8 SQ counters | "
                  f"6 SQ counters> --kernel-trace --output-format csv, separate passes; python3 bench.py --streams 1 --members {members} "
-                 f"--steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg (DFX_DUAL_CHAIN=0); checkpoint level: {ck}",
+                 f"--steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written (DFX_DUAL_CHAIN=0); checkpoint level: {ck}",
        "units": "mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB; gfx950 correction (MI355X_MICROARCH.md, HBM): read bytes = 2 * FETCH_SIZE * 1024",
+       "calibration": "the guide calibrates the x2 for 16-B-per-lane streaming reads only and calls other widths uncalibrated; these kernels mix "
+                      "16-B (records, node vectors, lambda / Ybar pairs) and 8-B (per-DOF arrays, void angles) loads.  Calibrated on the kernels' own "
+                      "access pattern instead: a by-hand count of the bytes each build REQUESTS per unit (DESIGN.md section 4) matched the corrected "
+                      "counter to 1 % for two builds that differ by 166 B/unit (r02_v3: 777 B counted by hand vs 777 B; r02_v9: 611 vs 611), i.e. "
+                      "the x2 holds for this mix; ratios between builds do not depend on it",
        "members": members, "checkpoint": ck, "counters": p}
 for k, name in (("fwd", "k_fwd_stage"), ("adj", "k_adj_stage")):
     rd, wr = 2 * p[k]["FETCH_SIZE"] * 1024 / members, p[k]["WRITE_SIZE"] * 1024 / members
