@@ -8,8 +8,8 @@ combined with ONE all-gather -- latency-bound, so ring vs tree is irrelevant.  G
 rank; gradients w.r.t. a SHARED design (multi-input problems) are summed with one all-reduce.
 
 The collective is native: ``RcclComm`` calls ``dfx_comm_init / dfx_gather_objectives / dfx_reduce_grads`` of libdfx (RCCL
-over xGMI inside the library, ``include/dfx.h``); the unique id travels from rank 0 to the others through a file named by the
-launcher (``DFX_UID_FILE``, or derived from ``MASTER_PORT`` and the launcher's pid).  ``SocketComm`` is a plain-TCP stand-in
+over xGMI inside the library, ``include/dfx.h``); the unique id travels from rank 0 to the others over a TCP control channel, over
+which the ranks also agree on go / no-go before any of them enters ``ncclCommInitRank``.  ``SocketComm`` is a plain-TCP stand-in
 with the same methods for rehearsing the N > 1 path where RCCL cannot run (several ranks on ONE GPU, or no GPU at all);
 any object with ``rank``, ``world``, ``all_gather``, ``all_reduce`` and ``barrier`` can be passed as ``comm=``.
 No PyTorch anywhere in this module.
