@@ -271,6 +271,17 @@ constexpr int kFnRows = kMaxStages + 1;
 __device__ __forceinline__ const double* fn_tab_row(const DevCtx& c, int m, int j, int r) {
   return c.fn_tab + (((size_t)m * kMaxGraphSteps + j) * kFnRows + r) * (DFX_MAX_FNS * kFnEntry);
 }
+// A table row has a uniform address, so the compiler reads it with scalar loads -- into scalar registers, of which the stage kernels
+// have none to spare (106 in use: the first version of this table cost the main path 60 v_readlane / v_writelane spills per wave, +8 %
+// of its instructions, found in the SQ counters).  An offset the compiler cannot prove uniform makes them ordinary vector loads.
+__device__ __forceinline__ u32 lane_zero() {
+  u32 z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+__device__ __forceinline__ double fn_tab_get(const double* row, int f, int e, u32 z) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + ((u32)((f * kFnEntry + e) * 8) + z));
+}
 struct StageTimes { double c[kFnRows]; };
 __global__ __launch_bounds__(64) void k_fn_table(DevCtx c, StageTimes st, int n_steps, double* tab) {
   const int m = blockIdx.y + c.m0;
@@ -534,7 +545,9 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   write_traj: also store the new record into the checkpoint of step n+1 (last stage, keep_trajectory)
 //   NPB: lanes per block (lane_pos); the packed mapping serves 3-node blocks on the fixed grid (not the adaptive controller's error
 //   reduction, not the distance-based contact, whose node rotations are quad moves)
-template <int MODEL, int CONTACT, int NPB = 4>
+//   TAB: the time functions come from the segment's table (k_fn_table) -- a build of its own, so that neither build carries the
+//   other's path: with both in one kernel the main path paid 26 scalar-register spills (v_readlane / v_writelane) per wave
+template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0>
 __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
@@ -558,11 +571,10 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   }
   const long long n = sg.base_step + j;
   const u32 nd = (u32)c.n_blocks * 3;
-  // time functions at this stage's time and at the next one: uniform addresses (scalar loads), or evaluated by the few lanes that
-  // need them when there is no table
-  const bool use_tab = c.fn_tab != nullptr && !c.clock;
-  const double* ft_i = use_tab ? fn_tab_row(c, m, j, i) : nullptr;
-  const double* ft_n = use_tab ? fn_tab_row(c, m, j, i + 1) : nullptr;
+  // time functions at this stage's time and at the next one: read from the segment's table by the few lanes that need them (the row
+  // addresses are formed INSIDE their branch: kept live across the kernel they cost scalar registers the main path spills for), or
+  // evaluated by those lanes when there is no table
+  constexpr bool use_tab = TAB != 0;
   // ---- load phase
   const double* POSin = pos_in(c, m, in_buf, n);
   const MemberBases B = member_bases(c, m);
@@ -627,7 +639,9 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       constrained = (sp.con_mask >> k) & 1;
       if (!constrained) {
         if (use_tab) {
-          for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * ft_i[f * kFnEntry];
+          const double* ft_i = fn_tab_row(c, m, j, i);
+          const u32 z = lane_zero();
+          for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * fn_tab_get(ft_i, f, 0, z);
         } else {
           double gp[kMaxFnParams];
           for (int f = 0; f < c.n_fns; ++f)
@@ -659,8 +673,10 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
     if (constrained && out_buf != -1) {
       if (use_tab) {
         const dfx_special& sp = c.special[sidx];
+        const double* ft_n = fn_tab_row(c, m, j, i + 1);
+        const u32 z = lane_zero();
         qnext = 0.0; vnext = 0.0;
-        for (int f = 0; f < c.n_fns; ++f) { qnext += sp.con_coef[k][f] * ft_n[f * kFnEntry]; vnext += sp.con_coef[k][f] * ft_n[f * kFnEntry + 1]; }
+        for (int f = 0; f < c.n_fns; ++f) { qnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 0, z); vnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 1, z); }
       } else {
         TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + sc.c_next * h);
         qnext = tv.g; vnext = tv.gt;
@@ -896,7 +912,7 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
@@ -1070,16 +1086,17 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
       const dfx_special& sp = c.special[sidx];
       constrained = (sp.con_mask >> k) & 1;
       const double t_i = t_n + ac.c_i * h;
-      const double* ft = (c.fn_tab != nullptr && !local_only) ? fn_tab_row(c, m, j, i) : nullptr;     // tabulated per segment: k_fn_table
+      const double* ft = TAB ? fn_tab_row(c, m, j, i) : nullptr;     // tabulated per segment: k_fn_table (a build of its own, see k_fwd_stage)
       double gp[kMaxFnParams];
       for (int f = 0; f < c.n_fns; ++f) {
         const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
         const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
         if ((coef != 0.0 && c.fn_g) || loaded) {
           double g, gt;
-          if (ft) {
-            g = ft[f * kFnEntry];
-            if (coef != 0.0 && c.fn_g) for (int kk = 0; kk < kMaxFnParams; ++kk) gp[kk] = ft[f * kFnEntry + 2 + kk];
+          if (TAB) {
+            const u32 z = lane_zero();
+            g = fn_tab_get(ft, f, 0, z);
+            if (coef != 0.0 && c.fn_g) for (int kk = 0; kk < kMaxFnParams; ++kk) gp[kk] = fn_tab_get(ft, f, 2 + kk, z);
           } else eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t_i, g, gt, gp);
           if (loaded) fload += sp.load_coef[k][f] * g;
           if (coef != 0.0 && c.fn_g) {
@@ -1129,10 +1146,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   }
 }
 
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
-  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
+  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 // The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry
 // point, so that its occupancy can be pinned (DFX_ADJ_RB_OCC) without touching the others.
