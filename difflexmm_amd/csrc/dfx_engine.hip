@@ -181,6 +181,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
   c.slot_info = h->d_slot_info.p; c.block_special = h->d_block_special.p; c.special = h->d_special.p;
   c.p_lidx = h->d_l_idx.p; c.l_dict = h->d_l_dict.p; c.l_dict_on = h->pp.l_dict_ok ? 1 : 0; c.damping_uniform = h->pp.damping_uniform ? 1 : 0;
+  { const char* e = getenv("DFX_DICT_LDS"); c.l_dict_lds = (h->pp.l_dict_ok && h->pp.n_dict_max <= kDictLds && !(e && e[0] == '0')) ? 1 : 0; }
   c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;
   c.inv_m = h->d_inv_m.p; c.damping = h->d_damping.p; c.fns = h->d_fns.p;
   c.p_c = h->d_p_c.p; c.g_c = h->d_g_c.p; c.n_npb = pl.n_npb;

@@ -108,6 +108,8 @@ struct DevCtx {
   const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
   const double* l_dict;   // 256*4   lx ly |l0| 1/|l0|
   int l_dict_on, damping_uniform;
+  int l_dict_lds;         // the dictionary has at most kDictLds entries in every member: every wave copies it into LDS with its first batch of
+                          // loads and looks its entries up there (the global lookup was a second, dependent memory round trip)
   const double* cst;      // 16           min_angle cutoff_angle k_contact | uniform k_stretch k_shear k_rot
   const double* inv_m;    // n_blocks*3
   const double* damping;  // n_blocks*3
@@ -432,9 +434,10 @@ __device__ __forceinline__ void load_partner(const MemberBases& B, int pslot, co
 //   resolve_lane what depends on loaded values: the dictionary entry of the reference vector, and a second gather
 //                only for lanes whose real partner is not the guessed one (irregular connectivity).
 // Partner data comes from the same arrays the owners read (lines served by the XCD's L2).
+constexpr int kDictLds = 16;
 struct LaneRaw {
   Partner P;
-  double2 pc, ro, lv;
+  double2 pc, ro, lv, dl0, dl1;     // dl0 / dl1: dictionary entry min(lane, kDictLds - 1), on its way to LDS
   double ks, ksh, kr, phi;
   int info, guess, lidx, slot;
 };
@@ -449,6 +452,11 @@ __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B
   // branch-free (a branch here would end the batch of loads): the unused one of the two reads one shared valid address
   R.lidx = (int)ldg<uint8_t>(c.l_dict_on ? (const void*)B.p_lidx : (const void*)B.cst, c.l_dict_on ? (u32)slot : 0u);
   R.lv = ldg<double2>(c.l_dict_on ? B.cst : B.p_l, c.l_dict_on ? 0u : (u32)slot * 16);
+  if (c.l_dict_lds) {       // uniform; every lane loads (the entries share one or two cache lines), lanes 0 .. kDictLds-1 will store
+    const u32 e = min((u32)(threadIdx.x & 63), (u32)(kDictLds - 1)) * 32;
+    R.dl0 = ldg<double2>(B.l_dict, e);
+    R.dl1 = ldg<double2>(B.l_dict, e + 16);
+  }
   R.ks = R.ksh = R.kr = 0.0;
   if (!c.k_uniform) { R.ks = ldg<double>(B.p_k, (u32)slot * 32); R.ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); R.kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
   R.phi = 0.0;
@@ -457,13 +465,21 @@ __device__ __forceinline__ void issue_lane(const DevCtx& c, const MemberBases& B
   load_partner<CONTACT>(B, R.guess, POSin, R.P);
 }
 
-template <int CONTACT, int NPB = 4>
+template <int CONTACT, int NPB = 4, int WAVES = kWavesPerWg>
 __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases& B, const double* POSin, LaneRaw& R, LaneIn& L) {
   const int k_ = R.slot & 3;
   const int info = R.info;
   L.info = info;
   double2 lv = R.lv, ln = make_double2(0.0, 0.0);
-  if (c.l_dict_on) {
+  if (c.l_dict_lds) {
+    // wave-private copy: a wave's LDS operations complete in order, so its own stores are visible to its loads without a barrier
+    __shared__ double2 s_dict[WAVES][kDictLds][2];
+    double2 (*sd)[2] = s_dict[threadIdx.x >> 6];
+    const u32 ln_ = threadIdx.x & 63;
+    if (ln_ < (u32)kDictLds) { sd[ln_][0] = R.dl0; sd[ln_][1] = R.dl1; }
+    lv = sd[R.lidx][0];
+    ln = sd[R.lidx][1];
+  } else if (c.l_dict_on) {
     lv = ldg<double2>(B.l_dict, (u32)R.lidx * 32);
     ln = ldg<double2>(B.l_dict, (u32)R.lidx * 32 + 16);
   }

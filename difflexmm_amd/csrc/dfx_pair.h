@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * WROWS) DFX_PAIR_OCC void k_fwd_pair(DevCtx c, 
     double al[kMaxStages - 1];
 #pragma unroll
     for (int l = 0; l < kMaxStages - 1; ++l) al[l] = l < i ? ldg<double>(Am + (size_t)l * nd, o_dof) : 0.0;
-    resolve_lane<CONTACT>(c, B, POSin, R, L);
+    resolve_lane<CONTACT, 4, WROWS>(c, B, POSin, R, L);
     double sv = 0.0, sq = 0.0;
 #pragma unroll
     for (int l = 0; l < kMaxStages - 1; ++l) {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * WROWS) DFX_PAIR_OCC void k_adj_pair(DevCtx c, 
       sv2 += c2 * yb[jj].y;
     }
     const double w_d = (h * (ac1.cur[c.s] * lv + svc)) * invm;
-    resolve_lane<CONTACT>(c, B, POSin, R, L);
+    resolve_lane<CONTACT, 4, WROWS>(c, B, POSin, R, L);
     if (L.pslot != L.guess) {
       const u32 pb = (u32)(L.pslot >> 2) * 24;
       const double2 wxy = ldg<double2>(Win, pb); wpx = wxy.x; wpy = wxy.y;

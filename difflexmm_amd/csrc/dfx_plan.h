@@ -116,6 +116,7 @@ struct PackedParams {
   std::vector<uint8_t> l_idx;   // batch * n_slots : index into l_dict
   std::vector<double> l_dict;   // batch * 256 * 4 : lx, ly, |l0|, 1/|l0|
   bool l_dict_ok = true;        // <= 256 distinct reference vectors in every member
+  int n_dict_max = 0;           // the largest dictionary of any member (lattices have 2-3 entries: small ones are looked up in LDS)
   bool damping_uniform = true;  // the three per-DOF damping coefficients are the same for every block of a member (cst[6..8])
 };
 
@@ -174,7 +175,7 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       out.cst.assign((size_t)B * 16, 0.0);
       out.k_uniform = true;
       out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 1024, 0.0);
-      out.l_dict_ok = true; out.damping_uniform = true;
+      out.l_dict_ok = true; out.damping_uniform = true; out.n_dict_max = 0;
     }
     for (int s_ = 0; s_ < NS; ++s_) {
       const double* s = sp + (size_t)s_ * kSlotParams;
@@ -221,6 +222,7 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
         }
         out.l_idx[(size_t)m * NS + s_] = (uint8_t)hit;
       }
+      if (n_dict > out.n_dict_max) out.n_dict_max = n_dict;
     }
     for (int d = 0; d < 3; ++d) {
       const double d0 = out.damping[(size_t)m * NB * 3 + d];
