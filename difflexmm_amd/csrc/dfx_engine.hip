@@ -113,7 +113,8 @@ struct dfx_handle {
   bool have_params = false, have_traj = false, have_fields = false;
   bool use_graph = true;
   bool want_bond_grads = true, want_fn_grads = true, want_damping_grads = true;
-  DevBuf<int32_t> d_slot_info, d_block_special, d_slot_bond, d_touch;
+  DevBuf<int32_t> d_slot_info, d_block_special, d_slot_bond, d_touch, d_ovf_ptr, d_ovf_info, d_ovf_bond;
+  DevBuf<double> d_ovf_p, d_ovf_g;             // extra ligaments (general bond lists): parameters, gradient accumulators
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<double> d_resp;                           // dfx_response_data outputs
   DevBuf<dfx_special> d_special;
@@ -180,6 +181,8 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.nbuf = 2 * pl.tab.s;
   c.n_special = pl.n_special; c.k_uniform = h->pp.k_uniform ? 1 : 0; c.n_timepoints = (int)h->ts.size();
   c.slot_info = h->d_slot_info.p; c.block_special = h->d_block_special.p; c.special = h->d_special.p;
+  c.n_ovf = pl.n_ovf;
+  if (pl.n_ovf) { c.ovf_ptr = h->d_ovf_ptr.p; c.ovf_info = h->d_ovf_info.p; c.ovf_p = h->d_ovf_p.p; c.ovf_g = h->d_ovf_g.p; }
   c.p_lidx = h->d_l_idx.p; c.l_dict = h->d_l_dict.p; c.l_dict_on = h->pp.l_dict_ok ? 1 : 0; c.damping_uniform = h->pp.damping_uniform ? 1 : 0;
   { const char* e = getenv("DFX_DICT_LDS"); c.l_dict_lds = (h->pp.l_dict_ok && h->pp.n_dict_max <= kDictLds && !(e && e[0] == '0')) ? 1 : 0; }
   c.p_r = h->d_p_r.p; c.p_l = h->d_p_l.p; c.p_k = h->d_p_k.p; c.p_phi = h->d_p_phi.p; c.cst = h->d_cst.p;
@@ -199,7 +202,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.ad_stride = pl.batch ? (long long)(h->ck->AD.n / pl.batch) : 0;
   c.POS = h->d_POS.p; c.VEL = h->d_VEL.p; c.A = h->d_A.p;
   c.YB = h->d_YB.p; c.LAM = h->d_LAM.p; c.W = h->d_W.p; c.KQ = h->d_KQ.p; c.G = h->d_G.p;
-  c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = h->want_bond_grads ? h->d_g_b.p : nullptr;
+  c.g_r = h->d_g_r.p; c.g_phi = h->d_g_phi.p; c.g_b = (h->want_bond_grads || pl.n_ovf) ? h->d_g_b.p : nullptr;     // (general bond lists run the one reverse build that has them)
   c.touch = h->d_touch.p;
   c.lam_pairs = (c.g_b || c.AD) ? 0 : 1;      // the REBUILD builds of the reverse stage (launch_adj_t) keep the scalar layout
   c.blk_m = h->d_blk_m.p; c.blk_c = h->want_damping_grads ? h->d_blk_c.p : nullptr;
@@ -336,6 +339,11 @@ static bool pack3(const dfx_handle* h) {
 }
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
+  if (h->pl.n_ovf) {       // general bond lists: the build that walks a node's extra ligaments (quad mapping, in-kernel time functions)
+    if constexpr (CONTACT != 2)
+      hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 0, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+    return;
+  }
   const bool tab = c.fn_tab != nullptr && !c.clock;        // the segment's time-function table is there: the build that reads it
   if (CONTACT != 2 && pack3(h) && !(mode & 2)) {
     if constexpr (CONTACT != 2) {
@@ -363,7 +371,11 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   const int s = h->pl.tab.s;
   const int rb = (c.AD && !local_only) ? (i >= 2 ? i - 1 : (i == 0 ? s - 1 : 0)) : 0;
   const StageCoef rc = stage_coef(h->pl.tab, rb > 0 ? rb - 1 : 0);
-  if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  if (h->pl.n_ovf) {       // general bond lists: one build for every checkpoint level (per-ligament gradients on, rebuild on)
+    if constexpr (CONTACT != 2)
+      hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1, 4, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  }
+  else if (c.g_b) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else if (c.AD) hipLaunchKernelGGL((k_adj_stage_rb<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else if (CONTACT != 2 && pack3(h)) {
     if constexpr (CONTACT != 2) {
@@ -703,7 +715,8 @@ static int zero_grad_accumulators(dfx_handle* h) {
   HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
   HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots, h->stream));
   HIP_OK(hipMemsetAsync(h->d_touch.p, 0, sizeof(int32_t) * 4, h->stream));
-  if (h->want_bond_grads) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
+  if (pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_ovf_g.p, 0, sizeof(double) * B * pl.n_ovf * kOvfG, h->stream));
+  if (h->want_bond_grads || pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
   HIP_OK(hipMemsetAsync(h->d_blk_m.p, 0, sizeof(double) * B * nb * 3, h->stream));
   if (pl.contact == DFX_CONTACT_DISTANCE) HIP_OK(hipMemsetAsync(h->d_g_c.p, 0, sizeof(double) * B * nb * 2, h->stream));
   if (h->want_damping_grads) HIP_OK(hipMemsetAsync(h->d_blk_c.p, 0, sizeof(double) * B * nb * 3, h->stream));
@@ -738,7 +751,7 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
     int32_t touched = 1;
     HIP_OK(hipMemcpyAsync(&touched, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
-    if (!touched) {
+    if (!touched && !pl.n_ovf) {
       const size_t bytes = sizeof(double) * B * nbd * 2;
       if (h->zero_phi.n < bytes || !h->zero_phi.p) { HIP_OK(h->zero_phi.ensure(bytes)); memset(h->zero_phi.p, 0, h->zero_phi.n); }
       phi_zero = true; w_phi = false;
@@ -770,6 +783,7 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   if (pack_r || w_phi || w_lam) {
     if (pack_r) HIP_OK(h->d_out_r.ensure(n_r));
     if (w_phi) HIP_OK(h->d_out_phi.ensure(n_phi));
+    if (w_phi && pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_out_phi.p, 0, sizeof(double) * n_phi, h->stream));   // ends that are extra ligaments: added on the host
     if (w_lam) HIP_OK(h->d_out_lam.ensure(n_lam));
     DevCtx c = make_ctx(h);
     hipLaunchKernelGGL(k_pack_grads, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const int32_t*)h->d_slot_bond.p, npb, (int)nbd,
@@ -816,6 +830,22 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
         if (v.k_bond) for (int c = 0; c < 3; ++c) v.k_bond[(m * nbd + bond) * 3 + c] = q[2 + c];
         if (v.contact) for (int c = 0; c < 3; ++c) v.contact[m * 3 + c] += q[5 + c];
       }
+  if (pl.n_ovf && (v.void_angle0 || v.reference_vector || v.k_bond || v.contact)) {
+    // extra ligaments (general bond lists): a handful of entries, unpacked on the host
+    std::vector<double> og((size_t)B * pl.n_ovf * kOvfG);
+    HIP_OK(hipMemcpy(og.data(), h->d_ovf_g.p, sizeof(double) * og.size(), hipMemcpyDeviceToHost));
+    for (size_t m = 0; m < B; ++m)
+      for (int e = 0; e < pl.n_ovf; ++e) {
+        const double* q = og.data() + (m * pl.n_ovf + e) * kOvfG;
+        const size_t bond = (size_t)pl.ovf_bond[e];
+        const int end = pl.ovf_info[e] & 1;
+        if (v.void_angle0 && pl.contact == DFX_CONTACT_ANGLE) v.void_angle0[(m * nbd + bond) * 2 + end] += q[0];
+        if (end || !h->want_bond_grads) continue;
+        if (v.reference_vector) { v.reference_vector[(m * nbd + bond) * 2] = q[1]; v.reference_vector[(m * nbd + bond) * 2 + 1] = q[2]; }
+        if (v.k_bond) for (int c = 0; c < 3; ++c) v.k_bond[(m * nbd + bond) * 3 + c] = q[3 + c];
+        if (v.contact) for (int c = 0; c < 3; ++c) v.contact[m * 3 + c] += q[6 + c];
+      }
+  }
   if (want->fn_params) {
     v.fn_params = take(B * (size_t)std::max(1, pl.n_fns) * DFX_FN_PARAMS);
     const int W = DFX_MAX_FNS * DFX_FN_PARAMS;
@@ -931,6 +961,16 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   (void)hipMemcpy(h->d_slot_bond.p, pl.slot_bond.data(), sizeof(int32_t) * pl.n_slots, hipMemcpyHostToDevice);
   if (pl.n_special)
     (void)hipMemcpy(h->d_special.p, pl.special.data(), sizeof(dfx_special) * pl.n_special, hipMemcpyHostToDevice);
+  if (pl.n_ovf) {
+    if (h->d_ovf_ptr.ensure(pl.ovf_ptr.size()) != hipSuccess || h->d_ovf_info.ensure(pl.n_ovf) != hipSuccess || h->d_ovf_bond.ensure(pl.n_ovf) != hipSuccess ||
+        h->d_ovf_p.ensure((size_t)pl.batch * pl.n_ovf * kOvfParams) != hipSuccess || h->d_ovf_g.ensure((size_t)pl.batch * pl.n_ovf * kOvfG) != hipSuccess) {
+      h->err = "hipMalloc (extra-ligament tables) failed"; return fail(2);
+    }
+    (void)hipMemcpy(h->d_ovf_ptr.p, pl.ovf_ptr.data(), sizeof(int32_t) * pl.ovf_ptr.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(h->d_ovf_info.p, pl.ovf_info.data(), sizeof(int32_t) * pl.n_ovf, hipMemcpyHostToDevice);
+    (void)hipMemcpy(h->d_ovf_bond.p, pl.ovf_bond.data(), sizeof(int32_t) * pl.n_ovf, hipMemcpyHostToDevice);
+    h->tiling_ok = false;          // the pair launches keep to one ligament per node
+  }
   *out = h;
   return 0;
 }
@@ -940,6 +980,7 @@ int dfx_destroy(dfx_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
+  h->d_ovf_ptr.release(); h->d_ovf_info.release(); h->d_ovf_bond.release(); h->d_ovf_p.release(); h->d_ovf_g.release();
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release(); h->d_touch.release(); h->zero_phi.release();
   h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release(); h->d_resp.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
@@ -996,6 +1037,7 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
     HIP_OK(h->d_p_c.ensure(pp.centroid.size()));
     HIP_OK(hipMemcpyAsync(h->d_p_c.p, pp.centroid.data(), sizeof(double) * pp.centroid.size(), hipMemcpyHostToDevice, h->stream));
   }
+  if (h->pl.n_ovf) HIP_OK(hipMemcpyAsync(h->d_ovf_p.p, pp.ovf.data(), sizeof(double) * pp.ovf.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_fns.ensure(pp.fns.size()));
   HIP_OK(hipMemcpyAsync(h->d_fns.p, pp.fns.data(), sizeof(TimeFn) * pp.fns.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -1590,7 +1632,7 @@ int dfx_response_data(dfx_handle* h, double* strain_energy_stretch, double* stra
   double* d_k = d_b + (bonds ? B * T * nbd : 0);
   DevCtx c = make_ctx(h);
   dim3 grid((unsigned)((pl.n_slots + kThreads - 1) / kThreads), (unsigned)T, (unsigned)B);
-  hipLaunchKernelGGL(k_response, grid, dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_slot_bond.p, (int)nbd,
+  hipLaunchKernelGGL(k_response, grid, dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_slot_bond.p, (const int32_t*)h->d_ovf_bond.p, (int)nbd,
                      bonds ? d_s : (double*)nullptr, bonds ? d_sh : (double*)nullptr, bonds ? d_b : (double*)nullptr,
                      kinetic_energy ? d_k : (double*)nullptr);
   HIP_OK(hipGetLastError());

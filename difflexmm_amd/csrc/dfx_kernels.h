@@ -99,12 +99,18 @@ struct DevCtx {
   const int32_t* slot_info;
   const int32_t* block_special;
   const dfx_special* special;
+  // extra ligaments of nodes that carry more than one (Plan::ovf_*; null / 0 for every lattice the reference generates)
+  const int32_t* ovf_ptr;   // n_slots + 1
+  const int32_t* ovf_info;  // n_ovf: 2 * partner slot + end bit
+  const double* ovf_p;      // batch * n_ovf * kOvfParams
+  double* ovf_g;            // batch * n_ovf * kOvfG: d/d(own void angle | lx ly ks ksh kr am ac kc on end-0 entries)
+  int n_ovf, pad_ovf;
   // per-member parameter images, rows indexed by the lane's own slot / DOF (coalesced)
   const double* p_r;      // n_slots*2   own centroid->node vector
   const double* p_l;      // n_slots*2   reference vector of the slot's ligament
   const double* p_k;      // n_slots*4   stiffnesses (only read when they differ between ligaments)
   const double* p_c;      // n_blocks*2   block centroids (distance-based contact only)
-  const double* p_phi;    // n_slots     undeformed void angle: phi1 on end-0 slots, phi2 on end-1 slots (the other one is gathered from the partner slot)
+  const double* p_phi;    // n_slots*2   the two undeformed void angles (phi1, phi2) of the slot's ligament
   const uint8_t* p_lidx;  // n_slots     index of the slot's reference vector in l_dict (when l_dict_on)
   const double* l_dict;   // 256*4   lx ly |l0| 1/|l0|
   int l_dict_on, damping_uniform;
@@ -394,13 +400,14 @@ __device__ __forceinline__ void stg_s(void* base, u32 byte_off, T v) {
 
 // uniform bases of member m's parameter arrays
 struct MemberBases {
-  const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict, *p_c;
+  const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict, *p_c, *ovf_p;
   const uint8_t* p_lidx;
 };
 __device__ __forceinline__ MemberBases member_bases(const DevCtx& c, int m) {
   MemberBases B;
   const size_t ps = (size_t)m * (u32)c.n_slots;
-  B.p_r = c.p_r + ps * 2; B.p_phi = c.p_phi + ps; B.p_l = c.p_l + ps * 2; B.p_k = c.p_k + ps * 4;
+  B.p_r = c.p_r + ps * 2; B.p_phi = c.p_phi + ps * 2; B.p_l = c.p_l + ps * 2; B.p_k = c.p_k + ps * 4;
+  B.ovf_p = c.ovf_p + (size_t)m * (u32)c.n_ovf * kOvfParams;
   B.cst = c.cst + (size_t)m * 16; B.l_dict = c.l_dict + (size_t)m * 1024; B.p_lidx = c.p_lidx + ps;
   B.p_c = c.p_c + (size_t)m * (u32)c.n_blocks * 2;
   return B;
@@ -499,13 +506,10 @@ __device__ __forceinline__ void resolve_lane(const DevCtx& c, const MemberBases&
     // culling bound of pack_params (cst[9], cst[10]): a ligament whose ends have turned against each other by less than kappa_safe
     // cannot touch whatever its undeformed void angles are -- they are not loaded (32 B/unit and one gather), the member's smallest
     // one stands in and yields exact zeros; the others (rare) fetch theirs now, a second round trip for those lanes only
-    double ph_o = cst[10], ph_p = cst[10];
-    if (info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) {
-      ph_o = ldg<double>(B.p_phi, (u32)R.slot * 8);
-      ph_p = ldg<double>(B.p_phi, (u32)pslot * 8);
-    }
-    L.phi1 = (info & 1) ? ph_p : ph_o;
-    L.phi2 = (info & 1) ? ph_o : ph_p;
+    double2 ph = make_double2(cst[10], cst[10]);
+    if (info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) ph = ldg<double2>(B.p_phi, (u32)R.slot * 16);
+    L.phi1 = ph.x;
+    L.phi2 = ph.y;
   }
   L.rox = R.ro.x; L.roy = R.ro.y; L.rpx = R.P.rp.x; L.rpy = R.P.rp.y;
   L.lx = lv.x; L.ly = lv.y;
@@ -523,6 +527,29 @@ __device__ __forceinline__ void load_lane(const DevCtx& c, int m, int slot, cons
   LaneRaw R;
   issue_lane<CONTACT>(c, B, slot, POSin, R);
   resolve_lane<CONTACT>(c, B, POSin, R, L);
+}
+
+// ---- extra ligaments of a node (general bond lists) ----------------------------------------------------------------------------
+constexpr int kOvfG = 9;
+struct OvfLig {
+  BlockRec<double> p;
+  double rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, phi1, phi2, sgn;
+  int info, pslot;
+};
+__device__ __forceinline__ void load_ovf(const DevCtx& c, const MemberBases& B, int e, const double* POSin, OvfLig& X) {
+  X.info = ldg<int>(c.ovf_info, (u32)e * 4);
+  X.pslot = X.info >> 1;
+  const u32 rec = (u32)(X.pslot >> 2) * (kPos * 8);
+  const double2 b0 = ldg<double2>(POSin, rec), b1 = ldg<double2>(POSin, rec + 16);
+  const double2 rp = ldg<double2>(B.p_r, (u32)X.pslot * 16);
+  const u32 o = (u32)e * (kOvfParams * 8);
+  const double2 lv = ldg<double2>(B.ovf_p, o), k01 = ldg<double2>(B.ovf_p, o + 16), k2p = ldg<double2>(B.ovf_p, o + 32);
+  X.phi2 = ldg<double>(B.ovf_p, o + 48);
+  X.p.x = b0.x; X.p.y = b0.y; X.p.th = b1.x; X.p.sh = b1.y; X.p.ch = half_cos(b1.x, b1.y);
+  X.rpx = rp.x; X.rpy = rp.y; X.lx = lv.x; X.ly = lv.y;
+  X.l0 = sqrt(lv.x * lv.x + lv.y * lv.y); X.il0 = 1.0 / X.l0;
+  X.ks = k01.x; X.ksh = k01.y; X.kr = k2p.x; X.phi1 = k2p.y;
+  X.sgn = (X.info & 1) ? 1.0 : -1.0;
 }
 
 // ---- distance-based contact (CONTACT == 2; energy.py:222-330): what a lane needs beyond LaneIn ---------------------------------
@@ -563,7 +590,10 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   reduction, not the distance-based contact, whose node rotations are quad moves)
 //   TAB: the time functions come from the segment's table (k_fn_table) -- a build of its own, so that neither build carries the
 //   other's path: with both in one kernel the main path paid 26 scalar-register spills (v_readlane / v_writelane) per wave
-template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0>
+//   OVF: the build that also walks the extra ligaments of nodes with more than one (general bond lists) -- a build of its own: the
+//   second inlined copy of the ligament arithmetic costs the main path its registers (forward 96 VGPRs + 240 B scratch, reverse 225
+//   VGPRs when it sat in the common build), and no lattice the reference generates needs it
+template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0>
 __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
@@ -640,6 +670,21 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       DistContactGrad<double> dg;
       distance_contact_grad<double, double>(L.o, L.p, D.cox, D.coy, D.cpx, D.cpy, D.ro, D.rp, L.info & 1, L.am, L.ac, L.kc, dg);
       fx += dg.fx; fy += dg.fy; fth += dg.fth;
+    }
+  }
+  if (OVF) {              // nodes with more than one ligament: the others, one after the other
+    const int e1 = ldg<int>(c.ovf_ptr, (u32)slot * 4 + 4);
+    for (int e = ldg<int>(c.ovf_ptr, (u32)slot * 4); e < e1; ++e) {
+      OvfLig X;
+      load_ovf(c, B, e, POSin, X);
+      BondGrad<double> g;
+      bond_grad<MODEL, double>(L.o, X.p, L.rox, L.roy, X.rpx, X.rpy, X.lx, X.ly, X.l0, X.il0, X.ks, X.ksh, X.kr, X.sgn, g);
+      fx += g.fx; fy += g.fy; fth += g.fth;
+      if (CONTACT == 1) {
+        ContactGrad<double> cg;
+        contact_grad<double>(X.sgn * (L.o.th - X.p.th), X.phi1, X.phi2, L.am, L.ac, L.kc, cg);
+        fth += X.sgn * cg.dkap;
+      }
     }
   }
   const double dE = blk_reduce3<NPB>(fx, fy, fth, k);
@@ -874,6 +919,23 @@ __global__ __launch_bounds__(kThreads) void k_energy(DevCtx c, double* e_slot) {
       e += dg.e;
     }
   }
+  if (c.ovf_ptr) {
+    const MemberBases B = member_bases(c, m);
+    const int e1 = c.ovf_ptr[slot + 1];
+    for (int x = c.ovf_ptr[slot]; x < e1; ++x) {
+      OvfLig X;
+      load_ovf(c, B, x, pos_in(c, m, 0, 0), X);
+      if (X.info & 1) continue;                       // every ligament once: on its end-0 side
+      BondGrad<double> g;
+      bond_grad<MODEL, double>(L.o, X.p, L.rox, L.roy, X.rpx, X.rpy, X.lx, X.ly, X.l0, X.il0, X.ks, X.ksh, X.kr, X.sgn, g);
+      e += g.e;
+      if (CONTACT == 1) {
+        ContactGrad<double> cg;
+        contact_grad<double>(X.sgn * (L.o.th - X.p.th), X.phi1, X.phi2, L.am, L.ac, L.kc, cg);
+        e += cg.e;
+      }
+    }
+  }
   e_slot[(size_t)m * c.n_slots + slot] = e;
 }
 
@@ -928,7 +990,7 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
@@ -1070,6 +1132,35 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
       *gc -= k == 0 ? d_cx : d_cy;
     }
   }
+  if (OVF) {              // the node's other ligaments (general bond lists; a build of its own, see k_fwd_stage): same dual evaluation
+    const int e1 = ldg<int>(c.ovf_ptr, (u32)slot * 4 + 4);
+    for (int e = ldg<int>(c.ovf_ptr, (u32)slot * 4); e < e1; ++e) {
+      OvfLig X;
+      load_ovf(c, B, e, POSin, X);
+      const u32 pb = (u32)(X.pslot >> 2) * 24;
+      const double xwx = ldg<double>(Win, pb), xwy = ldg<double>(Win, pb + 8), xwth = ldg<double>(Win, pb + 16);
+      BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
+      BlockRec<Dual> p = seed_rec(X.p, xwx, xwy, xwth);
+      BondGrad<Dual> g;
+      bond_grad<MODEL, Dual>(o, p, L.rox, L.roy, X.rpx, X.rpy, X.lx, X.ly, X.l0, X.il0, X.ks, X.ksh, X.kr, X.sgn, g);
+      hx += g.fx.e; hy += g.fy.e; hth += g.fth.e;
+      ex += g.fx.v; ey += g.fy.v; eth += g.fth.v;
+      d_rx += g.rx.e; d_ry += g.ry.e;
+      double* q = c.ovf_g + ((size_t)m * (u32)c.n_ovf + e) * kOvfG;
+      ContactGrad<Dual> cg;
+      if (CONTACT == 1) {
+        contact_grad<Dual>(X.sgn * (o.th - p.th), X.phi1, X.phi2, L.am, L.ac, L.kc, cg);
+        hth += X.sgn * cg.dkap.e;
+        eth += X.sgn * cg.dkap.v;
+        const double dp = (X.info & 1) ? cg.p2.e : cg.p1.e;
+        if (dp != 0.0) { q[0] -= dp; c.touch[0] = 1; }
+      }
+      if (BOND_GRADS && !(X.info & 1)) {
+        q[1] -= g.lx.e; q[2] -= g.ly.e; q[3] -= g.ks.e; q[4] -= g.ksh.e; q[5] -= g.kr.e;
+        if (CONTACT == 1) { q[6] -= cg.am.e; q[7] -= cg.ac.e; q[8] -= cg.kc.e; }
+      }
+    }
+  }
   // ---- gradient accumulators.  Every address has exactly one writer per launch: plain load-add-store, with the old values of
   // ALL accumulators requested in one batch (issued here, consumed after the epilogue arithmetic) instead of one memory round
   // trip each at the end of the kernel.  (Fire-and-forget L2 atomics would spare the loads but were measured 10-25 % slower:
@@ -1162,10 +1253,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   }
 }
 
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
-  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
+  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 // The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry
 // point, so that its occupancy can be pinned (DFX_ADJ_RB_OCC) without touching the others.
@@ -1252,7 +1343,7 @@ __global__ __launch_bounds__(kThreads) void k_pack_grads(DevCtx c, const int32_t
 // Per-ligament strain energies (stretch / shear / bending: energy.py:522-534 strains, then 1/2 k (strain l0)^2) and per-block
 // kinetic energy of EVERY output time: one launch, grid = (slots, T, members); the end-0 lane of a ligament writes its three
 // entries, lanes 0 of a quad the block's kinetic energy.  Reads the (T, 2, n, 3) fields and the resident parameter images.
-__global__ __launch_bounds__(kThreads) void k_response(DevCtx c, const double* fields, const int32_t* slot_bond, int n_bonds,
+__global__ __launch_bounds__(kThreads) void k_response(DevCtx c, const double* fields, const int32_t* slot_bond, const int32_t* ovf_bond, int n_bonds,
                                                        double* e_stretch, double* e_shear, double* e_bend, double* e_kin) {
   const int m = blockIdx.z, kt = blockIdx.y;
   const int slot = blockIdx.x * kThreads + threadIdx.x;
@@ -1265,32 +1356,42 @@ __global__ __launch_bounds__(kThreads) void k_response(DevCtx c, const double* f
     const double* v = f + nd + (size_t)b * 3;
     e_kin[((size_t)m * c.n_timepoints + kt) * c.n_blocks + b] = 0.5 * (v[0] * v[0] / im[0] + v[1] * v[1] / im[1] + v[2] * v[2] / im[2]);
   }
-  const int info = c.slot_info[slot];
-  if (info < 0 || (info & 1) || !(e_stretch || e_shear || e_bend)) return;       // one lane per ligament: its end-0 slot
-  const int ps = info >> 1, pb = ps >> 2;
+  if (!(e_stretch || e_shear || e_bend)) return;
   const MemberBases B = member_bases(c, m);
-  BlockRec<double> o, p;
-  o.x = f[(size_t)b * 3]; o.y = f[(size_t)b * 3 + 1]; o.th = f[(size_t)b * 3 + 2];
-  p.x = f[(size_t)pb * 3]; p.y = f[(size_t)pb * 3 + 1]; p.th = f[(size_t)pb * 3 + 2];
-  fast_sincos(0.5 * o.th, &o.sh, &o.ch);
-  fast_sincos(0.5 * p.th, &p.sh, &p.ch);
-  const double2 ro = ldg<double2>(B.p_r, (u32)slot * 16), rp = ldg<double2>(B.p_r, (u32)ps * 16);
-  double lx, ly, l0, il0;
-  if (c.l_dict_on) {
-    const int li = B.p_lidx[slot];
-    lx = B.l_dict[li * 4]; ly = B.l_dict[li * 4 + 1]; l0 = B.l_dict[li * 4 + 2]; il0 = B.l_dict[li * 4 + 3];
-  } else {
-    lx = B.p_l[(size_t)slot * 2]; ly = B.p_l[(size_t)slot * 2 + 1]; l0 = sqrt(lx * lx + ly * ly); il0 = 1.0 / l0;
+  // one lane per ligament: the lane of its end-0 node -- that node's first ligament, then its extra ones (general bond lists)
+  const int n_extra = c.ovf_ptr ? c.ovf_ptr[slot + 1] - c.ovf_ptr[slot] : 0;
+  for (int which = 0; which <= n_extra; ++which) {
+    const int x = which ? c.ovf_ptr[slot] + which - 1 : -1;
+    const int info = which ? c.ovf_info[x] : c.slot_info[slot];
+    if (info < 0 || (info & 1)) continue;
+    const int ps = info >> 1, pb = ps >> 2;
+    BlockRec<double> o, p;
+    o.x = f[(size_t)b * 3]; o.y = f[(size_t)b * 3 + 1]; o.th = f[(size_t)b * 3 + 2];
+    p.x = f[(size_t)pb * 3]; p.y = f[(size_t)pb * 3 + 1]; p.th = f[(size_t)pb * 3 + 2];
+    fast_sincos(0.5 * o.th, &o.sh, &o.ch);
+    fast_sincos(0.5 * p.th, &p.sh, &p.ch);
+    const double2 ro = ldg<double2>(B.p_r, (u32)slot * 16), rp = ldg<double2>(B.p_r, (u32)ps * 16);
+    double lx, ly, l0, il0, ks, ksh, kr;
+    if (which) {
+      const double* op = B.ovf_p + (size_t)x * kOvfParams;
+      lx = op[0]; ly = op[1]; l0 = sqrt(lx * lx + ly * ly); il0 = 1.0 / l0; ks = op[2]; ksh = op[3]; kr = op[4];
+    } else {
+      if (c.l_dict_on) {
+        const int li = B.p_lidx[slot];
+        lx = B.l_dict[li * 4]; ly = B.l_dict[li * 4 + 1]; l0 = B.l_dict[li * 4 + 2]; il0 = B.l_dict[li * 4 + 3];
+      } else {
+        lx = B.p_l[(size_t)slot * 2]; ly = B.p_l[(size_t)slot * 2 + 1]; l0 = sqrt(lx * lx + ly * ly); il0 = 1.0 / l0;
+      }
+      if (c.k_uniform) { ks = B.cst[3]; ksh = B.cst[4]; kr = B.cst[5]; }
+      else { ks = B.p_k[(size_t)slot * 4]; ksh = B.p_k[(size_t)slot * 4 + 1]; kr = B.p_k[(size_t)slot * 4 + 2]; }
+    }
+    BondGrad<double> g;
+    bond_grad<kNonlinear, double>(o, p, ro.x, ro.y, rp.x, rp.y, lx, ly, l0, il0, ks, ksh, kr, -1.0, g);   // g.ks = (eps l0)^2 / 2, ...
+    const size_t oi = ((size_t)m * c.n_timepoints + kt) * n_bonds + (which ? ovf_bond[x] : slot_bond[slot]);
+    if (e_stretch) e_stretch[oi] = ks * g.ks;
+    if (e_shear) e_shear[oi] = ksh * g.ksh;
+    if (e_bend) e_bend[oi] = kr * g.kr;
   }
-  double ks, ksh, kr;
-  if (c.k_uniform) { ks = B.cst[3]; ksh = B.cst[4]; kr = B.cst[5]; }
-  else { ks = B.p_k[(size_t)slot * 4]; ksh = B.p_k[(size_t)slot * 4 + 1]; kr = B.p_k[(size_t)slot * 4 + 2]; }
-  BondGrad<double> g;
-  bond_grad<kNonlinear, double>(o, p, ro.x, ro.y, rp.x, rp.y, lx, ly, l0, il0, ks, ksh, kr, -1.0, g);   // g.ks = (eps l0)^2 / 2, ...
-  const size_t oi = ((size_t)m * c.n_timepoints + kt) * n_bonds + slot_bond[slot];
-  if (e_stretch) e_stretch[oi] = ks * g.ks;
-  if (e_shear) e_shear[oi] = ksh * g.ksh;
-  if (e_bend) e_bend[oi] = kr * g.kr;
 }
 
 // kinetic-energy objective: G <- m v on target blocks; per-member objective by one workgroup

@@ -197,13 +197,10 @@ __global__ __launch_bounds__(64 * WROWS) DFX_PAIR_OCC void k_fwd_pair(DevCtx c, 
     L.p.ch = half_cos(L.p.th, L.p.sh);
     if (CONTACT == 1) {
       const double* cst = B.cst;
-      double ph_o = cst[10], ph_p = cst[10];
-      if (L.info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) {
-        ph_o = ldg<double>(B.p_phi, (u32)slot * 8);
-        ph_p = ldg<double>(B.p_phi, (u32)L.pslot * 8);
-      }
-      L.phi1 = (L.info & 1) ? ph_p : ph_o;
-      L.phi2 = (L.info & 1) ? ph_o : ph_p;
+      double2 ph = make_double2(cst[10], cst[10]);
+      if (L.info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) ph = ldg<double2>(B.p_phi, (u32)slot * 16);
+      L.phi1 = ph.x;
+      L.phi2 = ph.y;
     }
     double fx = 0.0, fy = 0.0, fth = 0.0;
     if (L.info >= 0) {
@@ -432,13 +429,10 @@ __global__ __launch_bounds__(64 * WROWS) DFX_PAIR_OCC void k_adj_pair(DevCtx c, 
     L.p.ch = half_cos(L.p.th, L.p.sh);
     if (CONTACT == 1) {
       const double* cst = B.cst;
-      double ph_o = cst[10], ph_p = cst[10];
-      if (L.info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) {
-        ph_o = ldg<double>(B.p_phi, (u32)slot * 8);
-        ph_p = ldg<double>(B.p_phi, (u32)L.pslot * 8);
-      }
-      L.phi1 = (L.info & 1) ? ph_p : ph_o;
-      L.phi2 = (L.info & 1) ? ph_o : ph_p;
+      double2 ph = make_double2(cst[10], cst[10]);
+      if (L.info >= 0 && !(fabs(L.o.th - L.p.th) <= cst[9])) ph = ldg<double2>(B.p_phi, (u32)slot * 16);
+      L.phi1 = ph.x;
+      L.phi2 = ph.y;
     }
     double hx = 0.0, hy = 0.0, hth = 0.0, ex = 0.0, ey = 0.0, eth = 0.0;
     if (L.info >= 0) {

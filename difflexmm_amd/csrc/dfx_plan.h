@@ -38,7 +38,16 @@ struct Plan {
                                        // while slot_info is still in flight (regular lattices: right everywhere but the rim)
   std::vector<int32_t> block_special;  // n_blocks, index into special or -1
   std::vector<dfx_special> special;
+  // Nodes that carry MORE than one ligament (jax_md.smap.bond takes any bond list, energy.py:179-197; none of the reference's
+  // lattices has such nodes): the first ligament of a node lives in slot_info as always, the others in per-slot lists in CSR form.
+  // A lane loops over its node's extra ligaments after the first one; lattices without them never enter the loop.
+  int n_ovf = 0;
+  std::vector<int32_t> ovf_ptr;        // n_slots + 1 offsets into ovf_info (empty when n_ovf == 0)
+  std::vector<int32_t> ovf_info;       // 2 * partner_slot + own_is_end2
+  std::vector<int32_t> ovf_bond;       // bond id
 };
+constexpr int kOvfParams = 8;          // lx ly k_stretch k_shear k_rot phi1 phi2 pad   (per extra ligament end)
+constexpr int kOvfGrads = 12;          // CPU layout of a slot's bond part: - - l0(2) k(3) phi(2) contact(3)
 
 inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
   if (!p || p->n_blocks <= 0 || (p->n_npb != 3 && p->n_npb != 4)) { err = "invalid problem: n_blocks/n_npb"; return 1; }
@@ -66,17 +75,30 @@ inline int build_plan(const dfx_problem* p, Plan& pl, std::string& err) {
   pl.slot_info.assign(pl.n_slots, -1);
   pl.slot_bond.assign(pl.n_slots, -1);
   const int n_nodes = p->n_blocks * p->n_npb;
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> extra;     // per slot: (info, bond) of the ligaments after the first
   for (int b = 0; b < p->n_bonds; ++b) {
     int n1 = p->bonds[2 * b], n2 = p->bonds[2 * b + 1];
     if (n1 < 0 || n2 < 0 || n1 >= n_nodes || n2 >= n_nodes || n1 == n2) { err = "bond with invalid node id"; return 1; }
     int s1 = (n1 / p->n_npb) * kSlots + n1 % p->n_npb;
     int s2 = (n2 / p->n_npb) * kSlots + n2 % p->n_npb;
     if (n1 / p->n_npb == n2 / p->n_npb) { err = "bond joins two nodes of one block"; return 1; }
-    if (pl.slot_info[s1] != -1 || pl.slot_info[s2] != -1) { err = "node with more than one ligament (unsupported)"; return 1; }
-    pl.slot_info[s1] = 2 * s2 + 0;
-    pl.slot_info[s2] = 2 * s1 + 1;
-    pl.slot_bond[s1] = b;
-    pl.slot_bond[s2] = b;
+    const int ends[2][2] = {{s1, 2 * s2 + 0}, {s2, 2 * s1 + 1}};
+    for (auto& e : ends) {
+      if (pl.slot_info[e[0]] == -1) { pl.slot_info[e[0]] = e[1]; pl.slot_bond[e[0]] = b; continue; }
+      if (p->contact == DFX_CONTACT_DISTANCE) { err = "node with more than one ligament: not supported with the distance-based contact"; return 1; }
+      if (extra.empty()) extra.resize(pl.n_slots);
+      extra[e[0]].push_back({e[1], b});
+    }
+  }
+  pl.n_ovf = 0; pl.ovf_ptr.clear(); pl.ovf_info.clear(); pl.ovf_bond.clear();
+  if (!extra.empty()) {
+    pl.ovf_ptr.assign(pl.n_slots + 1, 0);
+    for (int s = 0; s < pl.n_slots; ++s) {
+      pl.ovf_ptr[s] = (int32_t)pl.ovf_info.size();
+      for (auto& e : extra[s]) { pl.ovf_info.push_back(e.first); pl.ovf_bond.push_back(e.second); }
+    }
+    pl.ovf_ptr[pl.n_slots] = (int32_t)pl.ovf_info.size();
+    pl.n_ovf = (int)pl.ovf_info.size();
   }
   for (int k = 0; k < kSlots; ++k) {
     std::map<int, int> votes;
@@ -109,7 +131,8 @@ struct PackedParams {
   std::vector<double> p_r;      // batch * n_slots * 2 : own node vector
   std::vector<double> p_l;      // batch * n_slots * 2 : reference vector (oriented node1 -> node2)
   std::vector<double> p_k;      // batch * n_slots * 4 : k_stretch, k_shear, k_rot, 0
-  std::vector<double> p_phi;    // batch * n_slots : undeformed void angle, phi1 on the end-0 slot of a ligament, phi2 on its end-1 slot
+  std::vector<double> p_phi;    // batch * n_slots * 2 : the two undeformed void angles (phi1, phi2) of the slot's first ligament
+  std::vector<double> ovf;      // batch * n_ovf * kOvfParams : parameters of the extra ligaments (CPU port and GPU image alike)
   std::vector<double> cst;      // batch * 16 (first 9 used) : min_angle, cutoff_angle, k_contact, k_stretch, k_shear, k_rot (if uniform), 0, 0
   bool k_uniform = true;        // every ligament of a member has the same three stiffnesses
   // dictionary compression of per-slot constants that take few distinct values (lattices have 2-3 reference vectors):
@@ -153,6 +176,17 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
           if (ph) { s[7] = ph[2 * bond]; s[8] = ph[2 * bond + 1]; }
         }
       }
+    if (pl.n_ovf) {
+      if (m == 0) out.ovf.assign((size_t)B * pl.n_ovf * kOvfParams, 0.0);
+      for (int e = 0; e < pl.n_ovf; ++e) {
+        double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
+        const int bond = pl.ovf_bond[e];
+        o[0] = l0[2 * bond]; o[1] = l0[2 * bond + 1];
+        if (!(o[0] * o[0] + o[1] * o[1] > 0.0)) { err = "set_params: zero-length reference vector"; return 1; }
+        o[2] = kb[3 * bond]; o[3] = kb[3 * bond + 1]; o[4] = kb[3 * bond + 2];
+        if (ph) { o[5] = ph[2 * bond]; o[6] = ph[2 * bond + 1]; }
+      }
+    }
     for (int i = 0; i < NB * 3; ++i) {
       double mass = q->inertia[(size_t)m * NB * 3 + i];
       if (!(mass > 0.0)) { err = "set_params: inertia must be positive"; return 1; }
@@ -171,7 +205,7 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     if (!gpu_image) continue;
     if (m == 0) {
       out.p_r.assign((size_t)B * NS * 2, 0.0); out.p_l.assign((size_t)B * NS * 2, 0.0);
-      out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS, 0.0);
+      out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
       out.cst.assign((size_t)B * 16, 0.0);
       out.k_uniform = true;
       out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 1024, 0.0);
@@ -182,16 +216,20 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       double* r = out.p_r.data() + ((size_t)m * NS + s_) * 2;
       double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
       double* k = out.p_k.data() + ((size_t)m * NS + s_) * 4;
-      double* ph = out.p_phi.data() + ((size_t)m * NS + s_);
+      double* ph = out.p_phi.data() + ((size_t)m * NS + s_) * 2;
       r[0] = s[0]; r[1] = s[1];
       int info = pl.slot_info[s_];
       if (info >= 0) {
         if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { err = "set_params: zero-length reference vector"; return 1; }
         l[0] = s[2]; l[1] = s[3];
         k[0] = s[4]; k[1] = s[5]; k[2] = s[6];
-        ph[0] = (info & 1) ? s[8] : s[7];
+        ph[0] = s[7]; ph[1] = s[8];
         if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) out.k_uniform = false;
       }
+    }
+    for (int e = 0; e < pl.n_ovf; ++e) {
+      const double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
+      if (o[2] != kb[0] || o[3] != kb[1] || o[4] != kb[2]) out.k_uniform = false;
     }
     if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + i] = q->contact[m * 3 + i];
     if (q->contact && pl.contact == 1) {
@@ -200,7 +238,8 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       // derivatives are exactly zero whatever phi is, so the kernels do not load phi for such ligaments (cst[9] = kappa_safe with a
       // rounding margin, <= 0: never skip; cst[10] = phi_lo, the stand-in value).
       double lo = 1e300, hi = -1e300;
-      for (int s_ = 0; s_ < NS; ++s_) if (pl.slot_info[s_] >= 0) { const double v = out.p_phi[(size_t)m * NS + s_]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+      for (int s_ = 0; s_ < NS; ++s_) if (pl.slot_info[s_] >= 0)
+        for (int a = 0; a < 2; ++a) { const double v = out.p_phi[((size_t)m * NS + s_) * 2 + a]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
       double safe = -1.0;
       if (lo <= hi) { const double a = lo - q->contact[m * 3 + 1], b2 = 3.14159265358979323846 - hi; safe = (a < b2 ? a : b2) * (1.0 - 1e-12) - 1e-12; }
       out.cst[(size_t)m * 16 + 9] = safe;
@@ -242,7 +281,7 @@ constexpr int kSlotGrads = 12;
 
 inline void unpack_grads(const Plan& pl, const std::vector<double>& slot_g, const std::vector<double>& blk_g,
                          const std::vector<double>& fn_g /* batch * max(1,n_special) * MAX_FNS*FN_PARAMS */,
-                         const std::vector<double>& inv_m, dfx_grads* g) {
+                         const std::vector<double>& inv_m, dfx_grads* g, const std::vector<double>* ovf_g = nullptr /* batch * n_ovf * kOvfGrads */) {
   const int B = pl.batch, NS = pl.n_slots, NB = pl.n_blocks;
   for (int m = 0; m < B; ++m) {
     const double* sg = slot_g.data() + (size_t)m * NS * kSlotGrads;
@@ -264,6 +303,15 @@ inline void unpack_grads(const Plan& pl, const std::vector<double>& slot_g, cons
       if (g->reference_vector) { g->reference_vector[((size_t)m * pl.n_bonds + bond) * 2] = q[2]; g->reference_vector[((size_t)m * pl.n_bonds + bond) * 2 + 1] = q[3]; }
       if (g->k_bond) for (int c = 0; c < 3; ++c) g->k_bond[((size_t)m * pl.n_bonds + bond) * 3 + c] = q[4 + c];
       if (g->void_angle0) { g->void_angle0[((size_t)m * pl.n_bonds + bond) * 2] = q[7]; g->void_angle0[((size_t)m * pl.n_bonds + bond) * 2 + 1] = q[8]; }
+      for (int c = 0; c < 3; ++c) con[c] += q[9 + c];
+    }
+    for (int e = 0; e < pl.n_ovf && ovf_g; ++e) {          // extra ligaments: like the slots, everything of a bond on its end-0 entry
+      const int bond = pl.ovf_bond[e], end = pl.ovf_info[e] & 1;
+      const double* q = ovf_g->data() + ((size_t)m * pl.n_ovf + e) * kOvfGrads;
+      if (end) continue;
+      if (g->void_angle0) { g->void_angle0[((size_t)m * pl.n_bonds + bond) * 2] = q[7]; g->void_angle0[((size_t)m * pl.n_bonds + bond) * 2 + 1] = q[8]; }
+      if (g->reference_vector) { g->reference_vector[((size_t)m * pl.n_bonds + bond) * 2] = q[2]; g->reference_vector[((size_t)m * pl.n_bonds + bond) * 2 + 1] = q[3]; }
+      if (g->k_bond) for (int c = 0; c < 3; ++c) g->k_bond[((size_t)m * pl.n_bonds + bond) * 3 + c] = q[4 + c];
       for (int c = 0; c < 3; ++c) con[c] += q[9 + c];
     }
     if (g->contact) for (int c = 0; c < 3; ++c) g->contact[m * 3 + c] = con[c];

@@ -34,7 +34,25 @@ struct Tables {
   const double* contact_p; // 3
   const double* centroid;  // n_blocks * 2 (distance-based contact)
   const TimeFn* fns;       // DFX_MAX_FNS
+  // extra ligaments of nodes that carry more than one (Plan::ovf_*), or null
+  const int32_t* ovf_ptr = nullptr;
+  const int32_t* ovf_info = nullptr;
+  const double* ovf_p = nullptr;     // n_ovf * kOvfParams
 };
+
+// Ligament number `which` of a slot: 0 = the slot's first one (slot_info / slot_p), 1.. = its extra ones.  Returns false past the end.
+struct LigRef { int info; const double* bp; /* l0(2) k(3) phi(2) */ int ovf; /* entry in the overflow list or -1 */ };
+DFX_HD bool slot_ligament(const Tables& tb, int slot, int which, LigRef& r) {
+  if (which == 0) {
+    r.info = tb.slot_info[slot]; r.bp = tb.slot_p + (size_t)slot * 9 + 2; r.ovf = -1;
+    return r.info >= 0;
+  }
+  if (!tb.ovf_ptr) return false;
+  const int e = tb.ovf_ptr[slot] + which - 1;
+  if (e >= tb.ovf_ptr[slot + 1]) return false;
+  r.info = tb.ovf_info[e]; r.bp = tb.ovf_p + (size_t)e * 8; r.ovf = e;
+  return true;
+}
 
 DFX_HD BlockRec<double> load_rec(const double* S, int b) {
   const double* r = S + (size_t)b * kRec;
@@ -58,17 +76,19 @@ template <int MODEL, int CONTACT>
 DFX_HD void fwd_slot(const Tables& tb, const double* S_in, int slot, double& fx, double& fy, double& fth, double* energy) {
   fx = 0.0; fy = 0.0; fth = 0.0;
   if (energy) *energy = 0.0;
-  int info = tb.slot_info[slot];
-  if (info < 0) return;
+  LigRef lr;
+  for (int which = 0; slot_ligament(tb, slot, which, lr); ++which) {
+  const int info = lr.info;
   int ps = info >> 1;
   double sgn = (info & 1) ? 1.0 : -1.0;
   const double* sp = tb.slot_p + (size_t)slot * kSlotParams;
   const double* pp = tb.slot_p + (size_t)ps * kSlotParams;
+  const double* bp = lr.bp;        // l0(2) k(3) phi(2) of THIS ligament
   BlockRec<double> o = load_rec(S_in, slot >> 2), p = load_rec(S_in, ps >> 2);
   BondGrad<double> g;
-  const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
-  bond_grad<MODEL, double>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], sgn, g);
-  fx = g.fx; fy = g.fy; fth = g.fth;
+  const double l0 = sqrt(bp[0] * bp[0] + bp[1] * bp[1]);
+  bond_grad<MODEL, double>(o, p, sp[0], sp[1], pp[0], pp[1], bp[0], bp[1], l0, 1.0 / l0, bp[2], bp[3], bp[4], sgn, g);
+  fx += g.fx; fy += g.fy; fth += g.fth;
   double e = g.e;
   if (CONTACT == 2) {
     double ro[3][2], rp[3][2];
@@ -82,11 +102,12 @@ DFX_HD void fwd_slot(const Tables& tb, const double* S_in, int slot, double& fx,
   } else if (CONTACT) {
     ContactGrad<double> c;
     double kap = sgn * (o.th - p.th);
-    contact_grad<double>(kap, sp[7], sp[8], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
+    contact_grad<double>(kap, bp[5], bp[6], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
     fth += sgn * c.dkap;
     e += c.e;
   }
-  if (energy && !(info & 1)) *energy = e;  // every ligament is counted once, on its end-1 slot
+  if (energy && !(info & 1)) *energy += e;  // every ligament is counted once, on its end-0 side
+  }
 }
 
 struct FwdStage {
@@ -183,6 +204,7 @@ struct GradAcc {
   double* blk_g;   // n_blocks * 6        (or null)
   double* fn_g;    // n_special * DFX_MAX_FNS * DFX_FN_PARAMS (or null)
   double* cen_g;   // n_blocks * 2: d/d(block_centroids) (distance-based contact; or null)
+  double* ovf_g = nullptr;   // n_ovf * kOvfGrads: the bond part of the extra ligaments (same layout as a slot's entries 2..11), or null
 };
 
 // Own-side Hessian-vector product of slot `slot` for direction W (n_blocks*3) at records S.
@@ -190,20 +212,22 @@ template <int MODEL, int CONTACT>
 DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slot, const GradAcc& acc,
                      double& hx, double& hy, double& hth) {
   hx = 0.0; hy = 0.0; hth = 0.0;
-  int info = tb.slot_info[slot];
-  if (info < 0) return;
+  LigRef lr;
+  for (int which = 0; slot_ligament(tb, slot, which, lr); ++which) {
+  const int info = lr.info;
   int ps = info >> 1;
   double sgn = (info & 1) ? 1.0 : -1.0;
   int bo = slot >> 2, bp = ps >> 2;
   const double* sp = tb.slot_p + (size_t)slot * kSlotParams;
   const double* pp = tb.slot_p + (size_t)ps * kSlotParams;
+  const double* lp = lr.bp;        // l0(2) k(3) phi(2) of THIS ligament
   BlockRec<double> ro = load_rec(S, bo), rp = load_rec(S, bp);
   BlockRec<Dual> o = seed_rec(ro, W[bo * 3], W[bo * 3 + 1], W[bo * 3 + 2]);
   BlockRec<Dual> p = seed_rec(rp, W[bp * 3], W[bp * 3 + 1], W[bp * 3 + 2]);
   BondGrad<Dual> g;
-  const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
-  bond_grad<MODEL, Dual>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], sgn, g);
-  hx = g.fx.e; hy = g.fy.e; hth = g.fth.e;
+  const double l0 = sqrt(lp[0] * lp[0] + lp[1] * lp[1]);
+  bond_grad<MODEL, Dual>(o, p, sp[0], sp[1], pp[0], pp[1], lp[0], lp[1], l0, 1.0 / l0, lp[2], lp[3], lp[4], sgn, g);
+  hx += g.fx.e; hy += g.fy.e; hth += g.fth.e;
   ContactGrad<Dual> c;
   DistContactGrad<Dual> dc;
   if (CONTACT == 2) {
@@ -227,7 +251,7 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
     if (acc.cen_g) { acc.cen_g[bo * 2] -= dc.cx.e; acc.cen_g[bo * 2 + 1] -= dc.cy.e; }
   } else if (CONTACT) {
     Dual kap = sgn * (o.th - p.th);
-    contact_grad<Dual>(kap, sp[7], sp[8], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
+    contact_grad<Dual>(kap, lp[5], lp[6], tb.contact_p[0], tb.contact_p[1], tb.contact_p[2], c);
     hth += sgn * c.dkap.e;
   }
   if (acc.slot_g) {
@@ -235,6 +259,7 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
     double* q = acc.slot_g + (size_t)slot * kSlotGrads;
     q[0] -= g.rx.e;
     q[1] -= g.ry.e;
+    if (lr.ovf >= 0) q = acc.ovf_g + (size_t)lr.ovf * kOvfGrads;      // the bond part of an extra ligament has its own entry
     if (!(info & 1)) {
       q[2] -= g.lx.e; q[3] -= g.ly.e;
       q[4] -= g.ks.e; q[5] -= g.ksh.e; q[6] -= g.kr.e;
@@ -243,6 +268,7 @@ DFX_HD void adj_slot(const Tables& tb, const double* S, const double* W, int slo
         q[9] -= c.am.e; q[10] -= c.ac.e; q[11] -= c.kc.e;
       }
     }
+  }
   }
 }
 

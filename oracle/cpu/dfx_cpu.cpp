@@ -56,6 +56,10 @@ static Tables member_tables(const dfx_handle* h, int m) {
   tb.damping = h->pp.damping.data() + (size_t)m * pl.n_blocks * 3;
   tb.contact_p = h->pp.contact.data() + (size_t)m * 3;
   tb.fns = h->pp.fns.data() + (size_t)m * DFX_MAX_FNS;
+  if (pl.n_ovf) {
+    tb.ovf_ptr = pl.ovf_ptr.data(); tb.ovf_info = pl.ovf_info.data();
+    tb.ovf_p = h->pp.ovf.data() + (size_t)m * pl.n_ovf * kOvfParams;
+  }
   return tb;
 }
 
@@ -378,13 +382,15 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
   auto t_begin = std::chrono::steady_clock::now();
   const int nsp = pl.n_special > 0 ? pl.n_special : 1;
   std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
-      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0);
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0),
+      ovf_g((size_t)B * pl.n_ovf * kOvfGrads + 1, 0.0);
   std::vector<double> Sst((size_t)T.s * rec), A((size_t)T.s * nb * 3), YB((size_t)T.s * nb * 6), LAM((size_t)nb * 6),
       W(2 * (size_t)nb * 3), KQ(2 * (size_t)nb * 3);
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
     GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
-                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2};
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2,
+                ovf_g.data() + (size_t)m * pl.n_ovf * kOvfGrads};
     const double* tr = h->traj.data() + (size_t)m * (N + 1) * rec;
     const double* G = Gall.data() + (size_t)m * Tn * nb * 6;
     int cur = 0;
@@ -436,7 +442,7 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
           grads->state0[(size_t)m * nb * 6 + nb * 3 + b * 3 + d] = LAM[b * 6 + 3 + d];
         }
   }
-  if (grads) unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, grads);
+  if (grads) unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, grads, &ovf_g);
   if (grads && grads->block_centroids) memcpy(grads->block_centroids, cen_g.data(), sizeof(double) * cen_g.size());
   if (stats) {
     memset(stats, 0, sizeof(*stats));
@@ -555,21 +561,25 @@ int dfx_response_data(dfx_handle* h, double* e_stretch, double* e_shear, double*
           e_kin[((size_t)m * Tn + k) * nb + b] = acc;
         }
       for (int s = 0; s < pl.n_slots; ++s) {
-        const int info = pl.slot_info[s];
-        if (info < 0 || (info & 1)) continue;
-        const int ps = info >> 1;
-        BlockRec<double> o, p;
-        const double* uo = f + (size_t)(s >> 2) * 3; const double* up = f + (size_t)(ps >> 2) * 3;
-        o.x = uo[0]; o.y = uo[1]; o.th = uo[2]; o.ch = cos(0.5 * uo[2]); o.sh = sin(0.5 * uo[2]);
-        p.x = up[0]; p.y = up[1]; p.th = up[2]; p.ch = cos(0.5 * up[2]); p.sh = sin(0.5 * up[2]);
-        const double* sp = tb.slot_p + (size_t)s * kSlotParams; const double* pp = tb.slot_p + (size_t)ps * kSlotParams;
-        const double l0 = sqrt(sp[2] * sp[2] + sp[3] * sp[3]);
-        BondGrad<double> g;
-        bond_grad<kNonlinear, double>(o, p, sp[0], sp[1], pp[0], pp[1], sp[2], sp[3], l0, 1.0 / l0, sp[4], sp[5], sp[6], -1.0, g);
-        const size_t oi = ((size_t)m * Tn + k) * nbd + pl.slot_bond[s];
-        if (e_stretch) e_stretch[oi] = sp[4] * g.ks;
-        if (e_shear) e_shear[oi] = sp[5] * g.ksh;
-        if (e_bend) e_bend[oi] = sp[6] * g.kr;
+        LigRef lr;
+        for (int which = 0; slot_ligament(tb, s, which, lr); ++which) {
+          const int info = lr.info;
+          if (info & 1) continue;                                   // every ligament once: on its end-0 side
+          const int ps = info >> 1;
+          BlockRec<double> o, p;
+          const double* uo = f + (size_t)(s >> 2) * 3; const double* up = f + (size_t)(ps >> 2) * 3;
+          o.x = uo[0]; o.y = uo[1]; o.th = uo[2]; o.ch = cos(0.5 * uo[2]); o.sh = sin(0.5 * uo[2]);
+          p.x = up[0]; p.y = up[1]; p.th = up[2]; p.ch = cos(0.5 * up[2]); p.sh = sin(0.5 * up[2]);
+          const double* sp = tb.slot_p + (size_t)s * kSlotParams; const double* pp = tb.slot_p + (size_t)ps * kSlotParams;
+          const double* bp = lr.bp;
+          const double l0 = sqrt(bp[0] * bp[0] + bp[1] * bp[1]);
+          BondGrad<double> g;
+          bond_grad<kNonlinear, double>(o, p, sp[0], sp[1], pp[0], pp[1], bp[0], bp[1], l0, 1.0 / l0, bp[2], bp[3], bp[4], -1.0, g);
+          const size_t oi = ((size_t)m * Tn + k) * nbd + (lr.ovf >= 0 ? pl.ovf_bond[lr.ovf] : pl.slot_bond[s]);
+          if (e_stretch) e_stretch[oi] = bp[2] * g.ks;
+          if (e_shear) e_shear[oi] = bp[3] * g.ksh;
+          if (e_bend) e_bend[oi] = bp[4] * g.kr;
+        }
       }
     }
   }
@@ -606,12 +616,14 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   const int nb = pl.n_blocks, B = pl.batch;
   const int nsp = pl.n_special > 0 ? pl.n_special : 1;
   std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
-      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0);
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0),
+      ovf_g((size_t)B * pl.n_ovf * kOvfGrads + 1, 0.0);
   std::vector<double> S((size_t)nb * kRec), A((size_t)pl.tab.s * nb * 3), W((size_t)nb * 3);
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
     GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
-                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2};
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2,
+                ovf_g.data() + (size_t)m * pl.n_ovf * kOvfGrads};
     for (int b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d) init_dof(tb, y + (size_t)m * nb * 6, t, S.data(), b, d);
     FwdStage st;
@@ -645,7 +657,7 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
   if (grads) {
     dfx_grads g = *grads;
     g.state0 = nullptr;
-    unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g);
+    unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, &g, &ovf_g);
     if (g.block_centroids) memcpy(g.block_centroids, cen_g.data(), sizeof(double) * cen_g.size());
   }
   return 0;

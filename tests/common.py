@@ -41,7 +41,7 @@ class Case:
     """A lattice + BCs + parameters, materialised for the engine (NumPy) and for the oracle (torch)."""
 
     def __init__(self, lattice="quads", n=4, nonlinear=True, contact=False, damping=True, seed=0, lib=None,
-                 cutoff_deg=-10.0, min_deg=-15.0, batch=1, integrator="dopri5", per_bond_k=False, perturb=0.02):
+                 cutoff_deg=-10.0, min_deg=-15.0, batch=1, integrator="dopri5", per_bond_k=False, perturb=0.02, extra_bonds=None):
         rng = np.random.default_rng(seed)
         self.rng = rng
         if lattice == "quads":
@@ -66,10 +66,19 @@ class Case:
         self.con = np.array(con)
         self.vec = np.array(vec)
         self.bonds = self.geo.bond_connectivity()
-        nbd = len(self.bonds)
         self.cnv = self.geo.centroid_node_vectors(*self.design)
         self.cen = self.geo.block_centroids(*self.design)
         self.refv = self.geo.reference_bond_vectors()
+        if extra_bonds is not None:
+            # ligaments the lattice generators never produce: a second (third) one on nodes that already carry one
+            # (jax_md.smap.bond takes any bond list, energy.py:179-197); reference vector = the undeformed node-to-node vector
+            extra = np.asarray(extra_bonds, dtype=self.bonds.dtype).reshape(-1, 2)
+            npb = self.geo.n_npb
+            X = (self.cen[:, None, :] + self.cnv).reshape(-1, 2)
+            assert np.all(extra[:, 0] // npb != extra[:, 1] // npb)
+            self.bonds = np.concatenate([self.bonds, extra])
+            self.refv = np.concatenate([np.broadcast_to(self.refv, (len(self.bonds) - len(extra), 2)), X[extra[:, 1]] - X[extra[:, 0]]])
+        nbd = len(self.bonds)
         ks = K_STRETCH * (1 + 0.1 * rng.uniform(-1, 1, nbd)) if per_bond_k else K_STRETCH
         ksh = K_SHEAR * (1 + 0.1 * rng.uniform(-1, 1, nbd)) if per_bond_k else K_SHEAR
         kr = K_ROT * (1 + 0.1 * rng.uniform(-1, 1, nbd)) if per_bond_k else K_ROT

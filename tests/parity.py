@@ -17,9 +17,10 @@ def T64(x, grad=False):
     return torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=grad)
 
 
-def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=True, scale_th=0.15, rtol=None, cutoff_deg=None):
+def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=True, scale_th=0.15, rtol=None, cutoff_deg=None,
+                      extra_bonds=None):
     cut = cutoff_deg if cutoff_deg is not None else (125.0 if lattice == "kagome" else 42.0)
-    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, per_bond_k=per_bond_k)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, per_bond_k=per_bond_k, extra_bonds=extra_bonds)
     s = c.solver
     flat = s._flatten(c.cp)
     s.engine.set_params(**{k: v[None] for k, v in flat.items()})
@@ -68,9 +69,9 @@ def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=Tr
 
 
 def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, contact=True, seed=5, spi=6, n_out=5, batch=1,
-                                 own_step_times=False):
+                                 own_step_times=False, extra_bonds=None):
     cut = (125.0 if lattice == "kagome" else 42.0)
-    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, integrator=integrator)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, integrator=integrator, extra_bonds=extra_bonds)
     fast = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)   # a full pulse inside the short window
     c.cp = c.cp._replace(constraint_params=fast)
     ts = np.linspace(0, 3e-4, n_out)
