@@ -281,23 +281,19 @@ static void setup_tiling(dfx_handle* h) {
   h->tile.tiles_y = tiles_along(h->tile.n_rows, h->pair_rows);
   h->tile.n_tiles = h->tile.tiles_x * h->tile.tiles_y;
 }
-// which launches the next solve uses.  The pair kernels cover: even stage count, no distance-based contact, fixed grid; reverse: the
-// records checkpoint without per-ligament gradients.  Measured (profiles/r03_pair_launches.txt): a pair launch is one 1024-thread
-// workgroup per compute unit whose 16 waves load, evaluate, meet at the barrier and evaluate again in lock step, so memory time and
-// arithmetic no longer overlap between workgroups, and the window's outer ring adds 27 % of arithmetic to kernels whose vector ALUs
-// are already busy half of the time: 16 x 128x128 forward pair 53 us against 2 x 19.4 us, reverse pair 98 - 138 us against 2 x 32.8 us.
-// They pay where the launches do not fill the chip anyway: the forward pass of ONE large lattice (128x128: 10.5 ms against 12.1 ms per
-// 250 steps).  Default: forward pairs for a single group of at most 1024 waves on lattices of >= 4096 blocks, reverse never;
-// DFX_PAIR=1 forces both where they apply, f / a one direction, 0 none.
+// which launches the next solve uses.  The pair kernels cover: even stage count, no distance-based contact, fixed grid, one ligament
+// per node; reverse: the records checkpoint without per-ligament gradients.  Measured (profiles/r03_pair_launches.txt): a pair launch
+// is one 1024-thread workgroup per compute unit whose 16 waves load, evaluate, meet at the barrier and evaluate again in lock step, so
+// memory time and arithmetic no longer overlap between workgroups, and the window's outer ring adds 15 - 26 % of arithmetic to kernels
+// whose vector ALUs are already busy half of the time: 16 x 128x128 forward pair 53 us against 2 x 19.4 us, reverse pair 98 - 138 us
+// against 2 x 32.8 us.  For ONE 128x128 system (launch-bound) the forward pairs were ahead (10.5 against 12.1 ms per 250 steps) until
+// the stage kernels stopped evaluating time functions in their tails (k_fn_table): 28.6 us per step against 29.1 us.  So the pair
+// launches are opt-in: DFX_PAIR=1 both directions where they apply, f / a one direction; the GPU tests keep them exercised.
 static void pair_plan(dfx_handle* h, const DevCtx& c) {
   const char* e = getenv("DFX_PAIR");
   const bool can = h->tiling_ok && (h->pl.tab.s % 2 == 0) && h->pl.contact != DFX_CONTACT_DISTANCE && !h->adaptive;
-  const long long waves = (long long)h->pl.batch * ((h->pl.n_slots + 63) / 64);
-  const bool pays_fwd = waves <= 1024 && h->pl.n_blocks >= 4096;
-  const bool want_f = e ? (e[0] == '1' || e[0] == 'f') : pays_fwd;
-  const bool want_a = e ? (e[0] == '1' || e[0] == 'a') : false;
-  h->pair_fwd = can && want_f;
-  h->pair_adj = can && want_a && c.rps > 1 && !c.g_b;
+  h->pair_fwd = can && e && (e[0] == '1' || e[0] == 'f');
+  h->pair_adj = can && e && (e[0] == '1' || e[0] == 'a') && c.rps > 1 && !c.g_b;
 }
 static TileCtx group_tile(const dfx_handle* h, int nm) { TileCtx t = h->tile; t.total_wg = t.n_tiles * nm; return t; }
 
