@@ -890,7 +890,7 @@ const char* dfx_last_error(const dfx_handle* h) { return h ? h->err.c_str() : g_
 
 int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   dfx_handle* h = new dfx_handle();
-  auto fail = [&](int rc) { g_create_error = h->err; delete h; return rc; };
+  auto fail = [&](int rc) { g_create_error = h->err; delete h->ck; delete h; return rc; };
   if (build_plan(problem, h->pl, h->err)) return fail(1);
   {  // the stage kernels index per-handle arrays with 32 bits
     const Plan& pl = h->pl;
