@@ -51,7 +51,7 @@ class dfx_stats(C.Structure):
                 ("stage_checkpoint", C.c_int64), ("checkpoint_records", C.c_int64)]
 
 
-EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid",
+EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid", "dfx_forward_grid_members",
            "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version", "dfx_share_checkpoint"]
@@ -75,6 +75,7 @@ def declare(lib):
     lib.dfx_reserve.argtypes = [H, C.c_int64, C.c_int32, C.c_int32]
     lib.dfx_forward.argtypes = [H, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, C.POINTER(dfx_stats)]
     lib.dfx_forward_grid.argtypes = [H, _dp, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_forward_grid_members.argtypes = [H, _dp, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, C.POINTER(dfx_stats)]
     lib.dfx_adaptive_step_counts.argtypes = [H, _ip]
     lib.dfx_adaptive_step_times.argtypes = [H, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]
     lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
@@ -270,10 +271,21 @@ class Engine:
         B, nb = self.batch, self.n_blocks
         state0 = _f64(state0, (B, 2, nb, 3)) if state0 is not None else None      # None: at rest (no upload)
         ts = _f64(timepoints)
-        T = len(ts)
+        T = ts.shape[-1]
         fields = np.empty((B, T, 2, nb, 3)) if want_fields else None
         st = dfx_stats()
-        if np.ndim(steps_per_interval) == 0 and step_times is None:
+        if ts.ndim == 2:        # (batch, T): every member its own output times and step boundaries, shared step counts
+            if ts.shape[0] != B:
+                raise ValueError(f"per-member timepoints must be (batch={B}, T)")
+            spis = np.ascontiguousarray(np.broadcast_to(steps_per_interval, (max(T - 1, 0),)), dtype=np.int32)
+            n = int(spis.sum())
+            if step_times is None:      # equal steps inside every member's own intervals
+                step_times = np.stack([np.concatenate([a + (b - a) * np.arange(k) / k for a, b, k in zip(row[:-1], row[1:], spis)] + [row[-1:]])
+                                       for row in ts])
+            step_times = _f64(step_times, (B, n + 1))
+            self._check(self.lib.dfx_forward_grid_members(self._h, _ptr(state0), _ptr(ts), T, spis.ctypes.data_as(_ip), _ptr(step_times),
+                                                          int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward_grid_members")
+        elif np.ndim(steps_per_interval) == 0 and step_times is None:
             self._check(self.lib.dfx_forward(self._h, _ptr(state0), _ptr(ts), T, int(steps_per_interval),
                                              int(bool(keep_trajectory)), _ptr(fields), C.byref(st)), "dfx_forward")
         else:   # its own number of equal steps in every output interval

@@ -142,7 +142,8 @@ struct dfx_handle {
   bool segments = false;           // ... or nothing but the outputs: the reverse sweep re-runs one output interval at a time (records level inside it)
   std::vector<int> seg_first, seg_last;   // first / last segment of every output interval
   bool records = false;            // ... or the records checkpoint (every stage record of every step): no rebuild, no recompute
-  std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps)
+  std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps); one grid, or one per member (ts_stride = n_total + 1)
+  long long ts_stride = 0;
   std::vector<long long> accepted_per_member;
   bool have_adaptive_record = false;
   long long n_total = 0;
@@ -195,6 +196,7 @@ static DevCtx make_ctx(dfx_handle* h) {
   c.step_counts = h->adaptive ? h->d_step_counts.p : nullptr;
   c.acc_times = h->adaptive ? h->d_acc_times.p : nullptr; c.acc_cap = kAccCap;
   c.t_steps = (!h->adaptive && !h->t_steps.empty()) ? h->d_tsteps.p : nullptr;
+  c.ts_stride = c.t_steps ? h->ts_stride : 0;
   c.rtol = h->rtol; c.atol = h->atol;
   c.traj = h->have_traj ? h->ck->traj.p : nullptr;
   c.rps = (h->have_traj && (h->records || h->segments)) ? pl.tab.s : 1;
@@ -1086,9 +1088,29 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   return dfx_forward_grid(h, state0, timepoints, n_timepoints, spis.data(), nullptr, keep_trajectory, fields, stats);
 }
 
+static int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats, bool per_member);
+
 int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                      const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
                      double* fields, dfx_stats* stats) {
+  return forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, step_times, keep_trajectory, fields, stats, false);
+}
+
+int dfx_forward_grid_members(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats) {
+  if (!step_times) { h->err = "forward_grid_members: step_times (batch, n_steps + 1) required"; return 1; }
+  return forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, step_times, keep_trajectory, fields, stats, true);
+}
+
+// timepoints: (T,) -- or, per_member, (batch, T); step_times: NULL / (n_steps + 1,) -- or, per_member, (batch, n_steps + 1): every
+// member integrates on its own time grid (same step COUNTS: the launches are shared).  Row 0's output times fill the segment table
+// (used only without step_times).
+static int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats, bool per_member) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
   h->adaptive = false;
@@ -1105,12 +1127,17 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   }
   h->n_total = h->step0[Tn - 1];
   h->t_steps.clear();
+  h->ts_stride = per_member ? h->n_total + 1 : 0;
   if (step_times) {
-    h->t_steps.assign(step_times, step_times + h->n_total + 1);
-    for (long long n = 0; n < h->n_total; ++n)
-      if (!(h->t_steps[n + 1] > h->t_steps[n])) { h->err = "forward: step_times must be strictly increasing"; return 1; }
-    for (int k = 0; k < Tn; ++k)
-      if (h->t_steps[h->step0[k]] != timepoints[k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
+    const size_t n_grids = per_member ? B : 1;
+    h->t_steps.assign(step_times, step_times + n_grids * (size_t)(h->n_total + 1));
+    for (size_t g = 0; g < n_grids; ++g) {
+      const double* tg = h->t_steps.data() + g * (size_t)(h->n_total + 1);
+      for (long long n = 0; n < h->n_total; ++n)
+        if (!(tg[n + 1] > tg[n])) { h->err = "forward: step_times must be strictly increasing"; return 1; }
+      for (int k = 0; k < Tn; ++k)
+        if (tg[h->step0[k]] != timepoints[g * (size_t)Tn + k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
+    }
     HIP_OK(h->d_tsteps.ensure(h->t_steps.size()));
     HIP_OK(hipMemcpyAsync(h->d_tsteps.p, h->t_steps.data(), sizeof(double) * h->t_steps.size(), hipMemcpyHostToDevice, h->stream));
   }
@@ -1161,7 +1188,7 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   pair_plan(h, c);
   h->launches = 0;
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL, 0LL);
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
@@ -1260,7 +1287,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   DevCtx c = make_ctx(h);
   h->launches = 0;
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL, 0LL);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
   // only the evaluation just made comes back (row 0 / row 1 of every member's seven stage accelerations), not all of d_A
@@ -1444,7 +1471,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   // the (w, Kbar_q) buffers alternate per launch, lambda (pair launches only) per step
   const int wb = (int)((h->n_total * step_units(h, 1) - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb,
-                     h->pair_adj ? (int)(h->n_total & 1) : 0);
+                     h->pair_adj ? (int)(h->n_total & 1) : 0, (long long)h->n_total);
   if (c.AD && h->n_total > 0) {     // stage checkpoint: the record the first reverse launch reads
     const long long nr = h->n_total - 1;
     const double t_nr = h->t_steps.empty() ? h->ts[Tn - 1] - h_last : h->t_steps[nr];
@@ -1465,7 +1492,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
         const Group& gr = h->groups[gi];
         const DevCtx cg = group_ctx(h, c, gi);
         hipLaunchKernelGGL(k_init, slot_grid(h, gr), dim3(kThreads), 0, gr.stream, cg, (const double*)(h->d_fields.p + (size_t)k * nb6), h->ts[k], 0,
-                           (long long)((size_t)Tn * nb6));
+                           (long long)((size_t)Tn * nb6), (long long)h->step0[k]);
         hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)(((size_t)pl.n_blocks * kStep + kThreads - 1) / kThreads), (unsigned)gr.nm), dim3(kThreads), 0,
                            gr.stream, cg, (long long)h->step0[k]);
         h->launches += 2;
@@ -1658,7 +1685,7 @@ static int hook_prepare(dfx_handle* h, const double* y, double t) {
   HIP_OK(hipMemcpyAsync(h->d_cur.p, &sg, sizeof(Seg), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(h->d_state0.p, y, sizeof(double) * B * nb * 6, hipMemcpyHostToDevice, h->stream));
   DevCtx c = make_ctx(h);
-  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, t, 0, 0LL);
+  hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, t, 0, 0LL, 0LL);
   return 0;
 }
 

@@ -129,6 +129,7 @@ struct DevCtx {
   double* acc_times;      // batch * acc_cap end times of the accepted steps (adaptive)
   int acc_cap;
   const double* t_steps;  // n_total+1 step boundaries of a caller-chosen grid, or null: equal steps (Seg.h)
+  long long ts_stride;    // elements between members in t_steps: 0 = one grid for all, n_total+1 = every member its own (dfx_forward_grid_members)
   double* AD;             // stage checkpoint: batch * (N * s * n_dof) stage accelerations of EVERY step, or null
   long long ad_stride;    // elements between members in AD
   const double* ts_dev;   // output times (adaptive mode)
@@ -251,6 +252,8 @@ __global__ void k_tick(const Seg* segs, int* seg_idx, int delta, Seg* cur) {
 __global__ void k_set_seg(const Seg* segs, int i, Seg* cur) { *cur = segs[i]; }
 
 struct TimeVals { double g, gt; };
+// step boundaries of member m (caller-chosen grids; one table for all members or one per member)
+__device__ __forceinline__ const double* steps_of(const DevCtx& c, int m) { return c.t_steps + (size_t)m * (size_t)c.ts_stride; }
 
 // value of the prescribed displacement of DOF d of special block sp at time t (and its rate)
 __device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, const dfx_special& sp, int d, double t) {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64) void k_fn_table(DevCtx c, StageTimes st, int n_
   const Seg sg = *c.cur;
   const long long n = sg.base_step + j;
   double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
-  if (c.t_steps) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
+  if (c.t_steps) { const double* ts = steps_of(c, m); t = ts[n]; h = ts[n + 1] - t; }
   double g, gt, gp[kMaxFnParams];
   eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + st.c[r] * h, g, gt, gp);
   double* e = tab + ((((size_t)m * kMaxGraphSteps + j) * kFnRows + r) * DFX_MAX_FNS + f) * kFnEntry;
@@ -309,8 +312,10 @@ __global__ __launch_bounds__(64) void k_fn_table(DevCtx c, StageTimes st, int n_
 
 // records of a full (2, n_blocks, 3) state at time t0 -> stage buffer `buf`  (constrained DOFs follow c(t0), c'(t0))
 //   stride: elements between members in state0 (0: packed (batch, 2, n, 3); a row of the resident (batch, T, 2, n, 3) history otherwise)
-__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf, long long stride) {
+//   n0: step ordinal of the state; with a caller-chosen grid its time is read there (every member may have its own)
+__global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state0, double t0, int buf, long long stride, long long n0) {
   const int m = blockIdx.y + c.m0;
+  if (c.t_steps) t0 = steps_of(c, m)[n0];
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   const double dE = blk_reduce3<NPB>(fx, fy, fth, k);
   // ---- DOF epilogue on lanes 0..2
   double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
-  if (c.t_steps && !c.clock) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
+  if (c.t_steps && !c.clock) { const double* ts = steps_of(c, m); t = ts[n]; h = ts[n + 1] - t; }
   double qnext = 0.0, vnext = 0.0;
   if (k < 3) {
     bool constrained = false;
@@ -980,6 +985,7 @@ __device__ __forceinline__ void rebuild_record(const DevCtx& c, int m, int b, in
 // that precedes its reader)
 __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef rc, int r, long long nr, double h, double t) {
   const int m = blockIdx.y + c.m0;
+  if (c.t_steps) { t = steps_of(c, m)[nr]; h = steps_of(c, m)[nr + 1] - t; }
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
   rebuild_record(c, m, slot >> 2, slot & 3, rc, r, nr, h, t);
@@ -1052,7 +1058,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
       }
       // own w = Kbar_v / m of this stage, from the same values (zero on constrained DOFs by itself: their lambda and Ybar are stored
       // as zeros); the neighbours read the copy the previous launch stored -- equal to rounding
-      w_d = ((c.t_steps ? c.t_steps[n + 1] - c.t_steps[n] : sg.h) * (ac.cur[c.s] * lv + svc)) * invm;
+      w_d = ((c.t_steps ? steps_of(c, m)[n + 1] - steps_of(c, m)[n] : sg.h) * (ac.cur[c.s] * lv + svc)) * invm;
     } else {
       if (i == 0 || ac.col[c.s] != 0.0) { lq = ldg<double>(LAMm, o_b6); lv = ldg<double>(LAMm, o_b6 + 24); }
       double yq[kMaxStages], yv[kMaxStages];
@@ -1185,7 +1191,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   if (phi_on) { stg<double>(gpm, (u32)slot * 8, p_old - d_phi); c.touch[0] = 1; }
   // ---- DOF epilogue
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
-  if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
+  if (c.t_steps) { const double* ts = steps_of(c, m); t_n = ts[n]; h = ts[n + 1] - t_n; h_before = n > 0 ? t_n - ts[n - 1] : 0.0; }
   if (k < 3) {
     bool constrained = false;
     double fload = 0.0;
@@ -1249,7 +1255,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   }
   if (REBUILD && rb > 0) {
     if (i > 0) rebuild_record(c, m, b, k, rc, rb, n, h, t_n);
-    else if (n > 0) rebuild_record(c, m, b, k, rc, rb, n - 1, h_before, c.t_steps ? c.t_steps[n - 1] : t_n - h_before);
+    else if (n > 0) rebuild_record(c, m, b, k, rc, rb, n - 1, h_before, c.t_steps ? steps_of(c, m)[n - 1] : t_n - h_before);
   }
 }
 
@@ -1268,8 +1274,9 @@ __global__ __launch_bounds__(kThreads) DFX_ADJ_RB_OCC void k_adj_stage_rb(DevCtx
 
 // start of the reverse sweep: lambda_N = G_last; kbar_{s-1} of the last step into buffer `buf`
 //   lam_par: which of the two lambda buffers (the pair launches double-buffer lambda by step parity; 0 otherwise)
-__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf, int lam_par) {
+__global__ __launch_bounds__(kThreads) void k_adj_begin(DevCtx c, double h_last, double b_last, int buf, int lam_par, long long n_total) {
   const int m = blockIdx.y + c.m0;
+  if (c.t_steps && n_total > 0) h_last = steps_of(c, m)[n_total] - steps_of(c, m)[n_total - 1];
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_slots) return;
   const int b = tid >> 2, d = tid & 3;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * WROWS) DFX_PAIR_OCC void k_fwd_pair(DevCtx c, 
   const bool keep_stages = c.AD != nullptr;
   double* Am = keep_stages ? c.AD + (size_t)m * c.ad_stride + (size_t)n * ((u32)(c.s - 1) * nd) : c.A + (size_t)m * (u32)(c.s + 1) * nd;
   double h = sg.h, t = sg.t_interval + (sg.j0 + j) * sg.h;
-  if (c.t_steps) { t = c.t_steps[n]; h = c.t_steps[n + 1] - t; }
+  if (c.t_steps) { const double* ts = steps_of(c, m); t = ts[n]; h = ts[n + 1] - t; }
   // what survives the barrier
   LaneIn L;
   double qn = 0.0, vn = 0.0, damp = 0.0, invm = 0.0, qnext = 0.0, vnext = 0.0, sv1 = 0.0, sq1 = 0.0, sn = 0.0;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WROWS) DFX_PAIR_OCC void k_adj_pair(DevCtx c, 
   const u32 o_dof = (u32)dof * 8, o_b6 = ((u32)b * 6 + 2 * kd) * 8;
   const MemberBases B = member_bases(c, m);
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
-  if (c.t_steps) { t_n = c.t_steps[n]; h = c.t_steps[n + 1] - t_n; h_before = n > 0 ? t_n - c.t_steps[n - 1] : 0.0; }
+  if (c.t_steps) { const double* ts = steps_of(c, m); t_n = ts[n]; h = ts[n + 1] - t_n; h_before = n > 0 ? t_n - ts[n - 1] : 0.0; }
   double* YBm = c.YB + (size_t)m * (u32)c.s * nd6;
   const double* LAMin = c.LAM + ((size_t)((n + 1) & 1) * (u32)c.batch + (u32)m) * nd6;
   double* LAMout = c.LAM + ((size_t)(n & 1) * (u32)c.batch + (u32)m) * nd6;

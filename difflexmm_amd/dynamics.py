@@ -194,6 +194,16 @@ class DynamicSolver:
         flats = [self._flatten(cp) for cp in cps]
         self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
         spi = steps_per_interval if steps_per_interval is not None else self.steps_per_interval
+        if np.ndim(timepoints) == 2:
+            # one row of output times per member (same number of outputs and of steps per interval: the members advance in the same
+            # launches, each on its own time grid) -- forward inputs whose static phases differ in length, static-tuning problem
+            if spi is None:
+                raise ValueError("per-member timepoints need steps_per_interval (the adaptive controller chooses one grid per call)")
+            fields, stats = self.engine.forward(state0 if np.ndim(state0) != 3 else np.broadcast_to(state0, (self.batch,) + np.shape(state0)),
+                                                timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times, want_fields=want_fields)
+            self._last = (cps, flats, np.asarray(timepoints, dtype=float))
+            self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control="fixed")
+            return fields
         state0 = np.asarray(state0, dtype=float)
         if state0.ndim == 3:
             state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
@@ -236,7 +246,7 @@ class DynamicSolver:
             n_con = len(self.constrained_pairs)
             dofs = self.constrained_pairs[:, 0] * 3 + self.constrained_pairs[:, 1]
             for m, (cp, tree) in enumerate(zip(cps, tl)):
-                fbm = fb[m].reshape(len(ts), 2, -1)
+                fbm = fb[m].reshape(ts.shape[-1], 2, -1)
                 for term in self.con_terms:
                     vec = _bcast(term.vector, n_con)
                     wq = fbm[:, 0, dofs] @ vec          # (T,) weights of g(t_k)
@@ -245,7 +255,7 @@ class DynamicSolver:
                         continue
                     p = term.resolve(cp.constraint_params)
                     g5 = np.zeros(_b.DFX_FN_PARAMS)
-                    for k, t in enumerate(ts):
+                    for k, t in enumerate(ts[m] if ts.ndim == 2 else ts):
                         if wq[k]:
                             g5 += wq[k] * term.param_partials(float(t), p, "value")
                         if wv[k]:

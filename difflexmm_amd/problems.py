@@ -395,11 +395,12 @@ class QuadsStaticTuningForward:
     bottom and top edges clamped and slowly compressed (``compressive_strain`` at ``compressive_strain_rate``), one pulse on the
     left edge once the compression has ended.
 
-    The reference maps the forward inputs over devices (``pmap``, ``:473-478``).  Here rows are ensemble members of one engine
-    call whenever they share their output times -- a member's time grid starts with the static phase ``[0, strain / strain_rate +
-    input_delay]``, so rows with different strains or rates have different grids and are integrated by calls of their own (on one
-    GPU one after the other; ``ensemble`` shards rows over ranks).  ``static_steps`` / ``steps_per_interval``: RK steps in the
-    static interval / between dynamic outputs (both None: the adaptive controller, and its frozen grid for gradients)."""
+    The reference maps the forward inputs over devices (``pmap``, ``:473-478``).  Here the rows are ensemble members of ONE engine
+    call: a member's time grid starts with its own static phase ``[0, strain / strain_rate + input_delay]``, so rows with different
+    strains or rates have different grids -- ``dfx_forward_grid_members`` integrates every member on its own times with shared step
+    counts (``static_steps`` RK steps in the static interval, ``steps_per_interval`` between dynamic outputs).  With both None the
+    adaptive controller chooses the grid (and freezes it for gradients) per call: then only rows with equal output times share one,
+    the others run one after the other (``ensemble`` shards rows over ranks)."""
     n1_blocks: int
     n2_blocks: int
     spacing: Any
@@ -497,17 +498,22 @@ class QuadsStaticTuningForward:
         (groups of equal size share a solver: the next solve replaces it)."""
         rows = np.asarray(rows, dtype=float).reshape(-1, 4)
         tps = [self.timepoints_of(r[1], r[2], r[3], full_simulation_time, n_timepoints) for r in rows]
+        # with explicit step counts every row may keep its own time grid inside one call (dfx_forward_grid_members: shared step
+        # counts, per-member times); the adaptive controller chooses one grid per call, so there only equal grids share a call
+        own_grids = self.steps_per_interval is not None
         keys = {}
         for i, tp in enumerate(tps):
-            keys.setdefault((tp.tobytes(), None if group_key is None else group_key(i)), []).append(i)
+            keys.setdefault((len(tp) if own_grids else tp.tobytes(), None if group_key is None else group_key(i)), []).append(i)
         sols, self.groups = [None] * len(rows), []
         for idx in keys.values():
             sd = self.solver(len(idx))
             cps = [self.control_params(design, *rows[i]) for i in idx]
             tp = tps[idx[0]]
-            fields = sd(self.state0, tp, cps if len(idx) > 1 else cps[0], keep_trajectory=keep_trajectory,
+            same = all(np.array_equal(tps[i], tp) for i in idx)
+            tp_call = tp if same else np.stack([tps[i] for i in idx])
+            fields = sd(self.state0, tp_call, cps if len(idx) > 1 else cps[0], keep_trajectory=keep_trajectory,
                         steps_per_interval=self.step_counts(tp, full_simulation_time), want_fields=want_fields)
-            self.groups.append((sd, idx, cps, tp))
+            self.groups.append((sd, idx, cps, tp_call))
             if after_group is not None:
                 after_group(sd, idx, cps)
             if fields is None:
@@ -515,6 +521,7 @@ class QuadsStaticTuningForward:
             for m, i in enumerate(idx):
                 f = fields[m] if len(idx) > 1 else fields
                 gp = cps[m].geometrical_params
+                tp = tps[i]
                 sols[i] = SolutionData(gp.block_centroids, gp.centroid_node_vectors, self.bond_connectivity,
                                        tp if full_simulation_time else tp[1:] - tp[1], f if full_simulation_time else f[1:])    # :268-276
         self._last_design = design

@@ -168,6 +168,14 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
                      const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
                      double* fields, dfx_stats* stats);
 
+/* The same with one time grid PER MEMBER: timepoints (batch, n_timepoints), step_times (batch, sum(steps_per_interval) + 1), required.
+ * The step counts are shared (all members advance in the same launches), the times are not: forward inputs whose static phases differ
+ * in length (problems/quads_kinetic_energy_static_tuning.py:246-259, mapped over devices with pmap at :473-478) are ensemble members
+ * of one call.  dfx_adjoint reverses it like any other fixed-grid solve. */
+int dfx_forward_grid_members(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats);
+
 /* The reference's own integrator semantics (jax.experimental.ode.odeint 0.4.8 called at dynamics.py:166): adaptive
  * Dormand-Prince 5(4), RMS error norm over the free (q, v) components with tolerance atol + rtol*max(|y0|,|y1|),
  * (state0 == NULL: every member starts at rest, as in dfx_forward / dfx_forward_grid)

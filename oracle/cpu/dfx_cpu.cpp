@@ -37,7 +37,9 @@ struct dfx_handle {
   std::vector<int64_t> step0;     // first step ordinal of every interval
   std::vector<int32_t> step_counts;  // accepted steps per member and interval (adaptive)
   std::vector<std::vector<double>> acc_times;  // end times of the accepted steps per member (adaptive)
-  std::vector<double> t_steps;       // caller-chosen step boundaries (empty: equal steps)
+  std::vector<double> t_steps;       // caller-chosen step boundaries (empty: equal steps); per member when ts_stride != 0
+  size_t ts_stride = 0, tp_stride = 0;   // elements between members in t_steps / ts (0: one grid for all members)
+  int n_tp = 0;                          // output times per member
   bool have_traj = false;
   std::vector<double> view_store[10];  // dfx_kinetic_value_and_grad: arrays behind the returned views
   std::vector<double> zero_state;
@@ -149,9 +151,26 @@ int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, i
   return dfx_forward_grid(h, state0, timepoints, n_timepoints, spis.data(), nullptr, keep_trajectory, fields, stats);
 }
 
+static int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats, bool per_member);
+
 int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                      const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
                      double* fields, dfx_stats* stats) {
+  return forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, step_times, keep_trajectory, fields, stats, false);
+}
+
+int dfx_forward_grid_members(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats) {
+  if (!step_times) { h->err = "forward_grid_members: step_times (batch, n_steps + 1) required"; return 1; }
+  return forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, step_times, keep_trajectory, fields, stats, true);
+}
+
+static int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                             const int32_t* steps_per_interval, const double* step_times, int32_t keep_trajectory,
+                             double* fields, dfx_stats* stats, bool per_member) {
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
   if (n_timepoints < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
   const Plan& pl = h->pl;
@@ -166,23 +185,33 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
   }
   const int64_t N = h->step0[Tn - 1];
   h->t_steps.clear();
+  h->ts_stride = per_member ? (size_t)N + 1 : 0;
+  h->tp_stride = per_member ? (size_t)Tn : 0;
+  const int n_grids = per_member ? B : 1;
   if (step_times) {
-    h->t_steps.assign(step_times, step_times + N + 1);
-    for (int64_t n = 0; n < N; ++n)
-      if (!(h->t_steps[n + 1] > h->t_steps[n])) { h->err = "forward: step_times must be strictly increasing"; return 1; }
-    for (int k = 0; k < Tn; ++k)
-      if (h->t_steps[h->step0[k]] != timepoints[k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
+    h->t_steps.assign(step_times, step_times + (size_t)n_grids * (N + 1));
+    for (int g = 0; g < n_grids; ++g) {
+      const double* tsg = h->t_steps.data() + (size_t)g * (N + 1);
+      for (int64_t n = 0; n < N; ++n)
+        if (!(tsg[n + 1] > tsg[n])) { h->err = "forward: step_times must be strictly increasing"; return 1; }
+      for (int k = 0; k < Tn; ++k)
+        if (tsg[h->step0[k]] != timepoints[(size_t)g * Tn + k]) { h->err = "forward: step_times must contain every timepoint at the start of its interval"; return 1; }
+    }
   }
   if (!state0) { h->zero_state.assign((size_t)B * nb * 6, 0.0); state0 = h->zero_state.data(); }   // NULL: at rest
   const bool own_grid = !h->t_steps.empty();
   auto t_begin = std::chrono::steady_clock::now();
-  h->ts.assign(timepoints, timepoints + Tn);
+  h->ts.assign(timepoints, timepoints + (size_t)n_grids * Tn);
+  h->n_tp = Tn;
+  const double* timepoints_all = timepoints;
   h->have_traj = keep_trajectory != 0;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
   if (keep_trajectory) h->traj.assign((size_t)B * (N + 1) * rec, 0.0);
   std::vector<double> Ybuf(2 * rec), Sbuf(2 * rec), A((size_t)T.s * nb * 3);
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
+    timepoints = timepoints_all + (size_t)m * h->tp_stride;            // this member's output times and step boundaries
+    const double* t_steps = own_grid ? h->t_steps.data() + (size_t)m * h->ts_stride : nullptr;
     double* fm = h->fields.data() + (size_t)m * Tn * nb * 6;
     double* tr = keep_trajectory ? h->traj.data() + (size_t)m * (N + 1) * rec : nullptr;
     double* Y = tr ? tr : Ybuf.data();
@@ -194,8 +223,8 @@ int dfx_forward_grid(dfx_handle* h, const double* state0, const double* timepoin
       const int spi = h->spis[k];
       const double heq = (timepoints[k + 1] - timepoints[k]) / spi;
       for (int j = 0; j < spi; ++j, ++n) {
-        const double t = own_grid ? h->t_steps[n] : timepoints[k] + j * heq;
-        const double hh = own_grid ? h->t_steps[n + 1] - t : heq;
+        const double t = own_grid ? t_steps[n] : timepoints[k] + j * heq;
+        const double hh = own_grid ? t_steps[n + 1] - t : heq;
         double* Ynext = tr ? tr + (size_t)(n + 1) * rec : (Y == Ybuf.data() ? Ybuf.data() + rec : Ybuf.data());
         for (int i = 0; i < T.s; ++i) {
           FwdStage st;
@@ -259,6 +288,7 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
   const Dopri D = make_dopri();
   if (!state0) { h->zero_state.assign((size_t)B * nb * 6, 0.0); state0 = h->zero_state.data(); }   // NULL: at rest
   h->ts.assign(timepoints, timepoints + Tn);
+  h->n_tp = Tn; h->tp_stride = 0; h->ts_stride = 0;
   h->have_traj = false;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
   h->step_counts.assign((size_t)B * std::max(0, Tn - 1), 0);
@@ -376,7 +406,7 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
   if (!h->have_traj) { h->err = "adjoint: run forward with keep_trajectory=1 first"; return 1; }
   const Plan& pl = h->pl;
   const Tableau& T = pl.tab;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp;
   const size_t rec = (size_t)nb * kRec;
   const int64_t N = h->step0[Tn - 1];
   auto t_begin = std::chrono::steady_clock::now();
@@ -395,17 +425,19 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
     const double* G = Gall.data() + (size_t)m * Tn * nb * 6;
     int cur = 0;
     const bool own_grid = !h->t_steps.empty();
-    const double h_last = Tn > 1 ? (own_grid ? h->t_steps[N] - h->t_steps[N - 1] : (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]) : 0.0;
+    const double* t_steps = own_grid ? h->t_steps.data() + (size_t)m * h->ts_stride : nullptr;     // this member's grid
+    const double* ts_m = h->ts.data() + (size_t)m * h->tp_stride;
+    const double h_last = Tn > 1 ? (own_grid ? t_steps[N] - t_steps[N - 1] : (ts_m[Tn - 1] - ts_m[Tn - 2]) / h->spis[Tn - 2]) : 0.0;
     for (int b = 0; b < nb; ++b)
       for (int d = 0; d < 3; ++d)
         adj_begin_dof(tb, T, G + (size_t)(Tn - 1) * nb * 6, h_last, LAM.data(), W.data() + (size_t)cur * nb * 3, KQ.data() + (size_t)cur * nb * 3, b, d);
     for (int k = Tn - 2; k >= 0; --k) {
       const int spi = h->spis[k];
-      const double heq = (h->ts[k + 1] - h->ts[k]) / spi;
+      const double heq = (ts_m[k + 1] - ts_m[k]) / spi;
       for (int j = spi - 1; j >= 0; --j) {
         const int64_t n = h->step0[k] + j;
-        const double t = own_grid ? h->t_steps[n] : h->ts[k] + j * heq;
-        const double hh = own_grid ? h->t_steps[n + 1] - t : heq;
+        const double t = own_grid ? t_steps[n] : ts_m[k] + j * heq;
+        const double hh = own_grid ? t_steps[n + 1] - t : heq;
         const double* Y = tr + (size_t)n * rec;
         // recompute the stage records of step n
         for (int i = 0; i < T.s; ++i) {
@@ -425,8 +457,8 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
           st.YB = YB.data(); st.LAM = LAM.data();
           st.G = (i == 0 && j == 0) ? G + (size_t)k * nb * 6 : nullptr;
           st.i = i; st.local_only = 0; st.t_i = t + T.c[i] * hh; st.h = hh;
-          st.h_prev = own_grid ? (n > 0 ? t - h->t_steps[n - 1] : 0.0)
-                               : (j > 0 ? hh : (k > 0 ? (h->ts[k] - h->ts[k - 1]) / h->spis[k - 1] : 0.0));
+          st.h_prev = own_grid ? (n > 0 ? t - t_steps[n - 1] : 0.0)
+                               : (j > 0 ? hh : (k > 0 ? (ts_m[k] - ts_m[k - 1]) / h->spis[k - 1] : 0.0));
           adj_stage(tb, T, st, acc);
           cur = 1 - cur;
         }
@@ -453,7 +485,7 @@ static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T
 }
 
 int dfx_adaptive_step_counts(dfx_handle* h, int32_t* counts) {
-  if (h->step_counts.empty() && h->ts.size() > 1) { h->err = "adaptive_step_counts: run forward_adaptive first"; return 1; }
+  if (h->step_counts.empty() && h->n_tp > 1) { h->err = "adaptive_step_counts: run forward_adaptive first"; return 1; }
   if (!h->step_counts.empty()) memcpy(counts, h->step_counts.data(), sizeof(int32_t) * h->step_counts.size());
   return 0;
 }
@@ -468,7 +500,7 @@ int dfx_adaptive_step_times(dfx_handle* h, int32_t member, double* times, int64_
 
 int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_stats* stats) {
   const Plan& pl = h->pl;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp;
   std::vector<double> G((size_t)B * Tn * nb * 6);
   for (int m = 0; m < B; ++m)
     for (int k = 0; k < Tn; ++k) {
@@ -482,7 +514,7 @@ int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_s
 
 int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective) {
   const Plan& pl = h->pl;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp;
   if (h->fields.empty()) { h->err = "objective: run forward first"; return 1; }
   for (int m = 0; m < B; ++m) {
     double acc = 0.0;
@@ -500,7 +532,7 @@ int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n
 
 int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, dfx_grads* grads, dfx_stats* stats) {
   const Plan& pl = h->pl;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size();
+  const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp;
   if (h->fields.empty()) { h->err = "adjoint_kinetic: run forward first"; return 1; }
   std::vector<double> G((size_t)B * Tn * nb * 6, 0.0);
   for (int m = 0; m < B; ++m)
@@ -548,7 +580,7 @@ int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int3
 
 int dfx_response_data(dfx_handle* h, double* e_stretch, double* e_shear, double* e_bend, double* e_kin) {
   const Plan& pl = h->pl;
-  const int nb = pl.n_blocks, B = pl.batch, Tn = (int)h->ts.size(), nbd = pl.n_bonds;
+  const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp, nbd = pl.n_bonds;
   if (h->fields.empty()) { h->err = "response_data: run forward first"; return 1; }
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);

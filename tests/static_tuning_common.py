@@ -61,7 +61,7 @@ def check_boundary_conditions_equal_oracle(lib):
 
 
 def check_trajectory_and_gradients(lib, tol_traj=1e-10, tol_grad=1e-9):
-    """Dynamic-step solution of both forward inputs (two engine calls: their time grids differ) against the oracle's fixed-grid
+    """Dynamic-step solution of both forward inputs (ONE engine call, every member on its own time grid) against the oracle's fixed-grid
     solver; weighted objective and its gradient w.r.t. the design AND the forward inputs (amplitude, loading rate incl. the
     input_delay = 0.1 / f path, compressive strain incl. the delay of the pulse, strain rate) against autograd through the
     unrolled oracle."""
@@ -70,9 +70,9 @@ def check_trajectory_and_gradients(lib, tol_traj=1e-10, tol_grad=1e-9):
     finp = P.ForwardInput(x[0], x[1], tuple(ROWS[:, 0]), tuple(ROWS[:, 1]), tuple(ROWS[:, 2]), tuple(ROWS[:, 3]))
     obj = P.StaticTuningKineticEnergy(fw, finp, ((2, 2), (1, 2)), ((1, 0), (1, 1)), weights=(0.75, -0.25))
     counts = np.array([STATIC_STEPS] + [SPI] * (NT - 1))
-    # trajectories
+    # trajectories: the two forward inputs have different static phases, hence different time grids -- and share ONE engine call
     sols = fw.solve_rows(x, ROWS)
-    assert len(fw.groups) == 2 and all(len(g[1]) == 1 for g in fw.groups)
+    assert len(fw.groups) == 1 and fw.groups[0][0].batch == 2 and fw.groups[0][3].shape == (2, NT + 1)
     import oracle.ref_dynamics as OD
     for r, sol in zip(ROWS, sols):
         osolver = OD.setup_dynamic_solver(ofw.geometry, ofw.energy, integrator="fixed", steps_per_interval=counts, **ofw.solver_args)
@@ -98,6 +98,28 @@ def check_trajectory_and_gradients(lib, tol_traj=1e-10, tol_grad=1e-9):
         mine = w * np.array([bar["amplitude"], bar["loading_rate"], bar["compressive_strain"], bar["compressive_strain_rate"]])
         assert np.all(np.abs(mine) > 0)
         assert np.abs(mine - og_in[i]).max() < 10 * tol_grad * np.abs(og_in[i]).max(), (i, mine, og_in[i])
+
+
+def check_members_on_their_own_grids_equal_separate_calls(lib):
+    """Two rows with different strains in one call (dfx_forward_grid_members) give exactly what each gives in a call of its own,
+    trajectories and gradients alike."""
+    fw = forward(lib)
+    x = design(fw)
+    finp = P.ForwardInput(x[0], x[1], tuple(ROWS[:, 0]), tuple(ROWS[:, 1]), tuple(ROWS[:, 2]), tuple(ROWS[:, 3]))
+    both = P.StaticTuningKineticEnergy(fw, finp, ((2, 2), (2, 2)), ((1, 0), (1, 0)), weights=(0.75, -0.25))
+    v, g = both.value_and_grad(x)
+    assert len(fw.groups) == 1 and fw.groups[0][0].batch == 2
+    vals, grads = [], []
+    for r in range(2):
+        fi = P.ForwardInput(x[0], x[1], (ROWS[r, 0],), (ROWS[r, 1],), (ROWS[r, 2],), (ROWS[r, 3],))
+        one = P.StaticTuningKineticEnergy(fw, fi, ((2, 2),), ((1, 0),), weights=(1.0,))
+        vr, gr = one.value_and_grad(x)
+        vals.append(vr); grads.append(gr)
+        for k in ("amplitude", "compressive_strain", "compressive_strain_rate", "loading_rate"):
+            assert abs(one.last_input_grads[0][k] - both.last_input_grads[r][k]) <= 1e-11 * abs(one.last_input_grads[0][k]), (r, k)
+    assert relerr(both.last_individual, vals) < 1e-13
+    for a, b0, b1 in zip(g, grads[0], grads[1]):
+        assert relerr(a, 0.75 * b0 - 0.25 * b1) < 1e-11
 
 
 def check_rows_with_equal_grids_share_one_call(lib):

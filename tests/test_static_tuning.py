@@ -11,6 +11,10 @@ def test_trajectory_objective_and_gradients_vs_autograd(cpu_lib):
     S.check_trajectory_and_gradients(cpu_lib)
 
 
+def test_members_on_their_own_time_grids_equal_separate_calls(cpu_lib):
+    S.check_members_on_their_own_grids_equal_separate_calls(cpu_lib)
+
+
 def test_rows_with_equal_time_grids_are_ensemble_members(cpu_lib):
     S.check_rows_with_equal_grids_share_one_call(cpu_lib)
 
