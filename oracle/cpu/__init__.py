@@ -8,6 +8,9 @@ _LIB = None
 
 
 def build(force=False):
+    # DFX_CPU_PORT_LIBRARY: another build of the same port (the sanitizer build of `make asan`, tools/sanitize_cpu.sh)
+    if os.environ.get("DFX_CPU_PORT_LIBRARY"):
+        return os.environ["DFX_CPU_PORT_LIBRARY"]
     so = os.path.join(_HERE, "libdfx_cpu.so")
     if force or not os.path.exists(so):
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))

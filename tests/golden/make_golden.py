@@ -137,14 +137,94 @@ def problem_layer():
     np.savez_compressed(os.path.join(OUT, "problems_objective.npz"), **res)
 
 
+def long_horizon():
+    """About a thousand steps on the autograd tape (the horizon is bounded by the dynamics, not by the tape: with the contact engaged at
+    these amplitudes a rounding difference grows ~100x per 400 steps -- oracle against C++ port 5e-16 / 9e-14 / 2e-12 / 3e-9 after
+    400 / 800 / 1200 / 2000 steps on the 8x8 quads, 5e-14 / 3e-12 / 2e-10 after 400 / 800 / 1200 on the 4x4 kagome): trajectory, objective and design gradient of small lattices over a horizon in which the
+    pulse crosses the lattice and rings down (nonlinear ligaments + damping + angle contact ENGAGED: the cutoff sits above the undeformed
+    void angles, `contact_energy` at the output times is in the file).  Pins the long-horizon behaviour of the engine and of the C++ port
+    (the second checker) to the torch oracle; the other oracle trajectories are a few tens of steps."""
+    from oracle import ref_energy as OE, ref_geometry as OG
+    for lattice, n, cut, steps, seed in (("quads", 8, 42.0, 1200, 21), ("kagome", 4, 125.0, 800, 22)):
+        c = Case(lattice, n, True, True, seed=seed, lib=load(), cutoff_deg=cut)
+        nb = c.geo.n_blocks
+        lv = dict(loading_rate=T64(3000.0), input_delay=T64(1e-5))
+        ts = np.linspace(0.0, 1.5e-6 * steps, 9)
+        spi = steps // 8
+        design = [T64(d, True) for d in c.design]
+        cnv = c.ogeo.centroid_node_vectors(*design)
+        cen = c.ogeo.block_centroids(*design)
+        osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi)
+        hist, _ = OD.solve_fixed_differentiable(osol, c.ogeo, T64(np.zeros((2, nb, 3))), ts, c.oracle_cp(dict(cnv=cnv, cen=cen, **lv)), spi)
+        free = list(osol.free_DOF_ids)
+        target = np.array([nb // 2 + 1, nb // 2 + 2])
+        inertia = OG.compute_inertia(cnv, 6.18e-9)
+        obj = 0.0
+        for b in target:
+            for d in range(3):
+                col = free.index(b * 3 + d)
+                obj = obj + (inertia[b, d] * hist[:, 1, col] ** 2 / 2).sum()
+        g = torch.autograd.grad(obj, design)
+        cp = c.oracle_cp(lv)
+        fields = osol(np.zeros((2, nb, 3)), ts, cp).detach()    # all DOFs, prescribed ones with their rate (not under no_grad: the rate is autograd's)
+        with torch.no_grad():
+            ce = OE.build_contact_energy(c.bonds)
+            contact = np.array([float(ce(fields[k, 0], cp)) for k in range(len(ts))])
+        for part in (0, 1):       # the tape-free fixed-grid solve of the oracle and the taped one: the same arithmetic
+            a, b = fields.reshape(len(ts), 2, -1)[:, part][:, free], hist.detach()[:, part]
+            assert float((a - b).abs().max() / b.abs().max()) < 1e-10
+        np.savez_compressed(os.path.join(OUT, f"long_horizon_{lattice}.npz"), timepoints=ts, spi=spi, target=target, seed=seed, n=n,
+                            cutoff_deg=cut, fields=fields.numpy(), objective=obj.item(), contact_energy=contact,
+                            **{f"design_{i}": d for i, d in enumerate(c.design)}, **{f"grad_{i}": a.numpy() for i, a in enumerate(g)})
+        print(lattice, "objective", obj.item(), "contact energy", contact[0], "->", contact[-1], flush=True)
+
+
+def pulse_rs_script(n1_cells=20, n2_cells=10, name="pulse_rs"):
+    """scripts/pulse_RS.py as written, on the oracle: 20 x 10 cells of rotated squares (40 x 20 blocks) at 0.35 rad, nonlinear
+    ligaments (1, 0.33, 0.0075), no constraints, no damping, the sech^2 tanh force pulse on the second column of blocks, the reference's
+    default adaptive odeint (rtol = atol = 1e-8) over t = 0 .. n1_blocks; inertia from the geometry.  Kept: every 11th of the script's
+    100 output times (the controller's steps do not depend on the output times)."""
+    import time
+    from oracle import ref_energy as OE, ref_geometry as OG
+    g = OG.RotatedSquareGeometry(n1_cells, n2_cells, 1.0, 0.1)
+    ang = 0.35
+    cnv, cen = g.centroid_node_vectors(ang), g.block_centroids(ang)
+    inertia = OG.compute_inertia(cnv, 1.0)
+    energy = OE.build_strain_energy(g.bond_connectivity(), OE.ligament_energy)
+    loaded = np.array([[g.n1_blocks * i + 1, 0] for i in range(g.n2_blocks)])
+    amp, sharp = 0.3, 4.0
+
+    def loading(state, t):
+        tt = torch.as_tensor(t, dtype=torch.float64)
+        return 2 * amp / sharp ** 2 * torch.cosh(tt / sharp - 3) ** (-2) * torch.tanh(3 - tt / sharp)
+
+    solver = OD.setup_dynamic_solver(g, energy, loaded_block_DOF_pairs=loaded, loading_fn=loading, constrained_block_DOF_pairs=np.zeros((0, 2), dtype=np.int64))
+    cp = OE.ControlParams(OE.GeometricalParams(T64(cen), T64(cnv)),
+                          OE.MechanicalParams(OE.LigamentParams(T64(1.0), T64(0.33), T64(0.0075), T64(g.reference_bond_vectors())), T64(1.0), inertia, None, None))
+    ts = np.linspace(0.0, float(g.n1_blocks), 100)[::11]
+    t0 = time.time()
+    f = solver(np.zeros((2, g.n_blocks, 3)), ts, cp).numpy()
+    print(name, "oracle adaptive solve", time.time() - t0, "s", solver.stats, "max |q|", np.abs(f[:, 0]).max(), flush=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), timepoints=ts, fields=f, attempted=solver.stats["attempted"], accepted=solver.stats["accepted"],
+                        n1_cells=n1_cells, n2_cells=n2_cells, inertia=np.asarray(inertia))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "problems":
         problem_layer()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pulse_rs":
+        pulse_rs_script()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        long_horizon()
         sys.exit(0)
     rhs_cases()
     adaptive_trajectory()
     focusing_gradient()
     problem_layer()
+    long_horizon()
+    pulse_rs_script()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

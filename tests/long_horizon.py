@@ -1,0 +1,37 @@
+"""Long-horizon goldens (tests/golden/long_horizon_*.npz, made by make_golden.py long_horizon): 1200 / 800 Dopri5 steps of the torch
+oracle kept on the autograd tape -- trajectory at 9 output times, target kinetic energy and its design gradient -- against an engine
+library (the HIP engine in the -m gpu test, the C++ port in the CPU test: that pins the second checker to the oracle over a horizon
+the live oracle tests cannot afford)."""
+import os
+
+import numpy as np
+
+from .common import Case, relerr
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# stated tolerances: rounding differences between the engine's hand-derived forces (fused multiply-adds, its own summation order) and
+# torch's autograd grow ~100x per 400 steps of these contact-engaged trajectories (make_golden.py long_horizon has the measured growth)
+TOL_FIELDS, TOL_OBJECTIVE, TOL_GRAD = 1e-9, 1e-9, 1e-8
+
+
+def check(lib, lattice):
+    g = np.load(os.path.join(GOLD, f"long_horizon_{lattice}.npz"))
+    c = Case(lattice, int(g["n"]), True, True, seed=int(g["seed"]), lib=lib, cutoff_deg=float(g["cutoff_deg"]))
+    design = tuple(g[f"design_{i}"] for i in range(len(c.design)))
+    for a, b in zip(design, c.design):
+        assert np.array_equal(a, b)                    # the seeded case is the one the golden was made from
+    assert g["contact_energy"].min() > 0.0             # contact engaged at every output time
+    cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+    nb = c.geo.n_blocks
+    f = c.solver(np.zeros((2, nb, 3)), g["timepoints"], cp, keep_trajectory=True, steps_per_interval=int(g["spi"]))
+    assert c.solver.stats["steps"] == int(g["spi"]) * (len(g["timepoints"]) - 1)
+    out = dict(q=relerr(f[:, 0], g["fields"][:, 0]), v=relerr(f[:, 1], g["fields"][:, 1]))
+    obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(g["target"].astype(np.int32))
+    grads = c.geo.vjp(design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
+    out["objective"] = abs(obj - float(g["objective"])) / abs(float(g["objective"]))
+    out["grad"] = max(relerr(a, g[f"grad_{i}"]) for i, a in enumerate(grads))
+    assert out["q"] < TOL_FIELDS and out["v"] < TOL_FIELDS, out
+    assert out["objective"] < TOL_OBJECTIVE, out
+    assert out["grad"] < TOL_GRAD, out
+    return out

@@ -4,6 +4,7 @@ import os
 import numpy as np
 import pytest
 
+from . import long_horizon
 from .common import Case, relerr, tensile_solver
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +45,19 @@ def test_golden_focusing_gradient(hip_lib):
                        tree.geometrical_params.block_centroids)
     assert abs(obj - float(gold["objective"])) / float(gold["objective"]) < 1e-10
     assert relerr(gh, gold["grad_h"]) < 1e-9 and relerr(gv, gold["grad_v"]) < 1e-9
+
+
+@pytest.mark.parametrize("lattice", ["quads", "kagome"])
+def test_long_horizon_trajectory_and_gradient_against_the_oracle(hip_lib, lattice):
+    """1200 (quads 8x8) / 800 (kagome 4x4) steps with the contact engaged throughout: trajectory, objective and design gradient of the
+    HIP engine against the torch oracle's taped solve (tests/golden/long_horizon_*.npz)."""
+    long_horizon.check(None, lattice)
+
+
+def test_pulse_rs_script_as_written(hip_lib):
+    """scripts/pulse_RS.py: unconstrained 40 x 20 rotated squares, force pulse, the default adaptive call -- against the oracle's golden."""
+    from . import pulse_rs
+    pulse_rs.check(None)
 
 
 @pytest.mark.parametrize("n1_cells,strain,nonlinear", [(5, 0.2, False), (5, 0.6, True), (20, 0.4, True), (10, 0.6, False)])
