@@ -5,13 +5,17 @@ re-uses the engine handle: the counterpart of calling the jitted solver again).
     python examples/pulse_rotated_squares.py [--n1 20] [--n2 10] [--out solution.npz]
 """
 import argparse
+import os
+import sys
 import time
 
 import numpy as np
 
-import difflexmm_amd as dm
-from difflexmm_amd import energy, geometry, loading
-from difflexmm_amd.dynamics import setup_dynamic_solver
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import difflexmm_amd as dm  # noqa: E402
+from difflexmm_amd import energy, geometry, loading  # noqa: E402
+from difflexmm_amd.dynamics import setup_dynamic_solver  # noqa: E402
 
 
 def main():
