@@ -41,7 +41,8 @@ class Case:
     """A lattice + BCs + parameters, materialised for the engine (NumPy) and for the oracle (torch)."""
 
     def __init__(self, lattice="quads", n=4, nonlinear=True, contact=False, damping=True, seed=0, lib=None,
-                 cutoff_deg=-10.0, min_deg=-15.0, batch=1, integrator="dopri5", per_bond_k=False, perturb=0.02, extra_bonds=None):
+                 cutoff_deg=-10.0, min_deg=-15.0, batch=1, integrator="dopri5", per_bond_k=False, perturb=0.02, extra_bonds=None,
+                 scramble=None):
         rng = np.random.default_rng(seed)
         self.rng = rng
         if lattice == "quads":
@@ -69,6 +70,25 @@ class Case:
         self.cnv = self.geo.centroid_node_vectors(*self.design)
         self.cen = self.geo.block_centroids(*self.design)
         self.refv = self.geo.reference_bond_vectors()
+        if scramble is not None:
+            # an arbitrary bond list out of the lattice's (jax_md.smap.bond takes any, energy.py:179-197): a quarter of the ligaments
+            # removed, the rest in random order, half of them with their ends swapped (reference vector negated: the same ligament
+            # seen from its other end), plus three ligaments between random nodes of different blocks
+            srng = np.random.default_rng(scramble)
+            refv = np.broadcast_to(self.refv, (len(self.bonds), 2)).copy()
+            keep = srng.permutation(len(self.bonds))[: (3 * len(self.bonds)) // 4]
+            bonds, refv = self.bonds[keep].copy(), refv[keep]
+            flip = srng.random(len(bonds)) < 0.5
+            bonds[flip] = bonds[flip][:, ::-1]
+            refv[flip] = -refv[flip]
+            self.bonds, self.refv = bonds, refv
+            npb = self.geo.n_npb
+            extra = []
+            while len(extra) < 3:
+                a, b = srng.integers(0, self.geo.n_blocks * npb, 2)
+                if a // npb != b // npb:
+                    extra.append([a, b])
+            extra_bonds = np.array(extra) if extra_bonds is None else np.concatenate([np.asarray(extra_bonds).reshape(-1, 2), extra])
         if extra_bonds is not None:
             # ligaments the lattice generators never produce: a second (third) one on nodes that already carry one
             # (jax_md.smap.bond takes any bond list, energy.py:179-197); reference vector = the undeformed node-to-node vector

@@ -18,9 +18,10 @@ def T64(x, grad=False):
 
 
 def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=True, scale_th=0.15, rtol=None, cutoff_deg=None,
-                      extra_bonds=None):
+                      extra_bonds=None, scramble=None):
     cut = cutoff_deg if cutoff_deg is not None else (125.0 if lattice == "kagome" else 42.0)
-    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, per_bond_k=per_bond_k, extra_bonds=extra_bonds)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, per_bond_k=per_bond_k, extra_bonds=extra_bonds,
+             scramble=scramble)
     s = c.solver
     flat = s._flatten(c.cp)
     s.engine.set_params(**{k: v[None] for k, v in flat.items()})
@@ -69,9 +70,10 @@ def check_rhs_and_vjp(lib, lattice, n, nonlinear, contact, seed=3, per_bond_k=Tr
 
 
 def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, contact=True, seed=5, spi=6, n_out=5, batch=1,
-                                 own_step_times=False, extra_bonds=None):
+                                 own_step_times=False, extra_bonds=None, scramble=None):
     cut = (125.0 if lattice == "kagome" else 42.0)
-    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, integrator=integrator, extra_bonds=extra_bonds)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, integrator=integrator, extra_bonds=extra_bonds,
+             scramble=scramble)
     fast = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)   # a full pulse inside the short window
     c.cp = c.cp._replace(constraint_params=fast)
     ts = np.linspace(0, 3e-4, n_out)

@@ -4,6 +4,7 @@ in a per-lane loop (Plan::ovf_*).  Quads with three kinds of extra ligaments -- 
 whose FIRST ligament is an extra one of its partner, and an extra ligament between two nodes that both already carry one -- against
 the torch oracle: one RHS + every VJP, then a short trajectory + discrete adjoint.  CPU port here, HIP engine in test_gpu_general_bonds."""
 import numpy as np
+import pytest
 
 from . import parity
 
@@ -21,6 +22,22 @@ def check_rhs(lib, contact):
 
 def check_trajectory(lib):
     parity.check_trajectory_and_adjoint(lib, "quads", 4, "dopri5", contact=True, extra_bonds=EXTRA, spi=6, n_out=4)
+
+
+SCRAMBLED = [("quads", 5, 80.0, 1), ("quads", 5, 80.0, 2), ("kagome", 3, 150.0, 3)]
+
+
+def check_scrambled(lib, lattice, n, cut, sc):
+    """An arbitrary bond list made from the lattice's: a quarter of the ligaments removed, random order, half of them with swapped ends
+    (reference vector negated), three ligaments between random nodes (tests/common.py Case(scramble=...)); contact engaged."""
+    for contact in (False, True):
+        parity.check_rhs_and_vjp(lib, lattice, n, True, contact, seed=10 + sc, scramble=sc, cutoff_deg=cut, rtol=1e-11)
+    parity.check_trajectory_and_adjoint(lib, lattice, n, "dopri5", contact=True, scramble=sc, spi=6, n_out=4)
+
+
+@pytest.mark.parametrize("lattice,n,cut,sc", SCRAMBLED)
+def test_scrambled_bond_lists_cpu_port(cpu_lib, lattice, n, cut, sc):
+    check_scrambled(cpu_lib, lattice, n, cut, sc)
 
 
 def test_extra_ligaments_rhs_and_vjp_cpu_port(cpu_lib):

@@ -7,6 +7,11 @@ from . import test_general_bonds as G
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("lattice,n,cut,sc", G.SCRAMBLED)
+def test_scrambled_bond_lists_hip(hip_lib, lattice, n, cut, sc):
+    G.check_scrambled(None, lattice, n, cut, sc)
+
+
 def test_extra_ligaments_rhs_and_vjp_hip(hip_lib):
     G.check_rhs(None, False)
     G.check_rhs(None, True)
