@@ -7,6 +7,6 @@ library raises ``RuntimeError``.
 """
 __version__ = "0.1.0"
 
-from .dynamics import setup_dynamic_solver  # noqa: F401
-from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentParams,  # noqa: F401
-                    MechanicalParams, SolutionData, StretchingTorsionalSpringParams)
+from .dynamics import linear_mode_analysis, setup_dynamic_solver  # noqa: F401
+from .utils import (ContactParams, ControlParams, EigenmodeData, GeometricalParams, LigamentParams,  # noqa: F401
+                    MagneticParams, MechanicalParams, SolutionData, StretchingTorsionalSpringParams)

@@ -371,3 +371,43 @@ def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loadi
     """Same positional/keyword arguments as ``difflexmm.dynamics.setup_dynamic_solver`` (dynamics.py:60-69)."""
     return DynamicSolver(geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
                          constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, _lib, streams)
+
+
+def linear_mode_analysis(displacement, geometry, energy_fn, control_params: ControlParams,
+                         constrained_block_DOF_pairs=np.array([]), *, device: int = 0, _lib=None, return_stiffness=False):
+    """Eigenvalues (squared angular frequencies) and eigenmodes of ``K q = w^2 M q`` around ``displacement`` -- same arguments and
+    results as ``difflexmm.dynamics.linear_mode_analysis`` (dynamics.py:189-245): ``(eigenvalues (n_free,), modes (n_free, n_blocks, 3))``,
+    every mode scaled to unit Euclidean norm, constrained DOFs zero.
+
+    The reference takes ``jax.hessian`` of the constrained energy; here the stiffness matrix is assembled on the device from the
+    engine's Hessian-vector hook (``dfx_rhs_vjp``): with no damping and no loading the acceleration is ``a = -M^-1 grad E``, so the
+    cotangent ``e_j`` on acceleration ``j`` returns ``-K[j, :] / m_j`` in the position part -- ``batch`` rows per call.  The dense
+    generalised eigenproblem then goes to ``scipy.linalg.eigh`` on the host, as in the reference."""
+    import scipy.linalg
+    pairs = np.asarray(constrained_block_DOF_pairs, dtype=np.int64).reshape(-1, 2)
+    n = geometry.n_blocks
+    free, _, _ = DOFsInfo(n, pairs)
+    nf = len(free)
+    B = int(min(64, max(nf, 1)))
+    solver = setup_dynamic_solver(geometry, energy_fn, constrained_block_DOF_pairs=pairs, batch=B, device=device, _lib=_lib)
+    flat = solver._flatten(control_params)
+    solver.engine.set_params(**{k: np.broadcast_to(v, (B,) + np.shape(v)).copy() for k, v in flat.items()})
+    inertia = np.asarray(flat["inertia"], dtype=float).reshape(-1)
+    u = np.asarray(displacement, dtype=float).reshape(n, 3)
+    y = np.zeros((B, 2, n, 3))
+    y[:, 0] = u
+    y[:, 0].reshape(B, -1)[:, solver.constrained_DOF_ids] = 0.0          # the constrained kinematics hold them at c(0) = 0
+    K = np.zeros((nf, nf))
+    for j0 in range(0, nf, B):
+        rows = free[j0:j0 + B]
+        lam = np.zeros((B, 2, n, 3))
+        lam[:, 1].reshape(B, -1)[np.arange(len(rows)), rows] = 1.0
+        y_bar, _ = solver.engine.rhs_vjp(y, 0.0, lam, which=())
+        K[j0:j0 + len(rows)] = -inertia[rows, None] * y_bar[:len(rows), 0].reshape(len(rows), -1)[:, free]
+    K = 0.5 * (K + K.T)
+    eigenvalues, vectors = scipy.linalg.eigh(K, np.diag(inertia[free]))
+    vectors = (vectors / np.linalg.norm(vectors, axis=0)).T                # row-wise, unit norm
+    modes = np.zeros((nf, n * 3))
+    modes[:, free] = vectors
+    out = (eigenvalues, modes.reshape(nf, n, 3))
+    return out + (K,) if return_stiffness else out

@@ -16,6 +16,14 @@ class SolutionData(NamedTuple):
     fields: Any
 
 
+class EigenmodeData(NamedTuple):
+    """utils.py:28-45: what ``linear_mode_analysis`` results are stored as (eigenvalues (n_modes,), fields (n_modes, 2, n_blocks, 3))."""
+    block_centroids: Any
+    centroid_node_vectors: Any
+    eigenvalues: Any
+    fields: Any
+
+
 class GeometricalParams(NamedTuple):
     """utils.py:48-59."""
     block_centroids: Any
@@ -46,6 +54,12 @@ class ContactParams(NamedTuple):
     k_contact: Any
 
 
+class MagneticParams(NamedTuple):
+    """utils.py:114-125 (the reference defines the container; no energy of its ``energy.py`` reads it)."""
+    dipole_angles: Any
+    dipole_strengths: Any
+
+
 class MechanicalParams(NamedTuple):
     """utils.py:128-142."""
     bond_params: BondParams
@@ -59,7 +73,7 @@ class ControlParams(NamedTuple):
     """utils.py:145-163."""
     geometrical_params: GeometricalParams
     mechanical_params: MechanicalParams
-    magnetic_params: Optional[Any] = None
+    magnetic_params: Optional[MagneticParams] = None
     loading_params: Dict = dict()
     constraint_params: Dict = dict()
 
@@ -77,8 +91,8 @@ def load_data(path_or_filename: Union[str, Path]):
     """utils.py:183-201."""
     with open(path_or_filename, "rb") as file:
         data = pickle.load(file)
-    if isinstance(data, SolutionData):
-        return SolutionData(*(np.asarray(a) if isinstance(a, np.ndarray) else a for a in data))
+    if isinstance(data, (SolutionData, EigenmodeData)):
+        return type(data)(*(np.asarray(a) if isinstance(a, np.ndarray) else a for a in data))
     return data
 
 

@@ -208,3 +208,26 @@ def solve_fixed_differentiable(solver, geometry, state0, timepoints, control_par
                 y = y + h / 6.0 * (k1_ + 2 * k2 + 2 * k3 + k4)
         out.append(y)
     return torch.stack(out), inertia
+
+
+def linear_mode_analysis(displacement, geometry, energy_fn, control_params, constrained_block_DOF_pairs=()):
+    """dynamics.py:189-245: eigenvalues / eigenmodes of K q = w^2 M q around ``displacement``; K = Hessian of the constrained energy
+    w.r.t. the free DOFs (autograd, where the reference calls ``jax.hessian``), generalised problem by ``scipy.linalg.eigh`` as in the
+    reference, eigenvectors scaled to unit norm and scattered row-wise into (n_free, n_blocks, 3).  Also returns K."""
+    import scipy.linalg
+    kinematics = build_constrained_kinematics(geometry, constrained_block_DOF_pairs)
+    constrained_energy = constrain_energy(energy_fn, kinematics)
+    free_ids, _, all_ids = DOFsInfo(geometry.n_blocks, constrained_block_DOF_pairs)
+    free_t = torch.as_tensor(free_ids, dtype=torch.long)
+    u = _t(displacement).reshape(-1)[free_t]
+    mp = control_params.mechanical_params
+    if mp.inertia is None:
+        inertia = compute_inertia(control_params.geometrical_params.centroid_node_vectors, mp.density).reshape(-1)[free_t]
+    else:
+        inertia = _t(mp.inertia).reshape(-1)[free_t]
+    K = torch.autograd.functional.hessian(lambda q: constrained_energy(q, 0.0, control_params), u).detach().numpy()
+    w2, vec = scipy.linalg.eigh(K, np.diag(inertia.detach().numpy()))
+    vec = (vec / np.linalg.norm(vec, axis=0)).T
+    modes = np.zeros((len(free_ids), len(all_ids)))
+    modes[:, np.asarray(free_ids)] = vec
+    return w2, modes.reshape(len(free_ids), geometry.n_blocks, 3), K

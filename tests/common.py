@@ -110,6 +110,7 @@ class Case:
         energy = en_mod.build_strain_energy(self.bonds, efn)
         if contact:
             energy = en_mod.combine_block_energies(energy, en_mod.build_contact_energy(self.bonds))
+        self.energy = energy
         self.solver = setup_dynamic_solver(self.geo, energy, constrained_block_DOF_pairs=self.con,
                                            constrained_DOFs_fn=ld.Pulse(self.vec), damped_blocks=self.damped,
                                            integrator=integrator, batch=batch, _lib=lib)
