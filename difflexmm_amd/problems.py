@@ -207,6 +207,68 @@ class QuadsFocusingForward:
         return sols if many else sols[0]
 
 
+@dataclass
+class RotatedSquaresForward(QuadsFocusingForward):
+    """``problems/reference_design.py:ForwardProblem``: the regular rotated-squares domain (``RotatedSquareGeometry`` of
+    n1_blocks/2 x n2_blocks/2 cells at ``initial_angle``) with the boundary conditions and the pulse of the focusing problems -- the
+    design the optimised lattices are compared with.  ``solve()`` takes no design; ``setup(excited_blocks_fn=...)`` replaces the
+    synthetic pulse by a recorded signal (a ``loading.Table``, the reference's ``excited_blocks_fn(t)``, reference_design.py:206-216)."""
+    initial_angle: Any = None
+    name: str = "rotated_squares"
+
+    def setup(self, excited_blocks_fn=None):
+        from .geometry import RotatedSquareGeometry
+        if self.initial_angle is None:
+            raise ValueError("RotatedSquaresForward needs initial_angle")
+        g = self.geometry = RotatedSquareGeometry(self.n1_blocks // 2, self.n2_blocks // 2, self.spacing, self.bond_length)
+        self.bond_connectivity = g.bond_connectivity()
+        self.reference_bond_vectors = g.reference_bond_vectors()
+        pairs, vec, self.driven_blocks_ids, self.clamped_blocks_ids = quads_focusing_constraints(
+            g, self.n_excited_blocks, self.loaded_side, self.input_shift, self.n_blocks_clamped_corner)
+        self.constrained_block_DOF_pairs = pairs
+        self.moving_blocks_ids = np.setdiff1d(np.arange(g.n_blocks), self.clamped_blocks_ids)
+        strain = E.build_strain_energy(self.bond_connectivity,
+                                       E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
+        energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
+        if excited_blocks_fn is None:
+            drive = self._drive_cls(vec)
+        else:
+            if not isinstance(excited_blocks_fn, L.Table):
+                raise TypeError("excited_blocks_fn must be a difflexmm_amd.loading.Table (a recorded signal the device can interpolate)")
+            drive = L.Table(excited_blocks_fn.times, excited_blocks_fn.values, vector=vec)
+        self._recorded = excited_blocks_fn is not None
+        self.solve_dynamics = setup_dynamic_solver(
+            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=drive,
+            damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
+        self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
+        self.state0 = np.zeros((2, g.n_blocks, 3))
+        self.signed_amplitude = self.amplitude if self.loaded_side in ("left", "bottom") else -self.amplitude
+        self.is_setup = True
+
+    def control_params(self, design=None):
+        g = self.geometry
+        return ControlParams(
+            geometrical_params=GeometricalParams(block_centroids=g.block_centroids(self.initial_angle),
+                                                 centroid_node_vectors=g.centroid_node_vectors(self.initial_angle)),
+            mechanical_params=MechanicalParams(
+                bond_params=LigamentParams(self.k_stretch, self.k_shear, self.k_rot, self.reference_bond_vectors),
+                density=self.density, damping=self.damping,
+                contact_params=ContactParams(min_angle=self.min_angle, cutoff_angle=self.cutoff_angle, k_contact=self.k_contact)),
+            constraint_params=dict(amplitude=1.0, delay=0.0) if self._recorded else
+            dict(amplitude=self.signed_amplitude, loading_rate=self.loading_rate, input_delay=self.input_delay))
+
+    def solve(self, design=None, keep_trajectory=False, want_fields=True):
+        cp = self.control_params()
+        fields = self.solve_dynamics(self.state0, self.timepoints, cp, keep_trajectory=keep_trajectory, want_fields=want_fields)
+        if fields is None:
+            return None
+        sol = SolutionData(cp.geometrical_params.block_centroids, cp.geometrical_params.centroid_node_vectors, self.bond_connectivity,
+                           self.timepoints, fields)
+        self._last_solutions, self._last_solve_id, self.solution_data = [sol], self.solve_dynamics.solve_count, sol
+        return sol
+
+
 def _compute_response_data(self, solution_data=None):
     """Strain-energy and kinetic-energy histories of a solution (problems/quads_focusing.py:319-372): the fields of
     SolutionData plus strain_energy_{stretch,shear,bending} (T, n_bonds) and kinetic_energy (T, n_blocks).
@@ -650,6 +712,50 @@ class TargetKineticEnergy:
         return (obj, grads) if many else (float(obj[0]), grads[0])
 
 
+class SplitTargetKineticEnergy:
+    """objective(design) = weights @ [kinetic energy of every target region] for ONE forward problem -- the energy of a single input
+    split between several targets (problems/quads_energy_splitting.py:14-88).  One forward solve and ONE reverse sweep: the cotangent
+    of the weighted sum goes through ``solve_dynamics.vjp`` (w_k m v on the velocities of target k), the explicit dependence on the
+    inertia of the target blocks (w_k sum_t v^2 / 2) is added here."""
+
+    def __init__(self, forward, target_sizes, target_shifts, weights):
+        self.forward = forward
+        if not getattr(forward, "is_setup", False):
+            forward.setup()
+        pick = kagome_target_blocks if isinstance(forward.geometry, KagomeGeometry) else quads_target_blocks
+        self.target_sizes, self.target_shifts = tuple(map(tuple, target_sizes)), tuple(map(tuple, target_shifts))
+        if len(self.target_sizes) != len(self.target_shifts) or len(weights) != len(self.target_sizes):
+            raise ValueError("target_sizes, target_shifts and weights must have the same length")
+        self.weights = np.asarray(weights, dtype=float)
+        self.target_blocks_list = [pick(forward.geometry, ts, sh) for ts, sh in zip(self.target_sizes, self.target_shifts)]
+
+    def _individual(self, sol):
+        inertia = compute_inertia(sol.centroid_node_vectors, self.forward.density)
+        return np.array([E.kinetic_energy(sol.fields[:, 1, tb, :], inertia[tb]) for tb in self.target_blocks_list]), inertia
+
+    def individual(self, design):
+        """quads_energy_splitting.py:66-83 (``objective_fn_individual``)."""
+        return self._individual(self.forward.solve(design))[0]
+
+    def value(self, design):
+        return float(self.weights @ self.individual(design))
+
+    def value_and_grad(self, design):
+        fw = self.forward
+        sol = fw.solve(design, keep_trajectory=True)
+        vals, inertia = self._individual(sol)
+        self.last_individual = vals
+        fb = np.zeros_like(sol.fields)
+        raw_m = np.zeros((fw.geometry.n_blocks, 3))
+        for w, tb in zip(self.weights, self.target_blocks_list):
+            v = sol.fields[:, 1, tb, :]
+            fb[:, 1, tb, :] += w * inertia[tb] * v            # (overlapping targets add up)
+            np.add.at(raw_m, tb, w * 0.5 * (v ** 2).sum(0))
+        raw = {k: np.array(v, dtype=float) for k, v in fw.solve_dynamics.vjp_raw(fb).items()}
+        raw["inertia"][0] += raw_m
+        return float(self.weights @ vals), design_gradients(fw, [design], raw)[0]
+
+
 class TargetAngularMomentum:
     """objective(design) = sum_t sum_{b in target} [ (c_b + u_b - p) x (m v_b) + J omega_b ]: angular momentum of the
     target blocks about ``spin_center`` summed over the output times (problems/quads_spin.py:380-430 with
@@ -869,11 +975,35 @@ def run_ensemble_optimization(objective, initial_guesses, n_iterations, lower_bo
 
 # -- geometric constraints of the optimisation (problems/quads_focusing.py:473-544) ------------------------------------
 
-def angle_constraints(geometry, design, min_void_angle=0., min_block_angle=0.):
-    """<= 0 when satisfied: -(angle mod 2pi - min) for the two void and the two block angles of every bond."""
+def quads_boundary_nodes(geometry):
+    """Nodes of the rim blocks that face outwards and carry no ligament (problems/quads_focusing.py:477-489): bottom edge (node 3),
+    right edge (node 0), top edge (node 1, right to left), left edge (node 2)."""
+    n1, nb = geometry.n1_blocks, geometry.n_blocks
+    return np.concatenate([np.arange(n1) * 4 + 3, np.arange(n1 - 1, nb, n1) * 4 + 0, np.arange(nb - 1, nb - n1 - 1, -1) * 4 + 1,
+                           np.arange(0, nb, n1) * 4 + 2])
+
+
+def _boundary_edges(geometry, ref):
+    """Block, node, next and previous node, and the two edge vectors at the boundary nodes (geometry.py:181-202)."""
+    nodes = quads_boundary_nodes(geometry)
+    n = geometry.n_npb
+    b, l = nodes // n, nodes % n
+    nx, pv = (l + 1) % n, (l - 1) % n
+    return b, l, nx, pv, ref[b, nx] - ref[b, l], ref[b, pv] - ref[b, l]
+
+
+def angle_constraints(geometry, design, min_void_angle=0., min_block_angle=0., boundary_angle_constraint=False):
+    """<= 0 when satisfied: -(angle mod 2pi - min) for the two void and the two block angles of every bond; with
+    ``boundary_angle_constraint`` also for the block angle at every boundary node (problems/quads_focusing.py:473-532)."""
     from .geometry import compute_edge_angles
-    a = np.mod(np.stack(compute_edge_angles(geometry.centroid_node_vectors(*design), geometry.bond_connectivity())), 2 * np.pi)
-    return np.concatenate([-(a[0] - min_void_angle), -(a[1] - min_void_angle), -(a[2] - min_block_angle), -(a[3] - min_block_angle)])
+    cnv = geometry.centroid_node_vectors(*design)
+    a = np.mod(np.stack(compute_edge_angles(cnv, geometry.bond_connectivity())), 2 * np.pi)
+    out = [-(a[0] - min_void_angle), -(a[1] - min_void_angle), -(a[2] - min_block_angle), -(a[3] - min_block_angle)]
+    if boundary_angle_constraint:
+        _, _, _, _, e_next, e_prev = _boundary_edges(geometry, cnv)
+        ang = np.arctan2(e_next[:, 0] * e_prev[:, 1] - e_next[:, 1] * e_prev[:, 0], (e_next * e_prev).sum(1))
+        out.append(-(np.mod(ang, 2 * np.pi) - min_block_angle))
+    return np.concatenate(out)
 
 
 def edge_length_constraints(geometry, design, min_edge_length):
@@ -916,9 +1046,9 @@ def _angle_rows(rows, cols, vals, row0, imap, bu, iu, lu, u, bw, iw, lw, w, sign
             rows.append(r); cols.append(imap[blk, node, c]); vals.append(d[:, c])
 
 
-def angle_constraints_jac(geometry, design):
-    """Sparse Jacobian (4 n_bonds, n_design) of :func:`angle_constraints` (the reference takes ``jax.jacobian`` of it,
-    problems/quads_focusing.py:586-587).  Edge vectors are differences of node vectors of one block, so the centroid
+def angle_constraints_jac(geometry, design, boundary_angle_constraint=False):
+    """Sparse Jacobian (4 n_bonds [+ n_boundary_nodes], n_design) of :func:`angle_constraints` (the reference takes ``jax.jacobian``
+    of it, problems/quads_focusing.py:586-587).  Edge vectors are differences of node vectors of one block, so the centroid
     shift cancels and the reference node vectors can be differentiated directly."""
     import scipy.sparse as sp
     ref = geometry.reference_node_vectors(*design)
@@ -937,8 +1067,13 @@ def angle_constraints_jac(geometry, design):
     _angle_rows(rows, cols, vals, 1 * nb, imap, b1, p1, l1, e1m, b2, n2, l2, e2p, -1.0)
     _angle_rows(rows, cols, vals, 2 * nb, imap, b1, n1, l1, e1p, b1, p1, l1, e1m, -1.0)
     _angle_rows(rows, cols, vals, 3 * nb, imap, b2, n2, l2, e2p, b2, p2, l2, e2m, -1.0)
+    n_rows = 4 * nb
+    if boundary_angle_constraint:
+        bb, bl, bnx, bpv, e_next, e_prev = _boundary_edges(geometry, ref)
+        _angle_rows(rows, cols, vals, n_rows, imap, bb, bnx, bl, e_next, bb, bpv, bl, e_prev, -1.0)
+        n_rows += len(bb)
     n_design = int(sum(np.prod(sh) for sh in geometry.design_shapes()))
-    return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(4 * nb, n_design)).tocsr()
+    return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n_rows, n_design)).tocsr()
 
 
 def edge_length_constraints_jac(geometry, design):
@@ -959,6 +1094,42 @@ def edge_length_constraints_jac(geometry, design):
     return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nbk * npb, n_design)).tocsr()
 
 
+class RestrictedDesignSpace:
+    """Only the shifts inside a window of ``design_patch_size`` blocks centred on the target are design variables, the others stay at
+    ``initial_guess_all`` (problems/quads_focusing_restricted_space.py:417-469): the masks, ``all_to_reduced_shifts`` and
+    ``reduced_to_all_shifts`` of the reference, plus what an optimiser on the reduced vector needs -- the positions of the reduced
+    variables in the flattened full design (gradient entries / Jacobian columns to keep)."""
+
+    def __init__(self, n1_blocks, n2_blocks, initial_guess_all, target_shift, design_patch_size=None):
+        self.initial_guess_all = tuple(np.array(a, dtype=float) for a in initial_guess_all)
+        patch = design_patch_size if design_patch_size is not None else max(n1_blocks, n2_blocks)
+        self.design_patch_size = patch
+        x0 = int(np.clip((n1_blocks - patch) // 2 + target_shift[0], 0, n1_blocks))
+        x1 = int(np.clip((n1_blocks + patch) // 2 + target_shift[0], 0, n1_blocks))
+        y0 = int(np.clip((n2_blocks - patch) // 2 + target_shift[1], 0, n2_blocks))
+        y1 = int(np.clip((n2_blocks + patch) // 2 + target_shift[1], 0, n2_blocks))
+        self.horizontal_shifts_mask = np.full(self.initial_guess_all[0].shape, False)
+        self.horizontal_shifts_mask[x0:x1 + 1, y0:y1] = True
+        self.vertical_shifts_mask = np.full(self.initial_guess_all[1].shape, False)
+        self.vertical_shifts_mask[x0:x1, y0:y1 + 1] = True
+        self.columns = np.flatnonzero(np.concatenate([self.horizontal_shifts_mask.ravel(), self.vertical_shifts_mask.ravel()]))
+        self.sizes = (int(self.horizontal_shifts_mask.sum()), int(self.vertical_shifts_mask.sum()))
+
+    def all_to_reduced_shifts(self, all_shifts):
+        horizontal_shifts, vertical_shifts = all_shifts
+        return np.asarray(horizontal_shifts)[self.horizontal_shifts_mask], np.asarray(vertical_shifts)[self.vertical_shifts_mask]
+
+    def reduced_to_all_shifts(self, reduced_shifts):
+        horizontal_shifts, vertical_shifts = (a.copy() for a in self.initial_guess_all)
+        horizontal_shifts[self.horizontal_shifts_mask] = reduced_shifts[0]
+        vertical_shifts[self.vertical_shifts_mask] = reduced_shifts[1]
+        return horizontal_shifts, vertical_shifts
+
+    def unflatten(self, x):
+        x = np.asarray(x, dtype=float)
+        return x[:self.sizes[0]], x[self.sizes[0]:]
+
+
 @dataclass
 class OptimizationProblem:
     """Inverse design loop with the bookkeeping of the reference's ``OptimizationProblem``
@@ -971,11 +1142,28 @@ class OptimizationProblem:
     design_values: Optional[list] = None
     constraints_violation: Optional[dict] = None
     name: str = "quads_focusing"
+    # restricted design space (problems/quads_focusing_restricted_space.py:417-420): with ``initial_guess_all`` given, the loop of
+    # ``run_optimization_nlopt`` runs on the reduced shifts (its ``initial_guess`` and ``design_values`` are reduced shifts, as in
+    # the reference) and everything outside the patch stays at ``initial_guess_all``
+    initial_guess_all: Optional[tuple] = None
+    design_patch_size: Optional[int] = None
 
     def __post_init__(self):
         self.objective_values = [] if self.objective_values is None else self.objective_values
         self.design_values = [] if self.design_values is None else self.design_values
         self.constraints_violation = {"angles": [], "edge_lengths": []} if self.constraints_violation is None else self.constraints_violation
+        self.space = None
+        if self.initial_guess_all is not None:
+            g = self.objective.forward.geometry
+            self.space = RestrictedDesignSpace(g.n1_blocks, g.n2_blocks, self.initial_guess_all, self.objective.target_shift,
+                                               self.design_patch_size)
+            self.design_patch_size = self.space.design_patch_size
+
+    def all_to_reduced_shifts(self, all_shifts):
+        return self.space.all_to_reduced_shifts(all_shifts)
+
+    def reduced_to_all_shifts(self, reduced_shifts):
+        return self.space.reduced_to_all_shifts(reduced_shifts)
 
     def violation(self, design, min_void_angle, min_block_angle, min_edge_length):
         g = self.objective.forward.geometry
@@ -1017,7 +1205,8 @@ class OptimizationProblem:
         return x
 
     def run_optimization_nlopt(self, initial_guess, n_iterations, max_time=None, lower_bound=None, upper_bound=None,
-                               min_void_angle=None, min_block_angle=None, min_edge_length=None, verbose=True):
+                               min_void_angle=None, min_block_angle=None, min_edge_length=None, boundary_angle_constraint=False,
+                               verbose=True):
         """The reference's loop (problems/quads_focusing.py:546-652) with the same arguments and bookkeeping: maximise the
         objective with the method of moving asymptotes (``difflexmm_amd.optimize``, standing in for ``nlopt.LD_MMA``)
         under the angle and edge-length inequality constraints, ``n_iterations`` objective evaluations at most."""
@@ -1029,39 +1218,63 @@ class OptimizationProblem:
         class _TimeUp(Exception):
             pass
 
+        space = self.space
+        # optimisation vector -> (what the histories keep, the full design the solver gets); gradients / Jacobians back
+        if space is None:
+            def designs_of(x):
+                d = _unflatten_design(g, x)
+                return d, d
+            cols = None
+        else:
+            def designs_of(x):
+                r = space.unflatten(x)
+                return r, space.reduced_to_all_shifts(r)
+            cols = space.columns
+
         def fun(x):
             if max_time is not None and self.objective_values and time.perf_counter() - t0 > max_time:
                 raise _TimeUp
-            design = _unflatten_design(g, x)
+            kept, design = designs_of(x)
             v, grad = self.objective.value_and_grad(design)
             self.objective_values.append(float(v))
-            self.design_values.append(design)
+            self.design_values.append(kept)
             if verbose:
                 print(f"Iteration: {len(self.objective_values)}\nObjective = {self.objective_values[-1]}")
-            return float(v), _flatten_design(grad)
+            gflat = _flatten_design(grad)
+            return float(v), gflat if cols is None else gflat[cols]
+
+        def restrict(J):
+            return J if cols is None else J[:, cols]
 
         constraints = []
         if min_void_angle is not None and min_block_angle is not None:
             def ca(x):
-                r = angle_constraints(g, _unflatten_design(g, x), min_void_angle, min_block_angle)
+                r = angle_constraints(g, designs_of(x)[1], min_void_angle, min_block_angle, boundary_angle_constraint)
                 self.constraints_violation["angles"].append(float(r.max()))
                 return r
-            constraints.append((ca, lambda x: angle_constraints_jac(g, _unflatten_design(g, x))))
+            constraints.append((ca, lambda x: restrict(angle_constraints_jac(g, designs_of(x)[1], boundary_angle_constraint))))
         if min_edge_length is not None:
             def ce(x):
-                r = edge_length_constraints(g, _unflatten_design(g, x), min_edge_length)
+                r = edge_length_constraints(g, designs_of(x)[1], min_edge_length)
                 self.constraints_violation["edge_lengths"].append(float(r.max()))
                 return r
-            constraints.append((ce, lambda x: edge_length_constraints_jac(g, _unflatten_design(g, x))))
+            constraints.append((ce, lambda x: restrict(edge_length_constraints_jac(g, designs_of(x)[1]))))
         try:
             res = mma_maximize(fun, _flatten_design(initial_guess), lower=lower_bound, upper=upper_bound,
                                constraints=constraints, maxeval=n_iterations,
                                constraint_tol=1e-8)      # the reference passes 1e-8 per constraint to add_inequality_mconstraint
             self.mma_result = res
-            best = _unflatten_design(g, res.x)
+            best = designs_of(res.x)[0]
         except _TimeUp:
             best = self.design_values[int(np.argmax(self.objective_values))]
         return best
+
+    def compute_best_forward(self):
+        """problems/quads_focusing_restricted_space.py:649-660 (quads_focusing.py:654-664): forward solution of the last design."""
+        if len(self.design_values) == 0:
+            raise ValueError("No design has been optimized yet.")
+        last = self.design_values[-1]
+        return self.objective.forward.solve(self.space.reduced_to_all_shifts(last) if self.space is not None else last)
 
     def to_dict(self):
         """problems/quads_focusing.py:686-690 (multi-input: quads_focusing_multi_input.py:183-189): the forward problem(s) as
@@ -1070,6 +1283,9 @@ class OptimizationProblem:
         out = dict(name=self.name, target_size=getattr(obj, "target_size", None), target_shift=getattr(obj, "target_shift", None),
                    objective_values=list(self.objective_values), design_values=list(self.design_values),
                    constraints_violation={k: list(v) for k, v in self.constraints_violation.items()})
+        if self.space is not None:
+            out["initial_guess_all"] = tuple(np.array(a) for a in self.space.initial_guess_all)
+            out["design_patch_size"] = self.design_patch_size
         if hasattr(obj, "objectives"):
             out["forward_problems"] = [o.forward.to_dict() for o in obj.objectives]
             out["weights"] = [float(w) for w in obj.weights]
@@ -1094,4 +1310,5 @@ class OptimizationProblem:
         return OptimizationProblem(objective, objective_values=list(d.get("objective_values", [])),
                                    design_values=list(d.get("design_values", [])),
                                    constraints_violation={k: list(v) for k, v in d.get("constraints_violation", {"angles": [], "edge_lengths": []}).items()},
-                                   name=d.get("name", "quads_focusing"))
+                                   name=d.get("name", "quads_focusing"), initial_guess_all=d.get("initial_guess_all"),
+                                   design_patch_size=d.get("design_patch_size"))

@@ -155,6 +155,11 @@ class ForwardProblem:
         if lattice == "quads":
             self.geometry = OG.QuadGeometry(n1, n2, spacing, bond_length)
             bc = quads_constraints(n1, n2, n_excited_blocks, loaded_side, input_shift, n_blocks_clamped_corner)
+        elif lattice == "rotated_squares":
+            # problems/reference_design.py:75-80, 88-197: RotatedSquareGeometry of n1/2 x n2/2 cells, the design is the initial angle;
+            # driven / clamped DOF lists are the ones of quads_focusing.py written on the n1 x n2 block grid
+            self.geometry = OG.RotatedSquareGeometry(n1 // 2, n2 // 2, spacing, bond_length)
+            bc = quads_constraints(n1, n2, n_excited_blocks, loaded_side, input_shift, n_blocks_clamped_corner)
         else:
             basis = spacing * np.array([[1.0, 0.0], [math.cos(math.pi / 3), math.sin(math.pi / 3)]])   # kagome_focusing.py:83-88
             self.geometry = OG.KagomeGeometry(n1, n2, basis, bond_length)
@@ -205,6 +210,19 @@ def target_kinetic_energy(problem, design, target_blocks, steps_per_interval):
     vel = hist[:, 1][:, cols]                                            # (T, n_target, 3)
     inertia = OG.compute_inertia(problem.geometry.centroid_node_vectors(*design), _t(problem.p["density"]))[torch.as_tensor(target_blocks)]
     return OE.kinetic_energy(vel, inertia)
+
+
+def split_kinetic_energies(problem, design, target_blocks_list, steps_per_interval):
+    """problems/quads_energy_splitting.py:66-83: ONE forward solve, the kinetic energy of every target region (same expression as
+    target_kinetic_energy); the objective of :86-87 is ``weights @`` this vector."""
+    hist, solver = problem.velocity_history(design, steps_per_interval)
+    free = list(solver.free_DOF_ids)
+    inertia_all = OG.compute_inertia(problem.geometry.centroid_node_vectors(*design), _t(problem.p["density"]))
+    vals = []
+    for target_blocks in target_blocks_list:
+        cols = torch.as_tensor([[free.index(int(b) * 3 + d) for d in range(3)] for b in target_blocks], dtype=torch.long)
+        vals.append(OE.kinetic_energy(hist[:, 1][:, cols], inertia_all[torch.as_tensor(target_blocks)]))
+    return torch.stack(vals)
 
 
 def angular_momentum(block_position, block_velocity, inertia, reference_point):
@@ -348,3 +366,59 @@ def static_tuning_objective(problem, design, rows, target_blocks_list, weights, 
         vals.append(OE.kinetic_energy(vel, inertia))
     vals = torch.stack(vals)
     return (_t(weights) * vals).sum(), vals
+
+
+# ---- geometric constraints of the design loop and the restricted design space --------------------------------------------------------
+
+def quads_boundary_nodes(n1_blocks, n2_blocks):
+    """problems/quads_focusing.py:477-489: bottom edge (node 3), right edge (node 0), top edge (node 1, from the last block backwards),
+    left edge (node 2)."""
+    n_blocks = n1_blocks * n2_blocks
+    return np.concatenate([
+        np.arange(n1_blocks) * 4 + 3,
+        np.arange(n1_blocks - 1, n_blocks, n1_blocks) * 4 + 0,
+        np.arange(n_blocks - 1, n_blocks - n1_blocks - 1, -1) * 4 + 1,
+        np.arange(0, n_blocks, n1_blocks) * 4 + 2,
+    ])
+
+
+def angle_constraints(geometry, design, min_void_angle=0., min_block_angle=0., boundary_angle_constraint=False):
+    """problems/quads_focusing.py:473-532 (restricted_space / energy_splitting: the variant without the boundary rows): <= 0 when
+    satisfied, concatenation of -(void_1 - min_void), -(void_2 - min_void), -(block_1 - min_block), -(block_2 - min_block), every angle
+    taken mod 2 pi, [and -(boundary block angle - min_block)]."""
+    node_vectors = geometry.centroid_node_vectors(*design)
+    angles = [torch.remainder(a, 2 * math.pi) for a in OG.compute_edge_angles(node_vectors, geometry.bond_connectivity())]
+    out = [-(angles[0] - min_void_angle), -(angles[1] - min_void_angle), -(angles[2] - min_block_angle), -(angles[3] - min_block_angle)]
+    if boundary_angle_constraint:
+        u1, u2 = OG.compute_edge_unit_vectors(node_vectors, quads_boundary_nodes(geometry.n1_blocks, geometry.n2_blocks))
+        out.append(-(torch.remainder(OG.angle_between_unit_vectors(u1, u2), 2 * math.pi) - min_block_angle))
+    return torch.cat(out)
+
+
+def edge_length_constraints(geometry, design, min_edge_length):
+    """problems/quads_focusing.py:535-544."""
+    return -(OG.compute_edge_lengths(geometry.centroid_node_vectors(*design)).reshape(-1) - min_edge_length)
+
+
+def restricted_space_masks(n1_blocks, n2_blocks, shapes, target_shift, design_patch_size=None):
+    """problems/quads_focusing_restricted_space.py:435-455: boolean masks over the horizontal / vertical shift arrays of the window of
+    ``design_patch_size`` blocks centred on the target."""
+    patch = design_patch_size if design_patch_size is not None else max(n1_blocks, n2_blocks)
+    x_start = int(np.clip((n1_blocks - patch) // 2 + target_shift[0], 0, n1_blocks))
+    x_end = int(np.clip((n1_blocks + patch) // 2 + target_shift[0], 0, n1_blocks))
+    y_start = int(np.clip((n2_blocks - patch) // 2 + target_shift[1], 0, n2_blocks))
+    y_end = int(np.clip((n2_blocks + patch) // 2 + target_shift[1], 0, n2_blocks))
+    hm = np.full(shapes[0], False)
+    hm[x_start:x_end + 1, y_start:y_end] = True
+    vm = np.full(shapes[1], False)
+    vm[x_start:x_end, y_start:y_end + 1] = True
+    return hm, vm
+
+
+def reduced_to_all_shifts(reduced, initial_guess_all, masks):
+    """problems/quads_focusing_restricted_space.py:462-469 (differentiable in the reduced shifts)."""
+    out = []
+    for r, full, m in zip(reduced, initial_guess_all, masks):
+        a = _t(full).clone()
+        out.append(a.masked_scatter(torch.as_tensor(m), r))
+    return tuple(out)
