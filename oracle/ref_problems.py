@@ -422,3 +422,86 @@ def reduced_to_all_shifts(reduced, initial_guess_all, masks):
         a = _t(full).clone()
         out.append(a.masked_scatter(torch.as_tensor(m), r))
     return tuple(out)
+
+
+# ---- hinge characterisation (problems/hinge_characterization.py) -------------------------------------------------------------------------
+
+class HingeForward:
+    """``ForwardProblem`` (:18-279) / ``ForwardProblemQuads`` (:281-545) on the oracle: clamped top and bottom rows, the top row ramped to
+    ``amplitude`` in tension / compression / shear, damping scaled by (k_stretch, density) of the problem, response = sum of the elastic
+    forces dE/du over the driven top-row DOFs at every output time.  ``lattice``: "rotated_squares" (design = (initial_angle,)) or
+    "quads" (design = (horizontal_shifts, vertical_shifts))."""
+
+    def __init__(self, lattice, n1, n2, spacing, bond_length, design, k_stretch, density, damping, loading_type, amplitude, loading_rate,
+                 n_timepoints, linearized_strains=False, force_multiplier=1.0, use_contact=True, k_contact=1.0, min_angle=0.0,
+                 cutoff_angle=5 * math.pi / 180):
+        g = self.geometry = OG.RotatedSquareGeometry(n1, n2, spacing, bond_length) if lattice == "rotated_squares" else OG.QuadGeometry(n1, n2, spacing, bond_length)
+        design = tuple(_t(d) for d in design)
+        self.block_centroids, self.centroid_node_vectors = g.block_centroids(*design), g.centroid_node_vectors(*design)
+        self.bonds, self.reference_bond_vectors = g.bond_connectivity(), g.reference_bond_vectors()
+        k_ref, mass_ref = k_stretch, density * spacing ** 2                                                         # :85-93
+        damping_ref = np.array([(k_ref * mass_ref) ** 0.5, (k_ref * mass_ref) ** 0.5, (k_ref * mass_ref) ** 0.5 * spacing ** 2])
+        self.damping_values = damping * damping_ref * np.ones((g.n_blocks, 3))
+        constrained_blocks = np.concatenate([np.arange(g.n_blocks - g.n1_blocks, g.n_blocks), np.arange(g.n1_blocks)])   # top row, bottom row
+        pairs = np.stack([np.concatenate([constrained_blocks] * 3),
+                          np.concatenate([k * np.ones(len(constrained_blocks), dtype=np.int64) for k in (0, 1, 2)])], 1)
+        loading_vector = np.zeros(len(pairs))
+        if loading_type == "tension":
+            top_row = np.where(pairs[:, 1] == 1)[0][:g.n1_blocks]
+            loading_vector[top_row] = 1.0
+        elif loading_type == "compression":
+            top_row = np.where(pairs[:, 1] == 1)[0][:g.n1_blocks]
+            loading_vector[top_row] = -1.0
+        elif loading_type == "shear":
+            top_row = np.where(pairs[:, 1] == 0)[0][:g.n1_blocks]
+            loading_vector[top_row] = 1.0
+        else:
+            raise ValueError("Loading type should be either tension, compression, or shear!")
+        self.constrained_block_DOF_pairs, self.loading_vector = pairs, loading_vector
+        self.reaction_block_DOF_pairs = pairs[top_row]
+        vec = _t(loading_vector)
+
+        def applied_displacement(t, amplitude, loading_rate):                                                        # :134-135
+            t = torch.as_tensor(t, dtype=torch.float64)
+            return amplitude * torch.where(t < loading_rate ** -1, t * loading_rate, torch.ones_like(t))
+        self.applied_displacement = applied_displacement
+        strain = OE.build_strain_energy(self.bonds, OE.ligament_energy_linearized if linearized_strains else OE.ligament_energy)
+        self.potential_energy = OE.combine_block_energies(strain, OE.build_contact_energy(self.bonds)) if use_contact else strain
+        self.solver_args = dict(constrained_block_DOF_pairs=pairs,
+                                constrained_DOFs_fn=lambda t, amplitude, loading_rate: vec * applied_displacement(t, amplitude, loading_rate),
+                                damped_blocks=np.arange(g.n_blocks))
+        self.timepoints = np.linspace(0, loading_rate ** -1, n_timepoints)
+        self.state0 = np.zeros((2, g.n_blocks, 3))
+        self.p = dict(density=density, amplitude=amplitude, loading_rate=loading_rate, k_contact=k_contact, min_angle=min_angle,
+                      cutoff_angle=cutoff_angle, force_multiplier=force_multiplier)
+
+    def control_params(self, k_values):
+        p = self.p
+        return OE.ControlParams(
+            OE.GeometricalParams(self.block_centroids, self.centroid_node_vectors),
+            OE.MechanicalParams(OE.LigamentParams(k_values[0], k_values[1], k_values[2], _t(self.reference_bond_vectors)), _t(p["density"]),
+                                None, _t(self.damping_values), OE.ContactParams(_t(p["min_angle"]), _t(p["cutoff_angle"]), _t(p["k_contact"]))),
+            constraint_params=dict(amplitude=_t(p["amplitude"]), loading_rate=_t(p["loading_rate"])))
+
+    def force_displacement(self, k_values, steps_per_interval):
+        """:225-244 on the taped fixed-grid solve: (applied displacement (T,), reaction force history (T,) * force_multiplier)."""
+        cp = self.control_params(k_values)
+        solver = OD.setup_dynamic_solver(self.geometry, self.potential_energy, integrator="fixed", steps_per_interval=steps_per_interval,
+                                         **self.solver_args)
+        hist, _ = OD.solve_fixed_differentiable(solver, self.geometry, _t(self.state0), self.timepoints, cp, steps_per_interval)
+        rb, rd = self.reaction_block_DOF_pairs[:, 0], self.reaction_block_DOF_pairs[:, 1]
+        forces = []
+        for k, t in enumerate(self.timepoints):
+            u = solver.kinematics(hist[k, 0], float(t), cp.constraint_params)                      # all DOFs, prescribed ones included
+            if not u.requires_grad:
+                u = u.clone().requires_grad_(True)
+            f = torch.autograd.grad(self.potential_energy(u, cp), u, create_graph=True)[0]       # elastic_forces = grad(potential_energy)
+            forces.append(f[rb, rd].sum())
+        applied = self.applied_displacement(self.timepoints, cp.constraint_params["amplitude"], cp.constraint_params["loading_rate"])
+        return applied, torch.stack(forces) * self.p["force_multiplier"]
+
+
+def hinge_response_squared_error(problems, target_forces, k_values, steps_per_interval):
+    """:637-646: mean over tests and output times of (reaction force - target force)^2."""
+    forces = torch.stack([p.force_displacement(k_values, steps_per_interval)[1] for p in problems])
+    return ((forces - _t(target_forces)) ** 2).mean()
