@@ -117,6 +117,25 @@ def kagome_target_blocks(geometry: KagomeGeometry, target_size, target_shift):
                     dtype=np.int32).flatten()
 
 
+def _make_drive(self, vec, excited_blocks_fn):
+    """The synthetic pulse (harmonic signal for the spin problem) on the driven DOFs, or -- ``setup(excited_blocks_fn=...)`` of the
+    reference's forward problems, e.g. problems/quads_focusing.py:213-222: "user-defined loading, can be used to apply the experimental
+    loading" -- a recorded signal.  The reference takes any callable of t; on the device it is a ``loading.Table`` (piecewise linear,
+    end values held: how the notebooks build theirs with ``jnp.interp``)."""
+    self._recorded = excited_blocks_fn is not None
+    if excited_blocks_fn is None:
+        return self._drive_cls(vec)
+    if not isinstance(excited_blocks_fn, L.Table):
+        raise TypeError("excited_blocks_fn must be a difflexmm_amd.loading.Table (a recorded signal the device can interpolate)")
+    return L.Table(excited_blocks_fn.times, excited_blocks_fn.values, vector=vec)
+
+
+def _drive_params(self):
+    if getattr(self, "_recorded", False):
+        return dict(amplitude=1.0, delay=0.0)
+    return dict(amplitude=self.signed_amplitude, loading_rate=self.loading_rate, input_delay=self.input_delay)
+
+
 @dataclass
 class QuadsFocusingForward:
     """NumPy counterpart of ``problems/quads_focusing.py:ForwardProblem`` (fields with the same names)."""
@@ -157,7 +176,7 @@ class QuadsFocusingForward:
         self._lib = _lib
     _drive_cls = L.Pulse          # problems/quads_focusing.py:211-222
 
-    def setup(self):
+    def setup(self, excited_blocks_fn=None):
         g = self.geometry = QuadGeometry(self.n1_blocks, self.n2_blocks, self.spacing, self.bond_length)
         self.bond_connectivity = g.bond_connectivity()
         self.reference_bond_vectors = g.reference_bond_vectors()
@@ -169,7 +188,7 @@ class QuadsFocusingForward:
                                        E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
         energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
         self.solve_dynamics = setup_dynamic_solver(
-            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=self._drive_cls(vec),
+            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
             damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
             steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
@@ -185,7 +204,7 @@ class QuadsFocusingForward:
                 bond_params=LigamentParams(self.k_stretch, self.k_shear, self.k_rot, self.reference_bond_vectors),
                 density=self.density, damping=self.damping,
                 contact_params=ContactParams(min_angle=self.min_angle, cutoff_angle=self.cutoff_angle, k_contact=self.k_contact)),
-            constraint_params=dict(amplitude=self.signed_amplitude, loading_rate=self.loading_rate, input_delay=self.input_delay))
+            constraint_params=_drive_params(self))
 
     def solve(self, design, keep_trajectory=False, want_fields=True):
         """design = (horizontal_shifts, vertical_shifts), or a list of ``batch`` such tuples.
@@ -230,15 +249,8 @@ class RotatedSquaresForward(QuadsFocusingForward):
         strain = E.build_strain_energy(self.bond_connectivity,
                                        E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
         energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
-        if excited_blocks_fn is None:
-            drive = self._drive_cls(vec)
-        else:
-            if not isinstance(excited_blocks_fn, L.Table):
-                raise TypeError("excited_blocks_fn must be a difflexmm_amd.loading.Table (a recorded signal the device can interpolate)")
-            drive = L.Table(excited_blocks_fn.times, excited_blocks_fn.values, vector=vec)
-        self._recorded = excited_blocks_fn is not None
         self.solve_dynamics = setup_dynamic_solver(
-            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=drive,
+            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
             damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
             steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
@@ -255,8 +267,7 @@ class RotatedSquaresForward(QuadsFocusingForward):
                 bond_params=LigamentParams(self.k_stretch, self.k_shear, self.k_rot, self.reference_bond_vectors),
                 density=self.density, damping=self.damping,
                 contact_params=ContactParams(min_angle=self.min_angle, cutoff_angle=self.cutoff_angle, k_contact=self.k_contact)),
-            constraint_params=dict(amplitude=1.0, delay=0.0) if self._recorded else
-            dict(amplitude=self.signed_amplitude, loading_rate=self.loading_rate, input_delay=self.input_delay))
+            constraint_params=_drive_params(self))
 
     def solve(self, design=None, keep_trajectory=False, want_fields=True):
         cp = self.control_params()
@@ -385,7 +396,9 @@ class KagomeFocusingForward:
     def __post_init__(self, _lib=None):
         self._lib = _lib
 
-    def setup(self):
+    _drive_cls = L.Pulse
+
+    def setup(self, excited_blocks_fn=None):
         if self.loaded_side != "left":
             raise ValueError(f"Unknown loaded_side: {self.loaded_side}. Only 'left' is implemented.")   # kagome_focusing.py:107-109
         basis = self.cell_size * np.array([[1.0, 0.0], [np.cos(self.cell_angle), np.sin(self.cell_angle)]])
@@ -400,7 +413,7 @@ class KagomeFocusingForward:
                                        E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
         energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
         self.solve_dynamics = setup_dynamic_solver(
-            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=L.Pulse(vec),
+            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
             damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
             steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)

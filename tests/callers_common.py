@@ -152,3 +152,33 @@ def check_reference_design(lib, tol=1e-10):
     s2 = fw2.solve()
     expect = np.interp(fw2.timepoints, tt, 0.3 * np.sin(np.pi * tt / tt[-1]) ** 2 + 0.2 * tt / tt[-1])
     assert np.allclose(s2.fields[:, 0, fw2.driven_blocks_ids[0], 0], expect, atol=1e-14)
+
+
+def check_recorded_input_signal(lib):
+    """``setup(excited_blocks_fn=...)`` of the forward problems (problems/quads_focusing.py:213-222, kagome_focusing.py, quads_spin.py):
+    the driven DOFs follow a recorded signal; value and rate of the prescribed DOFs are the table's, the design gradient still flows
+    (against central differences of the objective along a random direction)."""
+    from difflexmm_amd import loading as L
+    tt = np.linspace(0.0, TSIM, 11)          # (no output time falls on a knot: the rate there would be one-sided)
+    sig = 2.0 * np.sin(np.pi * tt / tt[-1]) ** 2
+    fw = P.QuadsFocusingForward(n1_blocks=N1, n2_blocks=N2, damping=damping(), loaded_side="right", input_shift=0, steps_per_interval=2 * SPI,
+                                _lib=lib, **KW)
+    fw.setup(excited_blocks_fn=L.Table(tt, sig))
+    _, _, x = quads_forward(lib)
+    sol = fw.solve(x)
+    d = fw.driven_blocks_ids[0]
+    assert np.allclose(sol.fields[:, 0, d, 0], np.interp(fw.timepoints, tt, sig), atol=1e-14)      # (the amplitude sign flip of the right side applies to the pulse only)
+    slope = np.gradient(sig, tt)
+    assert abs(sol.fields[1, 1, d, 0] - (np.interp(fw.timepoints[1] + 1e-9, tt, sig) - np.interp(fw.timepoints[1] - 1e-9, tt, sig)) / 2e-9) < 1e-4 * np.abs(slope).max()
+    obj = P.TargetKineticEnergy(fw, (2, 2), (1, 0))
+    v, g = obj.value_and_grad(x)
+    rng = np.random.default_rng(1)
+    dirn = tuple(rng.normal(size=a.shape) for a in x)
+    eps = 1e-6
+    vp = obj.value(tuple(a + eps * b for a, b in zip(x, dirn)))
+    vm = obj.value(tuple(a - eps * b for a, b in zip(x, dirn)))
+    fd = (vp - vm) / (2 * eps)
+    an = sum((a * b).sum() for a, b in zip(g, dirn))
+    assert v > 0 and abs(an - fd) < 1e-5 * abs(fd), (an, fd)
+    with np.testing.assert_raises(TypeError):
+        fw.setup(excited_blocks_fn=lambda t: 0.0)

@@ -16,3 +16,7 @@ def test_restricted_design_space_cpu_port(cpu_lib):
 
 def test_reference_design_cpu_port(cpu_lib):
     C.check_reference_design(cpu_lib)
+
+
+def test_recorded_input_signal_cpu_port(cpu_lib):
+    C.check_recorded_input_signal(cpu_lib)

@@ -16,3 +16,7 @@ def test_restricted_design_space_hip(hip_lib):
 
 def test_reference_design_hip(hip_lib):
     C.check_reference_design(None)
+
+
+def test_recorded_input_signal_hip(hip_lib):
+    C.check_recorded_input_signal(None)
