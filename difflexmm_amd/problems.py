@@ -1160,8 +1160,12 @@ class OptimizationProblem:
     # the reference) and everything outside the patch stays at ``initial_guess_all``
     initial_guess_all: Optional[tuple] = None
     design_patch_size: Optional[int] = None
+    # per-target / per-input values of every evaluation, for objectives that are weighted sums (quads_energy_splitting.py:26,
+    # quads_kinetic_energy_static_tuning.py, quads_focusing_multi_input.py: ``objective_values_individual``)
+    objective_values_individual: Optional[list] = None
 
     def __post_init__(self):
+        self.objective_values_individual = [] if self.objective_values_individual is None else self.objective_values_individual
         self.objective_values = [] if self.objective_values is None else self.objective_values
         self.design_values = [] if self.design_values is None else self.design_values
         self.constraints_violation = {"angles": [], "edge_lengths": []} if self.constraints_violation is None else self.constraints_violation
@@ -1250,6 +1254,8 @@ class OptimizationProblem:
             kept, design = designs_of(x)
             v, grad = self.objective.value_and_grad(design)
             self.objective_values.append(float(v))
+            if getattr(self.objective, "last_individual", None) is not None:
+                self.objective_values_individual.append(np.array(self.objective.last_individual))
             self.design_values.append(kept)
             if verbose:
                 print(f"Iteration: {len(self.objective_values)}\nObjective = {self.objective_values[-1]}")
@@ -1287,7 +1293,22 @@ class OptimizationProblem:
         if len(self.design_values) == 0:
             raise ValueError("No design has been optimized yet.")
         last = self.design_values[-1]
-        return self.objective.forward.solve(self.space.reduced_to_all_shifts(last) if self.space is not None else last)
+        last = self.space.reduced_to_all_shifts(last) if self.space is not None else last
+        if hasattr(self.objective, "objectives"):       # several inputs share the design (quads_focusing_multi_input.py:230-244)
+            return [o.forward.solve(last) for o in self.objective.objectives]
+        if hasattr(self.objective, "forward_input"):
+            return self.compute_best_forwards()
+        return self.objective.forward.solve(last)
+
+    def compute_best_forwards(self, n_timepoints: int = 200):
+        """problems/quads_kinetic_energy_static_tuning.py:627-652: the last design solved for every forward input, dynamic step only,
+        ``n_timepoints`` output times."""
+        if len(self.design_values) == 0:
+            raise ValueError("No design has been optimized yet.")
+        fw = self.objective.forward
+        fw.solution_data = [fw.solve(self.design_values[-1], *row, full_simulation_time=False, n_timepoints=n_timepoints)
+                            for row in self.objective.forward_input.rows()]
+        return fw.solution_data
 
     def to_dict(self):
         """problems/quads_focusing.py:686-690 (multi-input: quads_focusing_multi_input.py:183-189): the forward problem(s) as
@@ -1299,6 +1320,10 @@ class OptimizationProblem:
         if self.space is not None:
             out["initial_guess_all"] = tuple(np.array(a) for a in self.space.initial_guess_all)
             out["design_patch_size"] = self.design_patch_size
+        if self.objective_values_individual:
+            out["objective_values_individual"] = [np.array(a) for a in self.objective_values_individual]
+        if hasattr(obj, "target_sizes") and not hasattr(obj, "forward_input"):        # energy splitting (quads_energy_splitting.py:20-23)
+            out.update(target_sizes=obj.target_sizes, target_shifts=obj.target_shifts, weights=[float(w) for w in obj.weights])
         if hasattr(obj, "objectives"):
             out["forward_problems"] = [o.forward.to_dict() for o in obj.objectives]
             out["weights"] = [float(w) for w in obj.weights]
@@ -1315,7 +1340,9 @@ class OptimizationProblem:
         def forward(fd):
             cls = KagomeFocusingForward if "n1_cells" in fd else QuadsFocusingForward
             return cls.from_dict(fd, _lib=_lib)
-        if "forward_problems" in d:
+        if "target_sizes" in d and "forward_problem" in d:
+            objective = SplitTargetKineticEnergy(forward(d["forward_problem"]), d["target_sizes"], d["target_shifts"], d["weights"])
+        elif "forward_problems" in d:
             objective = MultiInputTargetKineticEnergy([forward(fd) for fd in d["forward_problems"]], d["target_size"], d["target_shift"],
                                                       d["weights"])
         else:
@@ -1324,4 +1351,5 @@ class OptimizationProblem:
                                    design_values=list(d.get("design_values", [])),
                                    constraints_violation={k: list(v) for k, v in d.get("constraints_violation", {"angles": [], "edge_lengths": []}).items()},
                                    name=d.get("name", "quads_focusing"), initial_guess_all=d.get("initial_guess_all"),
-                                   design_patch_size=d.get("design_patch_size"))
+                                   design_patch_size=d.get("design_patch_size"),
+                                   objective_values_individual=list(d.get("objective_values_individual", [])))

@@ -52,6 +52,14 @@ def check_energy_splitting(lib, tol=1e-9):
     for a, b in zip(g, og):
         assert np.abs(a - b.numpy()).max() < tol * np.abs(b.numpy()).max()
     assert abs(obj.value(x) - v) < 1e-12 * abs(v) and np.allclose(obj.individual(x), obj.last_individual, rtol=1e-12)
+    # the loop (quads_energy_splitting.py:121-266) keeps the per-target values of every evaluation; dict round trip
+    opt = P.OptimizationProblem(obj, name="quads_energy_splitting")
+    opt.run_optimization_nlopt(x, 2, lower_bound=-4.5, upper_bound=4.5, min_void_angle=0.0, min_block_angle=0.0, min_edge_length=1.0, verbose=False)
+    assert len(opt.objective_values_individual) == len(opt.objective_values) == 2 and opt.objective_values_individual[0].shape == (3,)
+    assert abs(float(np.dot(weights, opt.objective_values_individual[0])) - opt.objective_values[0]) < 1e-12 * abs(opt.objective_values[0])
+    d = P.OptimizationProblem.from_dict(opt.to_dict(), _lib=lib)
+    assert isinstance(d.objective, P.SplitTargetKineticEnergy) and d.objective.target_shifts == obj.target_shifts
+    assert len(d.objective_values_individual) == 2
 
 
 def check_constraints_against_oracle():

@@ -133,3 +133,19 @@ def check_rows_with_equal_grids_share_one_call(lib):
     alone = fw.solve_rows(x, rows[1:2])[0]
     assert relerr(sols[1].fields, alone.fields) < 1e-13
     assert relerr(sols[0].fields, sols[1].fields) > 1e-3
+
+
+def check_optimisation_loop(lib):
+    """quads_kinetic_energy_static_tuning.py:546-652: the loop on the weighted objective (MMA standing in for NLopt) and
+    ``compute_best_forwards`` -- one solution per forward input, dynamic step only, with its own number of output times."""
+    fw = forward(lib)
+    x = design(fw)
+    obj = P.StaticTuningKineticEnergy(fw, P.ForwardInput(x[0], x[1], tuple(ROWS[:, 0]), tuple(ROWS[:, 1]), tuple(ROWS[:, 2]), tuple(ROWS[:, 3])),
+                                      [(2, 2), (2, 2)], [(1, 0), (1, 1)], [1.0, -0.5])
+    opt = P.OptimizationProblem(obj, name="quads_kinetic_energy_static_tuning")
+    opt.run_optimization_nlopt(x, 2, lower_bound=-4.5, upper_bound=4.5, min_void_angle=0.0, min_block_angle=0.0, min_edge_length=1.0,
+                               verbose=False)
+    assert len(opt.objective_values) == 2 and abs(opt.objective_values[0] - obj.value(x)) < 1e-10 * abs(opt.objective_values[0])
+    sols = opt.compute_best_forwards(n_timepoints=6)
+    assert len(sols) == len(ROWS) and all(s.fields.shape == (6, 2, N1 * N2, 3) for s in sols)
+    assert opt.compute_best_forward() is not None and fw.solution_data is not None

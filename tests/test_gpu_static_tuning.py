@@ -23,6 +23,10 @@ def test_rows_with_equal_time_grids_are_ensemble_members(hip_lib):
     S.check_rows_with_equal_grids_share_one_call(None)
 
 
+def test_optimisation_loop_and_best_forwards(hip_lib):
+    S.check_optimisation_loop(None)
+
+
 def test_spin_problem_angular_momentum_vs_autograd(hip_lib):
     """problems/quads_spin.py on the HIP engine: harmonic drive, angular-momentum objective and design gradient vs the oracle twin."""
     from . import spin_common

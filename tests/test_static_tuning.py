@@ -19,6 +19,10 @@ def test_rows_with_equal_time_grids_are_ensemble_members(cpu_lib):
     S.check_rows_with_equal_grids_share_one_call(cpu_lib)
 
 
+def test_optimisation_loop_and_best_forwards(cpu_lib):
+    S.check_optimisation_loop(cpu_lib)
+
+
 def test_spin_problem_angular_momentum_vs_autograd(cpu_lib):
     """problems/quads_spin.py on the CPU port: harmonic drive, angular-momentum objective and design gradient vs the oracle twin."""
     from . import spin_common
