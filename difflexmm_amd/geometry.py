@@ -58,6 +58,32 @@ def _recall_props(v):
     return None
 
 
+def current_coordinates(vertices, centroids, angles, displacements):
+    """geometry.py:26-36: deformed vertex coordinates, (n_blocks, n_npb, 2): every block's vertices rotated by its angle, then moved
+    to centroid + displacement."""
+    v, ang = np.asarray(vertices, dtype=float), np.asarray(angles, dtype=float)
+    c, s = np.cos(ang), np.sin(ang)
+    Q = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2)
+    return np.einsum("bij,bnj->bni", Q, v) + (np.asarray(centroids, dtype=float) + np.asarray(displacements, dtype=float))[:, None, :]
+
+
+def get_point_ids_in_bounding_box(points, bounding_box):
+    """geometry.py:39-53: indices of the points inside [[x_min, y_min], [x_max, y_max]] (borders included)."""
+    p, bb = np.asarray(points), np.asarray(bounding_box)
+    return np.where((p[:, 0] >= bb[0, 0]) & (p[:, 0] <= bb[1, 0]) & (p[:, 1] >= bb[0, 1]) & (p[:, 1] <= bb[1, 1]))[0]
+
+
+def get_point_ids_in_circle(points, center, radius):
+    """geometry.py:56-68."""
+    return np.where(np.linalg.norm(np.asarray(points) - np.asarray(center), axis=1) <= radius)[0]
+
+
+def compute_xy_limits(points):
+    """geometry.py:256-267: [[x_min, x_max], [y_min, y_max]]."""
+    p = np.asarray(points)
+    return np.array([p.min(axis=0), p.max(axis=0)]).T
+
+
 def polygon_area(v):
     return polygon_props(np.asarray(v, dtype=float))[0]
 
@@ -68,6 +94,12 @@ def polygon_centroid(v):
 
 def polygon_polar_moment(v):
     return polygon_props(np.asarray(v, dtype=float))[2]
+
+
+def polygons_geometric_properties(vertices):
+    """geometry.py:131-142: (centroid, area, polar moment of area) of an array of polygons."""
+    a, c, j = polygon_props(np.asarray(vertices, dtype=float))
+    return c, a, j
 
 
 def polygon_props_jac(v):
@@ -212,6 +244,24 @@ def _edge_pairs(cnv, bonds):
     e2p = cnv[b2, idx[6]] - cnv[b2, l2]
     e2m = cnv[b2, idx[7]] - cnv[b2, l2]
     return idx, e1p, e1m, e2p, e2m
+
+
+def compute_edge_unit_vectors(current_block_nodes, node_id):
+    """geometry.py:181-202: unit vectors from node ``node_id`` (global index, or an array of them) to the next and to the previous node
+    of its block."""
+    nodes = np.asarray(current_block_nodes, dtype=float)
+    n = nodes.shape[1]
+    nid = np.asarray(node_id, dtype=np.int64)
+    b, l = nid // n, nid % n
+    u1 = nodes[b, (l + 1) % n] - nodes[b, l]
+    u2 = nodes[b, (l - 1) % n] - nodes[b, l]
+    return u1 / np.linalg.norm(u1, axis=-1, keepdims=True), u2 / np.linalg.norm(u2, axis=-1, keepdims=True)
+
+
+def angle_between_unit_vectors(u1, u2):
+    """geometry.py:221-231: signed angle from u1 to u2 (counter-clockwise positive), in [-pi, pi]."""
+    u1, u2 = np.asarray(u1, dtype=float), np.asarray(u2, dtype=float)
+    return np.arctan2(u1[..., 0] * u2[..., 1] - u1[..., 1] * u2[..., 0], u1[..., 0] * u2[..., 0] + u1[..., 1] * u2[..., 1])
 
 
 def _angle(u, w):

@@ -24,6 +24,9 @@ class EigenmodeData(NamedTuple):
     fields: Any
 
 
+SolutionType = Union[SolutionData, EigenmodeData]      # utils.py:46
+
+
 class GeometricalParams(NamedTuple):
     """utils.py:48-59."""
     block_centroids: Any

@@ -1,0 +1,62 @@
+"""Small host-side names of the reference's geometry / kinematics / utils modules that notebooks and scripts import
+(geometry.py:26-68, 131-142, 181-231, 256-267; kinematics.py:13-81; utils.py:46) against the oracle's restatements or closed forms."""
+import math
+
+import numpy as np
+import torch
+
+from difflexmm_amd import geometry as G
+from difflexmm_amd import kinematics as K
+from difflexmm_amd import utils as U
+from oracle import ref_dynamics as OD
+from oracle import ref_energy as OE
+from oracle import ref_geometry as OG
+
+
+def test_geometry_helpers():
+    rng = np.random.default_rng(0)
+    g = G.QuadGeometry(4, 3, 15.0, 2.25)
+    design = tuple(rng.uniform(-0.5, 0.5, s) for s in g.design_shapes())
+    cnv, cen = g.centroid_node_vectors(*design), g.block_centroids(*design)
+    ang, disp = rng.uniform(-0.4, 0.4, 12), rng.normal(size=(12, 2))
+    cur = G.current_coordinates(cnv, cen, ang, disp)
+    b, k = 7, 2
+    assert np.allclose(cur[b, k], G.rotation_matrix(ang[b]) @ cnv[b, k] + cen[b] + disp[b], atol=1e-14)
+    nodes = np.array([5, 17, 30, 47])
+    u1, u2 = G.compute_edge_unit_vectors(cur, nodes)
+    o1, o2 = OG.compute_edge_unit_vectors(torch.tensor(cur), nodes)
+    assert np.allclose(u1, o1.numpy(), atol=1e-14) and np.allclose(u2, o2.numpy(), atol=1e-14)
+    assert np.allclose(G.angle_between_unit_vectors(u1, u2), OG.angle_between_unit_vectors(o1, o2).numpy(), atol=1e-14)
+    single = G.compute_edge_unit_vectors(cur, 17)
+    assert single[0].shape == (2,) and np.allclose(single[0], u1[1])
+    assert abs(G.angle_between_unit_vectors(np.array([1.0, 0.0]), np.array([0.0, 1.0])) - math.pi / 2) < 1e-15
+    pts = cur.reshape(-1, 2)
+    lim = G.compute_xy_limits(pts)
+    assert lim.shape == (2, 2) and lim[0, 0] == pts[:, 0].min() and lim[1, 1] == pts[:, 1].max()
+    ids = G.get_point_ids_in_bounding_box(cen, np.array([[10.0, 10.0], [40.0, 25.0]]))
+    assert set(ids) == {i for i, c in enumerate(cen) if 10 <= c[0] <= 40 and 10 <= c[1] <= 25} and len(ids) > 0
+    ids = G.get_point_ids_in_circle(cen, cen[5], 15.5)
+    assert 5 in ids and set(ids) == {i for i, c in enumerate(cen) if np.hypot(*(c - cen[5])) <= 15.5}
+    c, a, j = G.polygons_geometric_properties(cnv)
+    assert np.allclose(a, G.polygon_area(cnv)) and np.allclose(c, G.polygon_centroid(cnv)) and np.allclose(j, G.polygon_polar_moment(cnv))
+
+
+def test_kinematics_module_and_solution_type():
+    rng = np.random.default_rng(1)
+    g = G.QuadGeometry(3, 3, 15.0, 2.25)
+    og = OG.QuadGeometry(3, 3, 15.0, 2.25)
+    pairs = np.array([[0, 0], [0, 1], [4, 2]])
+    free, con, _ = G.DOFsInfo(9, pairs)
+    fn = lambda t, amplitude: amplitude * t * np.array([1.0, 0.0, -2.0])          # noqa: E731
+    kin = K.build_constrained_kinematics(g, pairs, fn)
+    okin = OD.build_constrained_kinematics(og, pairs, lambda t, amplitude: amplitude * t * torch.tensor([1.0, 0.0, -2.0], dtype=torch.float64))
+    q = rng.normal(size=len(free))
+    a = kin(q, 0.3, dict(amplitude=2.0))
+    b = okin(torch.tensor(q), 0.3, dict(amplitude=torch.tensor(2.0, dtype=torch.float64))).numpy()
+    assert a.shape == (9, 3) and np.allclose(a, b, atol=1e-15) and a[0, 0] == 0.6 and a[4, 2] == -1.2
+    assert np.array_equal(K.build_constrained_kinematics(g, np.zeros((0, 2), dtype=int))(np.arange(27.0), 0.0).ravel(), np.arange(27.0))
+    cnv = g.centroid_node_vectors(*[rng.uniform(-0.3, 0.3, s) for s in g.design_shapes()])
+    u = rng.normal(size=(9, 3)) * np.array([1.0, 1.0, 0.3])
+    assert np.allclose(K.block_to_node_kinematics(u, cnv), OE.block_to_node_kinematics(torch.tensor(u), torch.tensor(cnv)).numpy(), atol=1e-14)
+    assert np.allclose(K._block_to_node_displacement(u[2], cnv[2, 1]), K.block_to_node_kinematics(u, cnv)[2, 1])
+    assert U.SolutionType.__args__ == (U.SolutionData, U.EigenmodeData)
