@@ -395,10 +395,14 @@ def main():
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the separate 1-stream per-launch measurement")
     ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx; strict: exits non-zero if it "
                                                       "does not come up on N distinct GPUs) | socket (rehearsal on one GPU)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
                     help="c3: 128x128 quads, fixed designs per GPU (weak scaling; the headline).  c4: BASELINE config 4 -- 64 kagome "
                          "designs (64x64 cells) in all, sharded over the ranks, forward + design gradient through the problem layer, "
-                         "one all-gather of objectives (strong scaling)")
+                         "one all-gather of objectives (strong scaling).  c5: BASELINE config 5 -- the multi-input inverse design as "
+                         "an ensemble of --c5-members designs in lock-step, --c5-iterations objective evaluations each "
+                         "(examples/multi_input_ensemble.py; strong scaling)")
+    ap.add_argument("--c5-members", type=int, default=256)
+    ap.add_argument("--c5-iterations", type=int, default=4)
     ap.add_argument("--no-as-written", action="store_true", help="skip the extra C3-as-written leg (segments checkpoint, paper's pulse "
                                                                  "delay and target placement, 2500 steps)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
@@ -423,6 +427,12 @@ def main():
         else:
             while not os.path.exists(os.path.join(ROOT, "difflexmm_amd", "libdfx.so")):
                 time.sleep(0.5)
+    if args.workload == "c5":
+        # the example forks its host workers before anything touches the GPU and brings up its own communicator
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import multi_input_ensemble
+        return multi_input_ensemble.main(["--members", str(args.c5_members), "--iterations", str(args.c5_iterations), "--backend", args.backend,
+                                          "--json"])
     from difflexmm_amd import _binding as B
     if args.all_ranks_device >= 0:
         local_rank = args.all_ranks_device

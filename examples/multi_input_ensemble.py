@@ -24,7 +24,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--members", type=int, default=32, help="designs in the whole ensemble")
     ap.add_argument("--iterations", type=int, default=10, help="objective evaluations per design (nlopt maxeval)")
@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="the two halves of the chunk take turns on the device, the workers run one half's MMA steps while the other half is "
                          "integrated (same iterates; measured on config 5: no gain, half batches run the device less efficiently)")
-    args = ap.parse_args()
+    ap.add_argument("--json", action="store_true", help="rank 0 also prints one JSON line in the format of bench.py (bench.py --workload c5)")
+    args = ap.parse_args(argv)
 
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     from difflexmm_amd import problems as P
@@ -102,6 +103,22 @@ def main():
               f"-> packed arrays, gradient maps back to the design, the MMA sub-problems ({n_workers} host worker processes)")
         print("objective, first evaluation :", np.array2string(first, precision=3, max_line_width=160))
         print("objective, best feasible    :", np.array2string(final, precision=3, max_line_width=160))
+        if args.json:
+            import json
+            info = comm.info() if hasattr(comm, "info") else {}
+            print(json.dumps({
+                "metric": "timesteps*rigid-units/s (forward + adjoint, inside the full optimisation loop)", "value": solves * steps * nb / wall,
+                "unit": "timesteps*units/s", "n_gpus": world, "steps": args.iterations, "warmup": 0, "ms_per_step": 1e3 * wall / args.iterations,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"C5: problems/quads_focusing_multi_input, {args.members} designs (seeds 1000..) x 3 inputs, {args.n1}x{args.n2} "
+                                       f"quads, {steps} Dopri5 steps per solve, {args.iterations} objective evaluations per design: MMA under "
+                                       "the angle / edge-length constraints, all designs in lock-step, one all-gather of objectives",
+                           "designs_total": args.members, "members_per_gpu": mine, "host_workers": n_workers,
+                           "collective": info.get("collective", "none (1 rank)" if world == 1 else args.backend),
+                           "ranks_seen": info.get("ranks_seen", world), "rccl_version": info.get("rccl_runtime")},
+                "solves_per_s": solves / wall, "wall_s": wall, "device_s_rank0": dev, "evaluation_seconds_rank0": [float(t) for t in ev],
+                "objective_first": [float(x) for x in first[:8]], "objective_best": [float(x) for x in final[:8]],
+                "objectives_gathered": int(len(final))}), flush=True)
     if workers is not None:
         workers.close()
     comm.barrier()
