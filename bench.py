@@ -432,7 +432,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "examples"))
         import multi_input_ensemble
         return multi_input_ensemble.main(["--members", str(args.c5_members), "--iterations", str(args.c5_iterations), "--backend", args.backend,
-                                          "--json"])
+                                          "--all-ranks-device", str(args.all_ranks_device), "--json"])
     from difflexmm_amd import _binding as B
     if args.all_ranks_device >= 0:
         local_rank = args.all_ranks_device

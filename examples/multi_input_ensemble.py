@@ -40,10 +40,13 @@ def main(argv=None):
     ap.add_argument("--pipeline", action="store_true",
                     help="the two halves of the chunk take turns on the device, the workers run one half's MMA steps while the other half is "
                          "integrated (same iterates; measured on config 5: no gain, half batches run the device less efficiently)")
+    ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     ap.add_argument("--json", action="store_true", help="rank 0 also prints one JSON line in the format of bench.py (bench.py --workload c5)")
     args = ap.parse_args(argv)
 
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if args.all_ranks_device >= 0:
+        local_rank = args.all_ranks_device
     from difflexmm_amd import problems as P
     from difflexmm_amd import ensemble
     from difflexmm_amd.optimize import MemberWorkers
