@@ -60,3 +60,29 @@ def test_kinematics_module_and_solution_type():
     assert np.allclose(K.block_to_node_kinematics(u, cnv), OE.block_to_node_kinematics(torch.tensor(u), torch.tensor(cnv)).numpy(), atol=1e-14)
     assert np.allclose(K._block_to_node_displacement(u[2], cnv[2, 1]), K.block_to_node_kinematics(u, cnv)[2, 1])
     assert U.SolutionType.__args__ == (U.SolutionData, U.EigenmodeData)
+
+
+def test_cross_correlation_measures():
+    """objective.py:10-89 against the definition written out: sum_k a[k + lag] b[k] / max autocorrelation."""
+    from difflexmm_amd import objective as O
+    rng = np.random.default_rng(2)
+    t = np.linspace(0, 1, 60)
+    a = np.exp(-((t - 0.3) / 0.05) ** 2)
+    b = 0.7 * np.exp(-((t - 0.45) / 0.05) ** 2)                      # the same pulse 9 samples later
+    xc = O.compute_xcorr(a, b)
+    assert xc.shape == (119,)
+    lag = 4
+    direct = sum(a[k + lag] * b[k] for k in range(60 - lag)) / (a * a).sum()
+    assert abs(O.compute_xcorr(a, b, shift=lag) - direct) < 1e-14 and abs(O.compute_xcorr(a, a, shift=0) - 1.0) < 1e-14
+    A = rng.normal(size=(5, 40))
+    B = np.roll(A, 6, axis=1)                                        # every row delayed by 6 samples
+    B[:, :6] = 0.0
+    full = O.compute_xcorr2d(A, B)
+    assert full.shape == (9, 79)
+    i, j = 1, -3
+    direct = sum(A[r + i, c + j] * B[r, c] for r in range(5) for c in range(40) if 0 <= r + i < 5 and 0 <= c + j < 40) / (A * A).sum()
+    assert abs(O.compute_xcorr2d(A, B, shift=(i, j)) - direct) < 1e-13
+    assert np.allclose(O.compute_xcorr2d(A, B, shift=(0, None)), full[4]) and np.allclose(O.compute_xcorr2d(A, B, shift=(None, 2)), full[:, 41])
+    peak, delay = O.compute_space_time_xcorr(A, B)
+    assert delay == 6 and 0.5 < peak <= 1.0
+    assert O.compute_max_xcorr2d_at_shift(A, A, 0, shift_axis=1)[1] == 0
