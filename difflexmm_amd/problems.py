@@ -682,7 +682,8 @@ def design_gradients(fw, designs, raw):
     for m, d in enumerate(designs):
         _, cnv = geometry_from_design_cached(geo, d)
         cnv_bar = np.array(raw["centroid_node_vectors"][m], dtype=float)
-        if "void_angle0" in raw:
+        # (contacts are rare: an identically zero cotangent -- the engine hands out a view of a zero buffer then -- maps to exact zeros)
+        if "void_angle0" in raw and np.any(raw["void_angle0"][m]):
             cnv_bar += void_angles0_vjp(cnv, bonds, raw["void_angle0"][m])
         cnv_bar += compute_inertia_vjp(cnv, fw.density, raw["inertia"][m])[0]
         grads.append(geo.vjp(d, cnv_bar, raw["block_centroids"][m] if "block_centroids" in raw else None))
