@@ -344,9 +344,21 @@ def _forward_from_dict(cls, dict_in, _lib=None):
     return fw
 
 
+def _forward_to_data(self):
+    """problems/quads_focusing.py:378-379 (``to_data``): a copy without the solver -- what can be pickled."""
+    return type(self).from_dict(self.to_dict(), _lib=getattr(self, "_lib", None))
+
+
+def _forward_from_data(cls, problem_data, _lib=None):
+    """problems/quads_focusing.py:372-376 (``from_data``): from a stored problem object (or its dict), not set up."""
+    return cls.from_dict(problem_data if isinstance(problem_data, dict) else problem_data.to_dict(), _lib=_lib)
+
+
 QuadsFocusingForward.compute_response_data = _compute_response_data
 QuadsFocusingForward.to_dict = _forward_to_dict
 QuadsFocusingForward.from_dict = classmethod(_forward_from_dict)
+QuadsFocusingForward.to_data = _forward_to_data
+QuadsFocusingForward.from_data = classmethod(_forward_from_data)
 
 
 @dataclass
@@ -426,6 +438,8 @@ class KagomeFocusingForward:
     compute_response_data = _compute_response_data
     to_dict = _forward_to_dict
     from_dict = classmethod(_forward_from_dict)
+    to_data = _forward_to_data
+    from_data = classmethod(_forward_from_data)
 
 
 def static_tuning_constraints(geometry: QuadGeometry, n_excited_blocks: int, input_shift: int = 0):
@@ -618,6 +632,8 @@ class QuadsStaticTuningForward:
     compute_response_data = _compute_response_data
     to_dict = _forward_to_dict
     from_dict = classmethod(_forward_from_dict)
+    to_data = _forward_to_data
+    from_data = classmethod(_forward_from_data)
 
 
 class StaticTuningKineticEnergy:
@@ -1331,6 +1347,16 @@ class OptimizationProblem:
         else:
             out["forward_problem"] = obj.forward.to_dict()
         return out
+
+    def to_data(self):
+        """problems/quads_focusing.py:671-672."""
+        return OptimizationProblem.from_dict(self.to_dict(), _lib=getattr(self.objective.forward, "_lib", None)
+                                             if hasattr(self.objective, "forward") else None)
+
+    @staticmethod
+    def from_data(optimization_data, _lib=None):
+        """problems/quads_focusing.py:664-669."""
+        return OptimizationProblem.from_dict(optimization_data if isinstance(optimization_data, dict) else optimization_data.to_dict(), _lib=_lib)
 
     @staticmethod
     def from_dict(dict_in, _lib=None):

@@ -452,3 +452,19 @@ def test_closed_form_polygon_cotangents_match_the_complex_step_jacobians(n):
         got = G.polygon_props_vjp(vv, ab, cb, ib)
         assert (np.abs(got - ref).reshape(40, -1).max(1) / np.abs(ref).reshape(40, -1).max(1)).max() < 1e-11
         assert np.allclose(G.polygon_props_vjp(vv, area_bar=ab), ab[:, None, None] * dA, rtol=0, atol=1e-13)
+
+
+def test_to_data_and_from_data_round_trip(cpu_lib):
+    """problems/quads_focusing.py:372-379, 664-672: the object-level twins of to_dict / from_dict (what the notebooks pickle)."""
+    from . import callers_common as C
+    fw, _, x = C.quads_forward(cpu_lib)
+    sol = fw.solve(x)
+    copy = fw.to_data()
+    assert copy.is_setup is False and copy.n1_blocks == fw.n1_blocks and np.array_equal(copy.solution_data.fields, sol.fields)
+    again = P.QuadsFocusingForward.from_data(fw, _lib=cpu_lib)
+    again.setup()
+    assert np.array_equal(again.solve(x).fields, sol.fields)
+    opt = P.OptimizationProblem(P.TargetKineticEnergy(fw, (2, 2), (1, 0)))
+    opt.run_optimization_nlopt(x, 1, verbose=False)
+    assert P.OptimizationProblem.from_data(opt, _lib=cpu_lib).objective_values == opt.objective_values
+    assert len(opt.to_data().design_values) == 1
