@@ -41,9 +41,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (!P) { v[3] = a.in[3][i]; v[4] = a.in[4][i]; } else { v[3] = v[0]; v[4] = v[1]; }
   // reads 5-6 (+ 3 more with G): coalesced, or gathered from the neighbouring block
   double2 g0 = make_double2(0, 0), g1 = g0, g2 = g0;
-  if (G) {
+  if (G == 1) {
     const size_t j = base + (size_t)neighbour(b, k) * 4;
     v[5] = a.in[5][j]; v[6] = a.in[5][j + 1]; g0 = a.in[6][j + ((k + 2) & 3)]; g1 = a.in[7][j]; g2 = a.in[7][j + 1];
+  } else if (G == 2) {
+    // a wave = a 4 x 4 tile of blocks (tile-major records): the neighbour's data sits in another lane of the wave for 3 of 4 blocks per
+    // direction (ds_bpermute), only the tile's rim gathers from memory
+    const int tb = (threadIdx.x & 63) >> 2, tr = tb >> 2, tc = tb & 3;
+    const int dr = (k == 1) - (k == 3), dc = (k == 0) - (k == 2);
+    const bool inside = (unsigned)(tr + dr) < 4u && (unsigned)(tc + dc) < 4u;
+    const int src = ((tr + dr) * 4 + (tc + dc)) * 4;                    // first lane of the neighbour's quad
+    const double2 o5 = a.in[5][i], o6 = a.in[6][i], o7 = a.in[7][i];   // own data, coalesced
+    auto sh = [&](double x, int l) { return __shfl(x, l, 64); };
+    v[5] = make_double2(sh(o5.x, src), sh(o5.y, src)); v[6] = make_double2(sh(o5.x, src + 1), sh(o5.y, src + 1));
+    g0 = make_double2(sh(o6.x, src + ((k + 2) & 3)), sh(o6.y, src + ((k + 2) & 3)));
+    g1 = make_double2(sh(o7.x, src), sh(o7.y, src)); g2 = make_double2(sh(o7.x, src + 1), sh(o7.y, src + 1));
+    if (!inside) {
+      const size_t j = base + (size_t)neighbour(b, k) * 4;
+      v[5] = a.in[5][j]; v[6] = a.in[5][j + 1]; g0 = a.in[6][j + ((k + 2) & 3)]; g1 = a.in[7][j]; g2 = a.in[7][j + 1];
+    }
   } else { v[5] = a.in[5][i]; v[6] = a.in[6][i]; }
   double x[8];
 #pragma unroll
@@ -104,6 +120,9 @@ int main(int argc, char** argv) {
   run<1, 1, 38, 1>("gathers + narrow + arithmetic + two phases (the stage's shape)", members, a);
   run<1, 1, 76, 1>("  ... with twice the arithmetic", members, a);
   run<0, 0, 38, 1>("arithmetic + two phases, no gathers, wide reads", members, a);
+  run<2, 1, 0, 1>("tile-wave exchange (3 of 4 neighbours by ds_bpermute) + narrow + two phases", members, a);
+  run<2, 1, 38, 1>("tile-wave exchange + narrow + arithmetic + two phases", members, a);
+  run<2, 1, 19, 1>("tile-wave exchange + narrow + half the arithmetic + two phases", members, a);
   run<0, 0, 19, 0>("traffic + HALF the arithmetic (~300 fp64 instructions)", members, a);
   run<1, 1, 19, 1>("the stage's shape with half the arithmetic", members, a);
   return 0;
