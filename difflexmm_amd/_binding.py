@@ -48,7 +48,7 @@ class dfx_grads(C.Structure):
 class dfx_stats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("rhs_evals", C.c_int64), ("launches", C.c_int64),
                 ("kernel_ms", C.c_double), ("stage_kernel_us", C.c_double), ("streams", C.c_int64),
-                ("stage_checkpoint", C.c_int64), ("checkpoint_records", C.c_int64)]
+                ("stage_checkpoint", C.c_int64), ("checkpoint_records", C.c_int64), ("tile_kernels", C.c_int64)]
 
 
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid", "dfx_forward_grid_members",
@@ -428,4 +428,4 @@ class Engine:
 def _stats(st):
     return {"steps": st.steps, "rhs_evals": st.rhs_evals, "launches": st.launches, "kernel_ms": st.kernel_ms,
             "stage_kernel_us": st.stage_kernel_us, "streams": st.streams, "stage_checkpoint": st.stage_checkpoint,
-            "checkpoint_records": st.checkpoint_records}
+            "checkpoint_records": st.checkpoint_records, "tile_kernels": st.tile_kernels}

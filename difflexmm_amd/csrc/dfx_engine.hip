@@ -33,6 +33,7 @@
 
 #include "dfx_kernels.h"
 #include "dfx_pair.h"
+#include "dfx_tile.h"
 
 // ================================================================================================
 // host side
@@ -161,6 +162,15 @@ struct dfx_handle {
   bool tiling_ok = false;
   int pair_rows = 16;            // window rows = wavefronts per workgroup (16: 1024 threads, 8: 512)
   bool pair_fwd = false, pair_adj = false;   // what the current solve launches (decided per solve: pair_plan)
+  // every ligament evaluated once on lattice tiles (dfx_tile.h): the lane tables found at create, the ligament-major images of the
+  // parameters (k_lig_pack after every set_params) and of the node-vector / void-angle accumulators (k_lig_unpack after a sweep)
+  bool lig_ok = false, lig_used = false;      // lig_used: accumulators of the running sweep are ligament-major
+  bool lig_fwd_used = false, lig_adj_used = false;   // what the last forward pass / reverse sweep launched (dfx_stats)
+  int lig_nw = 4;                // wavefronts per tile workgroup (4: tiles of 16 x 7 blocks, 2: 16 x 3)
+  LigCtx lig;
+  std::vector<int32_t> lig_slots;
+  DevBuf<int32_t> d_lig_slots, d_lig_tab;
+  DevBuf<double> d_lig_p, d_lig_l, d_lig_k, d_lig_phi, d_lig_g, d_lig_gphi;
 };
 
 static void drop_graphs(dfx_handle* h) {
@@ -299,6 +309,80 @@ static void pair_plan(dfx_handle* h, const DevCtx& c) {
 }
 static TileCtx group_tile(const dfx_handle* h, int nm) { TileCtx t = h->tile; t.total_wg = t.n_tiles * nm; return t; }
 
+// ---- every ligament once, on lattice tiles (dfx_tile.h) -------------------------------------------------------------------------------
+// Ownership: the end on the lower block id.  Lane e = 0 of a block takes the ligament to block b + 1 (same lattice row), lane e = 1 the
+// one to the row above at column offset dc1 (one value per lattice: quads 0, kagome -1).  A lattice whose bond list does not fit that
+// pattern (a block owning two ligaments in one direction, diagonals both ways, extra ligaments per node) keeps the slot kernels.
+static void setup_lig(dfx_handle* h) {
+  h->lig_ok = false;
+  memset(&h->lig, 0, sizeof(h->lig));
+  const Plan& pl = h->pl;
+  // Measured (profiles/r04_tile_kernels.txt): correct, 0.65 x the vector instructions of the slot kernels, the same bytes -- and SLOWER
+  // (16 x 128x128: forward 21.4 against 18.3 us, reverse 40.2 against 32.9 us): a tile workgroup is a longer chain (loads, barrier,
+  // ligaments, barrier, epilogue) on fewer, larger units of work, the reverse kernel needs 208 registers (2 waves per SIMD).  Opt-in
+  // (DFX_TILE=1), kept exercised by the GPU tests.
+  { const char* e = getenv("DFX_TILE"); if (!(e && e[0] == '1')) return; }
+  if (!h->tiling_ok || pl.n_ovf || pl.contact == DFX_CONTACT_DISTANCE) return;
+  const int R = h->tile.R, nb = pl.n_blocks;
+  std::vector<int32_t> ls((size_t)4 * nb, -1);
+  int dc1 = 99;
+  for (int s = 0; s < pl.n_slots; ++s) {
+    const int info = pl.slot_info[s];
+    if (info < 0) continue;
+    const int ps = info >> 1, b = s >> 2, pb = ps >> 2;
+    if (pb < b) continue;
+    int e;
+    if (pb == b + 1 && (b % R) + 1 < R) e = 0;
+    else {
+      const int dr = pb / R - b / R, dc = pb % R - b % R;
+      if (dr != 1 || dc < -1 || dc > 1) return;
+      if (dc1 == 99) dc1 = dc; else if (dc1 != dc) return;
+      e = 1;
+    }
+    if (ls[(size_t)(2 * b + e) * 2] != -1) return;
+    ls[(size_t)(2 * b + e) * 2] = s; ls[(size_t)(2 * b + e) * 2 + 1] = ps;
+  }
+  if (const char* e = getenv("DFX_TILE_NW")) h->lig_nw = atoi(e) == 2 ? 2 : 4;
+  const int TH = 2 * h->lig_nw - 1;
+  h->lig.R = R; h->lig.n_rows = nb / R; h->lig.dc1 = dc1 == 99 ? 0 : dc1;
+  h->lig.tiles_x = (R + kTileW - 1) / kTileW;
+  h->lig.n_wg = h->lig.tiles_x * ((h->lig.n_rows + TH - 1) / TH);
+  h->lig_slots.swap(ls);
+  h->lig_ok = true;
+}
+// the images the tile kernels read, from the slot-major ones set_params has just uploaded (same stream)
+static int lig_pack(dfx_handle* h) {
+  if (!h->lig_ok) return 0;
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, n2 = (size_t)pl.n_blocks * 2;
+  if (!h->d_lig_slots.p) {
+    HIP_OK(h->d_lig_slots.ensure(n2 * 2));
+    HIP_OK(hipMemcpyAsync(h->d_lig_slots.p, h->lig_slots.data(), sizeof(int32_t) * n2 * 2, hipMemcpyHostToDevice, h->stream));
+  }
+  DevCtx c = make_ctx(h);
+  const bool need_l = !c.l_dict_lds, need_k = !c.k_uniform, need_phi = pl.contact == DFX_CONTACT_ANGLE;
+  HIP_OK(h->d_lig_tab.ensure(B * n2));
+  HIP_OK(h->d_lig_p.ensure(B * n2 * 4));
+  if (need_l) HIP_OK(h->d_lig_l.ensure(B * n2 * 2));
+  if (need_k) HIP_OK(h->d_lig_k.ensure(B * n2 * 4));
+  if (need_phi) HIP_OK(h->d_lig_phi.ensure(B * n2 * 2));
+  HIP_OK(h->d_lig_g.ensure(B * n2 * 4));
+  HIP_OK(h->d_lig_gphi.ensure(B * n2 * 2));
+  hipLaunchKernelGGL(k_lig_pack, dim3((unsigned)((n2 + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c,
+                     (const int32_t*)h->d_lig_slots.p, h->d_lig_tab.p, h->d_lig_p.p, need_l ? h->d_lig_l.p : (double*)nullptr,
+                     need_k ? h->d_lig_k.p : (double*)nullptr, need_phi ? h->d_lig_phi.p : (double*)nullptr);
+  h->lig.tab = h->d_lig_tab.p; h->lig.p = h->d_lig_p.p; h->lig.l = need_l ? h->d_lig_l.p : nullptr; h->lig.k = need_k ? h->d_lig_k.p : nullptr;
+  h->lig.phi = need_phi ? h->d_lig_phi.p : nullptr; h->lig.g = h->d_lig_g.p; h->lig.gphi = h->d_lig_gphi.p;
+  return 0;
+}
+// which launches may take the tile kernels: fixed grid with the segment's time-function table (or no time function at all)
+static bool lig_fwd_ok(const dfx_handle* h, const DevCtx& c, int mode) {
+  return h->lig_ok && h->lig.tab && !c.clock && !(mode & 2) && (c.fn_tab || h->pl.n_fns == 0);
+}
+static bool lig_adj_ok(const dfx_handle* h, const DevCtx& c, int wbuf, int local_only) {
+  return h->lig_ok && h->lig.tab && !c.clock && (c.fn_tab || h->pl.n_fns == 0) && !c.g_b && !c.AD && !local_only && wbuf < 0;
+}
+
 template <int MODEL, int CONTACT>
 static void launch_fwd_pair_t(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int i, int j, int in_buf, int mid_buf, int out_buf, int y_buf, int mode) {
   const TileCtx tc = group_tile(h, nm);
@@ -337,6 +421,14 @@ static bool pack3(const dfx_handle* h) {
 }
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
+  if constexpr (CONTACT != 2) {
+    if (lig_fwd_ok(h, c, mode)) {
+      const dim3 tg(h->lig.n_wg, grid.y);
+      if (h->lig_nw == 2) hipLaunchKernelGGL((k_fwd_tile<MODEL, CONTACT, 2>), tg, dim3(128), 0, st, c, h->lig, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+      else hipLaunchKernelGGL((k_fwd_tile<MODEL, CONTACT, 4>), tg, dim3(256), 0, st, c, h->lig, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+      return;
+    }
+  }
   if (h->pl.n_ovf) {       // general bond lists: the build that walks a node's extra ligaments (quad mapping, in-kernel time functions)
     if constexpr (CONTACT != 2)
       hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 0, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
@@ -369,6 +461,14 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   const int s = h->pl.tab.s;
   const int rb = (c.AD && !local_only) ? (i >= 2 ? i - 1 : (i == 0 ? s - 1 : 0)) : 0;
   const StageCoef rc = stage_coef(h->pl.tab, rb > 0 ? rb - 1 : 0);
+  if constexpr (CONTACT != 2) {
+    if (lig_adj_ok(h, c, wbuf, local_only)) {
+      const dim3 tg(h->lig.n_wg, grid.y);
+      if (h->lig_nw == 2) hipLaunchKernelGGL((k_adj_tile<MODEL, CONTACT, 2>), tg, dim3(128), 0, st, c, h->lig, adj_coef(h->pl.tab, i), i, j, in_buf);
+      else hipLaunchKernelGGL((k_adj_tile<MODEL, CONTACT, 4>), tg, dim3(256), 0, st, c, h->lig, adj_coef(h->pl.tab, i), i, j, in_buf);
+      return;
+    }
+  }
   if (h->pl.n_ovf) {       // general bond lists: one build for every checkpoint level (per-ligament gradients on, rebuild on)
     if constexpr (CONTACT != 2)
       hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 1, 1, 4, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
@@ -713,6 +813,11 @@ static int zero_grad_accumulators(dfx_handle* h) {
   HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
   HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots, h->stream));
   HIP_OK(hipMemsetAsync(h->d_touch.p, 0, sizeof(int32_t) * 4, h->stream));
+  h->lig_used = false;
+  if (h->lig_ok && h->lig.g) {
+    HIP_OK(hipMemsetAsync(h->d_lig_g.p, 0, sizeof(double) * B * nb * 8, h->stream));
+    HIP_OK(hipMemsetAsync(h->d_lig_gphi.p, 0, sizeof(double) * B * nb * 4, h->stream));
+  }
   if (pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_ovf_g.p, 0, sizeof(double) * B * pl.n_ovf * kOvfG, h->stream));
   if (h->want_bond_grads || pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
   HIP_OK(hipMemsetAsync(h->d_blk_m.p, 0, sizeof(double) * B * nb * 3, h->stream));
@@ -738,6 +843,12 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
     HIP_OK(hipStreamSynchronize(h->stream));
     HIP_OK(hipGetLastError());
     return 0;
+  }
+  if (h->lig_used) {        // the tile kernels accumulated ligament-major: fold into the slot-major accumulators read below
+    DevCtx c = make_ctx(h);
+    hipLaunchKernelGGL(k_lig_unpack, dim3((unsigned)((nb * 2 + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c,
+                       (const int32_t*)h->d_lig_slots.p, (const double*)h->d_lig_g.p, pl.contact == DFX_CONTACT_ANGLE ? (const double*)h->d_lig_gphi.p : (const double*)nullptr);
+    h->lig_used = false;
   }
   const bool w_r = want->centroid_node_vectors;
   bool w_phi = want->void_angle0 && pl.contact == DFX_CONTACT_ANGLE;
@@ -969,6 +1080,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     (void)hipMemcpy(h->d_ovf_bond.p, pl.ovf_bond.data(), sizeof(int32_t) * pl.n_ovf, hipMemcpyHostToDevice);
     h->tiling_ok = false;          // the pair launches keep to one ligament per node
   }
+  setup_lig(h);
   *out = h;
   return 0;
 }
@@ -979,6 +1091,8 @@ int dfx_destroy(dfx_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graphs(h);
   h->d_ovf_ptr.release(); h->d_ovf_info.release(); h->d_ovf_bond.release(); h->d_ovf_p.release(); h->d_ovf_g.release();
+  h->d_lig_slots.release(); h->d_lig_tab.release(); h->d_lig_p.release(); h->d_lig_l.release(); h->d_lig_k.release(); h->d_lig_phi.release();
+  h->d_lig_g.release(); h->d_lig_gphi.release();
   h->d_slot_info.release(); h->d_block_special.release(); h->d_special.release(); h->d_slot_bond.release(); h->d_touch.release(); h->zero_phi.release();
   h->d_out_r.release(); h->d_out_phi.release(); h->d_out_lam.release(); h->d_resp.release();
   h->d_p_r.release(); h->d_p_l.release(); h->d_p_k.release(); h->d_p_phi.release(); h->d_cst.release(); h->d_l_dict.release(); h->d_l_idx.release();
@@ -1038,6 +1152,7 @@ int dfx_set_params(dfx_handle* h, const dfx_params* params) {
   if (h->pl.n_ovf) HIP_OK(hipMemcpyAsync(h->d_ovf_p.p, pp.ovf.data(), sizeof(double) * pp.ovf.size(), hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_fns.ensure(pp.fns.size()));
   HIP_OK(hipMemcpyAsync(h->d_fns.p, pp.fns.data(), sizeof(TimeFn) * pp.fns.size(), hipMemcpyHostToDevice, h->stream));
+  if (lig_pack(h)) return 2;
   HIP_OK(hipStreamSynchronize(h->stream));
   if (timing) {
     auto t2 = std::chrono::steady_clock::now();
@@ -1187,6 +1302,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   if (h->segments) { c.traj = nullptr; c.rps = 1; }        // segments level: the forward pass keeps nothing but its outputs
   if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   pair_plan(h, c);
+  h->lig_fwd_used = !h->pair_fwd && lig_fwd_ok(h, c, 0);
   h->launches = 0;
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL, 0LL);
   if (c.traj)
@@ -1235,6 +1351,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
     stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
+    stats->tile_kernels = h->lig_fwd_used ? 1 : 0;
   }
   return 0;
 }
@@ -1468,6 +1585,8 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   pair_plan(h, c);
   if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
+  // tile kernels: their accumulators are ligament-major (decided here, not in the launch functions: a graph replay does not call them)
+  h->lig_used = h->lig_adj_used = !h->pair_adj && lig_adj_ok(h, c, -1, 0);
   // the (w, Kbar_q) buffers alternate per launch, lambda (pair launches only) per step
   const int wb = (int)((h->n_total * step_units(h, 1) - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb,
@@ -1525,6 +1644,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
     stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
+    stats->tile_kernels = h->lig_adj_used ? 1 : 0;
   }
   return 0;
 }

@@ -197,6 +197,14 @@ struct BondGrad {
   T e;             // bond energy
 };
 
+// What the PARTNER end of the same ligament owns, from the same evaluation (the tile kernels, dfx_tile.h, evaluate every
+// ligament once -- energy.py:179-197 -- and hand the partner its half): its translational forces are -(fx, fy).
+template <class T>
+struct BondPartner {
+  T fth;           // dE/d(theta) of the partner block
+  T rx, ry;        // dE/d(centroid_node_vector of the partner's node)
+};
+
 // Bond (node1 on block A) -> (node2 on block B).  `o` is the own block, `p` the partner;
 // sgn = +1 when the own block holds node2 (end B), -1 when it holds node1 (end A).
 // (ro) / (rp) are the centroid->node vectors of the two bonded nodes, (lx,ly) the
@@ -206,7 +214,7 @@ struct BondGrad {
 // per product (x * 0.0 cannot be folded away under IEEE semantics).
 template <int MODEL, class T, class P>
 DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, P rox, P roy, P rpx, P rpy,
-                      P lx, P ly, double l0v, double il0v, P ks, P ksh, P kr, double sgn, BondGrad<T>& g) {
+                      P lx, P ly, double l0v, double il0v, P ks, P ksh, P kr, double sgn, BondGrad<T>& g, BondPartner<T>* pg = nullptr) {
   // rotation of own / partner block from the half angles
   T co = o.ch * o.ch - o.sh * o.sh, so = 2.0 * (o.sh * o.ch);
   T cp = p.ch * p.ch - p.sh * p.sh, sp = 2.0 * (p.sh * p.ch);
@@ -294,6 +302,12 @@ DFX_HD void bond_grad(const BlockRec<T>& o, const BlockRec<T>& p, P rox, P roy, 
   g.fth = sgn * (gby * qox - gbx * qoy) + 0.5 * gtb + sgn * krk;
   g.rx = sgn * (co * gbx + so * gby - gbx);
   g.ry = sgn * (co * gby - so * gbx - gby);
+  if (pg) {
+    // seen from the partner (sgn' = -sgn, o' = p): dU, kap, gb and gtb are the same numbers
+    pg->fth = 0.5 * gtb - sgn * ((gby * qpx - gbx * qpy) + krk);
+    pg->rx = -(sgn * (cp * gbx + sp * gby - gbx));
+    pg->ry = -(sgn * (cp * gby - sp * gbx - gby));
+  }
 }
 
 // Angle-based contact of one bond (energy.py:333-361 on the two void angles of energy.py:204-219).

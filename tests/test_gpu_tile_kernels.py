@@ -1,0 +1,58 @@
+"""-m gpu: the tile kernels (every ligament evaluated once, two lanes per block on tiles of 16 x 7 / 16 x 3 blocks, dfx_tile.h)
+forced on with DFX_TILE=1, against the slot kernels and against the torch oracle.  Lattices larger than one tile in both directions
+with clipped last tiles, quads (e = 1 partner straight above) and kagome (diagonal: dc1 = -1), both tile heights, the checkpoint
+levels whose reverse sweep the tile build serves."""
+import os
+
+import numpy as np
+import pytest
+
+from .common import Case, relerr
+from .test_gpu_pair_launches import FAST, _solve
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(lattice, n, env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)            # the lane tables are built when the handle is created
+    try:
+        c = Case(lattice, n, True, True, seed=21, cutoff_deg=42.0 if lattice == "quads" else 125.0)
+        c.solver                      # noqa: B018  (creates the engine)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    c.cp = c.cp._replace(constraint_params=FAST)
+    return c
+
+
+@pytest.mark.parametrize("lattice,n,nw", [("quads", 37, "4"), ("quads", 37, "2"), ("kagome", 21, "4"), ("quads", 12, "2"), ("kagome", 7, "2")])
+def test_tile_kernels_equal_slot_kernels(hip_lib, lattice, n, nw):
+    ts = np.linspace(0.0, 3e-4, 4)
+    ref_c = _case(lattice, n, {"DFX_TILE": "0"})
+    mid = ref_c.geo.n_blocks // 2
+    target = np.array([mid + 1, mid + 2], dtype=np.int32)
+    ref = _solve(ref_c, ts, 7, target, {"DFX_CHECKPOINT": "records"})
+    assert ref_c.solver.stats["tile_kernels"] == 0 and ref[3]["tile_kernels"] == 0
+    c = _case(lattice, n, {"DFX_TILE": "1", "DFX_TILE_NW": nw})
+    for level in ("records", "segments", "state"):
+        out = _solve(c, ts, 7, target, {"DFX_CHECKPOINT": level})
+        assert c.solver.stats["tile_kernels"] == 1 and out[3]["tile_kernels"] == 1       # the tile kernels really ran, both directions
+        assert relerr(out[0], ref[0]) < 1e-12 and abs(out[1] - ref[1]) < 1e-12 * abs(ref[1]), level
+        for k in ref[2]:
+            assert relerr(out[2][k], ref[2][k]) < 1e-10, (level, k)
+    assert np.abs(ref[2]["centroid_node_vectors"]).max() > 0 and np.abs(ref[2]["void_angle0"]).max() > 0 and ref[1] > 0
+
+
+def test_tile_kernels_match_the_oracle(hip_lib):
+    """20 x 20 quads (2 x 3 tiles), contact engaged: fields of a 24-step solve against the oracle's fixed-grid solver."""
+    c = _case("quads", 20, {"DFX_TILE": "1"})
+    ts = np.linspace(0.0, 2.4e-4, 3)
+    fields = c.solver(np.zeros((2, 400, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=12)
+    import torch
+    lv = dict(loading_rate=torch.tensor(3000.0, dtype=torch.float64), input_delay=torch.tensor(1e-5, dtype=torch.float64))
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=12)
+    assert relerr(fields, osol(np.zeros((2, 400, 3)), ts, c.oracle_cp(lv)).numpy()) < 1e-10

@@ -6,7 +6,8 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            k = "fwd" if "k_fwd_stage" in r["Kernel_Name"] else "adj" if "k_adj_stage" in r["Kernel_Name"] else None
+            n_ = r["Kernel_Name"]
+            k = "fwd" if ("k_fwd_stage" in n_ or "k_fwd_tile" in n_) else "adj" if ("k_adj_stage" in n_ or "k_adj_tile" in n_) else None
             if k:
                 acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in acc.items():
