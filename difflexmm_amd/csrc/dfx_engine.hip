@@ -164,6 +164,7 @@ struct dfx_handle {
   bool pair_fwd = false, pair_adj = false;   // what the current solve launches (decided per solve: pair_plan)
   // every ligament evaluated once on lattice tiles (dfx_tile.h): the lane tables found at create, the ligament-major images of the
   // parameters (k_lig_pack after every set_params) and of the node-vector / void-angle accumulators (k_lig_unpack after a sweep)
+  bool wt = false;               // the table builds of the stage kernels store write-through (sc1): launches that fill the chip (dfx_create)
   bool lig_ok = false, lig_used = false;      // lig_used: accumulators of the running sweep are ligament-major
   bool lig_fwd_used = false, lig_adj_used = false;   // what the last forward pass / reverse sweep launched (dfx_stats)
   int lig_nw = 4;                // wavefronts per tile workgroup (4: tiles of 16 x 7 blocks, 2: 16 x 3)
@@ -185,7 +186,9 @@ static DevCtx make_ctx(dfx_handle* h) {
   DevCtx c;
   memset(&c, 0, sizeof(c));
   c.n_blocks = pl.n_blocks; c.n_slots = pl.n_slots; c.n_fns = pl.n_fns; c.batch = pl.batch; c.s = pl.tab.s;
+#ifdef DFX_ABLATE      // experiment builds only: no environment variable changes what the production library computes
   { const char* a = getenv("DFX_ABLATE"); c.ablate = a ? atoi(a) : 0; }
+#endif
   c.n_wg = (pl.n_slots + kThreads - 1) / kThreads;
   c.n_wg3 = (pl.n_blocks + (kThreads / 16) * 5 - 1) / ((kThreads / 16) * 5);
   for (int k = 0; k < 4; ++k) c.pred[k] = pl.pred_delta[k];
@@ -442,7 +445,8 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
     }
     return;
   }
-  if (tab) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+  if (tab && h->wt) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+  else if (tab) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
   else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 0>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
 }
 static void launch_fwd(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
@@ -481,6 +485,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
       else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 3, 0>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
     }
   }
+  else if (c.fn_tab && !local_only && h->wt) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else if (c.fn_tab && !local_only) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
 }
@@ -1059,6 +1064,10 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     }
   }
   setup_tiling(h);
+  {  // write-through stores in the stage kernels where a launch fills the chip (dfx_kernels.h, stg_m); DFX_WT=0|1 overrides (A/B runs)
+    const char* e = getenv("DFX_WT");
+    h->wt = e ? (e[0] != '0') : ((long long)h->pl.batch * ((h->pl.n_slots + 63) / 64) >= 2048);
+  }
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
             h->d_slot_bond.ensure(pl.n_slots) == hipSuccess && h->d_touch.ensure(4) == hipSuccess &&

@@ -90,7 +90,10 @@ struct DevCtx {
   int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
   int pred[4];            // guessed partner slot = own slot + pred[node slot]
-  int ablate, n_wg;       // DFX_ABLATE: profiling experiments only (results are wrong when non-zero); workgroups per member
+  int ablate, n_wg;       // ablate: profiling experiments on k_fwd_stage (results are wrong when non-zero).  Always 0 in the production library:
+                          // only a build with -DDFX_ABLATE reads it from the environment (make_ctx).  The three tests of this always-zero field
+                          // stay in the kernel on purpose: compiled out, the register allocator spills 12 scalar registers into the hot path
+                          // (forward launch 18.4 -> 19.1 us, profiles/r04_write_through_stores.txt);  n_wg: workgroups per member
   int n_wg3;              // ... of the launches that pack 3-node blocks densely (lane_pos<3>: 40 blocks per 128-thread workgroup)
   int rps;                // records per step in traj: 1 = the step states, s = every stage record (records checkpoint)
   int lam_pairs;          // layout of LAM / YB: 1 = (q, v) of one DOF side by side (b*6 + 2d, + 1), one 16-B access per lane; 0 = (q0 q1 q2 v0 v1 v2)
@@ -369,9 +372,38 @@ template <class T>
 __device__ __forceinline__ T ldg(const void* base, u32 byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// Stores.  Plain stores stay dirty in the XCD's L2 until the end-of-kernel release writes them back (nothing survives a kernel
+// boundary in the L2s anyway: the next launch's readers sit on other XCDs too); `sc1` stores are written through as they are issued, so
+// the launch does not end with a write-back burst (MI355X_MICROARCH.md: "publish-large").  The stage kernels' stores take that form when
+// DevCtx::wt is set (launches that fill the chip: 16 x 128x128 forward launch 18.3 -> 17.8 us, reverse 32.9 -> 32.3 us, job +1.5 %;
+// a single 128x128 system loses 3 % with it -- profiles/r04_write_through_stores.txt).
+typedef unsigned dfx_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned dfx_u2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ void stg_wt(void* base, u32 byte_off, T v) {
+  static_assert(sizeof(T) == 16 || sizeof(T) == 8 || sizeof(T) == 4, "write-through store: 4, 8 or 16 bytes");
+  if constexpr (sizeof(T) == 16) {
+    dfx_u4 x;
+    __builtin_memcpy(&x, &v, 16);
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(x), "s"(base) : "memory");
+  } else if constexpr (sizeof(T) == 8) {
+    dfx_u2 x;
+    __builtin_memcpy(&x, &v, 8);
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_off), "v"(x), "s"(base) : "memory");
+  } else {
+    unsigned x;
+    __builtin_memcpy(&x, &v, 4);
+    asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(byte_off), "v"(x), "s"(base) : "memory");
+  }
+}
 template <class T>
 __device__ __forceinline__ void stg(void* base, u32 byte_off, T v) {
   *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+// the stage kernels' own stores (uniform base, uniform choice)
+template <class T>
+__device__ __forceinline__ void stg_m(int wt /* compile-time constant at every call */, void* base, u32 byte_off, T v) {
+  if (wt) stg_wt<T>(base, byte_off, v); else stg<T>(base, byte_off, v);
 }
 // Streaming variants for data that is touched once per launch and next by a LATER launch (checkpoint records, Ybar, the accumulators'
 // read-modify-write): the non-temporal hint keeps them from displacing what the neighbour gathers hit in the L2.  Measured, not
@@ -393,7 +425,7 @@ __device__ __forceinline__ T ldg_s(const void* base, u32 byte_off) {
 }
 template <class T>
 __device__ __forceinline__ void stg_s(void* base, u32 byte_off, T v) {
-#ifdef DFX_NT
+#if defined(DFX_NT)
   typedef typename NtType<T>::type V;
   V x;
   __builtin_memcpy(&x, &v, sizeof(T));
@@ -598,7 +630,8 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   OVF: the build that also walks the extra ligaments of nodes with more than one (general bond lists) -- a build of its own: the
 //   second inlined copy of the ligament arithmetic costs the main path its registers (forward 96 VGPRs + 240 B scratch, reverse 225
 //   VGPRs when it sat in the common build), and no lattice the reference generates needs it
-template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0>
+//   WT: the stores are written through (stg_m) -- builds of the table kernels for launches that fill the chip (DevCtx::wt)
+template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0>
 __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
@@ -720,7 +753,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
       }
     }
     const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-    if (!(keep_stages && i == c.s - 1)) stg<double>(Am + (size_t)i * nd, o_dof, a);
+    if (!(keep_stages && i == c.s - 1)) stg_m<double>(WT, Am + (size_t)i * nd, o_dof, a);
     sv += sc.cv[i] * a;
     sq += sc.cq[i] * a;
     qnext = qn + h * (sc.c_next * vn + h * sq);
@@ -765,15 +798,15 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, St
   if (k < 3 && !(c.ablate & 2)) {
     const u32 o_chunk = ((u32)b * kPos + 2 * k) * 8;
     if (out_buf >= 0) {
-      if (k < 2) stg<double2>(c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
-      stg<double>(c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
+      if (k < 2) stg_m<double2>(WT, c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
+      stg_m<double>(WT, c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
     }
     if (write_traj || out_buf < -1) {
       // state checkpoint: the new step state, once more; records checkpoint (out_buf < -1): the record goes ONLY there, the
       // next launch reads it from there and so does the reverse sweep
       double* tr = out_buf < -1 ? traj_rec(c, m, out_buf, n) : traj_rec(c, m, -1, n + 1);
-      if (k < 2) stg_s<double2>(tr, o_chunk, chunk);
-      stg_s<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
+      if (k < 2) stg_m<double2>(WT, tr, o_chunk, chunk);
+      stg_m<double>(WT, tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
     }
   }
 }
@@ -996,7 +1029,7 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
@@ -1186,9 +1219,9 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
   const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
   if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
-    stg_s<double2>(grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
+    stg_m<double2>(WT, grm, (u32)slot * 16, make_double2(r_old.x - d_rx, r_old.y - d_ry));
   }
-  if (phi_on) { stg<double>(gpm, (u32)slot * 8, p_old - d_phi); c.touch[0] = 1; }
+  if (phi_on) { stg_m<double>(WT, gpm, (u32)slot * 8, p_old - d_phi); c.touch[0] = 1; }
   // ---- DOF epilogue
   double h = sg.h, t_n = sg.t_interval + (sg.j0 + j) * sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
   if (c.t_steps) { const double* ts = steps_of(c, m); t_n = ts[n]; h = ts[n + 1] - t_n; h_before = n > 0 ? t_n - ts[n - 1] : 0.0; }
@@ -1225,11 +1258,11 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
-      stg_s<double>(bmm, o_dof, bm_old - w_d * a_i);
-      if (c.blk_c) stg<double>(bcm, o_dof, bc_old - w_d * v_i);
+      stg_m<double>(WT, bmm, o_dof, bm_old - w_d * a_i);
+      if (c.blk_c) stg_m<double>(WT, bcm, o_dof, bc_old - w_d * v_i);
     }
-    if (!REBUILD) stg_s<double2>(YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
-    else { stg<double>(YBm + (size_t)i * nd6, o_b6, ybq); stg<double>(YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
+    if (!REBUILD) stg_m<double2>(WT, YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
+    else { stg_m<double>(WT, YBm + (size_t)i * nd6, o_b6, ybq); stg_m<double>(WT, YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
     if (!local_only) {
       double kq = 0.0, kv;       // Kbar of the next stage to run (records build: its Kbar_q is recomputed there)
       if (i > 0) {
@@ -1244,13 +1277,13 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
           lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
         }
         if (constrained) { lq = 0.0; lv = 0.0; }
-        if (!REBUILD) stg<double2>(LAMm, o_b6, make_double2(lq, lv));
-        else { stg<double>(LAMm, o_b6, lq); stg<double>(LAMm, o_b6 + 24, lv); }
+        if (!REBUILD) stg_m<double2>(WT, LAMm, o_b6, make_double2(lq, lv));
+        else { stg_m<double>(WT, LAMm, o_b6, lq); stg_m<double>(WT, LAMm, o_b6 + 24, lv); }
         if (REBUILD) kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
-      if (REBUILD) stg<double>(c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
-      stg<double>(c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
+      if (REBUILD) stg_m<double>(WT, c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
+      stg_m<double>(WT, c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
     }
   }
   if (REBUILD && rb > 0) {
@@ -1259,10 +1292,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   }
 }
 
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
-  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
+  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF, WT>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 // The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry
 // point, so that its occupancy can be pinned (DFX_ADJ_RB_OCC) without touching the others.
