@@ -116,3 +116,16 @@ def test_adaptive_graph_of_attempts_is_reused_and_rebuilt(hip_lib):
     assert np.array_equal(c.solver(np.zeros((2, 25, 3)), ts5, cp), fresh(ts5, 1e-7)[2])
     c.solver.rtol = c.solver.atol = 1e-9
     assert np.array_equal(c.solver(np.zeros((2, 25, 3)), ts5, cp), f5)
+
+
+def test_energy_splitting_notebook_ratio_on_hip(hip_lib):
+    """The reference-computed anchor (tests/notebook_kat.py: notebooks/quads_energy_splitting_3dp_pla_shims.ipynb cell 23, entry 0 =
+    0.33490634) through the problem layer on the HIP engine: device-side adaptive Dopri5 at rtol 1e-8 / atol 1e-4, contact, damping,
+    pulse drive, kinetic energies of the two targets."""
+    from . import notebook_kat as NK
+    r, vals = NK.engine_ratio(None)
+    assert abs(r - NK.NOTEBOOK_RATIO) < NK.TOL, r
+    assert 1.70 < vals[0] < 1.74 and 5.10 < vals[1] < 5.17, vals
+    for angle, printed in NK.ANCHORS:       # both printed anchors (cells 23 and 33)
+        r, _ = NK.engine_ratio(None, angle)
+        assert abs(r - printed) < NK.TOL, (angle, r)
