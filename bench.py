@@ -131,14 +131,13 @@ def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
     return execute(fw, obj, adjoint, spi)
 
 
-def c3_as_written_leg(args, device, sync, steps=5000):
-    """C3 as BASELINE.json / SURVEY 8(d) write it, at the only checkpoint level its 50 000-step horizon can use.  The headline times
-    K steps at the records level with the pulse at t = 0 and the target next to the drive; a user of C3 gets: pulse delayed by
-    0.1/f, 2x2 target shifted by (N//6, N//5) = (21, 25), and -- 4.4 TB of stage records do not fit -- the SEGMENTS level (the reverse
-    sweep re-runs one output interval at a time: 3 s launches per step instead of 2 s).  Timed here: `steps` steps of that solve,
-    the window that starts when the pulse does (t0 = 0.1/f: the lattice is exactly at rest until then, so the window is steps
-    2 500 .. 2 500 + `steps` of the 50 000; 5 000 steps so that the wave reaches the far target and the objective and its gradient
-    are not exact zeros), all members, forward + adjoint."""
+def c3_as_written_leg(args, device, sync, steps=50000):
+    """C3 as BASELINE.json / SURVEY 8(d) write it, whole: 128 x 128 quads with contact, **50 000 steps** over 2/f, forward + adjoint
+    w.r.t. the design, pulse delayed by 0.1/f, 2x2 target shifted by (N//6, N//5) = (21, 25), all members.  4.4 TB of stage records
+    do not fit, so the solve runs at the SEGMENTS level (the reverse sweep re-runs one output interval at a time: 3 s launches per
+    step instead of 2 s) -- what a user of C3 gets, next to the headline's K-step window at the records level.  ~18 s.
+    (`--as-written-steps K` shortens it: the window then starts with the pulse, t0 = 0.1/f; below ~4 000 steps the wave has not
+    reached the far target and objective and gradient are numerical dust.)"""
     t_d = 0.1 / FREQ
     keep = os.environ.get("DFX_CHECKPOINT")
     os.environ["DFX_CHECKPOINT"] = "segments"
@@ -148,9 +147,10 @@ def c3_as_written_leg(args, device, sync, steps=5000):
                                       target_shift=(args.size // 6, args.size // 5))
         eng = fw.solve_dynamics.engine
         eng.reserve(steps, steps // SPI + 2, keep_trajectory=True)
+        t_start = 0.0 if steps >= 50000 else t_d
         prepare(fw, designs, 2 * SPI, t_start=t_d)
         execute(fw, obj)                                         # warm-up: two output intervals, same kernels
-        prepare(fw, designs, steps, t_start=t_d)
+        prepare(fw, designs, steps, t_start=t_start)
         spin_up(fw)
         sync()
         t0 = time.perf_counter()
@@ -172,7 +172,7 @@ def c3_as_written_leg(args, device, sync, steps=5000):
     a_us = max(1e-9, (1e3 * res["adj_ms"] - n_adj * f_us) / n_adj)
     per_step_bytes = 6 * BYTES_FWD_STAGE + 48 + 6 * BYTES_ADJ_STAGE          # what ONE forward + ONE reverse pass need
     total = steps * n_units * args.members
-    return {"value": total / wall, "unit": "timesteps*units/s", "steps": steps, "window": f"steps 2500..{2500 + steps} of 50000 (t0 = 0.1/f: the pulse starts; the wave reaches the target after ~4000 steps)",
+    return {"value": total / wall, "unit": "timesteps*units/s", "steps": steps, "window": "the whole horizon: steps 0..50000, t = 0 .. 2/f" if steps >= 50000 else f"steps 2500..{2500 + steps} of 50000 (t0 = 0.1/f: the pulse starts)",
             "members_per_gpu": args.members, "checkpoint": res.get("checkpoint"), "input_delay_s": t_d,
             "target_shift": [args.size // 6, args.size // 5], "target_blocks": [int(b) for b in obj.target_blocks],
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
@@ -289,8 +289,10 @@ def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
     all usable cores, one warm-up run, median of `repeats` timed runs each; `value` is the faster of the two.  A 4-step probe
     per leg shortens the sample when the host is too slow for the time budget (and says so)."""
     import ctypes
-    from oracle.cpu import load
-    lib = load()
+    from oracle.cpu import load, load_native
+    lib, build_flags = load_native()              # SURVEY 8(d): -march=native, compiled on the host that is timed
+    if lib is None:
+        lib, build_flags = load(), build_flags + " (oracle/cpu/Makefile)"
     try:
         gomp = ctypes.CDLL("libgomp.so.1")
     except OSError:
@@ -327,7 +329,7 @@ def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
     best = max(legs, key=legs.get)
     return {"value": legs[best], "unit": "timesteps*units/s", "cores": best, "kind": "port",
             "one_thread": legs.get(1), "all_cores": legs.get(ncpu) if ncpu > 1 else None, "usable_cpus": ncpu,
-            "logical_cpus": os.cpu_count(),
+            "logical_cpus": os.cpu_count(), "build": build_flags,
             "sample": f"{n_steps} Dopri5 steps forward+adjoint of the same {size}x{size} lattice, 1 member; C++ port of the "
                       f"oracle (OpenMP over blocks), 1 thread and {ncpu} threads, 1 warm-up + median of {repeats} runs each"
                       + ("; " + "; ".join(notes) if notes else "")}
@@ -405,6 +407,7 @@ def main():
     ap.add_argument("--c5-iterations", type=int, default=4)
     ap.add_argument("--no-as-written", action="store_true", help="skip the extra C3-as-written leg (segments checkpoint, paper's pulse "
                                                                  "delay and target placement, 2500 steps)")
+    ap.add_argument("--as-written-steps", type=int, default=50000, help="steps of the C3-as-written leg (default: the whole 50 000-step horizon, ~18 s)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     ap.add_argument("--input-delay", type=float, default=0.0, help="pulse delay in s (C3 text: 0.1/f = 3.33e-3)")
     ap.add_argument("--contact-cutoff-deg", type=float, default=-10.0,
@@ -655,7 +658,7 @@ def main():
         if single is not None:
             line["single_system"] = single
         if world == 1 and adjoint and not args.no_as_written and args.size == 128:
-            line["c3_as_written"] = c3_as_written_leg(args, local_rank, sync)
+            line["c3_as_written"] = c3_as_written_leg(args, local_rank, sync, steps=args.as_written_steps)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.size, 3)
         print(json.dumps(line), flush=True)
@@ -663,15 +666,35 @@ def main():
     comm.close()
 
 
+def csrc_digest():
+    """sha256 over the engine's sources (difflexmm_amd/csrc/*.h, *.hip, sorted by name): what identifies the build a counter file belongs
+    to on the GPU box, where the snapshot has no .git."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "difflexmm_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc_traffic():
     """HBM bytes per member and launch of the two stage kernels from this round's committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json: FETCH_SIZE with the guide's x2 correction for gfx950 + WRITE_SIZE, separate passes), or None.
-    Counters cannot be read from inside the run; the file names the command they were collected with."""
+    Counters cannot be read from inside the run; the file names the command they were collected with and the sources they were collected
+    for (`csrc_sha256`, `commit`): counters of another engine build are NOT reported -- `traffic` stays null and `traffic_source` says why."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(p))
+        t = json.load(open(p))
     except Exception:       # noqa: BLE001
         return None
+    now = csrc_digest()
+    if t.get("csrc_sha256") != now:
+        return {"source": f"STALE, not reported: profiles/pmc_traffic.json was collected for engine sources {t.get('csrc_sha256')} "
+                          f"(commit {t.get('commit')}), this tree's difflexmm_amd/csrc is {now}"}
+    t["source"] = f"{t.get('source')}; engine sources {now} = commit {t.get('commit')}"
+    return t
 
 
 if __name__ == "__main__":

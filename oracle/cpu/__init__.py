@@ -37,3 +37,34 @@ def set_threads(n):
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
     except OSError:
         pass
+
+
+def load_native():
+    """The same port built ON THIS HOST with -march=native (SURVEY 8(d): the CPU baseline is timed with the host's own instruction set;
+    the prebuilt library is x86-64-v3 so that it runs on whatever host the GPU box has).  Compiled into the temp directory on first use
+    (~25 s), keyed by the sources and the CPU's flags.  Returns (handle, flags string); (None, reason) when no compiler is there."""
+    import hashlib
+    import tempfile
+    from difflexmm_amd._binding import declare
+    srcs = [os.path.join(_HERE, "dfx_cpu.cpp")] + [os.path.join(_HERE, "..", "..", "difflexmm_amd", "csrc", f)
+                                                   for f in ("dfx_physics.h", "dfx_plan.h", "dfx_stage.h")] + [os.path.join(_HERE, "..", "..", "include", "dfx.h")]
+    h = hashlib.sha256()
+    for f in srcs:
+        h.update(open(f, "rb").read())
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags"))
+        h.update(flags.encode())
+    except Exception:       # noqa: BLE001
+        pass
+    so = os.path.join(tempfile.gettempdir(), f"libdfx_cpu_native_{h.hexdigest()[:12]}.so")
+    cflags = "-O3 -march=native -std=c++17 -fPIC -fopenmp"
+    if not os.path.exists(so):
+        try:
+            subprocess.check_call(["g++"] + cflags.split() + ["-Wno-unknown-pragmas", "-shared", "-o", so + ".tmp", srcs[0]],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.replace(so + ".tmp", so)
+        except Exception as e:       # noqa: BLE001
+            return None, f"-march=native build failed ({type(e).__name__}): prebuilt x86-64-v3 library used"
+    lib = declare(ctypes.CDLL(so))
+    lib._dfx_test_only = True
+    return lib, "g++ " + cflags + " (built on this host)"
