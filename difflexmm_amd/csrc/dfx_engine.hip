@@ -745,15 +745,23 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
     else if (fits(grow(want_state, have_t))) mode = kCkState;
     else mode = kCkSegments;
   }
+  // A re-allocated (or, after a failed allocation, freed) buffer no longer holds what its last writer put there: handles that share the
+  // pool (dfx_share_checkpoint) must not run a reverse sweep on it.  DevBuf::ensure frees before it allocates, so the pointers tell.
+  const double* t0 = h->ck->traj.p;
+  const double* a0 = h->ck->AD.p;
+  auto done = [&](int m) {
+    if (h->ck->traj.p != t0 || h->ck->AD.p != a0) h->ck->writer = nullptr;
+    return m;
+  };
   if (mode == kCkSegments) {
-    if (h->ck->traj.ensure(want_seg) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    return mode;
+    if (h->ck->traj.ensure(want_seg) != hipSuccess) { (void)hipGetLastError(); return done(-1); }
+    return done(mode);
   }
   // allocate; a failed allocation falls back one level (forced modes included: the solve still runs)
   if (mode == kCkRecords && h->ck->traj.ensure(want_rec) != hipSuccess) { (void)hipGetLastError(); mode = kCkStages; }
-  if (mode != kCkRecords && h->ck->traj.ensure(want_state) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (mode != kCkRecords && h->ck->traj.ensure(want_state) != hipSuccess) { (void)hipGetLastError(); return done(-1); }
   if (mode == kCkStages && h->ck->AD.ensure(want_ad) != hipSuccess) { (void)hipGetLastError(); mode = kCkState; }
-  return mode;
+  return done(mode);
 }
 
 static void build_segments(dfx_handle* h) {

@@ -37,7 +37,7 @@ class DynamicSolver:
     """Callable returned by :func:`setup_dynamic_solver`."""
 
     def __init__(self, geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
-                 constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, lib, streams=0):
+                 constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, lib, streams=0, grid_refine=1):
         if not isinstance(energy_fn, _EnergyFn) or energy_fn.spec.bond_model is None:
             raise TypeError("energy_fn must be built with difflexmm_amd.energy.build_strain_energy "
                             "(optionally combined with build_contact_energy)")
@@ -47,6 +47,9 @@ class DynamicSolver:
         self.bonds = self.spec.bond_connectivity
         self.rtol, self.atol = rtol, atol
         self.steps_per_interval = steps_per_interval
+        if int(grid_refine) < 1:
+            raise ValueError("grid_refine must be >= 1")
+        self.grid_refine = int(grid_refine)
         self.batch = int(batch)
         self.damped_blocks = None if damped_blocks is None else np.asarray(damped_blocks, dtype=np.int64)
         self.constrained_pairs = np.asarray(constrained_block_DOF_pairs, dtype=np.int64).reshape(-1, 2)
@@ -165,11 +168,17 @@ class DynamicSolver:
         span = np.diff(np.asarray(timepoints, dtype=float)).max() if len(timepoints) > 1 else 0.0
         return max(1, int(np.ceil(span / dt)))
 
-    def adaptive_grid(self, state0, timepoints, flats):
+    def adaptive_grid(self, state0, timepoints, flats, refine=None):
         """(steps per output interval, step boundaries) frozen from a forward-only adaptive solve of the same problem
         (parameters already on the device): the step boundaries the controller accepted for the member that needed
         the most steps, merged with the output times (the controller steps across them and interpolates; a fixed grid
-        has to land on them).  Accepted boundaries closer to an output time than 1 % of the neighbouring step are dropped."""
+        has to land on them).  Accepted boundaries closer to an output time than 1 % of the neighbouring step are dropped.
+
+        ``refine = k`` (default: the solver's ``grid_refine``, 1) splits every step of the frozen grid into k equal ones.  Why one
+        would: the discrete adjoint differentiates the fixed-grid solve exactly, but at loose tolerances (the paper's atol = 1e-4) that
+        solve -- on steps the controller sized for ITS error estimate -- is further from the exact gradient than the reference's
+        continuous adjoint, which re-integrates the adjoint equations with its own controller (6.9e-3 against 1.7e-3 on the paper
+        lattice; with k = 2 the frozen-grid gradient is the closer one, at twice the steps: python -m tests.adjoint_semantics)."""
         ts = np.asarray(timepoints, dtype=float)
         if len(ts) < 2:
             return np.zeros(0, dtype=np.int32), None
@@ -183,6 +192,11 @@ class DynamicSolver:
             near = np.abs(acc[:, None] - ts[None, :]).min(1)
             acc = acc[near > 0.01 * step]
         grid = np.union1d(ts, acc)
+        k = self.grid_refine if refine is None else int(refine)
+        if k > 1:
+            fr = np.arange(k) / k
+            grid = np.concatenate([(grid[:-1, None] + np.diff(grid)[:, None] * fr[None, :]).reshape(-1), grid[-1:]])
+            grid[::k] = np.union1d(ts, acc)          # the original boundaries exactly (output times must be hit bit for bit)
         spis = np.array([np.count_nonzero((grid >= a) & (grid < b)) for a, b in zip(ts[:-1], ts[1:])], dtype=np.int32)
         return spis, grid
 
@@ -199,11 +213,16 @@ class DynamicSolver:
             # launches, each on its own time grid) -- forward inputs whose static phases differ in length, static-tuning problem
             if spi is None:
                 raise ValueError("per-member timepoints need steps_per_interval (the adaptive controller chooses one grid per call)")
-            fields, stats = self.engine.forward(state0 if np.ndim(state0) != 3 else np.broadcast_to(state0, (self.batch,) + np.shape(state0)),
-                                                timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times, want_fields=want_fields)
+            s0 = None if state0 is None else np.asarray(state0, dtype=float)
+            if s0 is not None and s0.ndim == 3:
+                s0 = np.broadcast_to(s0, (self.batch,) + s0.shape)
+            fields, stats = self.engine.forward(s0, timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times, want_fields=want_fields)
             self._last = (cps, flats, np.asarray(timepoints, dtype=float))
             self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control="fixed")
-            return fields
+            if fields is None:
+                return None
+            # same convention as the common path: one ControlParams (not a list) and batch 1 -> no leading member axis
+            return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
         state0 = np.asarray(state0, dtype=float)
         if state0.ndim == 3:
             state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
@@ -367,10 +386,13 @@ def setup_dynamic_solver(geometry, energy_fn, loaded_block_DOF_pairs=None, loadi
                          constrained_block_DOF_pairs=np.array([]), constrained_DOFs_fn=zero,
                          damped_blocks=None, rtol: float = 1e-8, atol: float = 1e-8, *,
                          integrator: str = "dopri5", steps_per_interval: Optional[int] = None,
-                         batch: int = 1, device: int = 0, streams: int = 0, _lib=None):
-    """Same positional/keyword arguments as ``difflexmm.dynamics.setup_dynamic_solver`` (dynamics.py:60-69)."""
+                         batch: int = 1, device: int = 0, streams: int = 0, grid_refine: int = 1, _lib=None):
+    """Same positional/keyword arguments as ``difflexmm.dynamics.setup_dynamic_solver`` (dynamics.py:60-69).
+    Keyword-only extras of this engine: ``steps_per_interval`` (fixed grid), ``batch``, ``device``, ``streams``, and ``grid_refine``:
+    with ``keep_trajectory=True`` and no explicit grid the adaptive controller's accepted steps are frozen into the grid the reverse
+    sweep differentiates; ``grid_refine = k`` splits each of them into k (accuracy knob of the gradient, see ``adaptive_grid``)."""
     return DynamicSolver(geometry, energy_fn, loaded_block_DOF_pairs, loading_fn, constrained_block_DOF_pairs,
-                         constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, _lib, streams)
+                         constrained_DOFs_fn, damped_blocks, rtol, atol, integrator, steps_per_interval, batch, device, _lib, streams, grid_refine)
 
 
 def linear_mode_analysis(displacement, geometry, energy_fn, control_params: ControlParams,

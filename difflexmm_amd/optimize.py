@@ -290,8 +290,10 @@ class MemberWorkers:
 
     def __init__(self, n_workers):
         import multiprocessing as mp
+        import queue
+        import threading
         ctx = mp.get_context("fork")
-        self._conns, self._procs = [], []
+        self._conns, self._procs, self._replies, self._readers = [], [], [], []
         for _ in range(max(1, int(n_workers))):
             parent, child = ctx.Pipe()
             proc = ctx.Process(target=_worker_main, args=(child,), daemon=True)
@@ -299,7 +301,25 @@ class MemberWorkers:
             child.close()
             self._conns.append(parent)
             self._procs.append(proc)
+        # Replies are drained by one reader thread per worker (started after every fork: the children stay single-threaded).  Without
+        # them the pipelined ensemble deadlocks on large messages: post() blocks in Connection.send to a worker that is itself blocked
+        # sending the reply of the OTHER half, which the caller has not collected yet (a 128 x 128 design is 528 KB, a pipe buffer 208 KB).
+        for conn in self._conns:
+            q = queue.Queue()
+            t = threading.Thread(target=self._drain, args=(conn, q), daemon=True)
+            t.start()
+            self._replies.append(q)
+            self._readers.append(t)
         self._owner = {}
+
+    @staticmethod
+    def _drain(conn, q):
+        while True:
+            try:
+                q.put(conn.recv())
+            except (EOFError, OSError, ValueError):
+                q.put(("error", "the worker's connection closed"))
+                return
 
     def __len__(self):
         return len(self._procs)
@@ -307,7 +327,7 @@ class MemberWorkers:
     def _collect(self, used):
         out = {}
         for w in used:
-            status, payload = self._conns[w].recv()
+            status, payload = self._replies[w].get()
             if status != "ok":
                 raise RuntimeError(f"ensemble worker {w} failed: {payload}")
             for idx, done, value in payload:
@@ -355,7 +375,9 @@ class MemberWorkers:
             p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
-        self._conns, self._procs = [], []
+        for t in self._readers:
+            t.join(timeout=1)
+        self._conns, self._procs, self._replies, self._readers = [], [], [], []
 
     def __enter__(self):
         return self

@@ -165,6 +165,7 @@ class QuadsFocusingForward:
     atol: float = 1e-8              # solver tolerances (problems/quads_focusing.py:73-74): the adaptive controller's, and those of
     rtol: float = 1e-8              # the grid it freezes for gradients, when steps_per_interval is None
     steps_per_interval: Optional[int] = None
+    grid_refine: int = 1            # gradients on the frozen adaptive grid: every accepted step split into this many (DynamicSolver.adaptive_grid)
     integrator: str = "dopri5"
     batch: int = 1
     device: int = 0
@@ -190,7 +191,8 @@ class QuadsFocusingForward:
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
             damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
-            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams,
+            grid_refine=getattr(self, "grid_refine", 1), _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
         self.signed_amplitude = self.amplitude if self.loaded_side in ("left", "bottom") else -self.amplitude
@@ -252,7 +254,8 @@ class RotatedSquaresForward(QuadsFocusingForward):
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
             damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
-            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams,
+            grid_refine=getattr(self, "grid_refine", 1), _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
         self.signed_amplitude = self.amplitude if self.loaded_side in ("left", "bottom") else -self.amplitude
@@ -427,7 +430,8 @@ class KagomeFocusingForward:
         self.solve_dynamics = setup_dynamic_solver(
             g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
             damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
-            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams, _lib=self._lib)
+            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams,
+            grid_refine=getattr(self, "grid_refine", 1), _lib=self._lib)
         self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
         self.state0 = np.zeros((2, g.n_blocks, 3))
         self.signed_amplitude = self.amplitude
@@ -653,6 +657,15 @@ class StaticTuningKineticEnergy:
         self.target_blocks = [quads_target_blocks(forward.geometry, ts, sh) for ts, sh in zip(target_sizes, target_shifts)]
         if not (len(self.rows) == len(self.weights) == len(self.target_blocks)):
             raise ValueError("forward inputs, weights and targets must have one entry per forward problem")
+        # The device objective sums over every output row, the extra t = 0 row of the dynamic-step grid included; value() and the
+        # reference drop that row (:268-276).  The two agree because a target block is at rest at t = 0 -- unless it carries a prescribed
+        # DOF (the capped ramp gives the clamped rows a velocity L * rate / 2 from the first instant), whose kinetic energy the reverse
+        # sweep would not differentiate w.r.t. the drive either.  The reference's targets are interior blocks: refuse the others.
+        prescribed = np.unique(np.asarray(forward.constrained_block_DOF_pairs).reshape(-1, 2)[:, 0])
+        for tb in self.target_blocks:
+            if np.intersect1d(tb, prescribed).size:
+                raise ValueError("StaticTuningKineticEnergy: a target block carries a prescribed DOF (clamped / driven rows); "
+                                 "choose targets inside the lattice")
 
     def individual(self, design):
         fw = self.forward

@@ -112,12 +112,12 @@ def continuous_adjoint_design_gradient(fw, design, target_blocks, rtol, atol):
     return value, grad, dict(forward=st_f, reverse=st_r, rhs_evals=prov.evals)
 
 
-def paper_problem(n1, n2, n_timepoints, rtol, atol, lib):
+def paper_problem(n1, n2, n_timepoints, rtol, atol, lib, grid_refine=1):
     damping = 0.0186 * np.array([2 * math.sqrt(0.36125 * 6.18e-9 * 225 * 1.19)] * 2 + [2 * math.sqrt(0.02175026 * 6.18e-9 * 15.0 ** 4 * 1.5)]) * np.ones((n1 * n2, 1))
     fw = P.QuadsFocusingForward(n1_blocks=n1, n2_blocks=n2, spacing=15.0, bond_length=2.25, k_stretch=120.0, k_shear=1.19, k_rot=1.5,
                                 density=6.18e-9, damping=damping, amplitude=7.5, loading_rate=30.0, input_delay=0.1 / 30, n_excited_blocks=2,
                                 loaded_side="left", input_shift=0, simulation_time=2.0 / 30, n_timepoints=n_timepoints, use_contact=True,
-                                k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180, rtol=rtol, atol=atol, _lib=lib)
+                                k_contact=1.5, min_angle=-15 * math.pi / 180, cutoff_angle=-10 * math.pi / 180, rtol=rtol, atol=atol, grid_refine=grid_refine, _lib=lib)
     fw.setup()
     return fw
 
@@ -148,6 +148,15 @@ def main(n1=24, n2=16, n_timepoints=11):
         grads[label] = (v_d, g_d, v_c, g_c)
         rows.append((label, rtol, atol, int(np.sum(st["steps_per_interval"])), st_c["forward"]["accepted"], st_c["reverse"]["accepted"], t_d, t_c))
         fw.solve_dynamics.engine.close()
+    # the accuracy knob of the discrete adjoint at the paper's tolerances: every step of the frozen grid split into k (grid_refine)
+    refined = []
+    for k in (2, 4):
+        fw = paper_problem(n1, n2, n_timepoints, 1e-8, 1e-4, lib, grid_refine=k)
+        obj = P.TargetKineticEnergy(fw, (2, 2), (n1 // 6, n2 // 5))
+        t0 = time.time()
+        v_k, g_k = obj.value_and_grad(design)
+        refined.append((k, int(np.sum(fw.solve_dynamics.stats["steps_per_interval"])), v_k, g_k, time.time() - t0))
+        fw.solve_dynamics.engine.close()
     v_x, g_x = grads["tight"][0], grads["tight"][1]
     print(f"{n1}x{n2} quads, paper constants, {n_timepoints} outputs over 2/f; objective {v_x:.6e}; |grad|_max {max(np.abs(a).max() for a in g_x):.3e}")
     print(f"tight tolerances: continuous vs discrete adjoint {relerr(grads['tight'][3], g_x):.1e} (objective {abs(grads['tight'][2] - v_x) / abs(v_x):.1e})")
@@ -157,6 +166,8 @@ def main(n1=24, n2=16, n_timepoints=11):
         print(f"rtol {rtol:.0e} atol {atol:.0e} | steps {n_d:6d}  objective err {abs(v_d - v_x) / abs(v_x):.1e}  gradient err {relerr(g_d, g_x):.1e}  ({t_d:.0f} s) "
               f"| steps {n_f:6d} + {n_r:6d}  objective err {abs(v_c - v_x) / abs(v_x):.1e}  gradient err {relerr(g_c, g_x):.1e}  ({t_c:.0f} s) "
               f"| discrete vs continuous {relerr(g_d, g_c):.1e}")
+    for k, n_k, v_k, g_k, t_k in refined:
+        print(f"rtol 1e-08 atol 1e-04, grid_refine = {k} | steps {n_k:6d}  objective err {abs(v_k - v_x) / abs(v_x):.1e}  gradient err {relerr(g_k, g_x):.1e}  ({t_k:.0f} s)")
 
 
 if __name__ == "__main__":

@@ -46,6 +46,18 @@ def single_timepoint_returns_reconstructed_initial_state(lib):
 
 
 @case
+def one_row_of_per_member_timepoints_returns_the_same_shape_as_a_plain_grid(lib):
+    """round-3 advice: a (1, T) array of output times took the per-member branch and came back with a leading member axis that the
+    same solve with 1-D timepoints does not have."""
+    c = Case("quads", 4, True, False, seed=1, lib=lib)
+    ts = np.linspace(0.0, 2e-3, 3)
+    a = c.solver(np.zeros((2, 16, 3)), ts, c.cp, steps_per_interval=5)
+    b = c.solver(np.zeros((2, 16, 3)), ts[None, :], c.cp, steps_per_interval=5)
+    assert a.shape == b.shape == (3, 2, 16, 3) and np.array_equal(a, b)
+    assert c.solver(None, ts[None, :], c.cp, steps_per_interval=5).shape == (3, 2, 16, 3)      # state0 = None: at rest
+
+
+@case
 def no_constraints_no_damping_conserves_energy(lib):
     """defaults of dynamics.py:60-69 (no constrained pairs, damped_blocks=None): free vibration conserves E_kin + E_pot."""
     g, en, cp = _chain(lib)

@@ -336,6 +336,37 @@ def _failing_member():
     raise ValueError("boom")
 
 
+def _big_member(n, rounds, seed):
+    """Asks for `rounds` evaluations at points of n doubles (n = 70 000: 560 KB per message, beyond any pipe buffer)."""
+    x = np.full(n, float(seed))
+    total = 0.0
+    for _ in range(rounds):
+        value, grad = yield x
+        total += value
+        x = x + grad
+    return total, x[:3].copy()
+
+
+@pytest.mark.timeout(120)
+def test_pipelined_ensemble_survives_messages_larger_than_a_pipe_buffer():
+    """round-3 advice: with groups=2 the caller posted one half's (value, gradient) to a worker that was still blocked sending the
+    other half's reply -- both sides stuck in Connection.send once a message outgrew the socket buffer (~208 KB; one 128 x 128 design
+    is 528 KB).  Four members of 560 KB each on two workers that own members of BOTH halves, against the same run without workers."""
+    from difflexmm_amd.optimize import MemberWorkers, drive_ensemble
+    n, rounds = 70_000, 4
+    specs = [(_big_member, (n, rounds, k), {}) for k in range(4)]
+
+    def batch_fun(xs, ids=None):
+        return [(float(x[0]), np.ones_like(x)) for x in xs]
+    ref = drive_ensemble(batch_fun, specs)
+    with MemberWorkers(2) as workers:
+        out = drive_ensemble(batch_fun, specs, workers, groups=2)
+    with MemberWorkers(1) as workers:
+        out1 = drive_ensemble(batch_fun, specs, workers, groups=2)
+    for a, b, c in zip(ref, out, out1):
+        assert a[0] == b[0] == c[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[1], c[1])
+
+
 def test_bench_host_path_on_cpu_port(cpu_lib):
     """bench.py's workload builder and its prepare / execute split (the timed region) through the CPU port on a small
     lattice: same code path as on the GPU box up to the library behind the C ABI."""
