@@ -150,6 +150,37 @@ def test_c5_ensemble_of_8_designs_in_lock_step(hip_lib):
         assert all(np.abs(a - b).max() < 1e-9 for a, b in zip(x, best[m]))
 
 
+def test_c5_at_width_192_designs_three_inputs_shared_checkpoint(hip_lib):
+    """BASELINE config 5 at a width that exercises what the 8-member test cannot (problems/quads_focusing_multi_input.py:43-119 for
+    every member): 192 designs x 3 inputs x 2 lock-step evaluations through `run_ensemble_optimization` -- wide enough that every
+    engine fills the chip alone, so the inputs take turns and the three engines keep their trajectory checkpoints in ONE shared pool
+    (below ~170 members of this lattice the inputs run concurrently, each with its own).  The records level must have been taken (three separate checkpoints
+    used to push ensembles of this lattice down to the stages level), and members 3 and 141 must see exactly the numbers they see
+    alone."""
+    import time
+    n = 192
+    mi = P.MultiInputTargetKineticEnergy([_fw5(s, sh, batch=n) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
+    assert not mi.concurrent_inputs                                  # the inputs take turns: one checkpoint pool
+    x0s = [_design5(mi.forward, 2000 + i) for i in range(n)]
+    t0 = time.time()
+    best, logs = P.run_ensemble_optimization(mi, x0s, 2, **_CONS)
+    wall = time.time() - t0
+    assert wall < 60.0, wall
+    for fp in [o.forward for o in mi.objectives]:
+        st = fp.solve_dynamics.stats
+        assert st["checkpoint_records"] == 1 and st["stage_checkpoint"] == 0 and fp.solve_dynamics.adjoint_stats["checkpoint_records"] == 1
+    assert all(len(l["objective_values"]) == 2 and l["objective_values"][0] > 0 for l in logs)
+    assert len({l["objective_values"][0] for l in logs}) == n        # 192 designs, 192 objectives
+    mi1 = P.MultiInputTargetKineticEnergy([_fw5(s, sh) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
+    for m in (3, 141):
+        v1, g1 = mi1.value_and_grad(tuple(np.clip(a, _CONS["lower_bound"], _CONS["upper_bound"]) for a in x0s[m]))    # MMA starts inside the box
+        assert float(v1) == logs[m]["objective_values"][0]           # bit for bit: a member's arithmetic does not depend on its neighbours
+        opt = P.OptimizationProblem(mi1)
+        x = opt.run_optimization_nlopt(x0s[m], 2, verbose=False, **_CONS)
+        assert opt.objective_values == logs[m]["objective_values"]
+        assert all(np.array_equal(a, b) for a, b in zip(x, best[m]))
+
+
 def test_second_solve_with_a_larger_segment_table_on_one_handle(hip_lib, cpu_lib):
     """Two forward + adjoint solves on ONE handle, same timepoints and the same total number of steps, the second with step
     counts that need more graph segments: the segment table is re-allocated while every other buffer (hence the kernels'
