@@ -4,10 +4,11 @@ TAG=${1:-rXX}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/gpu_pytest.txt
 tools/profile_round.sh $TAG 16 > $OUT/profile_round.log 2>&1
-timeout 900 python bench.py --steps 50000 --warmup 250 --input-delay 0.0033333333333333335 --target-shift 21 25 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written > $OUT/bench_full_50000_steps_c3_as_written.json 2> $OUT/bench_full.err
+# (the whole 50 000-step C3 as written is the `c3_as_written` leg of the default bench line since round 4: profile_round.sh's bench.json)
+timeout 900 python bench.py --workload c5 > $OUT/bench_c5_256_designs.json 2> $OUT/bench_c5.err
 timeout 600 python bench.py --workload c4 --steps 4000 --warmup 1 > $OUT/bench_c4_64_designs.json 2> $OUT/bench_c4.err
 timeout 600 python tools/c4_problem_timing.py 8 4000 > $OUT/c4_8_designs.txt 2>&1
 timeout 900 python examples/multi_input_ensemble.py --members 256 --iterations 4 2>&1 | grep -E "designs x|evaluations of|device time" > $OUT/c5_256_designs_4_iterations.txt
 timeout 600 python bench.py --gpus 2 --backend socket --all-ranks-device 0 --steps 250 --warmup 250 --members 8 --no-cpu-baseline > $OUT/bench_two_rank_rehearsal_socket.json 2> $OUT/bench_two_rank.err
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
-tail -3 $OUT/gpu_pytest.txt; cat $OUT/c5_256_designs_4_iterations.txt; tail -2 $OUT/smoke.txt; cut -c1-200 $OUT/bench_full_50000_steps_c3_as_written.json
+tail -3 $OUT/gpu_pytest.txt; cat $OUT/c5_256_designs_4_iterations.txt; tail -2 $OUT/smoke.txt; tail -c 600 $OUT/bench_c5_256_designs.json
