@@ -167,7 +167,6 @@ struct dfx_handle {
   bool wt = false;               // the table builds of the stage kernels store write-through (sc1): launches that fill the chip (dfx_create)
   bool lig_ok = false, lig_used = false;      // lig_used: accumulators of the running sweep are ligament-major
   bool lig_fwd_used = false, lig_adj_used = false;   // what the last forward pass / reverse sweep launched (dfx_stats)
-  int lig_nw = 4;                // wavefronts per tile workgroup (4: tiles of 16 x 7 blocks, 2: 16 x 3)
   LigCtx lig;
   std::vector<int32_t> lig_slots;
   DevBuf<int32_t> d_lig_slots, d_lig_tab;
@@ -345,11 +344,12 @@ static void setup_lig(dfx_handle* h) {
     if (ls[(size_t)(2 * b + e) * 2] != -1) return;
     ls[(size_t)(2 * b + e) * 2] = s; ls[(size_t)(2 * b + e) * 2 + 1] = ps;
   }
-  if (const char* e = getenv("DFX_TILE_NW")) h->lig_nw = atoi(e) == 2 ? 2 : 4;
-  const int TH = 2 * h->lig_nw - 1;
   h->lig.R = R; h->lig.n_rows = nb / R; h->lig.dc1 = dc1 == 99 ? 0 : dc1;
-  h->lig.tiles_x = (R + kTileW - 1) / kTileW;
-  h->lig.n_wg = h->lig.tiles_x * ((h->lig.n_rows + TH - 1) / TH);
+  h->lig.tiles_x = (R + kTW - 1) / kTW;
+  h->lig.n_tiles = h->lig.tiles_x * ((h->lig.n_rows + kTH - 1) / kTH);
+  h->lig.n_wg = (h->lig.n_tiles + kTileWaves - 1) / kTileWaves;
+  h->lig.inv_tiles_x = (unsigned)((0x100000000ull + (unsigned long long)h->lig.tiles_x - 1) / (unsigned long long)h->lig.tiles_x);   // exact for tile < 2^32 / tiles_x
+  if (h->lig.tiles_x < 2) return;            // (2^32 / 1 does not fit the multiplier; a lattice one tile wide gains nothing anyway)
   h->lig_slots.swap(ls);
   h->lig_ok = true;
 }
@@ -427,8 +427,7 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   if constexpr (CONTACT != 2) {
     if (lig_fwd_ok(h, c, mode)) {
       const dim3 tg(h->lig.n_wg, grid.y);
-      if (h->lig_nw == 2) hipLaunchKernelGGL((k_fwd_tile<MODEL, CONTACT, 2>), tg, dim3(128), 0, st, c, h->lig, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
-      else hipLaunchKernelGGL((k_fwd_tile<MODEL, CONTACT, 4>), tg, dim3(256), 0, st, c, h->lig, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+      hipLaunchKernelGGL((k_fwd_tile<MODEL, CONTACT>), tg, dim3(64 * kTileWaves), 0, st, c, h->lig, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
       return;
     }
   }
@@ -468,8 +467,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   if constexpr (CONTACT != 2) {
     if (lig_adj_ok(h, c, wbuf, local_only)) {
       const dim3 tg(h->lig.n_wg, grid.y);
-      if (h->lig_nw == 2) hipLaunchKernelGGL((k_adj_tile<MODEL, CONTACT, 2>), tg, dim3(128), 0, st, c, h->lig, adj_coef(h->pl.tab, i), i, j, in_buf);
-      else hipLaunchKernelGGL((k_adj_tile<MODEL, CONTACT, 4>), tg, dim3(256), 0, st, c, h->lig, adj_coef(h->pl.tab, i), i, j, in_buf);
+      hipLaunchKernelGGL((k_adj_tile<MODEL, CONTACT>), tg, dim3(64 * kTileWaves), 0, st, c, h->lig, adj_coef(h->pl.tab, i), i, j, in_buf);
       return;
     }
   }
@@ -725,6 +723,12 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
     }
   } else if (const char* e2 = getenv("DFX_STAGE_CHECKPOINT")) forced = e2[0] != '0' ? kCkStages : kCkState;
   const size_t want_seg = B * ((size_t)std::max<long long>(max_interval_steps, 1) * pl.tab.s + 1) * rec;
+  // the kernels address trajectory records by a 32-bit ordinal ((step * records per step + record) * members + member; at the segments
+  // level the step is the global one against a shifted base): 2^32 records are 44 million Dopri5 steps of 16 members
+  if ((double)B * ((double)N * pl.tab.s + 1.0) >= 4294967296.0) {
+    h->err = "steps x members too large: the trajectory checkpoint is addressed by 32-bit record ordinals (split the ensemble or the horizon)";
+    return -2;
+  }
   size_t free_b = 0, total_b = 0;
   const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
   // a level whose buffers already exist fits whatever else has been allocated since (adjoint work buffers, sibling engines of a
@@ -1194,7 +1198,11 @@ int dfx_reserve(dfx_handle* h, int64_t max_steps, int32_t max_timepoints, int32_
   HIP_OK(h->d_target.ensure(nb));
   HIP_OK(h->d_obj.ensure(B));
   HIP_OK(h->d_segs.ensure((size_t)max_timepoints * (2 + (size_t)(max_steps / std::max(1, max_timepoints - 1)) / kMaxGraphSteps)));
-  if (keep_trajectory && choose_checkpoint(h, max_steps, std::max<long long>(1, max_steps / std::max(1, max_timepoints - 1))) < 0) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
+  if (keep_trajectory) {
+    const int ck_mode = choose_checkpoint(h, max_steps, std::max<long long>(1, max_steps / std::max(1, max_timepoints - 1)));
+    if (ck_mode == -2) return 1;
+    if (ck_mode < 0) { h->err = "reserve: cannot allocate the trajectory checkpoint"; return 2; }
+  }
   (void)rec;
   return 0;
 }
@@ -1288,6 +1296,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
       fprintf(stderr, "[dfx] choose_checkpoint: level %d, %.1f ms (traj %.1f GB, AD %.1f GB, shared by %d)\n", mode,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(),
               h->ck->traj.n * 8e-9, h->ck->AD.n * 8e-9, h->ck->users);
+    if (mode == -2) return 1;
     if (mode < 0) {
       h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string((B * (h->n_total + 1) * rec * 8) >> 20) + " MiB)";
       return 2;

@@ -233,17 +233,22 @@ __device__ __forceinline__ int logical_wg(int bid, int n_wg) {
 }
 
 // buf >= 0: stage buffer `buf`;  buf < 0: record (-1 - buf) of step n in the trajectory checkpoint (record 0 = the step state;
-// records 1 .. s-1 exist in the records checkpoint only; record s of step n IS record 0 of step n + 1)
+// records 1 .. s-1 exist in the records checkpoint only; record s of step n IS record 0 of step n + 1).
+// Addressing is 32-bit up to the last multiply (round 4): these three functions are inlined five times into a stage kernel, and with
+// 64-bit operands throughout each copy was a chain of ~30 scalar instructions (five 64 x 64 multiplies) in every wave's prologue --
+// ~150 of the 320 scalar instructions of a forward wave, on the one scalar unit a compute unit has.  The record ordinal fits 32 bits
+// (choose_checkpoint refuses a checkpoint of 2^32 records or more), stage-buffer element indices fit 31 bits (check_index_range).
 __device__ __forceinline__ double* traj_rec(const DevCtx& c, int m, int buf, long long n) {
-  return c.traj + (((size_t)n * c.rps + (size_t)(-1 - buf)) * (u32)c.batch + (u32)m) * ((size_t)c.n_blocks * kStep);
+  const u32 ord = ((u32)n * (u32)c.rps + (u32)(-1 - buf)) * (u32)c.batch + (u32)m;
+  return c.traj + (size_t)ord * (size_t)((u32)c.n_blocks * (u32)kStep);
 }
 __device__ __forceinline__ const double* pos_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.POS + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * kPos;
+  if (buf >= 0) return c.POS + (size_t)(((u32)m * (u32)c.nbuf + (u32)buf) * (u32)c.n_blocks * (u32)kPos);
   return traj_rec(c, m, buf, n);
 }
 __device__ __forceinline__ const double* vel_in(const DevCtx& c, int m, int buf, long long n) {
-  if (buf >= 0) return c.VEL + ((size_t)m * c.nbuf + buf) * (u32)c.n_blocks * 3;
-  return traj_rec(c, m, buf, n) + (size_t)c.n_blocks * kPos;
+  if (buf >= 0) return c.VEL + (size_t)(((u32)m * (u32)c.nbuf + (u32)buf) * (u32)c.n_blocks * 3u);
+  return traj_rec(c, m, buf, n) + (size_t)((u32)c.n_blocks * (u32)kPos);
 }
 
 __global__ void k_tick(const Seg* segs, int* seg_idx, int delta, Seg* cur) {
