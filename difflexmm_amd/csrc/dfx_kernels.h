@@ -440,6 +440,18 @@ __device__ __forceinline__ void stg_s(void* base, u32 byte_off, T v) {
 #endif
 }
 
+// A pointer-typed field of the DevCtx kernel argument, loaded from the kernel-argument segment AT THE POINT OF USE.  The compiler
+// fetches every argument a kernel reads with its first cluster of scalar loads; pointers that only the epilogue needs then occupy
+// scalar registers across the whole ligament evaluation -- the reverse stage kernel, at its limit of 102, spilled 17 of them into
+// v_writelane / v_readlane pairs in its hot path (34 vector instructions per wave of 630).  DevCtx is the first kernel argument.
+template <class T>
+__device__ __forceinline__ T* late_arg(u32 byte_offset) {
+  T* v;
+  asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(byte_offset) : "memory");
+  return v;
+}
+#define DFX_LATE(T, field) late_arg<T>((u32)offsetof(DevCtx, field))
+
 // uniform bases of member m's parameter arrays
 struct MemberBases {
   const double *p_r, *p_phi, *p_l, *p_k, *cst, *l_dict, *p_c, *ovf_p;
@@ -1210,17 +1222,18 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   // trip each at the end of the kernel.  (Fire-and-forget L2 atomics would spare the loads but were measured 10-25 % slower:
   // four fp64 atomics per lane saturate the L2 atomic units.)  Lanes without a ligament / constrained DOFs add zero.
   const size_t ms = (size_t)m * (u32)c.n_slots;
-  double* grm = c.g_r + ms * 2;
+  double* const blk_c_ = REBUILD ? c.blk_c : DFX_LATE(double, blk_c);        // (the records build: epilogue pointers fetched late, late_arg)
+  double* grm = (REBUILD ? c.g_r : DFX_LATE(double, g_r)) + ms * 2;
   double* gpm = c.g_phi + ms;
-  double* bmm = c.blk_m + (size_t)m * nd;
-  double* bcm = c.blk_c + (size_t)m * nd;
+  double* bmm = (REBUILD ? c.blk_m : DFX_LATE(double, blk_m)) + (size_t)m * nd;
+  double* bcm = blk_c_ + (size_t)m * nd;
   const double2 r_old = ldg_s<double2>(grm, (u32)slot * 16);
   // the void-angle accumulator moves only where a contact is engaged in this stage (d_phi is an exact zero elsewhere, and contacts
   // are rare: 64 B/unit of the launch's traffic otherwise)
   const bool phi_on = CONTACT == 1 && d_phi != 0.0;
   const double p_old = phi_on ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
   const double bm_old = ldg_s<double>(bmm, o_dof);
-  const double bc_old = c.blk_c ? ldg<double>(bcm, o_dof) : 0.0;
+  const double bc_old = blk_c_ ? ldg<double>(bcm, o_dof) : 0.0;
   const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
   const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
   if (L.info >= 0 || CONTACT == 2) {     // distance contact: a node without a ligament can still be the neighbour of a bonded node
@@ -1264,7 +1277,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
       ybq = -hw;
       ybv = kq_in - damp * w_d;
       stg_m<double>(WT, bmm, o_dof, bm_old - w_d * a_i);
-      if (c.blk_c) stg_m<double>(WT, bcm, o_dof, bc_old - w_d * v_i);
+      if (blk_c_) stg_m<double>(WT, bcm, o_dof, bc_old - w_d * v_i);
     }
     if (!REBUILD) stg_m<double2>(WT, YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
     else { stg_m<double>(WT, YBm + (size_t)i * nd6, o_b6, ybq); stg_m<double>(WT, YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
@@ -1288,7 +1301,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
         kv = h_before * ac.col[c.s] * lv;
       }
       if (REBUILD) stg_m<double>(WT, c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
-      stg_m<double>(WT, c.W + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
+      stg_m<double>(WT, (REBUILD ? c.W : DFX_LATE(double, W)) + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
     }
   }
   if (REBUILD && rb > 0) {
