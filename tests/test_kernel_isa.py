@@ -86,7 +86,9 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     adj_w = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
     assert not any(x.startswith("scratch_") for x in fwd_w + adj_w)
     assert sum(x.startswith(("v_readlane", "v_writelane")) for x in fwd_w) <= 8, "k_fwd_stage<..., table, WT>: scalar-register spills"
-    assert sum(x.startswith(("v_readlane", "v_writelane")) for x in adj_w[:1200]) <= 40
+    # (round 4: the reverse kernel's 17 spilled scalar registers are gone -- its epilogue pointers are fetched late, late_arg -- and
+    # were worth 2 us of its 33: keep them gone)
+    assert sum(x.startswith(("v_readlane", "v_writelane")) for x in adj_w) <= 4, "k_adj_stage<..., table, WT>: scalar-register spills are back"
     for body in (fwd_w, adj_w):
         stores = [x for x in body if x.startswith("global_store")]
         assert sum("sc1" in x for x in stores) >= 4 and sum("sc1" not in x for x in stores) <= 1, stores   # (the one plain store: the adaptive controller's error partial / nothing)
