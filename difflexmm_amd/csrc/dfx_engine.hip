@@ -444,7 +444,17 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
     }
     return;
   }
-  if (tab && h->wt) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+  if (tab && h->wt) {
+    // one build per stage for the ligament models the reference's problems use (the stage index as a compile-time constant)
+    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {
+      const StageCoef scf = stage_coef(h->pl.tab, i);
+#define DFX_FWD_I(I) case I: hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return;
+      if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')
+        switch (i) { DFX_FWD_I(0) DFX_FWD_I(1) DFX_FWD_I(2) DFX_FWD_I(3) DFX_FWD_I(4) DFX_FWD_I(5) default: break; }
+#undef DFX_FWD_I
+    }
+    hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
+  }
   else if (tab) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
   else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 0>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
 }
@@ -483,7 +493,16 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
       else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 3, 0>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
     }
   }
-  else if (c.fn_tab && !local_only && h->wt) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  else if (c.fn_tab && !local_only && h->wt) {
+    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {      // one build per stage (see launch_fwd_t)
+      const AdjCoef acf = adj_coef(h->pl.tab, i);
+#define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, wbuf, local_only, rc, rb); return;
+      if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')
+        switch (i) { DFX_ADJ_I(0) DFX_ADJ_I(1) DFX_ADJ_I(2) DFX_ADJ_I(3) DFX_ADJ_I(4) DFX_ADJ_I(5) default: break; }
+#undef DFX_ADJ_I
+    }
+    hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
+  }
   else if (c.fn_tab && !local_only) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 0>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
 }

@@ -648,10 +648,14 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   second inlined copy of the ligament arithmetic costs the main path its registers (forward 96 VGPRs + 240 B scratch, reverse 225
 //   VGPRs when it sat in the common build), and no lattice the reference generates needs it
 //   WT: the stores are written through (stg_m) -- builds of the table kernels for launches that fill the chip (DevCtx::wt)
-template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0>
-__global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i, int j, int in_buf, int out_buf,
+//   ISTAGE >= 0: the stage index is a compile-time constant (builds of the write-through table kernels, one per stage: which earlier
+//   accelerations to load, which coefficients to use and whether this is the last stage are then decided by the compiler, not by
+//   ~12 scalar compares and branches per wave)
+template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
+__global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i_arg, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
+  const int i = ISTAGE >= 0 ? ISTAGE : i_arg;
   const int m = blockIdx.y + c.m0;
   const int lwg = logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3);
   const LanePos lp = lane_pos<NPB>(lwg, c.n_blocks);
@@ -1046,12 +1050,13 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
-__device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& ac, int i, int j, int in_buf, int wbuf_static,
+__device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& ac, int i_arg, int j, int in_buf, int wbuf_static,
                                                int local_only, const StageCoef& rc, int rb) {
+  const int i = ISTAGE >= 0 ? ISTAGE : i_arg;        // ISTAGE: see k_fwd_stage
   static_assert(NPB == 4 || (CONTACT != 2 && !REBUILD && !BOND_GRADS), "the packed mapping serves the records build without distance contact");
   const int m = blockIdx.y + c.m0;
   const LanePos lp = lane_pos<NPB>(logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3), c.n_blocks);
@@ -1310,10 +1315,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& a
   }
 }
 
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
-  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF, WT>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
+  adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF, WT, ISTAGE>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 // The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry
 // point, so that its occupancy can be pinned (DFX_ADJ_RB_OCC) without touching the others.
