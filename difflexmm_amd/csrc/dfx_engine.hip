@@ -422,6 +422,12 @@ static bool pack3(const dfx_handle* h) {
   const char* e = getenv("DFX_PACK3");
   return h->pl.n_npb == 3 && !h->adaptive && !(e && e[0] == '0');
 }
+// The per-stage builds of the stage kernels (template parameter ISTAGE) assume the common parameter shape and compile its run-time flags
+// away: uniform stiffnesses and damping, the reference-vector dictionary in LDS, equal steps, no stage checkpoint, no adaptive clock,
+// records read from / written to the trajectory checkpoint (the caller checks the buffer arguments).
+static bool hot_shape(const DevCtx& c) {
+  return c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps && !c.AD && !c.clock && c.rps > 1;
+}
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   if constexpr (CONTACT != 2) {
@@ -446,7 +452,7 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   }
   if (tab && h->wt) {
     // one build per stage for the ligament models the reference's problems use (the stage index as a compile-time constant)
-    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {
+    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) if (hot_shape(c) && in_buf == -1 - i && out_buf == -2 - i && y_buf == -1 && mode == 0) {
       const StageCoef scf = stage_coef(h->pl.tab, i);
 #define DFX_FWD_I(I) case I: hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return;
       if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')
@@ -494,7 +500,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
     }
   }
   else if (c.fn_tab && !local_only && h->wt) {
-    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {      // one build per stage (see launch_fwd_t)
+    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {      // one build per stage (the stage index only: see adj_stage_body)
       const AdjCoef acf = adj_coef(h->pl.tab, i);
 #define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, wbuf, local_only, rc, rb); return;
       if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')

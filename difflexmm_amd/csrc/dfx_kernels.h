@@ -652,10 +652,18 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   accelerations to load, which coefficients to use and whether this is the last stage are then decided by the compiler, not by
 //   ~12 scalar compares and branches per wave)
 template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
-__global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c, StageCoef sc, int i_arg, int j, int in_buf, int out_buf,
+__global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg, StageCoef sc, int i_arg, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
   const int i = ISTAGE >= 0 ? ISTAGE : i_arg;
+  // The per-stage builds are also the builds of the COMMON parameter shape, which the launch code checks before it takes them
+  // (hot_shape in dfx_engine.hip): uniform stiffnesses and damping, the reference-vector dictionary in LDS, equal steps, records read
+  // from and written to the trajectory checkpoint.  What is a run-time flag in the generic builds is a constant here.
+  DevCtx c = c_arg;
+  if (ISTAGE >= 0) {
+    c.k_uniform = 1; c.l_dict_on = 1; c.l_dict_lds = 1; c.damping_uniform = 1; c.t_steps = nullptr; c.AD = nullptr; c.clock = nullptr;
+    in_buf = -1 - ISTAGE; out_buf = -2 - ISTAGE; y_buf = -1; mode = 0;
+  }
   const int m = blockIdx.y + c.m0;
   const int lwg = logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3);
   const LanePos lp = lane_pos<NPB>(lwg, c.n_blocks);
@@ -1056,7 +1064,10 @@ template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int 
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
 __device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& ac, int i_arg, int j, int in_buf, int wbuf_static,
                                                int local_only, const StageCoef& rc, int rb) {
-  const int i = ISTAGE >= 0 ? ISTAGE : i_arg;        // ISTAGE: see k_fwd_stage
+  // ISTAGE: see k_fwd_stage.  Here the stage index only: with the forward kernel's common-shape constants as well the reverse builds
+  // shed another third of their scalar instructions and were no faster alone and 4 % slower with two member groups on the chip
+  // (profiles/r04_scalar_diet.txt) -- the reverse kernel is bound by its vector instructions, not by the scalar unit.
+  const int i = ISTAGE >= 0 ? ISTAGE : i_arg;
   static_assert(NPB == 4 || (CONTACT != 2 && !REBUILD && !BOND_GRADS), "the packed mapping serves the records build without distance contact");
   const int m = blockIdx.y + c.m0;
   const LanePos lp = lane_pos<NPB>(logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3), c.n_blocks);
