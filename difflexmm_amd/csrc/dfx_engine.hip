@@ -426,7 +426,7 @@ static bool pack3(const dfx_handle* h) {
 // away: uniform stiffnesses and damping, the reference-vector dictionary in LDS, equal steps, no stage checkpoint, no adaptive clock,
 // records read from / written to the trajectory checkpoint (the caller checks the buffer arguments).
 static bool hot_shape(const DevCtx& c) {
-  return c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps && !c.AD && !c.clock && c.rps > 1;
+  return c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps && !c.AD && !c.clock;
 }
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
@@ -452,9 +452,11 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   }
   if (tab && h->wt) {
     // one build per stage for the ligament models the reference's problems use (the stage index as a compile-time constant)
-    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) if (hot_shape(c) && in_buf == -1 - i && out_buf == -2 - i && y_buf == -1 && mode == 0) {
+    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) if (hot_shape(c)) {
       const StageCoef scf = stage_coef(h->pl.tab, i);
-#define DFX_FWD_I(I) case I: hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return;
+      const bool recs = c.rps > 1 && in_buf == -1 - i && out_buf == -2 - i && y_buf == -1 && mode == 0;
+#define DFX_FWD_I(I) case I: if (recs) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I, 1>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); \
+                             else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I, 0>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return;
       if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')
         switch (i) { DFX_FWD_I(0) DFX_FWD_I(1) DFX_FWD_I(2) DFX_FWD_I(3) DFX_FWD_I(4) DFX_FWD_I(5) default: break; }
 #undef DFX_FWD_I

@@ -651,7 +651,10 @@ __device__ __forceinline__ void load_dist(const DevCtx& c, const MemberBases& B,
 //   ISTAGE >= 0: the stage index is a compile-time constant (builds of the write-through table kernels, one per stage: which earlier
 //   accelerations to load, which coefficients to use and whether this is the last stage are then decided by the compiler, not by
 //   ~12 scalar compares and branches per wave)
-template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
+//   RECS (per-stage builds): 1 = the records are read from and written to the trajectory checkpoint (records level, and the interval
+//   re-runs of the segments level): the buffer arguments are constants too; 0 = they are run-time arguments (stage buffers: the first
+//   forward pass of the segments level, the state and stages levels)
+template <int MODEL, int CONTACT, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1, int RECS = 1>
 __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg, StageCoef sc, int i_arg, int j, int in_buf, int out_buf,
                                                         int y_buf, int mode) {
   static_assert(NPB == 4 || CONTACT != 2, "distance-based contact uses the quad mapping");
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg
   DevCtx c = c_arg;
   if (ISTAGE >= 0) {
     c.k_uniform = 1; c.l_dict_on = 1; c.l_dict_lds = 1; c.damping_uniform = 1; c.t_steps = nullptr; c.AD = nullptr; c.clock = nullptr;
-    in_buf = -1 - ISTAGE; out_buf = -2 - ISTAGE; y_buf = -1; mode = 0;
+    if (RECS) { in_buf = -1 - ISTAGE; out_buf = -2 - ISTAGE; y_buf = -1; mode = 0; }
   }
   const int m = blockIdx.y + c.m0;
   const int lwg = logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3);

@@ -24,7 +24,7 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "difflexmm_amd", "csrc", "dfx_engine.hip")], stderr=subprocess.DEVNULL)
     txt = out.read_text()
-    fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+    fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
     adj = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi0ELin1EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
     # forward: 5 waves per SIMD are bought with ~100 B/lane of scratch, all of it inside the time-function path that only the lanes of
     # driven blocks execute -- the ligament + contact evaluation (the first ~1000 instructions) must stay free of scratch traffic
@@ -40,7 +40,7 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
         if x.startswith("s_waitcnt") and "vmcnt" in x:
             break
     assert n_loads >= 20, f"k_fwd_stage: first vmcnt wait after only {n_loads} loads"
-    meta = re.search(r"\.name:\s+_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1EEEvNS_6DevCtxENS_9StageCoefEiiiiii.*?\.vgpr_count:\s+(\d+)", txt, re.S)
+    meta = re.search(r"\.name:\s+_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii.*?\.vgpr_count:\s+(\d+)", txt, re.S)
     assert meta and int(meta.group(1)) <= 102, "k_fwd_stage<nonlinear,contact> no longer fits 5 waves per SIMD"
     # reverse: both builds must keep four waves per SIMD (<= 128 VGPRs); the stage-checkpoint build, pinned to that occupancy, may
     # spill a little (12 B/lane when this was written) but not more
@@ -57,7 +57,7 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     # the builds that read the time functions from the segment's table (fixed-grid solves: the hot ones): the forward kernel has no
     # scratch at all, neither build spills scalar registers in its main path (v_readlane / v_writelane: the first version of the table
     # cost the main path 26 of them per wave, found in the SQ counters)
-    fwd_t = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi0ELin1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+    fwd_t = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi0ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
     assert not any(x.startswith("scratch_") for x in fwd_t), "k_fwd_stage<nonlinear,contact,4,table> spills"
     assert sum(x.startswith(("v_readlane", "v_writelane")) for x in fwd_t) <= 8, "k_fwd_stage<..., table>: scalar-register spills"
     n_loads = 0
@@ -69,20 +69,20 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     # (the first wait now belongs to the dictionary's hand-off to LDS, which needs two of the early loads; the five stage-acceleration
     # loads that follow it are independent of it)
     assert n_loads >= 18, f"k_fwd_stage<..., table>: first vmcnt wait after only {n_loads} loads"
-    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi0ELin1EE")
+    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi0ELin1ELi1EE")
     assert vgprs <= 96 and scratch == 0, ("k_fwd_stage<nonlinear,contact,4,table>", vgprs, scratch)
     assert sum(x.startswith(("v_readlane", "v_writelane")) for x in adj[:1200]) <= 40, "k_adj_stage<..., table>: scalar-register spills in the main path"
     # the packed mapping of 3-node blocks (lane_pos<3>): same budgets
     scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi0ELin1EE")
     assert vgprs <= 128 and scratch == 0, ("k_adj_stage<nonlinear,contact,0,0,3>", vgprs, scratch)
-    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi0ELin1EE")
+    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi0ELin1ELi1EE")
     assert vgprs <= 102, ("k_fwd_stage<nonlinear,contact,3>", vgprs, scratch)
     scratch, vgprs = meta_of("_ZN12_GLOBAL__N_114k_adj_stage_rbILi1ELi1EE")
     assert vgprs <= 128 and scratch <= 32, ("k_adj_stage_rb<nonlinear,contact>", vgprs, scratch)
     # round 4: the write-through builds (template parameter WT = 1: what 16 x 128x128 launches run) keep the same budgets -- the
     # forward one was lost once already to 30 scalar-register spills in its hot path (profiles/r04_write_through_stores.txt) -- and
     # their stores really carry sc1
-    fwd_w = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELin1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+    fwd_w = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
     adj_w = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELin1EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
     assert not any(x.startswith("scratch_") for x in fwd_w + adj_w)
     assert sum(x.startswith(("v_readlane", "v_writelane")) for x in fwd_w) <= 8, "k_fwd_stage<..., table, WT>: scalar-register spills"
@@ -92,18 +92,18 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     for body in (fwd_w, adj_w):
         stores = [x for x in body if x.startswith("global_store")]
         assert sum("sc1" in x for x in stores) >= 4 and sum("sc1" not in x for x in stores) <= 1, stores   # (the one plain store: the adaptive controller's error partial / nothing)
-    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELin1EE")
+    scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELin1ELi1EE")
     assert vgprs <= 96 and scratch == 0, ("k_fwd_stage<nonlinear,contact,4,table,WT>", vgprs, scratch)
     scratch, vgprs = meta_of("_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELin1EE")
     assert vgprs <= 128 and scratch == 0, ("k_adj_stage<nonlinear,contact,0,0,4,table,WT>", vgprs, scratch)
     # the per-stage builds of the two (stage index a template parameter: what 16 x 128x128 launches of Dopri5 really run): no scalar spills,
     # no scratch, the register budgets of their generic builds
     for st in range(6):
-        f = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+        f = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
         a = _function(txt, f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
         assert not any(x.startswith("scratch_") for x in f + a), st
         assert sum(x.startswith(("v_readlane", "v_writelane")) for x in f) <= 8 and sum(x.startswith(("v_readlane", "v_writelane")) for x in a) <= 4, st
-        assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}EE")[1] <= 96, st
+        assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EE")[1] <= 96, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EE")[1] <= 128, st
     # the opt-in tile kernels (dfx_tile.h): no scratch, no workgroup barrier (wave-private tiles: LDS operations of a wave are in order)
     for nm in ("_ZN12_GLOBAL__N_110k_fwd_tileILi1ELi1EEEvNS_6DevCtxENS_6LigCtxENS_9StageCoefEiiiiii",
