@@ -165,6 +165,7 @@ struct dfx_handle {
   // every ligament evaluated once on lattice tiles (dfx_tile.h): the lane tables found at create, the ligament-major images of the
   // parameters (k_lig_pack after every set_params) and of the node-vector / void-angle accumulators (k_lig_unpack after a sweep)
   bool wt = false;               // the table builds of the stage kernels store write-through (sc1): launches that fill the chip (dfx_create)
+  bool stage_builds = true;      // ... and take their per-stage builds (DFX_STAGE_BUILDS=0: the generic ones, for A/B runs)
   bool lig_ok = false, lig_used = false;      // lig_used: accumulators of the running sweep are ligament-major
   bool lig_fwd_used = false, lig_adj_used = false;   // what the last forward pass / reverse sweep launched (dfx_stats)
   LigCtx lig;
@@ -457,7 +458,7 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
       const bool recs = c.rps > 1 && in_buf == -1 - i && out_buf == -2 - i && y_buf == -1 && mode == 0;
 #define DFX_FWD_I(I) case I: if (recs) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I, 1>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); \
                              else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I, 0>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return;
-      if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')
+      if (h->stage_builds)
         switch (i) { DFX_FWD_I(0) DFX_FWD_I(1) DFX_FWD_I(2) DFX_FWD_I(3) DFX_FWD_I(4) DFX_FWD_I(5) default: break; }
 #undef DFX_FWD_I
     }
@@ -505,7 +506,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
     if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {      // one build per stage (the stage index only: see adj_stage_body)
       const AdjCoef acf = adj_coef(h->pl.tab, i);
 #define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, wbuf, local_only, rc, rb); return;
-      if (getenv("DFX_STAGE_BUILDS") == nullptr || getenv("DFX_STAGE_BUILDS")[0] != '0')
+      if (h->stage_builds)
         switch (i) { DFX_ADJ_I(0) DFX_ADJ_I(1) DFX_ADJ_I(2) DFX_ADJ_I(3) DFX_ADJ_I(4) DFX_ADJ_I(5) default: break; }
 #undef DFX_ADJ_I
     }
@@ -1106,6 +1107,8 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   {  // write-through stores in the stage kernels where a launch fills the chip (dfx_kernels.h, stg_m); DFX_WT=0|1 overrides (A/B runs)
     const char* e = getenv("DFX_WT");
     h->wt = e ? (e[0] != '0') : ((long long)h->pl.batch * ((h->pl.n_slots + 63) / 64) >= 2048);
+    const char* sb = getenv("DFX_STAGE_BUILDS");
+    h->stage_builds = !(sb && sb[0] == '0');
   }
   const Plan& pl = h->pl;
   bool ok = h->d_slot_info.ensure(pl.n_slots) == hipSuccess && h->d_block_special.ensure(pl.n_blocks) == hipSuccess &&
