@@ -160,7 +160,19 @@ DFX_HD void fast_sincos(double x, double* sn, double* cs) {
 DFX_HD double half_cos(double th, double sh) {
   const double t = th * 0.07957747154594767280;                 // th / (4 pi): cos(th/2) = cos(2 pi t)
   const double f = t - rint(t);
-  const double c = sqrt(fmax(0.0, fma(-sh, sh, 1.0)));
+  const double x = fmax(0.0, fma(-sh, sh, 1.0));
+#if defined(__HIP_DEVICE_COMPILE__)
+  // x is in (0, 1] and far from the denormals unless |th| is within 1e-150 of pi: v_rsq_f64 + two coupled Newton steps (<= 1 ulp)
+  // instead of the correctly rounded library sqrt with its range scaling (~14 instructions, twice per lane in both stage kernels)
+  const double r = __builtin_amdgcn_rsq(x);                     // (x = 0: inf, selected away below -- no branch)
+  double y = x * r, hh = 0.5 * r;
+  double e = fma(-hh, y, 0.5);
+  y = fma(y, e, y); hh = fma(hh, e, hh);
+  e = fma(-y, y, x);
+  const double c = x > 1e-300 ? fma(e, hh, y) : 0.0;
+#else
+  const double c = sqrt(x);
+#endif
   return fabs(f) <= 0.25 ? c : -c;
 }
 // wrap an angle into [-pi, pi] (value only; derivative 1)
