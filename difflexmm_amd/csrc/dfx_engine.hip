@@ -503,7 +503,7 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
     }
   }
   else if (c.fn_tab && !local_only && h->wt) {
-    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {      // one build per stage (the stage index only: see adj_stage_body)
+    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) if (c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps) {      // one build per stage, common parameter shape (adj_stage_body)
       const AdjCoef acf = adj_coef(h->pl.tab, i);
 #define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, wbuf, local_only, rc, rb); return;
       if (h->stage_builds)

@@ -1065,12 +1065,15 @@ template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int 
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
-__device__ __forceinline__ void adj_stage_body(const DevCtx& c, const AdjCoef& ac, int i_arg, int j, int in_buf, int wbuf_static,
+__device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoef& ac, int i_arg, int j, int in_buf, int wbuf_static,
                                                int local_only, const StageCoef& rc, int rb) {
-  // ISTAGE: see k_fwd_stage.  Here the stage index only: with the forward kernel's common-shape constants as well the reverse builds
-  // shed another third of their scalar instructions and were no faster alone and 4 % slower with two member groups on the chip
-  // (profiles/r04_scalar_diet.txt) -- the reverse kernel is bound by its vector instructions, not by the scalar unit.
+  // ISTAGE: see k_fwd_stage.  The per-stage builds take the stage index and the PARAMETER shape (uniform stiffnesses / damping, LDS
+  // dictionary, equal steps) as constants -- launch 29.7 -> 29.1 us, 112 VGPRs -- but not the buffer / mode arguments: with those
+  // folded as well (in_buf, local_only, wbuf, rb, AD, clock) three variants measured 0.6 - 1.5 us SLOWER although they shed more
+  // instructions (profiles/r04_scalar_diet.txt): the reverse kernel is bound by vector issue and those builds schedule worse.
   const int i = ISTAGE >= 0 ? ISTAGE : i_arg;
+  DevCtx c = c_arg;
+  if (ISTAGE >= 0) { c.damping_uniform = 1; c.k_uniform = 1; c.l_dict_on = 1; c.l_dict_lds = 1; c.t_steps = nullptr; }
   static_assert(NPB == 4 || (CONTACT != 2 && !REBUILD && !BOND_GRADS), "the packed mapping serves the records build without distance contact");
   const int m = blockIdx.y + c.m0;
   const LanePos lp = lane_pos<NPB>(logical_wg(blockIdx.x, NPB == 4 ? c.n_wg : c.n_wg3), c.n_blocks);
