@@ -429,6 +429,32 @@ static bool pack3(const dfx_handle* h) {
 static bool hot_shape(const DevCtx& c) {
   return c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps && !c.AD && !c.clock;
 }
+// the per-stage builds (stage index, common parameter shape and -- where the records live in the checkpoint -- the buffer arguments as
+// compile-time constants) of the write-through table kernels, quad mapping (NPB = 4) or packed triangles (NPB = 3); false: not applicable
+template <int MODEL, int CONTACT, int NPB>
+static bool launch_fwd_hot(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
+  if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {
+    if (!h->wt || !h->stage_builds || !hot_shape(c)) return false;
+    const StageCoef scf = stage_coef(h->pl.tab, i);
+    const bool recs = c.rps > 1 && in_buf == -1 - i && out_buf == -2 - i && y_buf == -1 && mode == 0;
+#define DFX_FWD_I(I) case I: if (recs) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, NPB, 1, 0, 1, I, 1>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); \
+                             else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, NPB, 1, 0, 1, I, 0>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return true;
+    switch (i) { DFX_FWD_I(0) DFX_FWD_I(1) DFX_FWD_I(2) DFX_FWD_I(3) DFX_FWD_I(4) DFX_FWD_I(5) default: break; }
+#undef DFX_FWD_I
+  }
+  return false;
+}
+template <int MODEL, int CONTACT, int NPB>
+static bool launch_adj_hot(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only, const StageCoef& rc, int rb) {
+  if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {
+    if (!h->wt || !h->stage_builds || !(c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps)) return false;
+    const AdjCoef acf = adj_coef(h->pl.tab, i);
+#define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, NPB, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, wbuf, local_only, rc, rb); return true;
+    switch (i) { DFX_ADJ_I(0) DFX_ADJ_I(1) DFX_ADJ_I(2) DFX_ADJ_I(3) DFX_ADJ_I(4) DFX_ADJ_I(5) default: break; }
+#undef DFX_ADJ_I
+  }
+  return false;
+}
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   if constexpr (CONTACT != 2) {
@@ -446,22 +472,14 @@ static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   const bool tab = c.fn_tab != nullptr && !c.clock;        // the segment's time-function table is there: the build that reads it
   if (CONTACT != 2 && pack3(h) && !(mode & 2)) {
     if constexpr (CONTACT != 2) {
+      if (tab && launch_fwd_hot<MODEL, CONTACT, 3>(h, c, st, dim3(c.n_wg3, grid.y), i, j, in_buf, out_buf, y_buf, mode)) return;
       if (tab) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 3, 1>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
       else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 3, 0>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
     }
     return;
   }
   if (tab && h->wt) {
-    // one build per stage for the ligament models the reference's problems use (the stage index as a compile-time constant)
-    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) if (hot_shape(c)) {
-      const StageCoef scf = stage_coef(h->pl.tab, i);
-      const bool recs = c.rps > 1 && in_buf == -1 - i && out_buf == -2 - i && y_buf == -1 && mode == 0;
-#define DFX_FWD_I(I) case I: if (recs) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I, 1>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); \
-                             else hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1, I, 0>), grid, dim3(kThreads), 0, st, c, scf, i, j, in_buf, out_buf, y_buf, mode); return;
-      if (h->stage_builds)
-        switch (i) { DFX_FWD_I(0) DFX_FWD_I(1) DFX_FWD_I(2) DFX_FWD_I(3) DFX_FWD_I(4) DFX_FWD_I(5) default: break; }
-#undef DFX_FWD_I
-    }
+    if (launch_fwd_hot<MODEL, CONTACT, 4>(h, c, st, grid, i, j, in_buf, out_buf, y_buf, mode)) return;
     hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
   }
   else if (tab) hipLaunchKernelGGL((k_fwd_stage<MODEL, CONTACT, 4, 1>), grid, dim3(kThreads), 0, st, c, stage_coef(h->pl.tab, i), i, j, in_buf, out_buf, y_buf, mode);
@@ -498,18 +516,13 @@ static void launch_adj_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 gr
   else if (c.AD) hipLaunchKernelGGL((k_adj_stage_rb<MODEL, CONTACT>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   else if (CONTACT != 2 && pack3(h)) {
     if constexpr (CONTACT != 2) {
+      if (c.fn_tab && !local_only && launch_adj_hot<MODEL, CONTACT, 3>(h, c, st, dim3(c.n_wg3, grid.y), i, j, in_buf, wbuf, local_only, rc, rb)) return;
       if (c.fn_tab && !local_only) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 3, 1>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
       else hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 3, 0>), dim3(c.n_wg3, grid.y), dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
     }
   }
   else if (c.fn_tab && !local_only && h->wt) {
-    if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) if (c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps) {      // one build per stage, common parameter shape (adj_stage_body)
-      const AdjCoef acf = adj_coef(h->pl.tab, i);
-#define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, wbuf, local_only, rc, rb); return;
-      if (h->stage_builds)
-        switch (i) { DFX_ADJ_I(0) DFX_ADJ_I(1) DFX_ADJ_I(2) DFX_ADJ_I(3) DFX_ADJ_I(4) DFX_ADJ_I(5) default: break; }
-#undef DFX_ADJ_I
-    }
+    if (launch_adj_hot<MODEL, CONTACT, 4>(h, c, st, grid, i, j, in_buf, wbuf, local_only, rc, rb)) return;
     hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1, 0, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   }
   else if (c.fn_tab && !local_only) hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, 4, 1>), grid, dim3(kThreads), 0, st, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
