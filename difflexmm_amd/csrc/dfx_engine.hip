@@ -455,6 +455,13 @@ static bool launch_adj_hot(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 
   }
   return false;
 }
+// what dfx_stats.tile_kernels reports: 1 tile kernels, 2 the per-stage / common-shape builds of the slot kernels, 0 their generic builds
+static int kernel_build_code(const dfx_handle* h, const DevCtx& c, bool tile) {
+  if (tile) return 1;
+  const bool model_ok = (h->pl.model == kNonlinear || h->pl.model == kLinearized) && h->pl.contact != DFX_CONTACT_DISTANCE;
+  const bool quad_or_packed = !h->pl.n_ovf && (h->pl.n_npb == 4 || pack3(h));
+  return (model_ok && quad_or_packed && h->wt && h->stage_builds && c.fn_tab && hot_shape(c) && h->pl.tab.s <= 6) ? 2 : 0;
+}
 template <int MODEL, int CONTACT>
 static void launch_fwd_t(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int out_buf, int y_buf, int mode) {
   if constexpr (CONTACT != 2) {
@@ -1420,7 +1427,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
     stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
-    stats->tile_kernels = h->lig_fwd_used ? 1 : 0;
+    stats->tile_kernels = kernel_build_code(h, c, h->lig_fwd_used);
   }
   return 0;
 }
@@ -1713,7 +1720,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
     stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
-    stats->tile_kernels = h->lig_adj_used ? 1 : 0;
+    stats->tile_kernels = (c.g_b || c.AD) ? 0 : kernel_build_code(h, c, h->lig_adj_used);
   }
   return 0;
 }

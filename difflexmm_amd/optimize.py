@@ -317,7 +317,7 @@ class MemberWorkers:
         while True:
             try:
                 q.put(conn.recv())
-            except (EOFError, OSError, ValueError):
+            except (EOFError, OSError, ValueError, TypeError):     # TypeError: the handle of a connection closed under the reader is None
                 q.put(("error", "the worker's connection closed"))
                 return
 

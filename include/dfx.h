@@ -130,8 +130,10 @@ typedef struct dfx_stats {
                                              taken when it fits; then stage_checkpoint = 0);
                                              2: "segments": nothing but the outputs was kept, the reverse sweep re-runs one output
                                              interval at a time with the records of that interval only */
-  int64_t tile_kernels;                   /* 1: the stage launches of this call were the tile kernels (every ligament evaluated once on
-                                             lattice tiles, DFX_TILE=1: an opt-in build), 0: the slot kernels */
+  int64_t tile_kernels;                   /* which builds of the stage kernels this call launched: 0 the generic slot kernels; 2 their
+                                             per-stage builds (stage index and common parameter shape compiled in: launches that fill the
+                                             chip; DFX_STAGE_BUILDS=0 switches them off); 1 the tile kernels (every
+                                             ligament evaluated once on lattice tiles, DFX_TILE=1: opt-in) */
 } dfx_stats;
 
 typedef struct dfx_handle dfx_handle;

@@ -57,3 +57,36 @@ def test_tile_kernels_match_the_oracle(hip_lib):
     lv = dict(loading_rate=torch.tensor(3000.0, dtype=torch.float64), input_delay=torch.tensor(1e-5, dtype=torch.float64))
     osol = c.oracle_solver(integrator="fixed", steps_per_interval=12)
     assert relerr(fields, osol(np.zeros((2, 400, 3)), ts, c.oracle_cp(lv)).numpy()) < 1e-10
+
+
+def test_per_stage_builds_equal_generic_builds(hip_lib):
+    """The per-stage / common-shape builds of the slot kernels (what an ensemble that fills the chip launches: DESIGN.md section 4) against
+    their generic builds on the same problem: 8 designs of 64 x 64 quads (2 048 waves per launch), records and segments levels --
+    fields 1e-13, every gradient the records build accumulates 1e-11 -- and dfx_stats says which build ran."""
+    ts = np.linspace(0.0, 3e-4, 4)
+    out = {}
+    for name, env in (("generic", {"DFX_STAGE_BUILDS": "0"}), ("plain", {"DFX_WT": "0"}), ("hot", {})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            c = Case("quads", 64, True, True, seed=21, cutoff_deg=42.0, batch=8, per_bond_k=False)
+            c.solver
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        c.cp = [c.cp._replace(constraint_params=dict(FAST, amplitude=7.5 * (1 + 0.02 * m))) for m in range(8)]
+        mid = c.geo.n_blocks // 2
+        target = np.array([mid + 1, mid + 2], dtype=np.int32)
+        res = []
+        for level in ("records", "segments"):
+            r = _solve(c, ts, 7, target, {"DFX_CHECKPOINT": level})
+            res.append(r)
+            want = 2 if name == "hot" else 0
+            assert c.solver.stats["tile_kernels"] == want and r[3]["tile_kernels"] == want, (name, level, c.solver.stats["tile_kernels"])
+        out[name] = res
+    for name in ("plain", "hot"):
+        for a, b in zip(out[name], out["generic"]):
+            assert relerr(a[0], b[0]) < 1e-13 and abs(a[1] - b[1]) < 1e-12 * abs(b[1]), name
+            for k in b[2]:
+                assert relerr(a[2][k], b[2][k]) < 1e-11, (name, k)
+    assert np.abs(out["hot"][0][2]["centroid_node_vectors"]).max() > 0
