@@ -94,16 +94,18 @@ def prepare(fw, designs, n_steps, spi=SPI, t_start=0.0):
     sd._last = (cps, flats, fw.timepoints)
 
 
-def execute(fw, obj, adjoint=True, spi=SPI):
-    """The hot path on resident inputs: forward (members start at rest: no upload) + objective + reverse sweep, gradients
-    returned as views of the engine's pinned result area; returns device milliseconds + stats."""
+def execute(fw, obj, adjoint=True, spi=SPI, device_outputs=False):
+    """The hot path on resident inputs: forward (members start at rest: no upload) + objective + reverse sweep; returns device
+    milliseconds + stats.  Gradients: views of the engine's pinned result area (they crossed PCIe inside this call), or with
+    ``device_outputs`` DeviceArray handles to the accumulators in HBM (dfx_kinetic_value_and_grad_device: outputs resident like the
+    inputs, what the reference's jit(value_and_grad) hands back) -- `fetch` downloads them afterwards."""
     eng = fw.solve_dynamics.engine
     _, st_f = eng.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=adjoint, want_fields=False)
     out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "streams": max(1, int(st_f.get("streams", 1))),
            "objective": None, "adj_ms": 0.0, "adj_launches": 0}
     if adjoint:
         out["objective"], grads, st_a = eng.kinetic_value_and_grad(
-            obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"))
+            obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"), device=device_outputs)
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
         out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
         out["checkpoint"] = {1: "records", 2: "segments"}.get(st_a.get("checkpoint_records", 0)) or ("stages" if st_a.get("stage_checkpoint", 0) else "state")
@@ -111,7 +113,18 @@ def execute(fw, obj, adjoint=True, spi=SPI):
     return out
 
 
+def fetch(res):
+    """Download device-resident gradients of `execute(device_outputs=True)`; returns the seconds it took (0 for host views)."""
+    g = res.get("grads")
+    if not g or not any(hasattr(a, "to_host") for a in g.values()):
+        return 0.0
+    t0 = time.perf_counter()
+    res["grads"] = {k: (a.to_host() if hasattr(a, "to_host") else a) for k, a in g.items()}
+    return time.perf_counter() - t0
+
+
 def grad_norm(res):
+    fetch(res)
     g = res.get("grads")
     return None if g is None else float(np.sqrt(sum(float(np.vdot(a, a)) for a in g.values())))
 
@@ -124,11 +137,11 @@ def spin_up(fw, n_steps=500, spi=SPI):
     eng.forward(None, ts, spi, keep_trajectory=False, want_fields=False)
 
 
-def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI):
+def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI, device_outputs=False):
     prepare(fw, designs, n_steps, spi)
     if fw.solve_dynamics.engine.lib.dfx_device_count() > 0 and spi == SPI:
         spin_up(fw, spi=spi)
-    return execute(fw, obj, adjoint, spi)
+    return execute(fw, obj, adjoint, spi, device_outputs)
 
 
 def c3_as_written_leg(args, device, sync, steps=50000):
@@ -394,6 +407,9 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="member groups advanced concurrently, one HIP stream each")
     ap.add_argument("--no-single", action="store_true", help="skip the extra 1-member reference measurement")
+    ap.add_argument("--outputs", default="hbm", choices=("hbm", "host"),
+                    help="where the timed job leaves its gradients: hbm (device pointers; the download is timed after the region and "
+                         "reported) | host (pinned views: the D2H copy is inside the timed region)")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the separate 1-stream per-launch measurement")
     ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx; strict: exits non-zero if it "
                                                       "does not come up on N distinct GPUs) | socket (rehearsal on one GPU)")
@@ -528,15 +544,16 @@ def main():
         fw1.solve_dynamics.engine.close()
         del fw1, obj1, r1
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank, **prob)
+    device_outputs = adjoint and args.outputs == "hbm" and hasattr(fw.solve_dynamics.engine.lib, "dfx_kinetic_value_and_grad_device")
     fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=adjoint)
     if W:
-        run_once(fw, obj, designs, W, adjoint=adjoint)
+        run_once(fw, obj, designs, W, adjoint=adjoint, device_outputs=device_outputs)
     # hipGraphs are instantiated on first use: make sure every segment length the K timed steps replay has been used once
     # (a full output interval and the shorter last interval), whatever W was
     if K >= SPI and (W < SPI or W % SPI):
-        run_once(fw, obj, designs, SPI, adjoint=adjoint)
+        run_once(fw, obj, designs, SPI, adjoint=adjoint, device_outputs=device_outputs)
     if K % SPI:
-        run_once(fw, obj, designs, K % SPI, adjoint=adjoint)
+        run_once(fw, obj, designs, K % SPI, adjoint=adjoint, device_outputs=device_outputs)
 
     def barrier():
         sync()
@@ -549,10 +566,23 @@ def main():
     spin_up(fw)
     barrier()
     t0 = time.perf_counter()
-    res = execute(fw, obj, adjoint=adjoint)
+    res = execute(fw, obj, adjoint=adjoint, device_outputs=device_outputs)
     barrier()
     wall = time.perf_counter() - t0
+    out_bytes = sum(getattr(a, "nbytes", 0) for a in (res.get("grads") or {}).values())
+    fetch_s = fetch(res)                       # outputs over PCIe to the host: after the timed region, reported
     gnorm = grad_norm(res)
+    wall_host_outputs = None
+    if device_outputs and K <= 2500:
+        # the PCIe-inclusive rate of the same job: one more region through the host-output call (gradients arrive as pinned views)
+        run_once(fw, obj, designs, K, adjoint=adjoint)
+        prepare(fw, designs, K)
+        spin_up(fw)
+        barrier()
+        th = time.perf_counter()
+        execute(fw, obj, adjoint=adjoint)
+        barrier()
+        wall_host_outputs = float(comm.all_reduce([time.perf_counter() - th], "max")[0])
     objective = res["objective"] if res["objective"] is not None else np.zeros(args.members)
     wall = float(comm.all_reduce([wall], "max")[0])                    # MAX over ranks
     objective = comm.all_gather(objective).ravel()                     # the single collective of the path: objectives over xGMI
@@ -608,6 +638,13 @@ def main():
             "forward_only_value": K * n_units * args.members * world / (res["fwd_ms"] * 1e-3),
             "device_ms": {"forward": res["fwd_ms"], "adjoint": res["adj_ms"], "wall": 1e3 * wall},
             "host_prepare_ms": host_prepare_ms, "value_with_host_prepare": total_units_steps / (wall + 1e-3 * host_prepare_ms),
+            # the boundary's PCIe legs, never part of `value`: inputs in (host_prepare_ms: design -> packed arrays -> H2D) and
+            # gradients out (the accumulators stay in HBM inside the timed region; `--outputs host` times the pinned-copy call instead)
+            "outputs": {"where": "hbm" if device_outputs else "host (pinned views, inside the timed region)",
+                        "gradient_bytes": int(out_bytes), "download_ms": 1e3 * fetch_s,
+                        "value_with_outputs_on_host": total_units_steps / (wall_host_outputs or (wall + fetch_s)),
+                        "measured_with": ("a second region of the same K steps through dfx_kinetic_value_and_grad (pinned views)"
+                                          if wall_host_outputs else "timed region + download")},
             "launches": {"forward": res["fwd_launches"], "adjoint": res["adj_launches"]},
             # RHS evaluations per second (whole-lattice evaluations of every member; the reverse sweep adds one
             # Hessian-vector product per forward evaluation, counted as one more each)
@@ -657,7 +694,7 @@ def main():
         line["end_to_end_frac_of_hbm_peak"] = per_step_bytes * total_units_steps / wall / 1e9 / HBM_PEAK_GBS
         if single is not None:
             line["single_system"] = single
-        if world == 1 and adjoint and not args.no_as_written and args.size == 128:
+        if world == 1 and adjoint and not args.no_as_written and args.size == 128 and args.as_written_steps > 0:
             line["c3_as_written"] = c3_as_written_leg(args, local_rank, sync, steps=args.as_written_steps)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.size, 3)

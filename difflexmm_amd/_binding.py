@@ -58,7 +58,7 @@ EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
-                "dfx_mem_info", "dfx_device_synchronize"]
+                "dfx_mem_info", "dfx_device_synchronize", "dfx_kinetic_value_and_grad_device", "dfx_download"]
 EXPORTS = EXPORTS + COMM_EXPORTS
 
 
@@ -105,6 +105,8 @@ def declare(lib):
         lib.dfx_comm_last_error.restype = C.c_char_p
         lib.dfx_mem_info.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.dfx_device_synchronize.argtypes = [C.c_int32]
+        lib.dfx_kinetic_value_and_grad_device.argtypes = lib.dfx_kinetic_value_and_grad.argtypes
+        lib.dfx_download.argtypes = [H, _dp, C.c_void_p, C.c_int64]
     return lib
 
 
@@ -365,9 +367,10 @@ class Engine:
                     "dfx_adjoint_kinetic")
         return out, _stats(st)
 
-    def kinetic_value_and_grad(self, target_blocks, which=ALL_GRADS):
+    def kinetic_value_and_grad(self, target_blocks, which=ALL_GRADS, device=False):
         """objective (batch,) and the requested gradients in ONE call; the arrays are read-only views of library-owned pinned
-        memory (valid until the next call on this engine: copy what must outlive it)."""
+        memory (valid until the next call on this engine: copy what must outlive it).  ``device=True`` leaves the gradients in HBM
+        (HIP library only): the values are ``DeviceArray`` handles, ``.to_host()`` downloads one."""
         tb = np.ascontiguousarray(target_blocks, dtype=np.int32)
         sh = self.shapes()
         want, views = dfx_grads(), dfx_grads()
@@ -379,6 +382,12 @@ class Engine:
             setattr(want, n, _ptr(flag))
         obj = np.zeros(self.batch)
         st = dfx_stats()
+        if device:
+            if not hasattr(self.lib, "dfx_kinetic_value_and_grad_device"):
+                raise RuntimeError("device-resident gradients need the HIP library")
+            self._check(self.lib.dfx_kinetic_value_and_grad_device(self._h, tb.ctypes.data_as(_ip), len(tb), _ptr(obj), C.byref(want),
+                                                                   C.byref(views), C.byref(st)), "dfx_kinetic_value_and_grad_device")
+            return obj, {n: DeviceArray(self, C.cast(getattr(views, n), C.c_void_p).value, sh[n]) for n in names}, _stats(st)
         self._check(self.lib.dfx_kinetic_value_and_grad(self._h, tb.ctypes.data_as(_ip), len(tb), _ptr(obj), C.byref(want),
                                                         C.byref(views), C.byref(st)), "dfx_kinetic_value_and_grad")
         out = {}
@@ -423,6 +432,20 @@ class Engine:
         e = np.zeros(self.batch)
         self._check(self.lib.dfx_energy(self._h, _ptr(u), _ptr(e)), "dfx_energy")
         return e
+
+
+class DeviceArray:
+    """A float64 array in the HBM of an engine's GPU (a pointer the library handed out, valid until the next call on that engine)."""
+
+    def __init__(self, engine, ptr, shape):
+        self.engine, self.ptr, self.shape = engine, ptr, tuple(shape)
+        self.size = int(np.prod(self.shape))
+        self.nbytes = 8 * self.size
+
+    def to_host(self):
+        out = np.empty(self.shape)
+        self.engine._check(self.engine.lib.dfx_download(self.engine._h, _ptr(out), self.ptr, self.size), "dfx_download")
+        return out
 
 
 def _stats(st):

@@ -104,7 +104,7 @@ struct dfx_handle {
   std::vector<Group> groups;
   bool dual_chain = true;
   hipEvent_t ev_fork2 = nullptr;
-  PinnedBuf stage, obj_stage, zero_phi;   // zero_phi: an all-zero void-angle gradient handed out when the sweep never touched the accumulator
+  PinnedBuf stage, obj_stage, flag_stage, zero_phi;   // flag_stage: one-word results (non-finite flag, touched flag) land in pinned memory; zero_phi: an all-zero void-angle gradient handed out when the sweep never touched the accumulator
   hipEvent_t ev_fork = nullptr;
   PackedParams pp;
   std::string err;
@@ -118,6 +118,7 @@ struct dfx_handle {
   DevBuf<double> d_ovf_p, d_ovf_g;             // extra ligaments (general bond lists): parameters, gradient accumulators
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<double> d_resp;                           // dfx_response_data outputs
+  bool device_views = false;                       // this call hands out device pointers (dfx_kinetic_value_and_grad_device)
   DevBuf<dfx_special> d_special;
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict, d_p_c, d_g_c;
   DevBuf<uint8_t> d_l_idx;
@@ -777,12 +778,17 @@ static int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_int
     h->err = "steps x members too large: the trajectory checkpoint is addressed by 32-bit record ordinals (split the ensemble or the horizon)";
     return -2;
   }
-  size_t free_b = 0, total_b = 0;
-  const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
   // a level whose buffers already exist fits whatever else has been allocated since (adjoint work buffers, sibling engines of a
-  // multi-input objective, RCCL): only GROWTH is checked against the free memory, leaving 5 % of the device
-  const size_t free_now = dfx_test_free_bytes ? std::min<size_t>(free_b, dfx_test_free_bytes) : free_b;
-  auto fits = [&](size_t grow_elems) { return grow_elems == 0 || (have_info && grow_elems * sizeof(double) + total_b / 20 <= free_now); };
+  // multi-input objective, RCCL): only GROWTH is checked against the free memory, leaving 5 % of the device.  The driver is asked
+  // for the free memory only when something has to grow (the query costs ~0.1 ms: a repeated solve of the same shape skips it).
+  size_t free_b = 0, total_b = 0;
+  int have_info = -1;
+  auto fits = [&](size_t grow_elems) {
+    if (grow_elems == 0) return true;
+    if (have_info < 0) have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? 1 : 0;
+    const size_t free_now = dfx_test_free_bytes ? std::min<size_t>(free_b, dfx_test_free_bytes) : free_b;
+    return have_info == 1 && grow_elems * sizeof(double) + total_b / 20 <= free_now;
+  };
   const size_t have_t = h->ck->traj.n, have_a = h->ck->AD.n;
   auto grow = [](size_t want, size_t have) { return want > have ? want - have : (size_t)0; };   // DevBuf frees the old block before it allocates
   int mode = forced;
@@ -915,6 +921,37 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
                        (const int32_t*)h->d_lig_slots.p, (const double*)h->d_lig_g.p, pl.contact == DFX_CONTACT_ANGLE ? (const double*)h->d_lig_gphi.p : (const double*)nullptr);
     h->lig_used = false;
   }
+  if (h->device_views) {    // the gradients stay where the sweep accumulated them: re-layout on the device, no copy over PCIe
+    if (want->reference_vector || want->k_bond || want->contact || want->fn_params || pl.n_ovf ||
+        (want->void_angle0 && pl.contact != DFX_CONTACT_ANGLE) || (want->block_centroids && pl.contact != DFX_CONTACT_DISTANCE)) {
+      h->err = "device-resident gradients: centroid_node_vectors, void_angle0 (angle contact), inertia, damping, state0, block_centroids "
+               "(distance contact) of lattices without extra ligaments; the others are assembled on the host (dfx_kinetic_value_and_grad)";
+      return 1;
+    }
+    const bool d_r = want->centroid_node_vectors, d_phi = want->void_angle0, d_lam = with_state0 && want->state0;
+    const bool d_pack_r = d_r && npb != kSlots;
+    if (d_pack_r) HIP_OK(h->d_out_r.ensure(B * nb * npb * 2));
+    if (d_phi) HIP_OK(h->d_out_phi.ensure(B * nbd * 2));
+    if (d_lam) HIP_OK(h->d_out_lam.ensure(B * nb * 6));
+    if (d_pack_r || d_phi || d_lam) {
+      DevCtx c = make_ctx(h);
+      hipLaunchKernelGGL(k_pack_grads, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const int32_t*)h->d_slot_bond.p, npb, (int)nbd,
+                         d_pack_r ? h->d_out_r.p : (double*)nullptr, d_phi ? h->d_out_phi.p : (double*)nullptr,
+                         d_lam ? h->d_out_lam.p : (double*)nullptr);
+    }
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipGetLastError());
+    dfx_grads v;
+    memset(&v, 0, sizeof(v));
+    if (d_r) v.centroid_node_vectors = d_pack_r ? h->d_out_r.p : h->d_g_r.p;
+    if (d_phi) v.void_angle0 = h->d_out_phi.p;
+    if (want->inertia) v.inertia = h->d_blk_m.p;
+    if (want->damping) v.damping = h->d_blk_c.p;
+    if (d_lam) v.state0 = h->d_out_lam.p;
+    if (want->block_centroids) v.block_centroids = h->d_g_c.p;
+    if (views) *views = v;
+    return 0;
+  }
   const bool w_r = want->centroid_node_vectors;
   bool w_phi = want->void_angle0 && pl.contact == DFX_CONTACT_ANGLE;
   // contacts are rare: when no lane of the sweep added to the void-angle accumulator (one flag, known after the sweep) its gradient
@@ -922,9 +959,10 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   // gets a view of a zero buffer that is never written
   bool phi_zero = false;
   if (w_phi) {
-    int32_t touched = 1;
-    HIP_OK(hipMemcpyAsync(&touched, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h->flag_stage.ensure(64));
+    HIP_OK(hipMemcpyAsync(h->flag_stage.p, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
+    const int32_t touched = *reinterpret_cast<const int32_t*>(h->flag_stage.p);
     if (!touched && !pl.n_ovf) {
       const size_t bytes = sizeof(double) * B * nbd * 2;
       if (h->zero_phi.n < bytes || !h->zero_phi.p) { HIP_OK(h->zero_phi.ensure(bytes)); memset(h->zero_phi.p, 0, h->zero_phi.n); }
@@ -1174,7 +1212,7 @@ int dfx_destroy(dfx_handle* h) {
   h->d_fn_tab.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
-  h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release();
+  h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release(); h->flag_stage.release();
   for (auto& gr : h->groups) { for (auto e : gr.ev_a) (void)hipEventDestroy(e); for (auto e : gr.ev_b) (void)hipEventDestroy(e); if (gr.stream2) (void)hipStreamDestroy(gr.stream2); if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
@@ -1380,6 +1418,10 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   pair_plan(h, c);
   h->lig_fwd_used = !h->pair_fwd && lig_fwd_ok(h, c, 0);
   h->launches = 0;
+  const bool timing = getenv("DFX_TIMING") != nullptr;
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  if (timing) fprintf(stderr, "[dfx] forward: host setup before the first launch %.0f us\n", since(tw0));
+  const auto tl0 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL, 0LL);
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
@@ -1404,11 +1446,14 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   }
   if (join_groups(h)) return 2;
   HIP_OK(hipEventRecord(h->ev1, h->stream));
+  if (timing) fprintf(stderr, "[dfx] forward: launches enqueued in %.0f us\n", since(tl0));
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
-  int bad = 0;
-  HIP_OK(hipMemcpyAsync(&bad, h->d_seg_idx.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(h->flag_stage.ensure(64));
+  HIP_OK(hipMemcpyAsync(h->flag_stage.p, h->d_seg_idx.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
+  const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
+  if (timing) fprintf(stderr, "[dfx] forward: all done %.0f us after the first launch\n", since(tl0));
   h->have_fields = true;
   if (bad) {
     h->have_traj = false;
@@ -1652,6 +1697,9 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   set_grad_wishes(h, want);
   DevCtx c = make_ctx(h);
   h->launches = 0;
+  const bool timing = getenv("DFX_TIMING") != nullptr;
+  const auto ta0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   if (zero_grad_accumulators(h)) return 2;
   const int nseg = (int)h->segs.size();
   std::vector<int> cursors(kMaxGroups, nseg);
@@ -1707,7 +1755,13 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     hipLaunchKernelGGL(k_kinetic_mass_grad, g, dim3(64), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_target.p, n_target);
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
+  if (timing) fprintf(stderr, "[dfx] adjoint: sweep enqueued %.0f us after entry\n", since(ta0));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
+  if (timing) {
+    float ms0 = 0.f;
+    (void)hipEventElapsedTime(&ms0, h->ev0, h->ev1);
+    fprintf(stderr, "[dfx] adjoint: gradients collected %.0f us after entry (sweep on the device: %.0f us)\n", since(ta0), 1e3 * ms0);
+  }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;
@@ -1824,6 +1878,14 @@ int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int3
   return adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, views, stats);
 }
 
+int dfx_kinetic_value_and_grad_device(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
+                                      const dfx_grads* want, dfx_grads* device_views, dfx_stats* stats) {
+  h->device_views = true;
+  const int rc = adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, device_views, stats);
+  h->device_views = false;
+  return rc;
+}
+
 // device -> caller memory through the pinned staging area, in chunks (outputs here can be GBs; pageable DMA is slow)
 static int download(dfx_handle* h, double* dst, const double* src, size_t n) {
   const size_t chunk = (size_t)8 << 20;      // doubles per chunk: 64 MiB
@@ -1835,6 +1897,12 @@ static int download(dfx_handle* h, double* dst, const double* src, size_t n) {
     memcpy(dst + off, h->stage.p, cnt * sizeof(double));
   }
   return 0;
+}
+
+int dfx_download(dfx_handle* h, double* dst, const double* device_src, int64_t n) {
+  HIP_OK(hipSetDevice(h->device));
+  if (n < 0 || (n && (!dst || !device_src))) { h->err = "dfx_download: bad arguments"; return 1; }
+  return n ? download(h, dst, device_src, (size_t)n) : 0;
 }
 
 int dfx_response_data(dfx_handle* h, double* strain_energy_stretch, double* strain_energy_shear, double* strain_energy_bending,

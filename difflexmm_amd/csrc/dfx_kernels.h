@@ -459,11 +459,13 @@ struct MemberBases {
 };
 __device__ __forceinline__ MemberBases member_bases(const DevCtx& c, int m) {
   MemberBases B;
-  const size_t ps = (size_t)m * (u32)c.n_slots;
-  B.p_r = c.p_r + ps * 2; B.p_phi = c.p_phi + ps * 2; B.p_l = c.p_l + ps * 2; B.p_k = c.p_k + ps * 4;
-  B.ovf_p = c.ovf_p + (size_t)m * (u32)c.n_ovf * kOvfParams;
-  B.cst = c.cst + (size_t)m * 16; B.l_dict = c.l_dict + (size_t)m * 1024; B.p_lidx = c.p_lidx + ps;
-  B.p_c = c.p_c + (size_t)m * (u32)c.n_blocks * 2;
+  // element offsets in 32 bits (dfx_create refuses handles whose arrays reach 2^31 elements): one s_mul_i32 each instead of a
+  // 64-bit product (three multiplies and two adds on the CU's one scalar unit)
+  const u32 um = (u32)m, ps = um * (u32)c.n_slots;
+  B.p_r = c.p_r + (size_t)(ps * 2); B.p_phi = c.p_phi + (size_t)(ps * 2); B.p_l = c.p_l + (size_t)(ps * 2); B.p_k = c.p_k + (size_t)(ps * 4);
+  B.ovf_p = c.ovf_p + (size_t)(um * (u32)c.n_ovf * kOvfParams);
+  B.cst = c.cst + (size_t)(um * 16); B.l_dict = c.l_dict + (size_t)(um * 1024); B.p_lidx = c.p_lidx + (size_t)ps;
+  B.p_c = c.p_c + (size_t)(um * (u32)c.n_blocks * 2);
   return B;
 }
 
@@ -704,9 +706,9 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg
   // stage accelerations: the per-member scratch set, or (stage checkpoint) this step's own slot, kept for the reverse sweep
   // (the last stage's acceleration is not kept: no stage record depends on it)
   const bool keep_stages = c.AD && !c.clock;
-  double* Am = keep_stages ? c.AD + (size_t)m * c.ad_stride + (size_t)n * ((u32)(c.s - 1) * nd) : c.A + (size_t)m * (u32)(c.s + 1) * nd;
-  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
-  const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
+  double* Am = keep_stages ? c.AD + (size_t)m * c.ad_stride + (size_t)n * ((u32)(c.s - 1) * nd) : c.A + (size_t)((u32)m * (u32)(c.s + 1) * nd);
+  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)((u32)m * nd), o_dof);
+  const double invm = ldg<double>(c.inv_m + (size_t)((u32)m * nd), o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
   // earlier stage accelerations: all loads issued together (a rolled loop waits for each one in turn)
   double al[kMaxStages - 1];
@@ -830,8 +832,8 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg
   if (k < 3 && !(c.ablate & 2)) {
     const u32 o_chunk = ((u32)b * kPos + 2 * k) * 8;
     if (out_buf >= 0) {
-      if (k < 2) stg_m<double2>(WT, c.POS + ((size_t)m * c.nbuf + out_buf) * (u32)c.n_blocks * kPos, o_chunk, chunk);
-      stg_m<double>(WT, c.VEL + ((size_t)m * c.nbuf + out_buf) * nd, o_dof, vnext);
+      if (k < 2) stg_m<double2>(WT, c.POS + (size_t)(((u32)m * (u32)c.nbuf + (u32)out_buf) * (u32)c.n_blocks * kPos), o_chunk, chunk);
+      stg_m<double>(WT, c.VEL + (size_t)(((u32)m * (u32)c.nbuf + (u32)out_buf) * nd), o_dof, vnext);
     }
     if (write_traj || out_buf < -1) {
       // state checkpoint: the new step state, once more; records checkpoint (out_buf < -1): the record goes ONLY there, the
@@ -1093,7 +1095,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
   const int dof = b * 3 + kd;
   // per-lane byte offsets shared by the per-DOF arrays; lambda and Ybar: see DevCtx::lam_pairs (= !REBUILD)
   const u32 o_dof = (u32)dof * 8, o_b6 = REBUILD ? ((u32)b * 6 + kd) * 8 : ((u32)b * 6 + 2 * kd) * 8;
-  const double* Win = c.W + ((size_t)m * 2 + win) * nd;
+  const double* Win = c.W + (size_t)(((u32)m * 2 + (u32)win) * nd);
   double w_d = (REBUILD || local_only) ? ldg<double>(Win, o_dof) : 0.0;    // records build: own w recomputed below (like Kbar_q)
   // partner's w from the guessed slot (same batch as everything else)
   double wpx, wpy, wpth;
@@ -1104,12 +1106,12 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
   // Kbar_q of this stage: recomputed in the epilogue from lambda and the later stages' Ybar (already loaded for the next stage's
   // Kbar) in the records build -- 48 B/unit less than storing and re-reading it; the REBUILD builds (at their register limit, the
   // second coefficient column costs them scalar-register spills: 42 -> 46.6 us) and the single-RHS VJP hook read the stored / seeded one
-  double kq_in = (REBUILD || local_only) ? ldg<double>(c.KQ + ((size_t)m * 2 + win) * nd, o_dof) : 0.0;
-  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)m * nd, o_dof);
-  const double invm = ldg<double>(c.inv_m + (size_t)m * nd, o_dof);
+  double kq_in = (REBUILD || local_only) ? ldg<double>(c.KQ + (size_t)(((u32)m * 2 + (u32)win) * nd), o_dof) : 0.0;
+  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)((u32)m * nd), o_dof);
+  const double invm = ldg<double>(c.inv_m + (size_t)((u32)m * nd), o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
-  double* YBm = c.YB + (size_t)m * (u32)c.s * nd6;
-  double* LAMm = c.LAM + (size_t)m * nd6;
+  double* YBm = c.YB + (size_t)((u32)m * (u32)c.s * nd6);
+  double* LAMm = c.LAM + (size_t)((u32)m * nd6);
   double lq = 0.0, lv = 0.0, sq = 0.0, sv = 0.0, sqc = 0.0, svc = 0.0;
   if (!local_only) {
     if (!REBUILD) {
@@ -1118,7 +1120,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
 #pragma unroll
       for (int jj = 1; jj < kMaxStages; ++jj) {       // all loads issued together
         const bool on = jj > i && jj < c.s;
-        yb[jj] = on ? ldg_s<double2>(YBm + (size_t)jj * nd6, o_b6) : make_double2(0.0, 0.0);
+        yb[jj] = on ? ldg_s<double2>(YBm + (size_t)((u32)jj * nd6), o_b6) : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int jj = 1; jj < kMaxStages; ++jj) {
@@ -1243,12 +1245,12 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
   // ALL accumulators requested in one batch (issued here, consumed after the epilogue arithmetic) instead of one memory round
   // trip each at the end of the kernel.  (Fire-and-forget L2 atomics would spare the loads but were measured 10-25 % slower:
   // four fp64 atomics per lane saturate the L2 atomic units.)  Lanes without a ligament / constrained DOFs add zero.
-  const size_t ms = (size_t)m * (u32)c.n_slots;
+  const u32 ms = (u32)m * (u32)c.n_slots;
   double* const blk_c_ = REBUILD ? c.blk_c : DFX_LATE(double, blk_c);        // (the records build: epilogue pointers fetched late, late_arg)
-  double* grm = (REBUILD ? c.g_r : DFX_LATE(double, g_r)) + ms * 2;
-  double* gpm = c.g_phi + ms;
-  double* bmm = (REBUILD ? c.blk_m : DFX_LATE(double, blk_m)) + (size_t)m * nd;
-  double* bcm = blk_c_ + (size_t)m * nd;
+  double* grm = (REBUILD ? c.g_r : DFX_LATE(double, g_r)) + (size_t)(ms * 2);
+  double* gpm = c.g_phi + (size_t)ms;
+  double* bmm = (REBUILD ? c.blk_m : DFX_LATE(double, blk_m)) + (size_t)((u32)m * nd);
+  double* bcm = blk_c_ + (size_t)((u32)m * nd);
   const double2 r_old = ldg_s<double2>(grm, (u32)slot * 16);
   // the void-angle accumulator moves only where a contact is engaged in this stage (d_phi is an exact zero elsewhere, and contacts
   // are rare: 64 B/unit of the launch's traffic otherwise)
@@ -1301,7 +1303,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
       stg_m<double>(WT, bmm, o_dof, bm_old - w_d * a_i);
       if (blk_c_) stg_m<double>(WT, bcm, o_dof, bc_old - w_d * v_i);
     }
-    if (!REBUILD) stg_m<double2>(WT, YBm + (size_t)i * nd6, o_b6, make_double2(ybq, ybv));
+    if (!REBUILD) stg_m<double2>(WT, YBm + (size_t)((u32)i * nd6), o_b6, make_double2(ybq, ybv));
     else { stg_m<double>(WT, YBm + (size_t)i * nd6, o_b6, ybq); stg_m<double>(WT, YBm + (size_t)i * nd6, o_b6 + 24, ybv); }
     if (!local_only) {
       double kq = 0.0, kv;       // Kbar of the next stage to run (records build: its Kbar_q is recomputed there)
@@ -1322,8 +1324,8 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
         if (REBUILD) kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
-      if (REBUILD) stg_m<double>(WT, c.KQ + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, kq);
-      stg_m<double>(WT, (REBUILD ? c.W : DFX_LATE(double, W)) + ((size_t)m * 2 + (win ^ 1)) * nd, o_dof, constrained ? 0.0 : kv * invm);
+      if (REBUILD) stg_m<double>(WT, c.KQ + (size_t)(((u32)m * 2 + (u32)(win ^ 1)) * nd), o_dof, kq);
+      stg_m<double>(WT, (REBUILD ? c.W : DFX_LATE(double, W)) + (size_t)(((u32)m * 2 + (u32)(win ^ 1)) * nd), o_dof, constrained ? 0.0 : kv * invm);
     }
   }
   if (REBUILD && rb > 0) {

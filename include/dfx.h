@@ -216,6 +216,16 @@ int dfx_adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n_t
 int dfx_kinetic_value_and_grad(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
                                const dfx_grads* want, dfx_grads* views, dfx_stats* stats);
 
+/* The same call with the gradients left where the reverse sweep accumulated them: `device_views` receives DEVICE pointers (HBM of the
+ * handle's GPU, dfx_grads layout, valid until the next call on the handle) -- what jit(value_and_grad(objective)) hands back in the
+ * reference: device arrays, nothing crosses PCIe but the (batch,) objective.  Available for centroid_node_vectors, void_angle0,
+ * inertia, damping, state0, block_centroids on lattices without extra ligaments; asking for an entry the library assembles on the host
+ * (reference_vector, k_bond, contact, fn_params) returns 1.  dfx_download copies n doubles behind such a pointer to host memory
+ * (through the pinned staging area).  A device-side consumer (the design map, an optimiser update, dfx_reduce_grads) reads them in place. */
+int dfx_kinetic_value_and_grad_device(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, double* objective,
+                                      const dfx_grads* want, dfx_grads* device_views, dfx_stats* stats);
+int dfx_download(dfx_handle* h, double* dst, const double* device_src, int64_t n);
+
 /* Post-processing of the last forward solve on its device-resident history (problems/quads_focusing.py:319-372 with
  * energy.py:522-534): strain energies of every ligament 1/2 k (strain |l0|)^2 for the axial, shear and bending strain of
  * the NONLINEAR kinematics, (batch, T, n_bonds) each, and the kinetic energy of every block sum_d m_d v_d^2 / 2,
