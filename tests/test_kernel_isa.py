@@ -105,6 +105,13 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
         assert sum(x.startswith(("v_readlane", "v_writelane")) for x in f) <= 8 and sum(x.startswith(("v_readlane", "v_writelane")) for x in a) <= 4, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EE")[1] <= 96, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EE")[1] <= 128, st
+        # ... and of the packed-triangle mapping (kagome ensembles)
+        f3 = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi1ELi{st}ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+        a3 = _function(txt, f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi1ELi{st}EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
+        assert not any(x.startswith("scratch_") for x in f3 + a3), st
+        assert sum(x.startswith(("v_readlane", "v_writelane")) for x in f3) <= 8 and sum(x.startswith(("v_readlane", "v_writelane")) for x in a3) <= 4, st
+        assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi1ELi{st}ELi1EE")[1] <= 102, st
+        assert meta_of(f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi1ELi{st}EE")[1] <= 128, st
     # the opt-in tile kernels (dfx_tile.h): no scratch, no workgroup barrier (wave-private tiles: LDS operations of a wave are in order)
     for nm in ("_ZN12_GLOBAL__N_110k_fwd_tileILi1ELi1EEEvNS_6DevCtxENS_6LigCtxENS_9StageCoefEiiiiii",
                "_ZN12_GLOBAL__N_110k_adj_tileILi1ELi1EEEvNS_6DevCtxENS_6LigCtxENS_7AdjCoefEiii"):
