@@ -94,18 +94,29 @@ def prepare(fw, designs, n_steps, spi=SPI, t_start=0.0):
     sd._last = (cps, flats, fw.timepoints)
 
 
+FUSED_CALL = os.environ.get("DFX_BENCH_FUSED", "1") != "0"      # (A/B: the two-call sequence of rounds 1-3)
+
+
 def execute(fw, obj, adjoint=True, spi=SPI, device_outputs=False):
     """The hot path on resident inputs: forward (members start at rest: no upload) + objective + reverse sweep; returns device
     milliseconds + stats.  Gradients: views of the engine's pinned result area (they crossed PCIe inside this call), or with
     ``device_outputs`` DeviceArray handles to the accumulators in HBM (dfx_kinetic_value_and_grad_device: outputs resident like the
     inputs, what the reference's jit(value_and_grad) hands back) -- `fetch` downloads them afterwards."""
     eng = fw.solve_dynamics.engine
-    _, st_f = eng.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=adjoint, want_fields=False)
+    which = ("centroid_node_vectors", "void_angle0", "inertia")
+    fused = adjoint and FUSED_CALL and hasattr(eng.lib, "dfx_forward_kinetic_value_and_grad") and np.ndim(fw.timepoints) == 1
+    if fused:      # one library call, as jit(value_and_grad(objective)) is one program: the host does not wait between the two sweeps
+        objective, grads, st_f, st_a = eng.forward_kinetic_value_and_grad(None, fw.timepoints, fw.step_counts, obj.target_blocks,
+                                                                          which=which, device=device_outputs)
+    else:
+        _, st_f = eng.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=adjoint, want_fields=False)
     out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "streams": max(1, int(st_f.get("streams", 1))),
-           "objective": None, "adj_ms": 0.0, "adj_launches": 0}
+           "objective": None, "adj_ms": 0.0, "adj_launches": 0, "fused_call": bool(fused)}
     if adjoint:
-        out["objective"], grads, st_a = eng.kinetic_value_and_grad(
-            obj.target_blocks, which=("centroid_node_vectors", "void_angle0", "inertia"), device=device_outputs)
+        if fused:
+            out["objective"] = objective
+        else:
+            out["objective"], grads, st_a = eng.kinetic_value_and_grad(obj.target_blocks, which=which, device=device_outputs)
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
         out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
         out["checkpoint"] = {1: "records", 2: "segments"}.get(st_a.get("checkpoint_records", 0)) or ("stages" if st_a.get("stage_checkpoint", 0) else "state")
@@ -641,6 +652,8 @@ def main():
             # the boundary's PCIe legs, never part of `value`: inputs in (host_prepare_ms: design -> packed arrays -> H2D) and
             # gradients out (the accumulators stay in HBM inside the timed region; `--outputs host` times the pinned-copy call instead)
             "outputs": {"where": "hbm" if device_outputs else "host (pinned views, inside the timed region)",
+                        "library_calls": ("dfx_forward_kinetic_value_and_grad (one call)" if res.get("fused_call") else
+                                          "dfx_forward_grid + dfx_kinetic_value_and_grad" + ("_device" if device_outputs else "")),
                         "gradient_bytes": int(out_bytes), "download_ms": 1e3 * fetch_s,
                         "value_with_outputs_on_host": total_units_steps / (wall_host_outputs or (wall + fetch_s)),
                         "measured_with": ("a second region of the same K steps through dfx_kinetic_value_and_grad (pinned views)"

@@ -58,7 +58,7 @@ EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
-                "dfx_mem_info", "dfx_device_synchronize", "dfx_kinetic_value_and_grad_device", "dfx_download"]
+                "dfx_mem_info", "dfx_device_synchronize", "dfx_kinetic_value_and_grad_device", "dfx_download", "dfx_forward_kinetic_value_and_grad"]
 EXPORTS = EXPORTS + COMM_EXPORTS
 
 
@@ -107,6 +107,8 @@ def declare(lib):
         lib.dfx_device_synchronize.argtypes = [C.c_int32]
         lib.dfx_kinetic_value_and_grad_device.argtypes = lib.dfx_kinetic_value_and_grad.argtypes
         lib.dfx_download.argtypes = [H, _dp, C.c_void_p, C.c_int64]
+        lib.dfx_forward_kinetic_value_and_grad.argtypes = [H, _dp, _dp, C.c_int32, _ip, _ip, C.c_int32, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_grads),
+                                                           C.c_int32, C.POINTER(dfx_stats), C.POINTER(dfx_stats)]
     return lib
 
 
@@ -396,6 +398,43 @@ class Engine:
             a.flags.writeable = False
             out[n] = a
         return obj, out, _stats(st)
+
+    def forward_kinetic_value_and_grad(self, state0, timepoints, steps_per_interval, target_blocks, which=ALL_GRADS, device=False):
+        """``forward(keep_trajectory=True, want_fields=False)`` + ``kinetic_value_and_grad`` as ONE library call (HIP library only): the host
+        does not wait for the forward pass before it enqueues the reverse sweep.  Returns objective, gradients, forward stats, adjoint stats."""
+        if not hasattr(self.lib, "dfx_forward_kinetic_value_and_grad"):
+            raise RuntimeError("the fused call needs the HIP library")
+        B, nb = self.batch, self.n_blocks
+        state0 = _f64(state0, (B, 2, nb, 3)) if state0 is not None else None
+        ts = _f64(timepoints)
+        if ts.ndim != 1:
+            raise ValueError("forward_kinetic_value_and_grad: one time grid for all members")
+        T = len(ts)
+        spis = np.ascontiguousarray(np.broadcast_to(steps_per_interval, (max(T - 1, 0),)), dtype=np.int32)
+        tb = np.ascontiguousarray(target_blocks, dtype=np.int32)
+        sh = self.shapes()
+        want, views = dfx_grads(), dfx_grads()
+        names = [n for n in which if not (n == "fn_params" and self.n_fns == 0) and not (n == "contact" and not self.contact)
+                 and not (n == "void_angle0" and self.contact != CONTACT_ANGLE)
+                 and not (n == "block_centroids" and self.contact != CONTACT_DISTANCE)]
+        flag = np.zeros(1)
+        for n in names:
+            setattr(want, n, _ptr(flag))
+        obj = np.zeros(B)
+        st_f, st_a = dfx_stats(), dfx_stats()
+        self._check(self.lib.dfx_forward_kinetic_value_and_grad(self._h, _ptr(state0), _ptr(ts), T, spis.ctypes.data_as(_ip), tb.ctypes.data_as(_ip),
+                                                                len(tb), _ptr(obj), C.byref(want), C.byref(views), int(bool(device)),
+                                                                C.byref(st_f), C.byref(st_a)), "dfx_forward_kinetic_value_and_grad")
+        self.n_timepoints = T
+        if device:
+            out = {n: DeviceArray(self, C.cast(getattr(views, n), C.c_void_p).value, sh[n]) for n in names}
+        else:
+            out = {}
+            for n in names:
+                a = np.ctypeslib.as_array(getattr(views, n), shape=sh[n])
+                a.flags.writeable = False
+                out[n] = a
+        return obj, out, _stats(st_f), _stats(st_a)
 
     def response_data(self, strains=True, kinetic=True):
         """Per-ligament strain energies (batch, T, n_bonds) x 3 and per-block kinetic energy (batch, T, n_blocks) of the last

@@ -110,7 +110,9 @@ struct dfx_handle {
   std::string err;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // forward pass / reverse sweep (their own pairs: the fused call reads both at its end)
+  bool defer_forward_sync = false;                 // dfx_forward_kinetic_value_and_grad: the forward pass returns without waiting for the device
+  dfx_stats fwd_stats;                             // ... its statistics, completed by finish_forward
   bool have_params = false, have_traj = false, have_fields = false;
   bool use_graph = true;
   bool want_bond_grads = true, want_fn_grads = true, want_damping_grads = true;
@@ -960,9 +962,9 @@ static int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads,
   bool phi_zero = false;
   if (w_phi) {
     HIP_OK(h->flag_stage.ensure(64));
-    HIP_OK(hipMemcpyAsync(h->flag_stage.p, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(reinterpret_cast<int32_t*>(h->flag_stage.p) + 1, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));   // (word 0: the forward pass's flag)
     HIP_OK(hipStreamSynchronize(h->stream));
-    const int32_t touched = *reinterpret_cast<const int32_t*>(h->flag_stage.p);
+    const int32_t touched = reinterpret_cast<const int32_t*>(h->flag_stage.p)[1];
     if (!touched && !pl.n_ovf) {
       const size_t bytes = sizeof(double) * B * nbd * 2;
       if (h->zero_phi.n < bytes || !h->zero_phi.p) { HIP_OK(h->zero_phi.ensure(bytes)); memset(h->zero_phi.p, 0, h->zero_phi.n); }
@@ -1134,6 +1136,8 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
   }
   (void)hipEventCreate(&h->ev0);
   (void)hipEventCreate(&h->ev1);
+  (void)hipEventCreate(&h->ev2);
+  (void)hipEventCreate(&h->ev3);
   const char* g = getenv("DFX_NO_GRAPH");
   h->use_graph = !(g && g[0] == '1');
   {
@@ -1218,6 +1222,8 @@ int dfx_destroy(dfx_handle* h) {
   if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -1306,6 +1312,24 @@ int dfx_share_checkpoint(dfx_handle* h, dfx_handle* with) {
   h->ck = with->ck;
   h->ck->users++;
   h->have_traj = false;
+  return 0;
+}
+
+// after the stream has been waited for: the non-finite flag of the forward pass (pinned word 0 of flag_stage) and its statistics
+static int finish_forward(dfx_handle* h, dfx_stats* stats) {
+  const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
+  if (bad) {
+    h->have_traj = false;
+    h->err = "forward: non-finite state at output " + std::to_string(bad - 1) + " (unstable step size or contact blow-up)";
+    return 3;
+  }
+  if (stats) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    *stats = h->fwd_stats;
+    stats->kernel_ms = ms;
+    stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * h->pl.tab.s) : 0.0;
+  }
   return 0;
 }
 
@@ -1402,8 +1426,13 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
-  std::vector<int> cursors(2 + kMaxGroups, -1);   // [0] unused, [1] non-finite flag, [2+g] segment cursor of group g
+  std::vector<int> cursors(2 + kMaxGroups, -1);   // [0] unused, [1] non-finite flag (adaptive solves; fixed grids: pinned, below), [2+g] segment cursor of group g
   cursors[1] = 0;
+  // the non-finite flag of a fixed-grid solve lives in pinned host memory: k_snapshot stores into it directly (rare, any writer wins)
+  // and the host reads it after its wait -- no device-to-host copy on the stream between the forward pass and whatever follows it
+  HIP_OK(h->flag_stage.ensure(64));
+  int* const bad_flag = reinterpret_cast<int*>(h->flag_stage.p);
+  *bad_flag = 0;
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (state0) {       // through the pinned staging area (pageable DMA is slow here); NULL = every member starts at rest
     HIP_OK(h->stage.ensure(sizeof(double) * B * nb * 6));
@@ -1426,7 +1455,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, bad_flag, 0, 0LL);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
   const bool eager = solve_is_eager(h) || h->segments;
@@ -1439,7 +1468,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
         const Group& gr = h->groups[gi];
         // end of the interval: the state is in buffer 0, or (records checkpoint) only in the trajectory
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
-                           h->d_seg_idx.p + 1, c.rps > 1 ? -1 : (h->pair_fwd ? state_buf(h->step0[sg.interval + 1]) : 0),
+                           bad_flag, c.rps > 1 ? -1 : (h->pair_fwd ? state_buf(h->step0[sg.interval + 1]) : 0),
                            (long long)h->step0[sg.interval + 1]);
       }
     }
@@ -1448,33 +1477,20 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   if (timing) fprintf(stderr, "[dfx] forward: launches enqueued in %.0f us\n", since(tl0));
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(h->flag_stage.ensure(64));
-  HIP_OK(hipMemcpyAsync(h->flag_stage.p, h->d_seg_idx.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  h->have_fields = true;
+  memset(&h->fwd_stats, 0, sizeof(h->fwd_stats));
+  h->fwd_stats.steps = h->n_total;
+  h->fwd_stats.rhs_evals = h->n_total * pl.tab.s;
+  h->fwd_stats.launches = h->launches;
+  h->fwd_stats.streams = (int64_t)h->groups.size();
+  h->fwd_stats.stage_checkpoint = c.AD ? 1 : 0;
+  h->fwd_stats.checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
+  h->fwd_stats.tile_kernels = kernel_build_code(h, c, h->lig_fwd_used);
+  if (h->defer_forward_sync) return 0;          // the fused call goes on enqueueing the reverse sweep; finish_forward after its last wait
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
-  const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
   if (timing) fprintf(stderr, "[dfx] forward: all done %.0f us after the first launch\n", since(tl0));
-  h->have_fields = true;
-  if (bad) {
-    h->have_traj = false;
-    h->err = "forward: non-finite state at output " + std::to_string(bad - 1) + " (unstable step size or contact blow-up)";
-    return 3;
-  }
-  if (stats) {
-    memset(stats, 0, sizeof(*stats));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-    stats->steps = h->n_total;
-    stats->rhs_evals = h->n_total * pl.tab.s;
-    stats->launches = h->launches;
-    stats->kernel_ms = ms;
-    stats->streams = (int64_t)h->groups.size();
-    stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s) : 0.0;
-    stats->stage_checkpoint = c.AD ? 1 : 0;
-    stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
-    stats->tile_kernels = kernel_build_code(h, c, h->lig_fwd_used);
-  }
-  return 0;
+  return finish_forward(h, stats);
 }
 
 
@@ -1706,7 +1722,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p + 2, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   const double h_last = Tn > 1 ? (h->t_steps.empty() ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]
                                                      : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;
-  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  HIP_OK(hipEventRecord(h->ev2, h->stream));
   pair_plan(h, c);
   if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   // tile kernels: their accumulators are ligament-major (decided here, not in the launch functions: a graph replay does not call them)
@@ -1754,18 +1770,18 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     dim3 g((unsigned)((n_target * 3 + 63) / 64), (unsigned)B);
     hipLaunchKernelGGL(k_kinetic_mass_grad, g, dim3(64), 0, h->stream, c, (const double*)h->d_fields.p, (const int32_t*)h->d_target.p, n_target);
   }
-  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  HIP_OK(hipEventRecord(h->ev3, h->stream));
   if (timing) fprintf(stderr, "[dfx] adjoint: sweep enqueued %.0f us after entry\n", since(ta0));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
   if (timing) {
     float ms0 = 0.f;
-    (void)hipEventElapsedTime(&ms0, h->ev0, h->ev1);
+    (void)hipEventElapsedTime(&ms0, h->ev2, h->ev3);
     fprintf(stderr, "[dfx] adjoint: gradients collected %.0f us after entry (sweep on the device: %.0f us)\n", since(ta0), 1e3 * ms0);
   }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    (void)hipEventElapsedTime(&ms, h->ev2, h->ev3);
     stats->steps = h->n_total;
     stats->rhs_evals = h->n_total * pl.tab.s;
     stats->launches = h->launches;
@@ -1839,7 +1855,7 @@ int dfx_objective_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t n
   if (int rc = upload_targets(h, target_blocks, n_target)) return rc;
   DevCtx c = make_ctx(h);
   hipLaunchKernelGGL(k_kinetic, dim3(h->pl.batch), dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p,
-                     (const int32_t*)h->d_target.p, n_target, (double*)nullptr, h->d_obj.p);
+                     (const int32_t*)h->d_target.p, n_target, (double*)nullptr, h->d_obj.p, (double*)nullptr);
   HIP_OK(hipMemcpyAsync(objective, h->d_obj.p, sizeof(double) * h->pl.batch, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
@@ -1858,12 +1874,11 @@ static int adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t 
   HIP_OK(h->d_G.ensure(B * Tn * nb * 6));
   HIP_OK(hipMemsetAsync(h->d_G.p, 0, sizeof(double) * B * Tn * nb * 6, h->stream));
   DevCtx c = make_ctx(h);
+  // the objective rides along with the reverse sweep: the kernel stores it into pinned host memory as well (a copy on the stream would be
+  // a hop to the copy engine and back in front of the sweep), read after the sweep's final synchronisation
+  if (objective) HIP_OK(h->obj_stage.ensure(sizeof(double) * B));
   hipLaunchKernelGGL(k_kinetic, dim3(h->pl.batch), dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p,
-                     (const int32_t*)h->d_target.p, n_target, h->d_G.p, h->d_obj.p);
-  if (objective) {   // rides along with the reverse sweep: read after the sweep's final synchronisation
-    HIP_OK(h->obj_stage.ensure(sizeof(double) * B));
-    HIP_OK(hipMemcpyAsync(h->obj_stage.p, h->d_obj.p, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  }
+                     (const int32_t*)h->d_target.p, n_target, h->d_G.p, h->d_obj.p, objective ? reinterpret_cast<double*>(h->obj_stage.p) : (double*)nullptr);
   if (int rc = run_adjoint(h, want, grads, views, stats, true, n_target)) return rc;
   if (objective) memcpy(objective, h->obj_stage.p, sizeof(double) * B);
   return 0;
@@ -1884,6 +1899,22 @@ int dfx_kinetic_value_and_grad_device(dfx_handle* h, const int32_t* target_block
   const int rc = adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, device_views, stats);
   h->device_views = false;
   return rc;
+}
+
+int dfx_forward_kinetic_value_and_grad(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                       const int32_t* steps_per_interval, const int32_t* target_blocks, int32_t n_target,
+                                       double* objective, const dfx_grads* want, dfx_grads* views, int32_t device_views,
+                                       dfx_stats* forward_stats, dfx_stats* adjoint_stats) {
+  h->defer_forward_sync = true;
+  int rc = forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, nullptr, 1, nullptr, nullptr, false);
+  h->defer_forward_sync = false;
+  if (rc) return rc;
+  h->device_views = device_views != 0;
+  rc = adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, views, adjoint_stats);
+  h->device_views = false;
+  HIP_OK(hipStreamSynchronize(h->stream));          // (already idle when the sweep returned normally)
+  const int rcf = finish_forward(h, forward_stats);
+  return rcf ? rcf : rc;
 }
 
 // device -> caller memory through the pinned staging area, in chunks (outputs here can be GBs; pageable DMA is slow)

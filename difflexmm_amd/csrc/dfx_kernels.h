@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(kThreads) void k_response(DevCtx c, const double* f
 
 // kinetic-energy objective: G <- m v on target blocks; per-member objective by one workgroup
 __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fields, const int32_t* target, int n_target,
-                                                      double* G, double* objective) {
+                                                      double* G, double* objective, double* objective_host) {
   const int m = blockIdx.x;
   __shared__ double red[kThreads];
   double acc = 0.0;
@@ -1499,6 +1499,7 @@ __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fi
     __syncthreads();
   }
   if (threadIdx.x == 0 && objective) objective[m] = red[0];
+  if (threadIdx.x == 0 && objective_host) objective_host[m] = red[0];     // pinned host memory: no copy engine hop inside the stream
 }
 
 // explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_m

@@ -226,6 +226,17 @@ int dfx_kinetic_value_and_grad_device(dfx_handle* h, const int32_t* target_block
                                       const dfx_grads* want, dfx_grads* device_views, dfx_stats* stats);
 int dfx_download(dfx_handle* h, double* dst, const double* device_src, int64_t n);
 
+/* Forward solve + objective + reverse sweep in ONE call -- jit(value_and_grad(objective))(design) at problems/quads_focusing.py:565 is one
+ * XLA program too.  Equal to dfx_forward_grid(keep_trajectory = 1, fields = NULL) followed by dfx_kinetic_value_and_grad[_device]
+ * (device_views != 0: `views` receives device pointers) bit for bit; the host does not wait for the forward pass before it enqueues the
+ * sweep (one synchronisation and one round trip through the caller less: ~0.15 ms of a 5 ms job).  A non-finite forward state is
+ * reported at the end (return 3, as dfx_forward; the sweep has then run on that state and its outputs are meaningless).
+ * steps_per_interval: (n_timepoints - 1,); state0 NULL = at rest. */
+int dfx_forward_kinetic_value_and_grad(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                       const int32_t* steps_per_interval, const int32_t* target_blocks, int32_t n_target,
+                                       double* objective, const dfx_grads* want, dfx_grads* views, int32_t device_views,
+                                       dfx_stats* forward_stats, dfx_stats* adjoint_stats);
+
 /* Post-processing of the last forward solve on its device-resident history (problems/quads_focusing.py:319-372 with
  * energy.py:522-534): strain energies of every ligament 1/2 k (strain |l0|)^2 for the axial, shear and bending strain of
  * the NONLINEAR kinematics, (batch, T, n_bonds) each, and the kinetic energy of every block sum_d m_d v_d^2 / 2,

@@ -30,3 +30,42 @@ def test_device_resident_gradients_equal_host_views(hip_lib, lattice, n, batch):
     assert np.abs(g_h["centroid_node_vectors"]).max() > 0 and np.abs(g_h["void_angle0"]).max() > 0
     with pytest.raises(RuntimeError, match="assembled on the host"):
         eng.kinetic_value_and_grad(target, which=("k_bond",), device=True)
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_fused_forward_value_and_grad_equals_the_two_calls(hip_lib, device):
+    """dfx_forward_kinetic_value_and_grad (the host does not wait for the forward pass before it enqueues the reverse sweep) against
+    dfx_forward_grid + dfx_kinetic_value_and_grad: bit for bit, statistics included; ragged steps per interval."""
+    c = Case("quads", 12, True, True, seed=5, cutoff_deg=42.0, batch=3)
+    cps = [c.cp._replace(constraint_params=dict(FAST, amplitude=7.5 * (1 + 0.05 * m))) for m in range(3)]
+    ts = np.linspace(0.0, 3e-4, 4)
+    spis = np.array([7, 5, 9], dtype=np.int32)
+    c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, cps, keep_trajectory=True, steps_per_interval=7)      # packs and uploads the parameters
+    eng = c.solver.engine
+    mid = c.geo.n_blocks // 2
+    target = np.array([mid + 1, mid + 2], dtype=np.int32)
+    which = ("centroid_node_vectors", "void_angle0", "inertia")
+    _, st_f = eng.forward(None, ts, spis, keep_trajectory=True, want_fields=False)
+    obj2, g2, st_a = eng.kinetic_value_and_grad(target, which=which)
+    g2 = {k: np.array(v) for k, v in g2.items()}
+    obj1, g1, sf, sa = eng.forward_kinetic_value_and_grad(None, ts, spis, target, which=which, device=device)
+    assert np.array_equal(obj1, obj2) and obj1.min() > 0
+    for k in which:
+        a = g1[k].to_host() if device else np.array(g1[k])
+        assert np.array_equal(a, g2[k]), k
+    assert sf["steps"] == st_f["steps"] == 21 and sf["launches"] == st_f["launches"] and sa["launches"] == st_a["launches"]
+    assert sf["kernel_ms"] > 0 and sa["kernel_ms"] > 0
+
+
+def test_fused_call_reports_a_blown_up_forward_pass(hip_lib):
+    """The fused call checks the forward pass's non-finite flag at its end (recipe of test_unstable_step_reports_an_error)."""
+    c = Case("quads", 6, True, False, seed=1, lib=None)
+    c.cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=300.0, input_delay=0.0))
+    ts = np.linspace(0.0, 3e-4, 3)
+    c.solver(np.zeros((2, 36, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=7)      # packs and uploads the parameters
+    eng = c.solver.engine
+    target = np.array([1, 2], dtype=np.int32)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        eng.forward_kinetic_value_and_grad(None, np.linspace(0, 0.5, 3), 20, target, which=("inertia",))      # h = 12.5 ms >> 1/omega_max
+    obj, g, sf, sa = eng.forward_kinetic_value_and_grad(None, ts, 7, target, which=("inertia",))             # the handle still works
+    assert np.isfinite(obj).all() and np.isfinite(g["inertia"]).all() and sf["steps"] == 14
