@@ -120,6 +120,7 @@ struct dfx_handle {
   DevBuf<double> d_ovf_p, d_ovf_g;             // extra ligaments (general bond lists): parameters, gradient accumulators
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<double> d_resp;                           // dfx_response_data outputs
+  bool prelude_done = false;                       // adjoint_kinetic cleared the accumulators in the launch that cleared its cotangents
   bool device_views = false;                       // this call hands out device pointers (dfx_kinetic_value_and_grad_device)
   DevBuf<dfx_special> d_special;
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict, d_p_c, d_g_c;
@@ -879,24 +880,37 @@ static int ensure_adjoint_buffers(dfx_handle* h) {
   return 0;
 }
 
-static int zero_grad_accumulators(dfx_handle* h) {
+// One launch (k_prelude) clears the gradient accumulators -- and, for the callers that pass them, the cotangent array G, the groups'
+// segment cursors (set to `cursor_value`) and the target blocks (copied from the kernel arguments when they are few).
+static int zero_grad_accumulators(dfx_handle* h, double* extra = nullptr, size_t n_extra = 0, int cursor_value = -1,
+                                  const int32_t* targets = nullptr, int n_target = 0) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   const size_t nsp = std::max(1, pl.n_special);
-  HIP_OK(hipMemsetAsync(h->d_g_r.p, 0, sizeof(double) * B * pl.n_slots * 2, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_g_phi.p, 0, sizeof(double) * B * pl.n_slots, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_touch.p, 0, sizeof(int32_t) * 4, h->stream));
+  PreludeJob J;
+  memset(&J, 0, sizeof(J));
+  size_t most = 0;
+  auto zero = [&](double* p, size_t n) { if (p && n) { J.zp[J.n_zero] = p; J.zn[J.n_zero] = n; ++J.n_zero; most = std::max(most, n); } };
+  static_assert(kPreludeZero >= 11, "every accumulator below + one caller array");
+  zero(h->d_g_r.p, B * pl.n_slots * 2);
+  zero(h->d_g_phi.p, B * pl.n_slots);
+  zero(reinterpret_cast<double*>(h->d_touch.p), 2);              // 4 ints
   h->lig_used = false;
-  if (h->lig_ok && h->lig.g) {
-    HIP_OK(hipMemsetAsync(h->d_lig_g.p, 0, sizeof(double) * B * nb * 8, h->stream));
-    HIP_OK(hipMemsetAsync(h->d_lig_gphi.p, 0, sizeof(double) * B * nb * 4, h->stream));
+  if (h->lig_ok && h->lig.g) { zero(h->d_lig_g.p, B * nb * 8); zero(h->d_lig_gphi.p, B * nb * 4); }
+  if (pl.n_ovf) zero(h->d_ovf_g.p, B * pl.n_ovf * kOvfG);
+  if (h->want_bond_grads || pl.n_ovf) zero(h->d_g_b.p, B * pl.n_slots * 8);
+  zero(h->d_blk_m.p, B * nb * 3);
+  if (pl.contact == DFX_CONTACT_DISTANCE) zero(h->d_g_c.p, B * nb * 2);
+  if (h->want_damping_grads) zero(h->d_blk_c.p, B * nb * 3);
+  zero(h->d_fn_g.p, B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS);
+  zero(extra, n_extra);
+  if (cursor_value >= 0) { J.fill_dst = h->d_seg_idx.p + 2; J.fill_val = cursor_value; J.fill_n = kMaxGroups; }
+  if (targets && n_target > 0) {
+    if (n_target <= kPreludeInts) { J.copy_dst = h->d_target.p; J.copy_n = n_target; for (int i = 0; i < n_target; ++i) J.copy_val[i] = targets[i]; }
+    else HIP_OK(hipMemcpyAsync(h->d_target.p, targets, sizeof(int32_t) * n_target, hipMemcpyHostToDevice, h->stream));
   }
-  if (pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_ovf_g.p, 0, sizeof(double) * B * pl.n_ovf * kOvfG, h->stream));
-  if (h->want_bond_grads || pl.n_ovf) HIP_OK(hipMemsetAsync(h->d_g_b.p, 0, sizeof(double) * B * pl.n_slots * 8, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_blk_m.p, 0, sizeof(double) * B * nb * 3, h->stream));
-  if (pl.contact == DFX_CONTACT_DISTANCE) HIP_OK(hipMemsetAsync(h->d_g_c.p, 0, sizeof(double) * B * nb * 2, h->stream));
-  if (h->want_damping_grads) HIP_OK(hipMemsetAsync(h->d_blk_c.p, 0, sizeof(double) * B * nb * 3, h->stream));
-  HIP_OK(hipMemsetAsync(h->d_fn_g.p, 0, sizeof(double) * B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, h->stream));
+  const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(2048, (most / 2 + 255) / 256));
+  hipLaunchKernelGGL(k_prelude, dim3(gx, (unsigned)std::max(1, J.n_zero)), dim3(256), 0, h->stream, J);
   return 0;
 }
 
@@ -1716,10 +1730,9 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   const bool timing = getenv("DFX_TIMING") != nullptr;
   const auto ta0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
-  if (zero_grad_accumulators(h)) return 2;
   const int nseg = (int)h->segs.size();
-  std::vector<int> cursors(kMaxGroups, nseg);
-  HIP_OK(hipMemcpyAsync(h->d_seg_idx.p + 2, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (!h->prelude_done && zero_grad_accumulators(h, nullptr, 0, nseg)) return 2;      // (adjoint_kinetic did it together with its own arrays)
+  h->prelude_done = false;
   const double h_last = Tn > 1 ? (h->t_steps.empty() ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]
                                                      : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;
   HIP_OK(hipEventRecord(h->ev2, h->stream));
@@ -1840,11 +1853,11 @@ int dfx_adjoint(dfx_handle* h, const double* fields_bar, dfx_grads* grads, dfx_s
   return run_adjoint(h, grads, grads, nullptr, stats, false, 0);
 }
 
-static int upload_targets(dfx_handle* h, const int32_t* target_blocks, int32_t n_target) {
+static int upload_targets(dfx_handle* h, const int32_t* target_blocks, int32_t n_target, bool copy = true) {
   for (int i = 0; i < n_target; ++i)
     if (target_blocks[i] < 0 || target_blocks[i] >= h->pl.n_blocks) { h->err = "target block out of range"; return 1; }
   HIP_OK(h->d_target.ensure(std::max(1, n_target)));
-  HIP_OK(hipMemcpyAsync(h->d_target.p, target_blocks, sizeof(int32_t) * n_target, hipMemcpyHostToDevice, h->stream));
+  if (copy) HIP_OK(hipMemcpyAsync(h->d_target.p, target_blocks, sizeof(int32_t) * n_target, hipMemcpyHostToDevice, h->stream));
   HIP_OK(h->d_obj.ensure(h->pl.batch));
   return 0;
 }
@@ -1870,9 +1883,12 @@ static int adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t 
   const size_t B = pl.batch, nb = pl.n_blocks;
   const int Tn = (int)h->ts.size();
   if (ensure_adjoint_buffers(h)) return 2;
-  if (int rc = upload_targets(h, target_blocks, n_target)) return rc;
+  if (int rc = upload_targets(h, target_blocks, n_target, false)) return rc;
   HIP_OK(h->d_G.ensure(B * Tn * nb * 6));
-  HIP_OK(hipMemsetAsync(h->d_G.p, 0, sizeof(double) * B * Tn * nb * 6, h->stream));
+  // one launch: accumulators and cotangents cleared, cursors at the last segment, target blocks in place (zero_grad_accumulators)
+  set_grad_wishes(h, want);
+  if (zero_grad_accumulators(h, h->d_G.p, B * Tn * nb * 6, (int)h->segs.size(), target_blocks, n_target)) return 2;
+  h->prelude_done = true;
   DevCtx c = make_ctx(h);
   // the objective rides along with the reverse sweep: the kernel stores it into pinned host memory as well (a copy on the stream would be
   // a hop to the copy engine and back in front of the sweep), read after the sweep's final synchronisation

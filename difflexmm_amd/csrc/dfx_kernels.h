@@ -1502,6 +1502,36 @@ __global__ __launch_bounds__(kThreads) void k_kinetic(DevCtx c, const double* fi
   if (threadIdx.x == 0 && objective_host) objective_host[m] = red[0];     // pinned host memory: no copy engine hop inside the stream
 }
 
+// Everything a reverse sweep clears or sets before its first launch, in ONE launch instead of a dozen fills and small copies queued one
+// behind the other between the forward pass and the sweep (~85 us of a 5 ms job, profiles/r04_host_overhead.txt): up to kPreludeZero
+// arrays of doubles zeroed (blockIdx.y picks the array), a run of ints set to one value (the groups' segment cursors), a few ints
+// copied from the kernel arguments (the target blocks).
+constexpr int kPreludeZero = 12, kPreludeInts = 32;
+struct PreludeJob {
+  double* zp[kPreludeZero];
+  unsigned long long zn[kPreludeZero];
+  int n_zero;
+  int fill_val, fill_n, copy_n;
+  int* fill_dst;
+  int* copy_dst;
+  int copy_val[kPreludeInts];
+};
+__global__ __launch_bounds__(256) void k_prelude(PreludeJob J) {
+  const int job = blockIdx.y;
+  if (job < J.n_zero) {
+    double* p = J.zp[job];
+    const unsigned long long n = J.zn[job], n2 = n >> 1;
+    double2* p2 = reinterpret_cast<double2*>(p);          // (device allocations: 256-byte aligned)
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * 256)
+      p2[i] = make_double2(0.0, 0.0);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+  }
+  if (job == 0 && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < J.fill_n; i += 256) J.fill_dst[i] = J.fill_val;
+    for (int i = threadIdx.x; i < J.copy_n; i += 256) J.copy_dst[i] = J.copy_val[i];
+  }
+}
+
 // explicit d(objective)/d(inertia) = sum_t v^2/2 on target DOFs, added to blk_m
 __global__ void k_kinetic_mass_grad(DevCtx c, const double* fields, const int32_t* target, int n_target) {
   const int m = blockIdx.y + c.m0;
