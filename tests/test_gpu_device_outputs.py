@@ -69,3 +69,25 @@ def test_fused_call_reports_a_blown_up_forward_pass(hip_lib):
         eng.forward_kinetic_value_and_grad(None, np.linspace(0, 0.5, 3), 20, target, which=("inertia",))      # h = 12.5 ms >> 1/omega_max
     obj, g, sf, sa = eng.forward_kinetic_value_and_grad(None, ts, 7, target, which=("inertia",))             # the handle still works
     assert np.isfinite(obj).all() and np.isfinite(g["inertia"]).all() and sf["steps"] == 14
+
+
+def test_many_target_blocks_take_the_copy_path(hip_lib, cpu_lib):
+    """The reverse sweep's prelude kernel takes up to 32 target blocks by value; more are uploaded with a copy.  40 targets on 12 x 12
+    quads, HIP against the CPU port (objective and every gradient), and against the same call with 8 targets to make sure the two
+    objectives differ (the extra blocks are really read)."""
+    ts = np.linspace(0.0, 3e-4, 4)
+    res = {}
+    for name, lib in (("hip", None), ("cpu", cpu_lib)):
+        c = Case("quads", 12, True, True, seed=5, lib=lib, cutoff_deg=42.0)
+        c.cp = c.cp._replace(constraint_params=FAST)
+        c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=7)
+        targets = np.arange(20, 60, dtype=np.int32)
+        obj, g, _ = c.solver.engine.kinetic_value_and_grad(targets, which=("centroid_node_vectors", "void_angle0", "inertia"))
+        res[name] = (float(np.atleast_1d(obj)[0]), {k: np.array(v) for k, v in g.items()})
+        if lib is None:
+            obj8, _, _ = c.solver.engine.kinetic_value_and_grad(targets[:8], which=("inertia",))
+            assert float(np.atleast_1d(obj8)[0]) < res[name][0]
+    assert abs(res["hip"][0] - res["cpu"][0]) < 1e-10 * abs(res["cpu"][0]) and res["cpu"][0] > 0
+    for k in res["cpu"][1]:
+        d = np.abs(res["hip"][1][k] - res["cpu"][1][k]).max()
+        assert d <= 1e-9 * np.abs(res["cpu"][1][k]).max(), (k, d)
