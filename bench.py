@@ -16,6 +16,12 @@ paper's input delay of 0.1/f = 3.3 ms and the target 21 x 25 blocks away, the fi
 at rest and the reverse sweep propagates exact zeros): the pulse starts at t = 0 (`--input-delay`), and the 2x2 target sits
 next to the driven blocks (`--target-shift`; the C3 placement is `--target-shift 21 25`).  Neither changes a launch or a byte.
 
+What the timed region is (round 4): ONE library call, `dfx_forward_kinetic_value_and_grad` -- forward solve, objective, reverse
+sweep, as `jit(value_and_grad(objective))` is one program in the reference -- on inputs resident in HBM, with the gradients left in
+HBM too (device pointers come back; `--outputs host` / `DFX_BENCH_FUSED=0` restore rounds 1-3's region: two calls, gradients copied
+to pinned host memory inside it).  The PCIe legs either side are measured and reported next to `value`, never inside it:
+`host_prepare_ms` (design -> packed parameters -> H2D) and `outputs.value_with_outputs_on_host`.
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--members M] [--size 128]
 
 N > 1: one rank per GPU, every rank integrates its own designs (weak scaling, no data-path collective), objectives are
