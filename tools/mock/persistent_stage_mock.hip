@@ -13,7 +13,7 @@
 // Baseline form: the same arithmetic, one launch per stage, plain loads and stores.  The two must agree in every word.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o persistent_stage_mock persistent_stage_mock.hip     (no contraction: the two
 //   forms are different kernels, and only without it do they round alike -- any differing word is then a hand-off error)
-//   ./persistent_stage_mock [members=1] [steps=200] [n1=128] [skew=0] [iters=22: 16 fp64 operations each] [nosleep=0] [selfpoison=0]
+//   ./persistent_stage_mock [members=1] [steps=200] [n1=128] [skew=0] [iters=22: 16 fp64 operations each] [nosleep=0] [selfpoison=0] [ring=0: places in the hand-off ring (needs selfpoison=1, >= 5)]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +29,8 @@ typedef unsigned long long u64;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 struct Ctx {
-  int n1, nb, members, steps, iters, skew, nosleep, selfpoison;
+  int n1, nb, members, steps, iters, skew, nosleep, selfpoison, ring;
+  double* ringbuf;    // ring > 0: [ring][member][block][4] -- the records are handed over through a ring of `ring` places (self-poisoned); rec gets a plain copy
   double* rec;        // [ordinal = step * 6 + stage][member][block][4]   (ordinal steps*6 = the final state)
   double* vel;        // [ordinal][member][block][3]
   const double* par;  // [member][block*4 + slot][4]  synthetic per-slot parameters
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void k_persistent(Ctx c, double h) {
     for (int i = 0; i < kStages; ++i) {
       const size_t ord = (size_t)n * kStages + i;
       // the partner's record of this stage: poll until whole
-      const double* base = c.rec + ord * mrec;
+      const double* base = c.ring ? c.ringbuf + (ord % c.ring) * mrec : c.rec + ord * mrec;
       double p[4];
       int spins = 0;
       for (;;) {
@@ -143,19 +144,20 @@ __global__ __launch_bounds__(256) void k_persistent(Ctx c, double h) {
       // new record (x, y, th, sin th/2): every lane of the quad keeps a copy, lanes 0 and 1 publish one 16-byte chunk each
       o[0] = quad_bcast<0>(qnext); o[1] = quad_bcast<1>(qnext); o[2] = quad_bcast<2>(qnext);
       o[3] = half_sin(o[2]);
-      double* nbase = c.rec + (ord + 1) * mrec;
+      double* nbase = c.ring ? c.ringbuf + ((ord + 1) % c.ring) * mrec : c.rec + (ord + 1) * mrec;
       if (c.selfpoison && k < 2 && ord + kAhead <= (size_t)c.steps * kStages) {
         // the owner poisons the place of a record it will write kAhead stages from now: that store has completed (the s_waitcnt in every
         // poll covers it) long before a neighbour can ask for that record -- a neighbour reaches stage t only after this wave has finished
         // stage t - 2.  The host poisons the first kAhead - 1 records of a launch only.
         v4u x; x.x = x.y = x.z = x.w = 0xFFFFFFFFu;
-        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off_o), "v"(x), "s"(c.rec + (ord + kAhead) * mrec) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off_o), "v"(x), "s"(c.ring ? c.ringbuf + ((ord + kAhead) % c.ring) * mrec : c.rec + (ord + kAhead) * mrec) : "memory");
       }
       if (k < 2) {
         v4u x;
         const double s0 = k == 0 ? o[0] : o[2], s1 = k == 0 ? o[1] : o[3];
         x.x = __double2loint(s0); x.y = __double2hiint(s0); x.z = __double2loint(s1); x.w = __double2hiint(s1);
         asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off_o), "v"(x), "s"(nbase) : "memory");
+        if (c.ring) *reinterpret_cast<double2*>(reinterpret_cast<char*>(c.rec + (ord + 1) * mrec) + off_o) = make_double2(s0, s1);   // the checkpoint copy
       }
       if (k < 3) *reinterpret_cast<double*>(reinterpret_cast<char*>(c.vel + (ord + 1) * mvel) + off_v) = vnext;
     }
@@ -223,7 +225,7 @@ static double half_sin_host(double th) { const double x = 0.5 * th, x2 = x * x; 
 
 int main(int argc, char** argv) {
   const int members = argc > 1 ? atoi(argv[1]) : 1, steps = argc > 2 ? atoi(argv[2]) : 200, n1 = argc > 3 ? atoi(argv[3]) : 128;
-  const int skew = argc > 4 ? atoi(argv[4]) : 0, iters = argc > 5 ? atoi(argv[5]) : 22, nosleep = argc > 6 ? atoi(argv[6]) : 0, selfpoison = argc > 7 ? atoi(argv[7]) : 0;
+  const int skew = argc > 4 ? atoi(argv[4]) : 0, iters = argc > 5 ? atoi(argv[5]) : 22, nosleep = argc > 6 ? atoi(argv[6]) : 0, selfpoison = argc > 7 ? atoi(argv[7]) : 0, ring = argc > 8 ? atoi(argv[8]) : 0;
   const int nb = n1 * n1;
   if (nb % 16) { printf("n1*n1 must be a multiple of 16\n"); return 1; }
   hipDeviceProp_t prop;
@@ -261,7 +263,9 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < hr.size(); i += 4) { hr[i] = 0.1 * rnd(); hr[i + 1] = 0.1 * rnd(); hr[i + 2] = 0.2 * rnd() - 0.1; hr[i + 3] = sin(0.5 * hr[i + 2]); }
   for (auto& x : hv) x = 0.01 * (rnd() - 0.5);
   CK(hipMemcpy(par, hp.data(), hp.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dofp, hd.data(), hd.size() * 8, hipMemcpyHostToDevice));
-  Ctx c{n1, nb, members, steps, iters, skew, nosleep, selfpoison, recP, velP, par, dofp, err};
+  double* ringbuf = nullptr;
+  if (ring) CK(hipMalloc(&ringbuf, (size_t)ring * members * nb * 4 * 8));
+  Ctx c{n1, nb, members, steps, iters, skew, nosleep, selfpoison, ring, ringbuf, recP, velP, par, dofp, err};
   const double h = 1e-3;
   const int waves = members * nb / 16, grid = (waves + 3) / 4;
   hipEvent_t e0, e1;
@@ -291,6 +295,12 @@ int main(int argc, char** argv) {
     } else CK(hipMemset(recP, 0xFF, rec_elems * 8));
     CK(hipMemset(velP, 0xFF, vel_elems * 8)); CK(hipMemset(err, 0, 64));
     CK(hipMemcpy(recP, hr.data(), hr.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(velP, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
+    if (ring) {
+      std::vector<double> junk((size_t)ring * members * nb * 4, 2.0 + rep);
+      CK(hipMemcpy(ringbuf, junk.data(), junk.size() * 8, hipMemcpyHostToDevice));
+      CK(hipMemcpy(ringbuf, hr.data(), hr.size() * 8, hipMemcpyHostToDevice));
+      CK(hipMemset(ringbuf + (size_t)members * nb * 4, 0xFF, (size_t)(kAhead - 1) * members * nb * 4 * 8));
+    }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(k_persistent, dim3(grid), dim3(256), lds, 0, c, h);
