@@ -27,11 +27,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 
 #include "dfx_kernels.h"
+#include "dfx_persist_api.h"
 #include "dfx_pair.h"
 #include "dfx_tile.h"
 
@@ -173,6 +175,10 @@ struct dfx_handle {
   bool lig_ok = false, lig_used = false;      // lig_used: accumulators of the running sweep are ligament-major
   bool lig_fwd_used = false, lig_adj_used = false;   // what the last forward pass / reverse sweep launched (dfx_stats)
   LigCtx lig;
+  // the stage loop without kernel boundaries (dfx_persist.h): decided per solve (persist_plan); the hand-off ring
+  bool persist_fwd = false;
+  int persist_npb = 4, persist_wpm = 0, n_cu = 0;
+  DevBuf<double> d_ring;
   std::vector<int32_t> lig_slots;
   DevBuf<int32_t> d_lig_slots, d_lig_tab;
   DevBuf<double> d_lig_p, d_lig_l, d_lig_k, d_lig_phi, d_lig_g, d_lig_gphi;
@@ -550,6 +556,101 @@ static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf,
   launch_adj(h, c, h->stream, slot_grid(h), i, j, in_buf, wbuf, local_only);
 }
 
+// ---- the stage loop without kernel boundaries (dfx_persist.h) ---------------------------------------------------------------------
+// Two persistent launches must never share the device: each needs ALL its workgroups resident, and two half-resident launches would
+// wait for each other until their spins give up.  Every persistent launch of the process therefore waits for the one before it
+// (whatever handle or stream issued it) through one event per device.
+using namespace dfx_persist;
+static std::mutex g_persist_mu;
+static hipEvent_t g_persist_tail[64];
+static bool g_persist_tail_on[64];
+static const int kPersistLdsBudget = 150 * 1024;    // of a compute unit's 160 KB: room for the stage kernels' small LDS users next to us
+
+static const void* persist_fwd_fn(const dfx_handle* h) {
+  return dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, h->persist_npb);
+}
+// workgroups of `fn` a compute unit can hold at once (registers; 256-thread workgroups = one wave per SIMD each), capped where the
+// residency rule of MI355X_MICROARCH.md ("Residency and cooperative launch") starts to depend on the scalar-register count
+static int persist_wg_per_cu(const void* fn) {
+  hipFuncAttributes at;
+  if (!fn || hipFuncGetAttributes(&at, fn) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const int alloc = std::max(8, ((at.numRegs + 7) / 8) * 8);
+  int cap = std::min({8, 512 / alloc, 6});
+  if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
+  return cap;
+}
+// which lattices and solves the persistent kernels serve (everything else keeps one launch per stage)
+static bool persist_shape_ok(const dfx_handle* h) {
+  const Plan& pl = h->pl;
+  const char* e = getenv("DFX_PERSIST");
+  if (e && e[0] == '0') return false;
+  return (pl.model == kNonlinear || pl.model == kLinearized) && pl.contact != DFX_CONTACT_DISTANCE && !pl.n_ovf && pl.tab.s <= kPersistStages &&
+         (pl.n_npb == 3 || pl.n_npb == 4);
+}
+static int persist_waves_per_member(const dfx_handle* h, int npb) {
+  return npb == 3 ? (h->pl.n_blocks + 19) / 20 : (h->pl.n_slots + 63) / 64;
+}
+// do all waves of `nm` members fit on the chip at once?  (grid, LDS per workgroup) of the launch if so
+static bool persist_fits(dfx_handle* h, const void* fn, int npb, int nm, int* grid, int* lds) {
+  if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return false; h->n_cu = v; }
+  const int cap = persist_wg_per_cu(fn);
+  const long long waves = (long long)nm * persist_waves_per_member(h, npb);
+  const long long g = (waves + 3) / 4;
+  const long long per_cu = (g + h->n_cu - 1) / h->n_cu;
+  if (cap <= 0 || per_cu > cap) return false;
+  *grid = (int)g;
+  *lds = (kPersistLdsBudget / (int)per_cu) & ~1023;
+  return true;
+}
+// decided per solve, after the context is known
+static void persist_plan(dfx_handle* h, const DevCtx& c) {
+  h->persist_fwd = false;
+  if (!persist_shape_ok(h) || h->adaptive || h->groups.size() != 1 || h->pair_fwd || h->lig_fwd_used) return;
+  if (h->pl.n_fns > 0 && !c.fn_tab) return;
+  h->persist_npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
+  const void* fn = persist_fwd_fn(h);
+  int grid = 0, lds = 0;
+  if (!fn || !persist_fits(h, fn, h->persist_npb, h->pl.batch, &grid, &lds)) return;
+  if (h->d_ring.ensure((size_t)kPRing * h->pl.batch * h->pl.n_blocks * kPos) != hipSuccess) { (void)hipGetLastError(); return; }
+  h->persist_wpm = persist_waves_per_member(h, h->persist_npb);
+  h->persist_fwd = true;
+}
+static PersistCoef persist_coef(const Tableau& T) {
+  PersistCoef pc;
+  memset(&pc, 0, sizeof(pc));
+  for (int i = 0; i < T.s && i < kPersistStages; ++i)
+    for (int l = 0; l <= i; ++l) { pc.cv[i][l] = T.a[i + 1][l]; pc.cq[i][l] = T.aa[i + 1][l]; }
+  for (int r = 0; r <= T.s && r <= kPersistStages; ++r) pc.c[r] = T.c[r];
+  return pc;
+}
+static int* persist_give_up_word(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 1; }
+// one segment of the group's members: poison the first ring places, then the whole segment in one launch, chained behind the previous
+// persistent launch of the process
+static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void** args, int grid, int lds) {
+  static std::map<const void*, int> lds_set;
+  std::lock_guard<std::mutex> lk(g_persist_mu);
+  if (lds_set[fn] < lds) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLdsBudget); lds_set[fn] = kPersistLdsBudget; }
+  const int d = h->device & 63;
+  if (g_persist_tail_on[d]) (void)hipStreamWaitEvent(st, g_persist_tail[d], 0);
+  else { (void)hipEventCreateWithFlags(&g_persist_tail[d], hipEventDisableTiming); g_persist_tail_on[d] = true; }
+  (void)hipLaunchKernel(fn, dim3(grid), dim3(kPersistThreads), args, lds, st);
+  (void)hipEventRecord(g_persist_tail[d], st);
+  h->launches++;
+}
+static void launch_fwd_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) {
+  const void* fn = persist_fwd_fn(h);
+  int grid = 0, lds = 0;
+  (void)persist_fits(h, fn, h->persist_npb, nm, &grid, &lds);
+  dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, c.m0, nm, kPos);
+  h->launches++;
+  DevCtx cc = c;
+  PersistCoef pc = persist_coef(h->pl.tab);
+  PersistArgs pa;
+  pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = nm; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+  void* args[] = {&cc, &pc, &pa};
+  launch_persist(h, fn, st, args, grid, lds);
+}
+
 // forward: stage i reads buffer fin(i), writes fout(i); buffer 0 is the step state
 static int fin(int i) { return i == 0 ? 0 : 1 + ((i - 1) & 1); }
 static int fout(int i, int s) { return i == s - 1 ? 0 : 1 + (i & 1); }
@@ -602,7 +703,8 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, g.stream, (const Seg*)h->d_segs.p, h->d_seg_idx.p + 2 + gi, kind == 0 ? 1 : -1, h->d_cur.p + gi);
   h->launches++;
   launch_fn_table(h, c, g.stream, g.nm, n_steps);
-  if (kind == 0) {
+  if (kind == 0 && h->persist_fwd) launch_fwd_persist(h, c, g.stream, g.nm, n_steps);
+  else if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
       for (int u = 0; u < step_units(h, 0); ++u) launch_fwd_unit(h, c, g.stream, grid, u, j);
   } else if (c.AD || c.rps > 1) {
@@ -671,7 +773,9 @@ static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps,
     h->launches++;
     launch_fn_table(h, cg[gi], h->groups[gi].stream, h->groups[gi].nm, n_steps);
   }
-  if (kind == 0) {
+  if (kind == 0 && h->persist_fwd) {
+    for (int gi = 0; gi < ng; ++gi) launch_fwd_persist(h, cg[gi], h->groups[gi].stream, h->groups[gi].nm, n_steps);
+  } else if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
       for (int u = 0; u < step_units(h, 0); ++u)
         for (int gi = 0; gi < ng; ++gi)
@@ -1161,6 +1265,12 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     const char* e = getenv("DFX_STREAMS");
     const long long waves = (long long)h->pl.batch * ((h->pl.n_slots + 63) / 64);
     int want = e ? atoi(e) : (problem->streams > 0 ? problem->streams : (waves >= 2048 ? 2 : 1));
+    // solves that fit the persistent stage loop (dfx_persist.h) run all their members in ONE launch per segment
+    if (!e && problem->streams <= 0 && want > 1 && persist_shape_ok(h)) {
+      h->persist_npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
+      int pg = 0, plds = 0;
+      if (persist_fits(h, persist_fwd_fn(h), h->persist_npb, h->pl.batch, &pg, &plds)) want = 1;
+    }
     int ng = std::max(1, std::min({want, h->pl.batch, kMaxGroups}));
     (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming);
@@ -1227,7 +1337,7 @@ int dfx_destroy(dfx_handle* h) {
   for (int f = 0; f < DFX_MAX_FNS; ++f) h->d_fn_table[f].release();
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release(); h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release(); 
   if (--h->ck->users == 0) { h->ck->traj.release(); h->ck->AD.release(); delete h->ck; }
-  h->d_fn_tab.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
+  h->d_ring.release(); h->d_fn_tab.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
   h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release(); h->flag_stage.release();
@@ -1330,7 +1440,10 @@ int dfx_share_checkpoint(dfx_handle* h, dfx_handle* with) {
 }
 
 // after the stream has been waited for: the non-finite flag of the forward pass (pinned word 0 of flag_stage) and its statistics
+static const char* kPersistGaveUp = "a wave of the persistent stage loop gave up waiting for a neighbour's record (a workgroup of the launch was not resident: "
+                                    "another process on the device?); DFX_PERSIST=0 keeps one launch per stage";
 static int finish_forward(dfx_handle* h, dfx_stats* stats) {
+  if (*persist_give_up_word(h)) { h->have_traj = false; h->err = std::string("forward: ") + kPersistGaveUp; return 2; }
   const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
   if (bad) {
     h->have_traj = false;
@@ -1447,6 +1560,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   HIP_OK(h->flag_stage.ensure(64));
   int* const bad_flag = reinterpret_cast<int*>(h->flag_stage.p);
   *bad_flag = 0;
+  *persist_give_up_word(h) = 0;
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (state0) {       // through the pinned staging area (pageable DMA is slow here); NULL = every member starts at rest
     HIP_OK(h->stage.ensure(sizeof(double) * B * nb * 6));
@@ -1460,6 +1574,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   pair_plan(h, c);
   h->lig_fwd_used = !h->pair_fwd && lig_fwd_ok(h, c, 0);
+  persist_plan(h, c);
   h->launches = 0;
   const bool timing = getenv("DFX_TIMING") != nullptr;
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
@@ -1472,7 +1587,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, bad_flag, 0, 0LL);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
-  const bool eager = solve_is_eager(h) || h->segments;
+  const bool eager = solve_is_eager(h) || h->segments || h->persist_fwd;      // (a persistent segment is three launches: nothing to replay)
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
     if (eager) enqueue_interleaved(h, c, sg.n_steps, 0);
@@ -1499,7 +1614,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   h->fwd_stats.streams = (int64_t)h->groups.size();
   h->fwd_stats.stage_checkpoint = c.AD ? 1 : 0;
   h->fwd_stats.checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
-  h->fwd_stats.tile_kernels = kernel_build_code(h, c, h->lig_fwd_used);
+  h->fwd_stats.tile_kernels = h->persist_fwd ? 3 : kernel_build_code(h, c, h->lig_fwd_used);
   if (h->defer_forward_sync) return 0;          // the fused call goes on enqueueing the reverse sweep; finish_forward after its last wait
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
@@ -1512,6 +1627,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
 int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                          double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
+  h->persist_fwd = false;
   if (!h->have_params) { h->err = "forward_adaptive: set_params first"; return 1; }
   if (n_timepoints < 1) { h->err = "forward_adaptive: need >= 1 timepoint"; return 1; }
   if (h->pl.tab.s != 6) { h->err = "forward_adaptive: the adaptive controller is defined for the dopri5 tableau"; return 1; }

@@ -1,0 +1,275 @@
+// dfx_persist.h -- the stage loop WITHOUT kernel boundaries, for solves whose launches do not fill the chip (round 5).
+// Included by the engine after dfx_kernels.h (same anonymous namespace, same helpers, same per-ligament physics).
+//
+// Why.  One launch per Runge-Kutta stage is the right seam where a launch fills the chip (16 x 128x128: 15 / 29 us of work per launch
+// against a 1.5 us boundary).  One 128x128 system is 1 024 waves -- one per SIMD -- and its stage launch is a 1.6 us dispatch plus ONE
+// wave's dependent chain of memory round trips: 7.0 - 7.7 us per stage for 0.6 us of traffic (profiles/r04_v5_*: 0.09 - 0.18 of the
+// roofline), the reference's own use (one design) and config 4's per-GPU width.  reference loop: odeint's while_loop x 6 rhs,
+// /root/reference/difflexmm/dynamics.py:166.
+//
+// How.  A wave owns its 16 (20: packed triangles) blocks for a whole segment of <= 256 steps: parameters, step state and the stage
+// accelerations stay in registers.  What the NEXT stage of a neighbouring wave needs is the 32-byte stage record of a block (x, y, theta,
+// sin theta/2) -- nothing else crosses waves, and a wave has <= 4 neighbour waves on a lattice.  Hand-off (MI355X_MICROARCH.md,
+// "Valid forms", R2: the data is the flag):
+//   * records travel through a RING of kPRing places per member, [place][member][block][4 doubles]; the record of stage ordinal t of a
+//     launch lives in place t % kPRing;
+//   * every ring store is a 16-byte write-through store (sc1), every ring load a 16-byte sc1 load (served past the L1, which another
+//     CU's stores never refresh);
+//   * a place holds POISON (all-ones words: a NaN no arithmetic produces) until its record arrives; a lane polls its partner's record
+//     until none of its four doubles is poison.  An aligned 8-byte word is written by one store and is never seen torn, so no ordering
+//     between the stores, no flag and no fence is needed;
+//   * the owner re-poisons the place of ordinal t + kPAhead while it works on stage t; the s_waitcnt of its next poll completes that
+//     store long before a neighbour can ask for ordinal t + kPAhead (a neighbour reaches stage t only after this wave has finished
+//     stage t - 2).  The places of ordinals 0 .. kPAhead-1 are poisoned by a small launch in front (k_ring_poison), ordinal 0 is
+//     published by every wave at its start.  kPRing >= kPAhead + 1 keeps a re-poison from overtaking a reader.
+//   * every spin is bounded; a wave that gives up stores a code the host turns into an error (workgroup not resident).
+// The mock with this protocol (tools/mock/persistent_stage_mock.hip, profiles/r05_persistent_stage_mock.txt): 2.9 us per stage for one
+// 128x128 system with 352 fp64 operations per lane, every word of every record equal to the one-launch-per-stage form, also under
+// uneven load, 4 workgroups per compute unit, and with finite garbage in the unpoisoned places.
+//
+// Residency.  All waves of a launch must be resident at once: grid = ceil(waves / 4) workgroups of 256 threads (one wave per SIMD);
+// the launch asks for just enough dynamic LDS that a compute unit admits exactly ceil(grid / CUs) of them (an even spread: one wave
+// per SIMD for one 128x128 system), and the host refuses shapes that do not fit (persist_fits).  Two persistent launches of one
+// process never overlap on the device (a partial residency of both would starve both): the engine chains them through one event
+// (persist_serialize).  Checkpoint stores (records / state / stage accelerations) are plain stores beside the ring, in the layout the
+// stage kernels write, so every reverse path reads them unchanged.
+#pragma once
+#include "dfx_persist_api.h"
+
+namespace {
+using namespace dfx_persist;
+
+typedef unsigned p_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool is_poison(double x) { return (unsigned)__double2hiint(x) == kPoisonWord; }
+
+// one lane's two 16-byte chunks of a ring record, sc1 loads, waited for inside the statement (the compiler does not count asm loads)
+__device__ __forceinline__ void ring_load(const double* place, u32 byte_off, double (&r)[4]) {
+  p_u4 c0, c1;
+  asm volatile("global_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(c0), "=&v"(c1) : "v"(byte_off), "s"(place) : "memory");
+  r[0] = __hiloint2double(c0.y, c0.x); r[1] = __hiloint2double(c0.w, c0.z);
+  r[2] = __hiloint2double(c1.y, c1.x); r[3] = __hiloint2double(c1.w, c1.z);
+}
+__device__ __forceinline__ void ring_store(double* place, u32 byte_off, double a, double b) {
+  p_u4 x;
+  x.x = __double2loint(a); x.y = __double2hiint(a); x.z = __double2loint(b); x.w = __double2hiint(b);
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(x), "s"(place) : "memory");
+}
+__device__ __forceinline__ void ring_poison(double* place, u32 byte_off) {
+  p_u4 x; x.x = x.y = x.z = x.w = kPoisonWord;
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(x), "s"(place) : "memory");
+}
+
+// The resident parameters are loop invariants, and the compiler hoists every sub-expression of the ligament arithmetic that depends on
+// them alone out of the stage loop -- into registers it then keeps for the whole launch (the first build: 200 VGPRs, two waves per SIMD).
+// An empty asm that "rewrites" a value at the top of every stage makes what depends on it part of the stage again.
+__device__ __forceinline__ void keep_in_loop(double& x) { asm volatile("" : "+v"(x)); }
+
+// places 0 .. kPAhead-1 of the members of a launch, poisoned in front of it (stream order)
+__global__ __launch_bounds__(kThreads) void k_ring_poison(double* ring, int batch, int n_blocks, int m0, int width /* doubles per block */, int places) {
+  const int m = blockIdx.y + m0;
+  const int tid = blockIdx.x * kThreads + threadIdx.x;
+  if (tid >= n_blocks * width) return;
+  const unsigned long long p = ~0ull;
+  for (int pl = 0; pl < places; ++pl)
+    reinterpret_cast<unsigned long long*>(ring)[((size_t)pl * batch + m) * ((size_t)n_blocks * width) + tid] = p;
+}
+
+// lane -> (slot, block, node) of wave w of a member (lane_pos of dfx_kernels.h without the workgroup arithmetic)
+template <int NPB>
+__device__ __forceinline__ LanePos wave_lane_pos(int w, int n_blocks) {
+  LanePos p;
+  const int gtid = w * 64 + (int)(threadIdx.x & 63);
+  if (NPB == 4) { p.slot = gtid; p.b = gtid >> 2; p.k = gtid & 3; p.valid = p.b < n_blocks; return p; }
+  const int j = gtid & 15;
+  const int tri = min((j * 11) >> 5, 4);
+  p.k = j - 3 * tri;
+  p.b = (gtid >> 4) * 5 + tri;
+  p.valid = p.b < n_blocks;
+  p.slot = p.b * 4 + p.k;
+  return p;
+}
+
+// ---- forward: every stage of every step of one segment in one launch --------------------------------------------------------------
+//   records  c.rps > 1: stage i of step n also stores its new record (chunks + velocity) into record i + 1 of step n of the checkpoint
+//   state    c.rps == 1 && c.traj: the last stage stores the new step state into the checkpoint of step n + 1
+//   stages   c.AD: every stage but the last stores its acceleration
+//   none of them (forward only): nothing but the ring moves between stages
+// The segment starts from record 0 of its first step (records level) or from stage buffer 0, and -- unless the records level keeps the
+// state in the checkpoint -- leaves its last state in stage buffer 0, where k_snapshot and the next segment read it.
+#ifndef DFX_PERSIST_OCC
+#define DFX_PERSIST_OCC
+#endif
+template <int MODEL, int CONTACT, int NPB>
+__global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist(DevCtx c, PersistCoef pc, PersistArgs pa) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
+  if (wave >= pa.waves_per_member * pa.nm) return;
+  const int ml = wave / pa.waves_per_member, w = wave - ml * pa.waves_per_member;
+  const int m = c.m0 + ml;
+  const LanePos lp = wave_lane_pos<NPB>(w, c.n_blocks);
+  if (!lp.valid) return;
+  const int slot = lp.slot, b = lp.b, k = lp.k, kd = k < 3 ? k : 2;
+  const u32 nd = (u32)c.n_blocks * 3;
+  const int s = c.s;
+  const Seg sg = *c.cur;
+  const MemberBases B = member_bases(c, m);
+  // ---- resident per lane: the slot's ligament
+  const int info = ldg<int>(c.slot_info, (u32)slot * 4);
+  const int pslot = info < 0 ? slot : (info >> 1);          // a slot without a ligament watches its own block
+  double sgn = (info & 1) ? 1.0 : -1.0;
+  const double2 ro_ = ldg<double2>(B.p_r, (u32)slot * 16), rp_ = ldg<double2>(B.p_r, (u32)pslot * 16);
+  double rox = ro_.x, roy = ro_.y, rpx = rp_.x, rpy = rp_.y;
+  double lx, ly, l0, il0;
+  if (c.l_dict_on) {
+    const u32 li = (u32)ldg<uint8_t>(B.p_lidx, (u32)slot);
+    const double2 lv = ldg<double2>(B.l_dict, li * 32), ln = ldg<double2>(B.l_dict, li * 32 + 16);
+    lx = lv.x; ly = lv.y; l0 = ln.x; il0 = ln.y;
+  } else {
+    const double2 lv = ldg<double2>(B.p_l, (u32)slot * 16);
+    lx = lv.x; ly = lv.y;
+    l0 = info < 0 ? 1.0 : sqrt(lv.x * lv.x + lv.y * lv.y);
+    il0 = 1.0 / l0;
+  }
+  double ks, ksh, kr;
+  if (c.k_uniform) { ks = B.cst[3]; ksh = B.cst[4]; kr = B.cst[5]; }
+  else { ks = ldg<double>(B.p_k, (u32)slot * 32); ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
+  double am = 0.0, ac = 0.0, kc = 0.0, phi1 = 0.0, phi2 = 0.0, kap_safe = 0.0, phi_min = 0.0;
+  if (CONTACT == 1) {
+    am = B.cst[0]; ac = B.cst[1]; kc = B.cst[2]; kap_safe = B.cst[9]; phi_min = B.cst[10];
+    const double2 ph = ldg<double2>(B.p_phi, (u32)slot * 16);
+    phi1 = ph.x; phi2 = ph.y;
+  }
+  // ---- resident per DOF lane
+  const int dof = b * 3 + kd;
+  const u32 o_dof = (u32)dof * 8, o_rec = ((u32)b * kPos + kd) * 8, o_chunk = ((u32)b * kPos + 2 * (k & 1)) * 8;
+  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)((u32)m * nd), o_dof);
+  const double invm = ldg<double>(c.inv_m + (size_t)((u32)m * nd), o_dof);
+  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
+  const bool constrained = k < 3 && sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> k) & 1);
+  const bool recs = c.rps > 1;
+  const long long n0 = sg.base_step;
+  double qn, vn;
+  BlockRec<double> o;
+  {
+    const double* P0 = pos_in(c, m, recs ? -1 : 0, n0);
+    const double* V0 = vel_in(c, m, recs ? -1 : 0, n0);
+    const double2 a0 = ldg<double2>(P0, (u32)b * kPos * 8), a1 = ldg<double2>(P0, (u32)b * kPos * 8 + 16);
+    o.x = a0.x; o.y = a0.y; o.th = a1.x; o.sh = a1.y;
+    qn = ldg<double>(P0, o_rec);
+    vn = ldg<double>(V0, o_dof);
+  }
+  double al[kPersistStages];
+#pragma unroll
+  for (int l = 0; l < kPersistStages; ++l) al[l] = 0.0;
+  // ---- the ring: per-lane byte offsets inside a place; a place of all members is ring_stride doubles
+  const size_t ring_stride = (size_t)c.batch * c.n_blocks * kPos;
+  const u32 r_own = ((u32)m * (u32)c.n_blocks + (u32)b) * (kPos * 8) + 16u * (u32)(k & 1);
+  const u32 r_par = ((u32)m * (u32)c.n_blocks + (u32)(pslot >> 2)) * (kPos * 8);
+  if (k < 2) ring_store(pa.ring, r_own, k == 0 ? o.x : o.th, k == 0 ? o.y : o.sh);      // ordinal 0
+  const int total = pa.n_steps * s;
+  int t_ord = 0;
+  double v_i = vn;
+  for (int j = 0; j < pa.n_steps; ++j) {
+    const long long n = n0 + j;
+    double h = sg.h;
+    if (c.t_steps) { const double* ts = steps_of(c, m); h = ts[n + 1] - ts[n]; }
+    double* Am = c.AD ? c.AD + (size_t)m * c.ad_stride + (size_t)n * ((u32)(s - 1) * nd) : nullptr;
+    // (one copy of the stage body, the stage index a run-time value: unrolled six times the register allocator kept 200 registers live
+    // and the launch lost its second and third wave per SIMD)
+#pragma unroll 1
+    for (int i = 0; i < s; ++i) {
+      {
+        keep_in_loop(rox); keep_in_loop(roy); keep_in_loop(rpx); keep_in_loop(rpy); keep_in_loop(lx); keep_in_loop(ly); keep_in_loop(l0); keep_in_loop(il0);
+        keep_in_loop(ks); keep_in_loop(ksh); keep_in_loop(kr); keep_in_loop(sgn);
+        if (CONTACT == 1) { keep_in_loop(phi1); keep_in_loop(phi2); keep_in_loop(am); keep_in_loop(ac); keep_in_loop(kc); }
+        // ---- the partner's record of this stage
+        const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
+        double pr[4];
+        for (int spins = 0;;) {
+          ring_load(place, r_par, pr);
+          const bool ok = !(is_poison(pr[0]) || is_poison(pr[1]) || is_poison(pr[2]) || is_poison(pr[3]));
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit) { *pa.give_up = 1 + t_ord; return; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (k < 2 && t_ord + kPAhead <= total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
+        BlockRec<double> p;
+        p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];
+        p.ch = half_cos(p.th, p.sh);
+        o.ch = half_cos(o.th, o.sh);
+        // ---- ligament + contact of this slot (k_fwd_stage's arithmetic)
+        double fx = 0.0, fy = 0.0, fth = 0.0;
+        if (info >= 0) {
+          BondGrad<double> g;
+          bond_grad<MODEL, double>(o, p, rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, sgn, g);
+          fx = g.fx; fy = g.fy; fth = g.fth;
+          if (CONTACT == 1) {
+            // the stage kernels fetch a ligament's own void angles only beyond the culling bound and evaluate the member's smallest
+            // one otherwise (exact zeros either way); the same selection keeps the two forms equal bit for bit
+            const bool far = !(fabs(o.th - p.th) <= kap_safe);
+            ContactGrad<double> cg;
+            contact_grad<double>(sgn * (o.th - p.th), far ? phi1 : phi_min, far ? phi2 : phi_min, am, ac, kc, cg);
+            fth += sgn * cg.dkap;
+          }
+        }
+        const double dE = blk_reduce3<NPB>(fx, fy, fth, k);
+        // ---- DOF epilogue
+        double qnext = 0.0, vnext = 0.0;
+        if (k < 3) {
+          double fload = 0.0;
+          if (sidx >= 0 && !constrained) {
+            const dfx_special& sp = c.special[sidx];
+            const double* ft_i = fn_tab_row(c, m, j, i);
+            const u32 z = lane_zero();
+            for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * fn_tab_get(ft_i, f, 0, z);
+          }
+          const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
+          if (Am && i < s - 1) stg<double>(Am + (size_t)i * nd, o_dof, a);
+          // the stage kernels sum the earlier stages' terms in order and the own term last; the rows are zero beyond the diagonal, so the
+          // same sum runs over the whole row here (exact zeros added behind the own term)
+          double sv = 0.0, sq = 0.0;
+#pragma unroll
+          for (int l = 0; l < kPersistStages; ++l) {
+            al[l] = l == i ? a : al[l];
+            sv += pc.cv[i][l] * al[l];
+            sq += pc.cq[i][l] * al[l];
+          }
+          qnext = qn + h * (pc.c[i + 1] * vn + h * sq);
+          vnext = vn + h * sv;
+          if (constrained) {
+            const dfx_special& sp = c.special[sidx];
+            const double* ft_n = fn_tab_row(c, m, j, i + 1);
+            const u32 z = lane_zero();
+            qnext = 0.0; vnext = 0.0;
+            for (int f = 0; f < c.n_fns; ++f) { qnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 0, z); vnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 1, z); }
+          }
+        }
+        // ---- the next stage record: into the ring for the neighbours, into the checkpoint for the reverse sweep
+        const double y1 = blk_bcast<NPB, 1>(qnext, k), th2 = blk_bcast<NPB, 2>(qnext, k), x0 = blk_bcast<NPB, 0>(qnext, k);
+        double sn, cs;
+        fast_sincos(0.5 * th2, &sn, &cs);
+        o.x = x0; o.y = y1; o.th = th2; o.sh = sn;
+        ++t_ord;
+        const bool last = i == s - 1;
+        if (k < 2) ring_store(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_own, k == 0 ? x0 : th2, k == 0 ? y1 : sn);
+        if (k < 3) {
+          const double2 chunk = k == 0 ? make_double2(x0, y1) : make_double2(th2, sn);
+          if (recs || (last && c.traj)) {
+            double* tr = recs ? traj_rec(c, m, -2 - i, n) : traj_rec(c, m, -1, n + 1);
+            if (k < 2) stg<double2>(tr, o_chunk, chunk);
+            stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vnext);
+          }
+          if (last && !recs && j == pa.n_steps - 1) {      // the segment's last state, for k_snapshot and the next segment
+            if (k < 2) stg<double2>(c.POS + (size_t)((u32)m * (u32)c.nbuf * (u32)c.n_blocks * kPos), o_chunk, chunk);
+            stg<double>(c.VEL + (size_t)((u32)m * (u32)c.nbuf * nd), o_dof, vnext);
+          }
+        }
+        v_i = vnext;
+        if (last) { qn = qnext; vn = vnext; }
+      }
+    }
+  }
+}
+
+}  // namespace

@@ -1,0 +1,35 @@
+// dfx_persist_api.h -- what the engine's host code and the persistent kernels' translation unit (dfx_persist.hip) share.
+// The persistent kernels are compiled on their own because they need one compiler switch the stage kernels must not get:
+// -mllvm -disable-machine-licm.  Their stage loop is the first long loop around the ligament arithmetic, and the machine-level
+// loop-invariant code motion hoists every fp64 literal of that arithmetic (the polynomial coefficients of atan2 / sincos, ~80
+// registers of v_mov) out of it: 203 VGPRs and two waves per SIMD instead of 108 and four (profiles/r05_persistent_kernels.txt).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dfx_persist {
+
+constexpr int kPRing = 8;      // places in the hand-off ring
+constexpr int kPAhead = 4;     // a place is re-poisoned this many stage ordinals before its record is due
+constexpr int kPersistThreads = 256;
+constexpr unsigned kPoisonWord = 0xFFFFFFFFu;
+constexpr int kPersistStages = 6;   // fixed-grid tableaus of the library: 4 (RK4) and 6 (Dormand-Prince)
+constexpr int kSpinLimit = 1 << 23; // polls (>= 0.5 us each) before a wave gives up: seconds
+
+struct PersistCoef {            // the whole tableau in acceleration form, by value (scalar loads at compile-time offsets)
+  double cv[kPersistStages][kPersistStages];
+  double cq[kPersistStages][kPersistStages];
+  double c[kPersistStages + 1];
+};
+struct PersistArgs {
+  double* ring;                 // kPRing * batch * n_blocks * kPos
+  int* give_up;                 // pinned host word: != 0 once a wave gave up (1 + the stage ordinal it waited for)
+  int n_steps, nm, waves_per_member, pad;
+};
+
+
+// kernels by (bond model, contact, lanes per block); nullptr: no such build
+const void* fwd_kernel(int model, int contact, int npb);
+// places 0 .. kPAhead-1 of the ring, members [m0, m0 + nm), poisoned on `st`
+void launch_ring_poison(hipStream_t st, double* ring, int batch, int n_blocks, int m0, int nm, int width);
+
+}  // namespace dfx_persist

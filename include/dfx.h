@@ -133,7 +133,9 @@ typedef struct dfx_stats {
   int64_t tile_kernels;                   /* which builds of the stage kernels this call launched: 0 the generic slot kernels; 2 their
                                              per-stage builds (stage index and common parameter shape compiled in: launches that fill the
                                              chip; DFX_STAGE_BUILDS=0 switches them off); 1 the tile kernels (every
-                                             ligament evaluated once on lattice tiles, DFX_TILE=1: opt-in) */
+                                             ligament evaluated once on lattice tiles, DFX_TILE=1: opt-in); 3 the persistent stage
+                                             loop (one launch per segment of <= 256 steps, stage records handed between neighbouring waves: solves
+                                             whose launches do not fill the chip; DFX_PERSIST=0 switches it off) */
 } dfx_stats;
 
 typedef struct dfx_handle dfx_handle;

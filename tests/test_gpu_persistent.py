@@ -1,0 +1,99 @@
+"""-m gpu: the persistent stage loop (dfx_persist.h: one launch per segment, stage records handed between neighbouring waves through
+a self-poisoned ring) against one launch per stage (DFX_PERSIST=0).  Same arithmetic in the same order, so the bar is EQUALITY of every
+output field and -- the reverse sweep reads the checkpoint the persistent launch wrote -- of every gradient, at every checkpoint level
+and for forward-only solves.  Equality holds bit for bit in a build without floating-point contraction (make ... CXXFLAGS="... -ffp-contract=off",
+run with DFX_LIBRARY=<that build>: 6 passed, profiles/r05_persistent_kernels.txt); in the production build the compiler fuses multiply-adds
+differently in the two kernels, so there the bar is agreement to rounding (1e-13 of the largest entry; the reverse sweep amplifies it to
+1e-11 in the gradients).  Reference loop being replaced: odeint's while_loop x 6 rhs, /root/reference/difflexmm/dynamics.py:166."""
+import os
+
+import numpy as np
+import pytest
+
+from .common import Case, relerr
+
+pytestmark = pytest.mark.gpu
+
+EXACT = "nocontract" in os.environ.get("DFX_LIBRARY", "")
+
+
+def same(a, b, tol):
+    return np.array_equal(a, b) if EXACT else relerr(a, b) < tol
+
+FAST = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _solve(c, ts, spi, target, env, keep=True):
+    def run():
+        fields = c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, c.cp, keep_trajectory=keep, steps_per_interval=spi)
+        st = dict(c.solver.stats)
+        if not keep:
+            return fields.copy(), None, None, st
+        obj, raw = c.solver.kinetic_energy_value_and_raw(target)
+        return fields.copy(), float(np.atleast_1d(obj)[0]), {k: np.array(v) for k, v in raw.items()}, st
+    return _with_env(env, run)
+
+
+@pytest.mark.parametrize("lattice,n,contact,nonlinear", [("quads", 37, True, True), ("kagome", 21, True, True), ("quads", 12, False, False),
+                                                        ("kagome", 7, False, True)])
+def test_persistent_forward_equals_stage_launches(hip_lib, lattice, n, contact, nonlinear):
+    c = Case(lattice, n, nonlinear, contact, seed=31, cutoff_deg=42.0 if lattice == "quads" else 125.0)
+    c.cp = c.cp._replace(constraint_params=FAST)
+    ts = np.linspace(0.0, 3e-4, 4)
+    mid = c.geo.n_blocks // 2
+    target = np.array([mid + 1, mid + 2], dtype=np.int32)
+    for level in ("records", "stages", "state", "segments"):
+        ref = _solve(c, ts, 9, target, {"DFX_PERSIST": "0", "DFX_CHECKPOINT": level})
+        out = _solve(c, ts, 9, target, {"DFX_PERSIST": "1", "DFX_CHECKPOINT": level})
+        assert ref[3]["tile_kernels"] != 3 and out[3]["tile_kernels"] == 3, (level, ref[3], out[3])      # the persistent loop really ran
+        assert out[3]["launches"] < 0.2 * ref[3]["launches"]
+        assert same(out[0], ref[0], 1e-13), (level, relerr(out[0], ref[0]))
+        assert abs(out[1] - ref[1]) <= (0 if EXACT else 1e-12 * abs(ref[1]))
+        for k in ref[2]:
+            assert same(out[2][k], ref[2][k], 1e-11), (level, k, relerr(out[2][k], ref[2][k]))
+        assert np.abs(ref[0][-1]).max() > 0 and ref[1] > 0
+    ref = _solve(c, ts, 9, target, {"DFX_PERSIST": "0"}, keep=False)
+    out = _solve(c, ts, 9, target, {"DFX_PERSIST": "1"}, keep=False)
+    assert out[3]["tile_kernels"] == 3
+    assert same(out[0], ref[0], 1e-13)
+
+
+def test_persistent_forward_many_segments_and_members(hip_lib):
+    """More steps than one segment holds (256) and three members side by side: the ring wraps hundreds of times, every segment starts
+    from the state its predecessor left, the members' waves share workgroups."""
+    c = Case("quads", 10, True, True, seed=4, cutoff_deg=42.0, batch=3)
+    c.cp = c.cp._replace(constraint_params=FAST)
+    ts = np.linspace(0.0, 6e-4, 3)
+    target = np.array([44, 45], dtype=np.int32)
+    ref = _solve(c, ts, 300, target, {"DFX_PERSIST": "0"})
+    out = _solve(c, ts, 300, target, {"DFX_PERSIST": "1"})
+    assert out[3]["tile_kernels"] == 3
+    assert same(out[0], ref[0], 1e-12)
+    for k in ref[2]:
+        assert same(out[2][k], ref[2][k], 1e-10), k
+
+
+def test_persistent_forward_matches_the_oracle(hip_lib):
+    """20 x 20 quads, contact engaged: fields of a 24-step solve against the oracle's fixed-grid solver (independent arithmetic)."""
+    c = Case("quads", 20, True, True, seed=5, cutoff_deg=42.0)
+    c.cp = c.cp._replace(constraint_params=FAST)
+    ts = np.linspace(0.0, 2.4e-4, 3)
+    fields = _with_env({"DFX_PERSIST": "1"}, lambda: c.solver(np.zeros((2, 400, 3)), ts, c.cp, keep_trajectory=True, steps_per_interval=12))
+    assert c.solver.stats["tile_kernels"] == 3
+    import torch
+    lv = dict(loading_rate=torch.tensor(3000.0, dtype=torch.float64), input_delay=torch.tensor(1e-5, dtype=torch.float64))
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=12)
+    assert relerr(fields, osol(np.zeros((2, 400, 3)), ts, c.oracle_cp(lv)).numpy()) < 1e-10
