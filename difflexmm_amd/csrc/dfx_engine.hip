@@ -176,8 +176,9 @@ struct dfx_handle {
   bool lig_fwd_used = false, lig_adj_used = false;   // what the last forward pass / reverse sweep launched (dfx_stats)
   LigCtx lig;
   // the stage loop without kernel boundaries (dfx_persist.h): decided per solve (persist_plan); the hand-off ring
-  bool persist_fwd = false;
+  bool persist_fwd = false, persist_adj = false;
   int persist_npb = 4, persist_wpm = 0, n_cu = 0;
+  int persist_fwd_members = 0, persist_adj_members = 0;     // members per launch (the rest follow in further launches of the same segment)
   DevBuf<double> d_ring;
   std::vector<int32_t> lig_slots;
   DevBuf<int32_t> d_lig_slots, d_lig_tab;
@@ -561,14 +562,13 @@ static void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf,
 // wait for each other until their spins give up.  Every persistent launch of the process therefore waits for the one before it
 // (whatever handle or stream issued it) through one event per device.
 using namespace dfx_persist;
+static const char* kPersistGaveUp = "a wave of the persistent stage loop gave up waiting for a neighbour's record (a workgroup of the launch was not resident: "
+                                    "another process on the device?); DFX_PERSIST=0 keeps one launch per stage";
 static std::mutex g_persist_mu;
 static hipEvent_t g_persist_tail[64];
 static bool g_persist_tail_on[64];
 static const int kPersistLdsBudget = 150 * 1024;    // of a compute unit's 160 KB: room for the stage kernels' small LDS users next to us
 
-static const void* persist_fwd_fn(const dfx_handle* h) {
-  return dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, h->persist_npb);
-}
 // workgroups of `fn` a compute unit can hold at once (registers; 256-thread workgroups = one wave per SIMD each), capped where the
 // residency rule of MI355X_MICROARCH.md ("Residency and cooperative launch") starts to depend on the scalar-register count
 static int persist_wg_per_cu(const void* fn) {
@@ -590,30 +590,58 @@ static bool persist_shape_ok(const dfx_handle* h) {
 static int persist_waves_per_member(const dfx_handle* h, int npb) {
   return npb == 3 ? (h->pl.n_blocks + 19) / 20 : (h->pl.n_slots + 63) / 64;
 }
-// do all waves of `nm` members fit on the chip at once?  (grid, LDS per workgroup) of the launch if so
-static bool persist_fits(dfx_handle* h, const void* fn, int npb, int nm, int* grid, int* lds) {
-  if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return false; h->n_cu = v; }
+// how many members fit on the chip at once (0: not even one), and the launch shape for `nm` of them
+static int persist_members_that_fit(dfx_handle* h, const void* fn, int npb) {
+  if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return 0; h->n_cu = v; }
   const int cap = persist_wg_per_cu(fn);
+  const long long wpm = persist_waves_per_member(h, npb);
+  if (cap <= 0 || wpm <= 0) return 0;
+  return (int)std::min<long long>(h->pl.batch, ((long long)cap * h->n_cu * 4) / wpm);
+}
+static void persist_shape(const dfx_handle* h, int npb, int nm, int* grid, int* lds) {
   const long long waves = (long long)nm * persist_waves_per_member(h, npb);
   const long long g = (waves + 3) / 4;
-  const long long per_cu = (g + h->n_cu - 1) / h->n_cu;
-  if (cap <= 0 || per_cu > cap) return false;
+  const long long per_cu = std::max<long long>(1, (g + h->n_cu - 1) / h->n_cu);
   *grid = (int)g;
   *lds = (kPersistLdsBudget / (int)per_cu) & ~1023;
+}
+// launches per segment a solve may be cut into (members that do not fit at once follow in further launches); beyond it the stage launches
+// serve the solve.  1 by default: a launch that fills the chip several times over is what the stage kernels are tuned for.
+static int persist_max_chunks() {
+  const char* e = getenv("DFX_PERSIST_CHUNKS");
+  return e ? std::max(1, atoi(e)) : 1;
+}
+static bool persist_common_ok(dfx_handle* h, const DevCtx& c) {
+  if (!persist_shape_ok(h) || h->adaptive || h->groups.size() != 1) return false;
+  if (h->pl.n_fns > 0 && !c.fn_tab) return false;
+  h->persist_npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
+  h->persist_wpm = persist_waves_per_member(h, h->persist_npb);
   return true;
+}
+static bool persist_members_ok(const dfx_handle* h, int per_launch) {
+  return per_launch > 0 && (h->pl.batch + per_launch - 1) / per_launch <= persist_max_chunks();
 }
 // decided per solve, after the context is known
 static void persist_plan(dfx_handle* h, const DevCtx& c) {
   h->persist_fwd = false;
-  if (!persist_shape_ok(h) || h->adaptive || h->groups.size() != 1 || h->pair_fwd || h->lig_fwd_used) return;
-  if (h->pl.n_fns > 0 && !c.fn_tab) return;
-  h->persist_npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
-  const void* fn = persist_fwd_fn(h);
-  int grid = 0, lds = 0;
-  if (!fn || !persist_fits(h, fn, h->persist_npb, h->pl.batch, &grid, &lds)) return;
+  if (h->pair_fwd || h->lig_fwd_used || !persist_common_ok(h, c)) return;
+  const void* fn = dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, h->persist_npb);
+  if (!fn) return;
+  h->persist_fwd_members = persist_members_that_fit(h, fn, h->persist_npb);
+  if (!persist_members_ok(h, h->persist_fwd_members)) return;
   if (h->d_ring.ensure((size_t)kPRing * h->pl.batch * h->pl.n_blocks * kPos) != hipSuccess) { (void)hipGetLastError(); return; }
-  h->persist_wpm = persist_waves_per_member(h, h->persist_npb);
   h->persist_fwd = true;
+}
+static void persist_plan_adj(dfx_handle* h, const DevCtx& c) {
+  h->persist_adj = false;
+  if (h->pair_adj || h->lig_adj_used || !persist_common_ok(h, c)) return;
+  if (c.rps <= 1 || c.g_b || c.AD || !c.lam_pairs) return;          // the records build of the reverse stage, nothing else
+  const void* fn = dfx_persist::adj_kernel(h->pl.model, h->pl.contact, h->persist_npb);
+  if (!fn) return;
+  h->persist_adj_members = persist_members_that_fit(h, fn, h->persist_npb);
+  if (!persist_members_ok(h, h->persist_adj_members)) return;
+  if (h->d_ring.ensure((size_t)kPRing * h->pl.batch * h->pl.n_blocks * kPos) != hipSuccess) { (void)hipGetLastError(); return; }
+  h->persist_adj = true;
 }
 static PersistCoef persist_coef(const Tableau& T) {
   PersistCoef pc;
@@ -623,9 +651,8 @@ static PersistCoef persist_coef(const Tableau& T) {
   for (int r = 0; r <= T.s && r <= kPersistStages; ++r) pc.c[r] = T.c[r];
   return pc;
 }
-static int* persist_give_up_word(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 1; }
-// one segment of the group's members: poison the first ring places, then the whole segment in one launch, chained behind the previous
-// persistent launch of the process
+static int* persist_give_up_word(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 2; }   // (word 0: non-finite flag, word 1: touched flag)
+// one launch, chained behind the previous persistent launch of the process
 static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void** args, int grid, int lds) {
   static std::map<const void*, int> lds_set;
   std::lock_guard<std::mutex> lk(g_persist_mu);
@@ -637,19 +664,35 @@ static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void**
   (void)hipEventRecord(g_persist_tail[d], st);
   h->launches++;
 }
-static void launch_fwd_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) {
-  const void* fn = persist_fwd_fn(h);
-  int grid = 0, lds = 0;
-  (void)persist_fits(h, fn, h->persist_npb, nm, &grid, &lds);
-  dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, c.m0, nm, kPos);
-  h->launches++;
-  DevCtx cc = c;
-  PersistCoef pc = persist_coef(h->pl.tab);
-  PersistArgs pa;
-  pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = nm; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
-  void* args[] = {&cc, &pc, &pa};
-  launch_persist(h, fn, st, args, grid, lds);
+// one segment of the group's members: the first ring places poisoned, then the whole segment in one launch per `per_launch` members
+static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps, bool reverse) {
+  const int npb = h->persist_npb, per = reverse ? h->persist_adj_members : h->persist_fwd_members;
+  const void* fn = reverse ? dfx_persist::adj_kernel(h->pl.model, h->pl.contact, npb) : dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, npb);
+  PersistCoef pcf = persist_coef(h->pl.tab);
+  PersistAdjCoef pca;
+  memset(&pca, 0, sizeof(pca));
+  for (int i = 0; i < h->pl.tab.s && i < kPersistStages; ++i) {
+    const AdjCoef ac = adj_coef(h->pl.tab, i);
+    for (int jj = 0; jj <= kPersistStages; ++jj) { pca.col[i][jj] = ac.col[jj]; pca.cur[i][jj] = ac.cur[jj]; }
+    pca.c[i] = ac.c_i;
+  }
+  for (int off = 0; off < nm; off += per) {
+    const int cnt = std::min(per, nm - off);
+    DevCtx cc = c;
+    cc.m0 = c.m0 + off;
+    int grid = 0, lds = 0;
+    persist_shape(h, npb, cnt, &grid, &lds);
+    dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
+    h->launches++;
+    PersistArgs pa;
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+    void* args_f[] = {&cc, &pcf, &pa};
+    void* args_r[] = {&cc, &pca, &pa};
+    launch_persist(h, fn, st, reverse ? args_r : args_f, grid, lds);
+  }
 }
+static void launch_fwd_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) { launch_segment_persist(h, c, st, nm, n_steps, false); }
+static void launch_adj_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) { launch_segment_persist(h, c, st, nm, n_steps, true); }
 
 // forward: stage i reads buffer fin(i), writes fout(i); buffer 0 is the step state
 static int fin(int i) { return i == 0 ? 0 : 1 + ((i - 1) & 1); }
@@ -707,7 +750,8 @@ static void enqueue_segment(dfx_handle* h, const DevCtx& cbase, int gi, int n_st
   else if (kind == 0) {
     for (int j = 0; j < n_steps; ++j)
       for (int u = 0; u < step_units(h, 0); ++u) launch_fwd_unit(h, c, g.stream, grid, u, j);
-  } else if (c.AD || c.rps > 1) {
+  } else if (h->persist_adj) launch_adj_persist(h, c, g.stream, g.nm, n_steps);
+  else if (c.AD || c.rps > 1) {
     // stage checkpoint: no recompute launches; every reverse launch also rebuilds the record its successor reads
     for (int j = n_steps - 1; j >= 0; --j)
       for (int u = 0; u < step_units(h, 1); ++u) launch_adj_unit(h, c, g.stream, grid, u, j);
@@ -780,6 +824,8 @@ static void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps,
       for (int u = 0; u < step_units(h, 0); ++u)
         for (int gi = 0; gi < ng; ++gi)
           launch_fwd_unit(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), u, j);
+  } else if (h->persist_adj) {
+    for (int gi = 0; gi < ng; ++gi) launch_adj_persist(h, cg[gi], h->groups[gi].stream, h->groups[gi].nm, n_steps);
   } else {
     for (int j = n_steps - 1; j >= 0; --j)
       for (int u = 0; u < step_units(h, 1); ++u)
@@ -1268,8 +1314,7 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     // solves that fit the persistent stage loop (dfx_persist.h) run all their members in ONE launch per segment
     if (!e && problem->streams <= 0 && want > 1 && persist_shape_ok(h)) {
       h->persist_npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
-      int pg = 0, plds = 0;
-      if (persist_fits(h, persist_fwd_fn(h), h->persist_npb, h->pl.batch, &pg, &plds)) want = 1;
+      if (persist_members_ok(h, persist_members_that_fit(h, dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, h->persist_npb), h->persist_npb))) want = 1;
     }
     int ng = std::max(1, std::min({want, h->pl.batch, kMaxGroups}));
     (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
@@ -1440,8 +1485,6 @@ int dfx_share_checkpoint(dfx_handle* h, dfx_handle* with) {
 }
 
 // after the stream has been waited for: the non-finite flag of the forward pass (pinned word 0 of flag_stage) and its statistics
-static const char* kPersistGaveUp = "a wave of the persistent stage loop gave up waiting for a neighbour's record (a workgroup of the launch was not resident: "
-                                    "another process on the device?); DFX_PERSIST=0 keeps one launch per stage";
 static int finish_forward(dfx_handle* h, dfx_stats* stats) {
   if (*persist_give_up_word(h)) { h->have_traj = false; h->err = std::string("forward: ") + kPersistGaveUp; return 2; }
   const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
@@ -1856,6 +1899,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   if (use_fn_table(h)) c.fn_tab = h->d_fn_tab.p;
   // tile kernels: their accumulators are ligament-major (decided here, not in the launch functions: a graph replay does not call them)
   h->lig_used = h->lig_adj_used = !h->pair_adj && lig_adj_ok(h, c, -1, 0);
+  persist_plan_adj(h, c);
   // the (w, Kbar_q) buffers alternate per launch, lambda (pair launches only) per step
   const int wb = (int)((h->n_total * step_units(h, 1) - 1) & 1);
   hipLaunchKernelGGL(k_adj_begin, slot_grid(h), dim3(kThreads), 0, h->stream, c, h_last, pl.tab.a[pl.tab.s][pl.tab.s - 1], wb,
@@ -1867,7 +1911,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     h->launches++;
   }
   if (fork_groups(h)) return 2;
-  const bool eager = solve_is_eager(h);
+  const bool eager = solve_is_eager(h) || h->persist_adj;
   if (h->segments) {
     // output intervals backwards: records of interval k rebuilt by re-running its forward pass from the resident output row k
     // (bit-identical to the first pass: same state, same arithmetic), then its reverse stages read them
@@ -1902,6 +1946,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   HIP_OK(hipEventRecord(h->ev3, h->stream));
   if (timing) fprintf(stderr, "[dfx] adjoint: sweep enqueued %.0f us after entry\n", since(ta0));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
+  if (*persist_give_up_word(h)) { h->err = std::string("adjoint: ") + kPersistGaveUp; return 2; }
   if (timing) {
     float ms0 = 0.f;
     (void)hipEventElapsedTime(&ms0, h->ev2, h->ev3);
@@ -1919,7 +1964,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
     stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);
-    stats->tile_kernels = (c.g_b || c.AD) ? 0 : kernel_build_code(h, c, h->lig_adj_used);
+    stats->tile_kernels = h->persist_adj ? 3 : ((c.g_b || c.AD) ? 0 : kernel_build_code(h, c, h->lig_adj_used));
   }
   return 0;
 }

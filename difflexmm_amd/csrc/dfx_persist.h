@@ -61,11 +61,6 @@ __device__ __forceinline__ void ring_poison(double* place, u32 byte_off) {
   asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(x), "s"(place) : "memory");
 }
 
-// The resident parameters are loop invariants, and the compiler hoists every sub-expression of the ligament arithmetic that depends on
-// them alone out of the stage loop -- into registers it then keeps for the whole launch (the first build: 200 VGPRs, two waves per SIMD).
-// An empty asm that "rewrites" a value at the top of every stage makes what depends on it part of the stage again.
-__device__ __forceinline__ void keep_in_loop(double& x) { asm volatile("" : "+v"(x)); }
-
 // places 0 .. kPAhead-1 of the members of a launch, poisoned in front of it (stream order)
 __global__ __launch_bounds__(kThreads) void k_ring_poison(double* ring, int batch, int n_blocks, int m0, int width /* doubles per block */, int places) {
   const int m = blockIdx.y + m0;
@@ -74,6 +69,49 @@ __global__ __launch_bounds__(kThreads) void k_ring_poison(double* ring, int batc
   const unsigned long long p = ~0ull;
   for (int pl = 0; pl < places; ++pl)
     reinterpret_cast<unsigned long long*>(ring)[((size_t)pl * batch + m) * ((size_t)n_blocks * width) + tid] = p;
+}
+
+// what a lane keeps about its slot's ligament for the whole launch (the stage kernels load this at every stage: issue_lane / resolve_lane)
+struct LigRes {
+  double rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, sgn;
+  double am, ac, kc, phi1, phi2, kap_safe, phi_min;      // angle contact
+  int info, pslot;
+};
+template <int CONTACT>
+__device__ __forceinline__ void load_lig_res(const DevCtx& c, const MemberBases& B, int slot, LigRes& g) {
+  g.info = ldg<int>(c.slot_info, (u32)slot * 4);
+  g.pslot = g.info < 0 ? slot : (g.info >> 1);          // a slot without a ligament watches its own block
+  g.sgn = (g.info & 1) ? 1.0 : -1.0;
+  const double2 ro = ldg<double2>(B.p_r, (u32)slot * 16), rp = ldg<double2>(B.p_r, (u32)g.pslot * 16);
+  g.rox = ro.x; g.roy = ro.y; g.rpx = rp.x; g.rpy = rp.y;
+  if (c.l_dict_on) {
+    const u32 li = (u32)ldg<uint8_t>(B.p_lidx, (u32)slot);
+    const double2 lv = ldg<double2>(B.l_dict, li * 32), ln = ldg<double2>(B.l_dict, li * 32 + 16);
+    g.lx = lv.x; g.ly = lv.y; g.l0 = ln.x; g.il0 = ln.y;
+  } else {
+    const double2 lv = ldg<double2>(B.p_l, (u32)slot * 16);
+    g.lx = lv.x; g.ly = lv.y;
+    g.l0 = g.info < 0 ? 1.0 : sqrt(lv.x * lv.x + lv.y * lv.y);
+    g.il0 = 1.0 / g.l0;
+  }
+  if (c.k_uniform) { g.ks = B.cst[3]; g.ksh = B.cst[4]; g.kr = B.cst[5]; }
+  else { g.ks = ldg<double>(B.p_k, (u32)slot * 32); g.ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); g.kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
+  g.am = g.ac = g.kc = g.phi1 = g.phi2 = g.kap_safe = g.phi_min = 0.0;
+  if (CONTACT == 1) {
+    g.am = B.cst[0]; g.ac = B.cst[1]; g.kc = B.cst[2]; g.kap_safe = B.cst[9]; g.phi_min = B.cst[10];
+    const double2 ph = ldg<double2>(B.p_phi, (u32)slot * 16);
+    g.phi1 = ph.x; g.phi2 = ph.y;
+  }
+}
+// the partner's ring record of stage ordinal t: polled until none of its four doubles is poison; false: gave up
+__device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, double (&r)[4], int t_ord, int* give_up) {
+  for (int spins = 0;;) {
+    ring_load(place, byte_off, r);
+    const bool ok = !(is_poison(r[0]) || is_poison(r[1]) || is_poison(r[2]) || is_poison(r[3]));
+    if (__all(ok)) return true;
+    if (++spins > kSpinLimit) { *give_up = 1 + t_ord; return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
 }
 
 // lane -> (slot, block, node) of wave w of a member (lane_pos of dfx_kernels.h without the workgroup arithmetic)
@@ -114,32 +152,9 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
   const int s = c.s;
   const Seg sg = *c.cur;
   const MemberBases B = member_bases(c, m);
-  // ---- resident per lane: the slot's ligament
-  const int info = ldg<int>(c.slot_info, (u32)slot * 4);
-  const int pslot = info < 0 ? slot : (info >> 1);          // a slot without a ligament watches its own block
-  double sgn = (info & 1) ? 1.0 : -1.0;
-  const double2 ro_ = ldg<double2>(B.p_r, (u32)slot * 16), rp_ = ldg<double2>(B.p_r, (u32)pslot * 16);
-  double rox = ro_.x, roy = ro_.y, rpx = rp_.x, rpy = rp_.y;
-  double lx, ly, l0, il0;
-  if (c.l_dict_on) {
-    const u32 li = (u32)ldg<uint8_t>(B.p_lidx, (u32)slot);
-    const double2 lv = ldg<double2>(B.l_dict, li * 32), ln = ldg<double2>(B.l_dict, li * 32 + 16);
-    lx = lv.x; ly = lv.y; l0 = ln.x; il0 = ln.y;
-  } else {
-    const double2 lv = ldg<double2>(B.p_l, (u32)slot * 16);
-    lx = lv.x; ly = lv.y;
-    l0 = info < 0 ? 1.0 : sqrt(lv.x * lv.x + lv.y * lv.y);
-    il0 = 1.0 / l0;
-  }
-  double ks, ksh, kr;
-  if (c.k_uniform) { ks = B.cst[3]; ksh = B.cst[4]; kr = B.cst[5]; }
-  else { ks = ldg<double>(B.p_k, (u32)slot * 32); ksh = ldg<double>(B.p_k, (u32)slot * 32 + 8); kr = ldg<double>(B.p_k, (u32)slot * 32 + 16); }
-  double am = 0.0, ac = 0.0, kc = 0.0, phi1 = 0.0, phi2 = 0.0, kap_safe = 0.0, phi_min = 0.0;
-  if (CONTACT == 1) {
-    am = B.cst[0]; ac = B.cst[1]; kc = B.cst[2]; kap_safe = B.cst[9]; phi_min = B.cst[10];
-    const double2 ph = ldg<double2>(B.p_phi, (u32)slot * 16);
-    phi1 = ph.x; phi2 = ph.y;
-  }
+  LigRes g;
+  load_lig_res<CONTACT>(c, B, slot, g);
+  const int info = g.info, pslot = g.pslot;
   // ---- resident per DOF lane
   const int dof = b * 3 + kd;
   const u32 o_dof = (u32)dof * 8, o_rec = ((u32)b * kPos + kd) * 8, o_chunk = ((u32)b * kPos + 2 * (k & 1)) * 8;
@@ -180,19 +195,10 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
 #pragma unroll 1
     for (int i = 0; i < s; ++i) {
       {
-        keep_in_loop(rox); keep_in_loop(roy); keep_in_loop(rpx); keep_in_loop(rpy); keep_in_loop(lx); keep_in_loop(ly); keep_in_loop(l0); keep_in_loop(il0);
-        keep_in_loop(ks); keep_in_loop(ksh); keep_in_loop(kr); keep_in_loop(sgn);
-        if (CONTACT == 1) { keep_in_loop(phi1); keep_in_loop(phi2); keep_in_loop(am); keep_in_loop(ac); keep_in_loop(kc); }
         // ---- the partner's record of this stage
         const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
         double pr[4];
-        for (int spins = 0;;) {
-          ring_load(place, r_par, pr);
-          const bool ok = !(is_poison(pr[0]) || is_poison(pr[1]) || is_poison(pr[2]) || is_poison(pr[3]));
-          if (__all(ok)) break;
-          if (++spins > kSpinLimit) { *pa.give_up = 1 + t_ord; return; }
-          __builtin_amdgcn_s_sleep(1);
-        }
+        if (!ring_wait(place, r_par, pr, t_ord, pa.give_up)) return;
         if (k < 2 && t_ord + kPAhead <= total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
         BlockRec<double> p;
         p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];
@@ -201,16 +207,16 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
         // ---- ligament + contact of this slot (k_fwd_stage's arithmetic)
         double fx = 0.0, fy = 0.0, fth = 0.0;
         if (info >= 0) {
-          BondGrad<double> g;
-          bond_grad<MODEL, double>(o, p, rox, roy, rpx, rpy, lx, ly, l0, il0, ks, ksh, kr, sgn, g);
-          fx = g.fx; fy = g.fy; fth = g.fth;
+          BondGrad<double> bg;
+          bond_grad<MODEL, double>(o, p, g.rox, g.roy, g.rpx, g.rpy, g.lx, g.ly, g.l0, g.il0, g.ks, g.ksh, g.kr, g.sgn, bg);
+          fx = bg.fx; fy = bg.fy; fth = bg.fth;
           if (CONTACT == 1) {
             // the stage kernels fetch a ligament's own void angles only beyond the culling bound and evaluate the member's smallest
             // one otherwise (exact zeros either way); the same selection keeps the two forms equal bit for bit
-            const bool far = !(fabs(o.th - p.th) <= kap_safe);
+            const bool far = !(fabs(o.th - p.th) <= g.kap_safe);
             ContactGrad<double> cg;
-            contact_grad<double>(sgn * (o.th - p.th), far ? phi1 : phi_min, far ? phi2 : phi_min, am, ac, kc, cg);
-            fth += sgn * cg.dkap;
+            contact_grad<double>(g.sgn * (o.th - p.th), far ? g.phi1 : g.phi_min, far ? g.phi2 : g.phi_min, g.am, g.ac, g.kc, cg);
+            fth += g.sgn * cg.dkap;
           }
         }
         const double dE = blk_reduce3<NPB>(fx, fy, fth, k);
@@ -269,6 +275,191 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
         if (last) { qn = qnext; vn = vnext; }
       }
     }
+  }
+}
+
+
+// ---- reverse: every stage of every step of one segment in one launch --------------------------------------------------------------
+// The records build of k_adj_stage (records or segments checkpoint, no per-ligament gradients) with everything a DOF or a slot owns
+// kept in registers across the segment: lambda, the later stages' Ybar, the node-vector / void-angle / inertia / damping accumulators
+// (one read-modify-write per SEGMENT instead of one per stage: 176 of the launch's 611 B per unit), the ligament's parameters.  What
+// crosses waves is w = Kbar_v / m of the next stage to run, three doubles per block: the ring record is (w_x, w_y | w_theta, 0).
+// The stage records the sweep linearises about come from the checkpoint (plain loads: written by an earlier launch), issued in front
+// of the poll so that the two round trips overlap.  The first stage of a launch reads the partner's w where the previous launch
+// (k_adj_begin, a stage launch, or this kernel) left it -- DevCtx::W -- and the last one leaves its own there, with lambda in LAM and
+// the accumulators in their arrays: segments run by this kernel and by stage launches can alternate.
+
+template <int MODEL, int CONTACT, int NPB>
+__global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, PersistAdjCoef pc, PersistArgs pa) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
+  if (wave >= pa.waves_per_member * pa.nm) return;
+  const int ml = wave / pa.waves_per_member, w = wave - ml * pa.waves_per_member;
+  const int m = c.m0 + ml;
+  const LanePos lp = wave_lane_pos<NPB>(w, c.n_blocks);
+  if (!lp.valid) return;
+  const int slot = lp.slot, b = lp.b, k = lp.k, kd = k < 3 ? k : 2;
+  const u32 nd = (u32)c.n_blocks * 3, nd6 = (u32)c.n_blocks * 6;
+  const int s = c.s;
+  const Seg sg = *c.cur;
+  const MemberBases B = member_bases(c, m);
+  LigRes g;
+  load_lig_res<CONTACT>(c, B, slot, g);
+  const int info = g.info, pslot = g.pslot;
+  const int dof = b * 3 + kd;
+  const u32 o_dof = (u32)dof * 8, o_b6 = ((u32)b * 6 + 2 * kd) * 8;
+  const double damp = c.damping_uniform ? B.cst[6 + kd] : ldg<double>(c.damping + (size_t)((u32)m * nd), o_dof);
+  const double invm = ldg<double>(c.inv_m + (size_t)((u32)m * nd), o_dof);
+  const int sidx = ldg<int>(c.block_special, (u32)b * 4);
+  const bool constrained = k < 3 && sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> k) & 1);
+  // ---- resident: lambda, accumulators
+  double* LAMm = c.LAM + (size_t)((u32)m * nd6);
+  double2 lam = ldg<double2>(LAMm, o_b6);
+  const u32 ms = (u32)m * (u32)c.n_slots;
+  double* grm = c.g_r + (size_t)(ms * 2);
+  double* gpm = c.g_phi + (size_t)ms;
+  double* bmm = c.blk_m + (size_t)((u32)m * nd);
+  double* bcm = c.blk_c ? c.blk_c + (size_t)((u32)m * nd) : nullptr;
+  double2 r_acc = ldg<double2>(grm, (u32)slot * 16);
+  double p_acc = CONTACT == 1 ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
+  double bm_acc = ldg<double>(bmm, o_dof), bc_acc = bcm ? ldg<double>(bcm, o_dof) : 0.0;
+  bool phi_any = false;
+  double2 yb[kPersistStages];
+#pragma unroll
+  for (int jj = 0; jj < kPersistStages; ++jj) yb[jj] = make_double2(0.0, 0.0);
+  // ---- the ring
+  const size_t ring_stride = (size_t)c.batch * c.n_blocks * kPos;
+  const u32 r_own = ((u32)m * (u32)c.n_blocks + (u32)b) * (kPos * 8) + 16u * (u32)(k & 1);
+  const u32 r_par = ((u32)m * (u32)c.n_blocks + (u32)(pslot >> 2)) * (kPos * 8);
+  const int total = pa.n_steps * s;
+  int t_ord = 0;
+  for (int j = pa.n_steps - 1; j >= 0; --j) {
+    const long long n = sg.base_step + j;
+    double h = sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
+    if (c.t_steps) { const double* ts = steps_of(c, m); h = ts[n + 1] - ts[n]; h_before = n > 0 ? ts[n] - ts[n - 1] : 0.0; }
+#pragma unroll 1
+    for (int i = s - 1; i >= 0; --i) {
+      const int win = (int)((n * s + i) & 1);
+      // ---- the records this stage linearises about (checkpoint), in flight while the partner's w is polled
+      const double* POSin = traj_rec(c, m, -1 - i, n);
+      const double2 o0 = ldg<double2>(POSin, (u32)b * (kPos * 8)), o1 = ldg<double2>(POSin, (u32)b * (kPos * 8) + 16);
+      const double2 q0 = ldg<double2>(POSin, (u32)(pslot >> 2) * (kPos * 8)), q1 = ldg<double2>(POSin, (u32)(pslot >> 2) * (kPos * 8) + 16);
+      const double v_i = ldg<double>(POSin + (size_t)c.n_blocks * kPos, o_dof);
+      double wp[4];
+      if (t_ord == 0) {
+        const double* Win = c.W + (size_t)(((u32)m * 2 + (u32)win) * nd);
+        const u32 pb = (u32)(pslot >> 2) * 24;
+        const double2 wxy = ldg<double2>(Win, pb);
+        wp[0] = wxy.x; wp[1] = wxy.y; wp[2] = ldg<double>(Win, pb + 16);
+      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up)) return;
+      if (k < 2 && t_ord + kPAhead < total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
+      BlockRec<double> o, p;
+      o.x = o0.x; o.y = o0.y; o.th = o1.x; o.sh = o1.y; o.ch = half_cos(o.th, o.sh);
+      p.x = q0.x; p.y = q0.y; p.th = q1.x; p.sh = q1.y; p.ch = half_cos(p.th, p.sh);
+      // ---- Kbar sums over the later stages' Ybar (k_adj_stage, records build)
+      double sq = 0.0, sv = 0.0, sqc = 0.0, svc = 0.0;
+#pragma unroll
+      for (int jj = 1; jj < kPersistStages; ++jj) {
+        const bool on = jj > i && jj < s;
+        const double2 y = on ? yb[jj] : make_double2(0.0, 0.0);
+        const double cf = i > 0 ? pc.col[i][jj] : 1.0;
+        sq += cf * y.x;
+        sv += cf * y.y;
+        sqc += pc.cur[i][jj] * y.x;
+        svc += pc.cur[i][jj] * y.y;
+      }
+      const double col_s = pc.col[i][s], cur_s = pc.cur[i][s], col_i = pc.col[i][i];
+      const double lq = lam.x, lv = lam.y;
+      const double w_d = (h * (cur_s * lv + svc)) * invm;
+      const double wox = blk_bcast<NPB, 0>(w_d, k), woy = blk_bcast<NPB, 1>(w_d, k), woth = blk_bcast<NPB, 2>(w_d, k);
+      // ---- Hessian-vector product + mixed parameter derivatives of this slot
+      double hx = 0.0, hy = 0.0, hth = 0.0, ex = 0.0, ey = 0.0, eth = 0.0, d_rx = 0.0, d_ry = 0.0, d_phi = 0.0;
+      if (info >= 0) {
+        BlockRec<Dual> od = seed_rec(o, wox, woy, woth);
+        BlockRec<Dual> pd = seed_rec(p, wp[0], wp[1], wp[2]);
+        BondGrad<Dual> bg;
+        bond_grad<MODEL, Dual>(od, pd, g.rox, g.roy, g.rpx, g.rpy, g.lx, g.ly, g.l0, g.il0, g.ks, g.ksh, g.kr, g.sgn, bg);
+        hx = bg.fx.e; hy = bg.fy.e; hth = bg.fth.e;
+        ex = bg.fx.v; ey = bg.fy.v; eth = bg.fth.v;
+        d_rx = bg.rx.e; d_ry = bg.ry.e;
+        if (CONTACT == 1) {
+          const bool far = !(fabs(o.th - p.th) <= g.kap_safe);
+          ContactGrad<Dual> cg;
+          contact_grad<Dual>(g.sgn * (od.th - pd.th), far ? g.phi1 : g.phi_min, far ? g.phi2 : g.phi_min, g.am, g.ac, g.kc, cg);
+          hth += g.sgn * cg.dkap.e;
+          eth += g.sgn * cg.dkap.v;
+          d_phi = (info & 1) ? cg.p2.e : cg.p1.e;
+        }
+        r_acc = make_double2(r_acc.x - d_rx, r_acc.y - d_ry);
+      }
+      if (CONTACT == 1 && d_phi != 0.0) { p_acc -= d_phi; phi_any = true; }
+      const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
+      const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
+      // ---- DOF epilogue
+      double w_next = 0.0;
+      if (k < 3) {
+        double fload = 0.0;
+        if (sidx >= 0) {
+          const dfx_special& sp = c.special[sidx];
+          const double* ft = fn_tab_row(c, m, j, i);
+          double gp[kMaxFnParams];
+          for (int f = 0; f < c.n_fns; ++f) {
+            const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
+            const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
+            if ((coef != 0.0 && c.fn_g) || loaded) {
+              const u32 z = lane_zero();
+              const double gv = fn_tab_get(ft, f, 0, z);
+              if (coef != 0.0 && c.fn_g) for (int kk = 0; kk < kMaxFnParams; ++kk) gp[kk] = fn_tab_get(ft, f, 2 + kk, z);
+              if (loaded) fload += sp.load_coef[k][f] * gv;
+              if (coef != 0.0 && c.fn_g) {
+                double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
+                for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * gp[kk]);
+              }
+            }
+          }
+        }
+        const double a_i = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
+        const double kq_in = h * (cur_s * lq + sqc);
+        double ybq = 0.0, ybv = 0.0;
+        if (!constrained) {
+          ybq = -hw;
+          ybv = kq_in - damp * w_d;
+          bm_acc -= w_d * a_i;
+          bc_acc -= w_d * v_i;
+        }
+#pragma unroll
+        for (int jj = 1; jj < kPersistStages; ++jj) yb[jj] = jj == i ? make_double2(ybq, ybv) : yb[jj];
+        double kv;
+        if (i > 0) {
+          kv = h * (col_s * lv + col_i * ybv + sv);
+        } else {
+          double nlq = lq + (ybq + sq), nlv = lv + (ybv + sv);
+          const bool first = (sg.j0 + j) == 0;
+          if (first && c.G && !constrained) {
+            const double* G = c.G + ((size_t)sg.interval * c.batch + m) * (size_t)nd6;
+            nlq += G[b * 6 + k]; nlv += G[b * 6 + 3 + k];
+          }
+          if (constrained) { nlq = 0.0; nlv = 0.0; }
+          lam = make_double2(nlq, nlv);
+          kv = h_before * col_s * nlv;
+        }
+        w_next = constrained ? 0.0 : kv * invm;
+      }
+      // ---- w of the next stage to run: into the ring, or -- last stage of the launch -- where the next launch reads it
+      ++t_ord;
+      if (t_ord < total) {
+        const double w1 = blk_bcast<NPB, 1>(w_next, k), w2 = blk_bcast<NPB, 2>(w_next, k);
+        if (k < 2) ring_store(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_own, k == 0 ? w_next : w2, k == 0 ? w1 : 0.0);
+      } else if (k < 3) {
+        stg<double>(c.W + (size_t)(((u32)m * 2 + (u32)(win ^ 1)) * nd), o_dof, w_next);
+      }
+    }
+  }
+  // ---- what the segment leaves behind
+  if (info >= 0) stg<double2>(grm, (u32)slot * 16, r_acc);
+  if (CONTACT == 1 && phi_any) { stg<double>(gpm, (u32)slot * 8, p_acc); c.touch[0] = 1; }
+  if (k < 3) {
+    stg<double2>(LAMm, o_b6, lam);
+    if (!constrained) { stg<double>(bmm, o_dof, bm_acc); if (bcm) stg<double>(bcm, o_dof, bc_acc); }
   }
 }
 

@@ -27,8 +27,15 @@ struct PersistArgs {
 };
 
 
+struct PersistAdjCoef {         // AdjCoef of every stage
+  double col[kPersistStages][kPersistStages + 1];
+  double cur[kPersistStages][kPersistStages + 1];
+  double c[kPersistStages];
+};
+
 // kernels by (bond model, contact, lanes per block); nullptr: no such build
 const void* fwd_kernel(int model, int contact, int npb);
+const void* adj_kernel(int model, int contact, int npb);
 // places 0 .. kPAhead-1 of the ring, members [m0, m0 + nm), poisoned on `st`
 void launch_ring_poison(hipStream_t st, double* ring, int batch, int n_blocks, int m0, int nm, int width);
 

@@ -43,6 +43,7 @@ def _solve(c, ts, spi, target, env, keep=True):
         if not keep:
             return fields.copy(), None, None, st
         obj, raw = c.solver.kinetic_energy_value_and_raw(target)
+        st["adjoint"] = dict(c.solver.adjoint_stats)
         return fields.copy(), float(np.atleast_1d(obj)[0]), {k: np.array(v) for k, v in raw.items()}, st
     return _with_env(env, run)
 
@@ -60,6 +61,9 @@ def test_persistent_forward_equals_stage_launches(hip_lib, lattice, n, contact, 
         out = _solve(c, ts, 9, target, {"DFX_PERSIST": "1", "DFX_CHECKPOINT": level})
         assert ref[3]["tile_kernels"] != 3 and out[3]["tile_kernels"] == 3, (level, ref[3], out[3])      # the persistent loop really ran
         assert out[3]["launches"] < 0.2 * ref[3]["launches"]
+        # the reverse sweep: persistent where it reads stage records (records / segments levels), stage launches elsewhere
+        assert (out[3]["adjoint"]["tile_kernels"] == 3) == (level in ("records", "segments")), (level, out[3]["adjoint"])
+        assert ref[3]["adjoint"]["tile_kernels"] != 3
         assert same(out[0], ref[0], 1e-13), (level, relerr(out[0], ref[0]))
         assert abs(out[1] - ref[1]) <= (0 if EXACT else 1e-12 * abs(ref[1]))
         for k in ref[2]:
@@ -80,7 +84,7 @@ def test_persistent_forward_many_segments_and_members(hip_lib):
     target = np.array([44, 45], dtype=np.int32)
     ref = _solve(c, ts, 300, target, {"DFX_PERSIST": "0"})
     out = _solve(c, ts, 300, target, {"DFX_PERSIST": "1"})
-    assert out[3]["tile_kernels"] == 3
+    assert out[3]["tile_kernels"] == 3 and out[3]["adjoint"]["tile_kernels"] == 3
     assert same(out[0], ref[0], 1e-12)
     for k in ref[2]:
         assert same(out[2][k], ref[2][k], 1e-10), k
