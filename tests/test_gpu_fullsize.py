@@ -173,20 +173,23 @@ def test_c5_at_width_192_designs_three_inputs_shared_checkpoint(hip_lib):
     assert all(len(l["objective_values"]) == 2 and l["objective_values"][0] > 0 for l in logs)
     assert len({l["objective_values"][0] for l in logs}) == n        # 192 designs, 192 objectives
     # (the solo engines take the kernel builds the wide ensemble runs -- the chip-filling per-stage builds, which a 1-member handle
-    # would not choose by itself: DFX_WT is read when a handle is created.  Different builds of the same arithmetic differ in the last
-    # digit; a member's numbers must not depend on its NEIGHBOURS.)
+    # would not choose by itself: DFX_WT is read when a handle is created, and no persistent stage loop, which serves solves that fit
+    # on the chip at once: DFX_PERSIST is read per solve.  Different builds of the same arithmetic differ in the last digit; a
+    # member's numbers must not depend on its NEIGHBOURS.)
     os.environ["DFX_WT"] = "1"
+    os.environ["DFX_PERSIST"] = "0"
     try:
         mi1 = P.MultiInputTargetKineticEnergy([_fw5(s, sh) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
+        for m in (3, 141):
+            v1, g1 = mi1.value_and_grad(tuple(np.clip(a, _CONS["lower_bound"], _CONS["upper_bound"]) for a in x0s[m]))    # MMA starts inside the box
+            assert float(v1) == logs[m]["objective_values"][0]           # bit for bit: a member's arithmetic does not depend on its neighbours
+            opt = P.OptimizationProblem(mi1)
+            x = opt.run_optimization_nlopt(x0s[m], 2, verbose=False, **_CONS)
+            assert opt.objective_values == logs[m]["objective_values"]
+            assert all(np.array_equal(a, b) for a, b in zip(x, best[m]))
     finally:
         os.environ.pop("DFX_WT")
-    for m in (3, 141):
-        v1, g1 = mi1.value_and_grad(tuple(np.clip(a, _CONS["lower_bound"], _CONS["upper_bound"]) for a in x0s[m]))    # MMA starts inside the box
-        assert float(v1) == logs[m]["objective_values"][0]           # bit for bit: a member's arithmetic does not depend on its neighbours
-        opt = P.OptimizationProblem(mi1)
-        x = opt.run_optimization_nlopt(x0s[m], 2, verbose=False, **_CONS)
-        assert opt.objective_values == logs[m]["objective_values"]
-        assert all(np.array_equal(a, b) for a, b in zip(x, best[m]))
+        os.environ.pop("DFX_PERSIST")
 
 
 def test_second_solve_with_a_larger_segment_table_on_one_handle(hip_lib, cpu_lib):

@@ -11,6 +11,13 @@ from .common import Case, relerr
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _one_launch_per_stage(monkeypatch):
+    """These are A/B tests between builds of the STAGE launches: the persistent stage loop (dfx_persist.h), which would serve lattices of
+    this size by default, stays out of both arms (tests/test_gpu_persistent.py is its own A/B)."""
+    monkeypatch.setenv("DFX_PERSIST", "0")
+
+
 def _solve(c, ts, spi, target, env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

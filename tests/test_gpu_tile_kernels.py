@@ -14,6 +14,13 @@ from .test_gpu_pair_launches import FAST, _solve
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _one_launch_per_stage(monkeypatch):
+    """These are A/B tests between builds of the STAGE launches: the persistent stage loop (dfx_persist.h), which would serve lattices of
+    this size by default, stays out of both arms (tests/test_gpu_persistent.py is its own A/B)."""
+    monkeypatch.setenv("DFX_PERSIST", "0")
+
+
 def _case(lattice, n, env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)            # the lane tables are built when the handle is created
