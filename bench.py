@@ -52,6 +52,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # vector fp64: 256 CUs x 64 FMA lanes per clock x 
 BYTES_FWD_STAGE = 272 + 72          # one RHS evaluation (quads + contact) + its share of the stage combine (432 / 6)
 BYTES_ADJ_STAGE = 272 + 96 + 256    # stage data + lambda / Ybar read-write + parameter-gradient read-modify-write = 624
 ROOFLINE_LEG_STEPS = 250            # length of the per-launch measurement (1 stream, all members per launch), whatever K is
+# the same accounting for the other lattices of BASELINE.json (RHS bytes 256 quads without contact, 244 kagome + contact;
+# reverse: + 96 lambda / Ybar + read-modify-write of 2 x (16 n_npb + 16 + 24 + 24) parameter-gradient bytes)
+BYTES_FWD_STAGE_C2 = 256 + 72
+BYTES_FWD_STAGE_KAGOME = 244 + 72
+BYTES_ADJ_STAGE_KAGOME = 244 + 96 + 2 * (48 + 16 + 24 + 24)
+BUILD_NAMES = {0: "stage launches (generic builds)", 1: "tile kernels", 2: "stage launches (per-stage builds)", 3: "persistent stage loop"}
 
 
 def c3_problem(size, seed, members, lib=None, device=0, input_delay=0.0, target_shift=None, contact_cutoff_deg=-10.0, contact_min_deg=-15.0):
@@ -117,13 +123,15 @@ def execute(fw, obj, adjoint=True, spi=SPI, device_outputs=False):
     else:
         _, st_f = eng.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=adjoint, want_fields=False)
     out = {"fwd_ms": st_f["kernel_ms"], "fwd_launches": st_f["launches"], "streams": max(1, int(st_f.get("streams", 1))),
-           "objective": None, "adj_ms": 0.0, "adj_launches": 0, "fused_call": bool(fused)}
+           "objective": None, "adj_ms": 0.0, "adj_launches": 0, "fused_call": bool(fused), "fwd_build": int(st_f.get("tile_kernels", 0)),
+           "steps": int(st_f.get("steps", 0))}
     if adjoint:
         if fused:
             out["objective"] = objective
         else:
             out["objective"], grads, st_a = eng.kinetic_value_and_grad(obj.target_blocks, which=which, device=device_outputs)
         out["adj_ms"], out["adj_launches"] = st_a["kernel_ms"], st_a["launches"]
+        out["adj_build"] = int(st_a.get("tile_kernels", 0))
         out["stage_checkpoint"] = bool(st_a.get("stage_checkpoint", 0))
         out["checkpoint"] = {1: "records", 2: "segments"}.get(st_a.get("checkpoint_records", 0)) or ("stages" if st_a.get("stage_checkpoint", 0) else "state")
         out["grads"] = grads
@@ -159,6 +167,111 @@ def run_once(fw, obj, designs, n_steps, adjoint=True, spi=SPI, device_outputs=Fa
     if fw.solve_dynamics.engine.lib.dfx_device_count() > 0 and spi == SPI:
         spin_up(fw, spi=spi)
     return execute(fw, obj, adjoint, spi, device_outputs)
+
+
+def stage_roofline(kernel, bytes_per_unit, units, stage_us, **extra):
+    """Roofline entry of one Runge-Kutta stage of `units` rigid units that took `stage_us` on the device (HIP events around the sweep /
+    stages): ALGORITHMIC bytes against the 8 TB/s HBM peak -- a launch, or one stage of the persistent loop."""
+    ach = bytes_per_unit * units / (stage_us * 1e-6) / 1e9
+    d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+         "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_stage": units, "stage_us": stage_us}
+    d.update(extra)
+    return d
+
+
+def c2_problem(members, lib=None, device=0, size=32):
+    """BASELINE configs[1] (SURVEY 8(d) "C2"): 32x32 quads, nonlinear ligaments + damping, NO contact, seed 2, fixed-step Dopri5
+    with dt = (2/f)/10 000, forward only.  The caller is the reference's own: problems/quads_focusing.py restated."""
+    from difflexmm_amd.problems import QuadsFocusingForward, TargetKineticEnergy
+    spacing, bond, rho, ksh, kr = 15.0, 2.25, 6.18e-9, 1.19, 1.5
+    damping = 0.0186 * np.array([2 * math.sqrt(0.36125 * rho * spacing ** 2 * ksh)] * 2 +
+                                [2 * math.sqrt(0.02175026 * rho * spacing ** 4 * kr)]) * np.ones((size * size, 1))
+    fw = QuadsFocusingForward(n1_blocks=size, n2_blocks=size, spacing=spacing, bond_length=bond, k_stretch=120.0, k_shear=ksh, k_rot=kr,
+                              density=rho, damping=damping, amplitude=7.5, loading_rate=FREQ, input_delay=0.0, n_excited_blocks=2,
+                              loaded_side="left", input_shift=0, simulation_time=2.0 / FREQ, n_timepoints=41, use_contact=False,
+                              steps_per_interval=SPI, batch=members, device=device, _lib=lib)
+    fw.setup()
+    obj = TargetKineticEnergy(fw, (2, 2), (size // 6, size // 5))
+    designs = []
+    for m in range(members):
+        rng = np.random.default_rng(2 + m)
+        base = fw.geometry.get_design_from_rotated_square(25 * math.pi / 180)
+        designs.append(tuple(b + rng.uniform(-0.02 * spacing, 0.02 * spacing, b.shape) for b in base))
+    return fw, obj, designs
+
+
+C2_DT = (2.0 / FREQ) / 10000.0
+
+
+def c2_solve(fw, designs, n_steps, sync):
+    """Forward-only solve of `n_steps` steps of size C2_DT on resident inputs; returns (wall s, stats)."""
+    spi = min(SPI, n_steps)
+    counts = [spi] * (n_steps // spi) + ([n_steps % spi] if n_steps % spi else [])
+    fw.timepoints = np.concatenate([[0.0], np.cumsum(counts) * C2_DT])
+    fw.step_counts = spi if not n_steps % spi else np.array(counts, dtype=np.int32)
+    sd = fw.solve_dynamics
+    cps = [fw.control_params(d) for d in designs]
+    flats = [sd._flatten(cp) for cp in cps]
+    sd.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
+    sd._last = (cps, flats, fw.timepoints)
+    sync()
+    t0 = time.perf_counter()
+    _, st = sd.engine.forward(None, fw.timepoints, fw.step_counts, keep_trajectory=False, want_fields=False)
+    sync()
+    return time.perf_counter() - t0, st
+
+
+def launch_bound_block(device, sync, single, c4_steps=400, c2_steps=2000):
+    """The regimes whose launches do NOT fill the chip, as the driver's default line sees them (round-4 verdict): BASELINE configs[1]
+    with ONE member (32x32 quads, 64 waves in all), C3 with one member (one wave per SIMD: `single_system`), config 4 at its per-GPU
+    width of an 8-GPU run (8 designs of the 64x64-cell kagome lattice).  Device time per Runge-Kutta stage and its fraction of the
+    8 TB/s roofline in algorithmic bytes; `kernels` says what ran (the persistent stage loop where a solve fits on the chip at once)."""
+    out = {}
+    # (the engine chooses streams and checkpoint level itself here, as for any caller: the C3 legs of this script pin both)
+    pinned = {k: os.environ.pop(k) for k in ("DFX_STREAMS", "DFX_CHECKPOINT") if k in os.environ}
+    try:
+        _launch_bound_legs(out, device, sync, single, c4_steps, c2_steps)
+    finally:
+        os.environ.update(pinned)
+    return out
+
+
+def _launch_bound_legs(out, device, sync, single, c4_steps, c2_steps):
+    fw, obj, designs = c2_problem(1, device=device)
+    c2_solve(fw, designs, 500, sync)
+    wall, st = c2_solve(fw, designs, c2_steps, sync)
+    us = 1e3 * st["kernel_ms"] / (c2_steps * 6)
+    out["c2_1_member"] = {"lattice": "32x32 quads, nonlinear + damping, forward only", "steps": c2_steps, "stage_us": us,
+                          "value": c2_steps * 1024 / wall, "device_value": c2_steps * 1024 / (st["kernel_ms"] * 1e-3),
+                          "frac": BYTES_FWD_STAGE_C2 * 1024 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernels": BUILD_NAMES.get(int(st.get("tile_kernels", 0)))}
+    fw.solve_dynamics.engine.close()
+    if single is not None:
+        out["c3_1_member"] = {"lattice": "128x128 quads + contact, forward + adjoint", "steps": single["steps"],
+                              "fwd_stage_us": single["fwd_stage_us"], "adj_stage_us": single["adj_stage_us"], "value": single["value"],
+                              "fwd_frac": single["roofline"]["forward_frac"], "adj_frac": single["roofline"]["frac"], "kernels": single["kernels"]}
+    fw4, obj4, K4 = c4_problem(8, c4_steps, device=device)
+    designs4 = []
+    for seed in range(100, 108):
+        rng = np.random.default_rng(seed)
+        designs4.append(tuple(rng.uniform(-0.3, 0.3, sh) for sh in fw4.geometry.design_shapes()))
+    obj4.value_and_grad(designs4)
+    sync()
+    t0 = time.perf_counter()
+    obj4.value_and_grad(designs4)
+    sync()
+    wall4 = time.perf_counter() - t0
+    sd = fw4.solve_dynamics
+    n4 = fw4.geometry.n_blocks
+    f_us, a_us = 1e3 * sd.stats["kernel_ms"] / (K4 * 6), 1e3 * sd.adjoint_stats["kernel_ms"] / (K4 * 6)
+    out["c4_8_designs"] = {"lattice": "64x64-cell kagome + contact, 8 designs, forward + design gradient through the problem layer", "steps": K4,
+                           "fwd_stage_us": f_us, "adj_stage_us": a_us, "value": K4 * n4 * 8 / wall4,
+                           "device_value": K4 * n4 * 8 / (1e-3 * (sd.stats["kernel_ms"] + sd.adjoint_stats["kernel_ms"])),
+                           "fwd_frac": BYTES_FWD_STAGE_KAGOME * n4 * 8 / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "adj_frac": BYTES_ADJ_STAGE_KAGOME * n4 * 8 / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "checkpoint": {1: "records", 2: "segments"}.get(sd.adjoint_stats.get("checkpoint_records", 0)) or "stages/state",
+                           "kernels": {"forward": BUILD_NAMES.get(int(sd.stats.get("tile_kernels", 0))),
+                                       "adjoint": BUILD_NAMES.get(int(sd.adjoint_stats.get("tile_kernels", 0)))}}
+    sd.engine.close()
 
 
 def c3_as_written_leg(args, device, sync, steps=50000):
@@ -283,10 +396,94 @@ def run_c4(args, comm, comm_info, world, rank, local_rank):
                 "device_ms": {"forward": float(dev_ms[0]), "adjoint": float(dev_ms[1]), "wall": 1e3 * wall},
                 "device_only_value": K * n_units * C4_DESIGNS / (1e-3 * float(dev_ms[0] + dev_ms[1])),
                 "objective": [float(x) for x in allv[:8]], "objectives_gathered": int(len(allv)), "grad_norm_rank0": gn}
+        # the dominant kernel: one reverse stage of this rank's designs (a launch, or a stage of the persistent loop); device time of the
+        # sweep / stages.  At the segments level the reverse sweep also re-runs the forward pass: its share is taken out first.
+        f_us = 1e3 * float(dev_ms[0]) / (K * 6)
+        a_ms = float(dev_ms[1]) - (float(dev_ms[0]) if sd.adjoint_stats.get("checkpoint_records", 0) == 2 else 0.0)
+        a_us = max(1e-9, 1e3 * a_ms / (K * 6))
+        builds = {"forward": BUILD_NAMES.get(int(sd.stats.get("tile_kernels", 0))), "adjoint": BUILD_NAMES.get(int(sd.adjoint_stats.get("tile_kernels", 0)))}
+        line["roofline"] = stage_roofline("reverse stage <nonlinear,contact>, 3-node blocks", BYTES_ADJ_STAGE_KAGOME, n_units * members, a_us,
+                                          kernels=builds, members_per_stage=members,
+                                          measured_with="HIP events around the reverse sweep / (steps x 6 stages), max over ranks")
+        line["roofline_forward_kernel"] = stage_roofline("forward stage <nonlinear,contact>, 3-node blocks", BYTES_FWD_STAGE_KAGOME, n_units * members, f_us)
+        line["csrc"] = source_ids()
+        if world == 1 and not args.no_launch_bound:
+            # what ONE rank of an 8-GPU run integrates: 8 of the 64 designs, same steps, same call (round-4 verdict #3).  The ratio
+            # predicts the strong scaling of the data path before any collective or imbalance; it is NOT a measured 8-GPU number.
+            fw8, obj8, _ = c4_problem(C4_DESIGNS // 8, K, device=local_rank)
+            d8 = designs[:C4_DESIGNS // 8]
+            obj8.value_and_grad(d8)
+            B.device_synchronize(local_rank)
+            t8 = time.perf_counter()
+            obj8.value_and_grad(d8)
+            B.device_synchronize(local_rank)
+            w8 = time.perf_counter() - t8
+            s8 = fw8.solve_dynamics
+            v8 = K * n_units * (C4_DESIGNS // 8) / w8
+            line["per_rank_of_8"] = {"designs": C4_DESIGNS // 8, "value": v8, "wall_ms": 1e3 * w8,
+                                     "device_ms": {"forward": s8.stats["kernel_ms"], "adjoint": s8.adjoint_stats["kernel_ms"]},
+                                     "device_only_value": K * n_units * (C4_DESIGNS // 8) / (1e-3 * (s8.stats["kernel_ms"] + s8.adjoint_stats["kernel_ms"])),
+                                     "kernels": {"forward": BUILD_NAMES.get(int(s8.stats.get("tile_kernels", 0))),
+                                                 "adjoint": BUILD_NAMES.get(int(s8.adjoint_stats.get("tile_kernels", 0)))}}
+            line["predicted_strong_scaling"] = {"at_8_gpus": 8.0 * v8 / line["value"],
+                                                "how": "8 x value(8 designs on this GPU) / value(64 designs on this GPU): two 1-GPU runs of the same call; "
+                                                       "no collective, no imbalance, not a measured multi-GPU number"}
+            s8.engine.close()
+        if world == 1 and not args.no_cpu_baseline:
+            def make(lib):
+                fwc, objc, _ = c4_problem(1, 40, lib=lib)
+                rng = np.random.default_rng(100)
+                return fwc, objc, [tuple(rng.uniform(-0.3, 0.3, sh) for sh in fwc.geometry.design_shapes())]
+            line["cpu_baseline"] = cpu_baseline(64, 100, n_steps=40, repeats=3, budget_s=30.0, make=make,
+                                                what="the same 64x64-cell kagome lattice (8192 units)")
         print(json.dumps(line), flush=True)
     comm.barrier()
     comm.close()
     sd.engine.close()
+
+
+def run_c2(args, comm, comm_info, world, rank, local_rank):
+    """`--workload c2`: BASELINE configs[1] -- 32x32 quads, nonlinear ligaments + damping, 10 000 fixed Dopri5 steps over 2/f, forward
+    only, ONE member per GPU (what the config says; 64 waves in all: the launch-bound end of the path), and the same lattice
+    `--c2-members` wide beside it.  `--steps K` times exactly K steps (default of this workload: the whole 10 000)."""
+    from difflexmm_amd import _binding as B
+    K = 10000 if args.steps == 5000 else max(1, args.steps)
+    W = max(0, args.warmup)
+
+    def sync():
+        B.device_synchronize(local_rank)
+
+    legs = {}
+    for name, members in (("one_member", 1), ("batched", max(1, args.c2_members))):
+        fw, obj, designs = c2_problem(members, device=local_rank)
+        for _ in range(1 if W else 0):
+            c2_solve(fw, designs, min(K, max(W, SPI)), sync)
+        sync(); comm.barrier(); sync()
+        wall, st = c2_solve(fw, designs, K, sync)
+        comm.barrier()
+        wall = float(comm.all_reduce([wall], "max")[0])
+        us = 1e3 * st["kernel_ms"] / (K * 6)
+        legs[name] = {"members_per_gpu": members, "value": K * 1024 * members * world / wall, "wall_ms": 1e3 * wall, "device_ms": st["kernel_ms"],
+                      "device_value": K * 1024 * members * world / (st["kernel_ms"] * 1e-3), "launches": st["launches"],
+                      "roofline": stage_roofline("forward stage <nonlinear, no contact>", BYTES_FWD_STAGE_C2, 1024 * members, us,
+                                                 kernels=BUILD_NAMES.get(int(st.get("tile_kernels", 0))), members_per_stage=members,
+                                                 measured_with="HIP events around the forward pass / (steps x 6 stages)")}
+        fw.solve_dynamics.engine.close()
+    if rank == 0:
+        one = legs["one_member"]
+        line = {"metric": "timesteps*rigid-units/s (forward)", "value": one["value"], "unit": "timesteps*units/s", "n_gpus": world, "steps": K,
+                "warmup": W, "ms_per_step": one["wall_ms"] / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"C2: 32x32 quads (1024 units), nonlinear ligaments + damping, no contact, pulse drive, fixed-step Dopri5 "
+                                       f"dt={C2_DT:.3e}s, {K} of 10000 steps, forward only, 1 member per GPU",
+                           "members_per_gpu": 1, "collective": comm_info["collective"], "ranks_seen": comm_info.get("ranks_seen")},
+                "roofline": one["roofline"], "one_member": one, "batched": legs["batched"], "csrc": source_ids()}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(32, 2, n_steps=2000, repeats=3, budget_s=30.0, make=lambda lib: c2_problem(1, lib=lib), adjoint=False,
+                                                what="the same 32x32 lattice")
+        print(json.dumps(line), flush=True)
+    comm.barrier()
+    comm.close()
 
 
 def usable_cpus():
@@ -313,11 +510,12 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
+def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0, make=None, adjoint=True, what=None):
     """The CPU port of the oracle (same algorithm, same tableau, OpenMP over blocks) on a bounded sample of the same
     workload: `n_steps` Dopri5 steps forward + adjoint of the same lattice, one member.  SURVEY 8(d) protocol: 1 thread and
     all usable cores, one warm-up run, median of `repeats` timed runs each; `value` is the faster of the two.  A 4-step probe
-    per leg shortens the sample when the host is too slow for the time budget (and says so)."""
+    per leg shortens the sample when the host is too slow for the time budget (and says so).
+    `make(lib) -> (forward problem, objective, designs)` selects another lattice (default: C3), `adjoint=False` a forward-only sample."""
     import ctypes
     from oracle.cpu import load, load_native
     lib, build_flags = load_native()              # SURVEY 8(d): -march=native, compiled on the host that is timed
@@ -328,7 +526,8 @@ def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
     except OSError:
         gomp = None
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    fw, obj, designs = c3_problem(size, seed, 1, lib=lib)
+    fw, obj, designs = make(lib) if make else c3_problem(size, seed, 1, lib=lib)
+    n_units = fw.geometry.n_blocks
     ncpu = usable_cpus()
     thread_counts = [1, ncpu] if gomp is not None and ncpu > 1 else [1]
     legs, notes = {}, []
@@ -336,10 +535,10 @@ def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
         if gomp is not None:
             gomp.omp_set_num_threads(nt)
         prepare(fw, designs, 4, spi=2)
-        execute(fw, obj, spi=2)                                # touch everything once
+        execute(fw, obj, adjoint, spi=2)                                # touch everything once
         prepare(fw, designs, 4, spi=2)
         t0 = time.perf_counter()
-        execute(fw, obj, spi=2)
+        execute(fw, obj, adjoint, spi=2)
         per_step = (time.perf_counter() - t0) / 4
         n = n_steps
         leg_budget = budget_s / len(thread_counts)
@@ -348,19 +547,19 @@ def cpu_baseline(size, seed, n_steps=100, repeats=5, budget_s=40.0):
             notes.append(f"{nt} thread(s): {n} steps instead of {n_steps} (time budget)")
         spi = min(n, 50)
         prepare(fw, designs, n, spi=spi)
-        execute(fw, obj, spi=spi)                              # warm-up (first call excluded, scripts/pulse_RS.py:93-108)
+        execute(fw, obj, adjoint, spi=spi)                              # warm-up (first call excluded, scripts/pulse_RS.py:93-108)
         times = []
         for _ in range(repeats):
             prepare(fw, designs, n, spi=spi)                  # same split as the GPU leg: inputs prepared outside the timed region
             t0 = time.perf_counter()
-            execute(fw, obj, spi=spi)
+            execute(fw, obj, adjoint, spi=spi)
             times.append(time.perf_counter() - t0)
-        legs[nt] = n * size * size / float(np.median(times))
+        legs[nt] = n * n_units / float(np.median(times))
     best = max(legs, key=legs.get)
     return {"value": legs[best], "unit": "timesteps*units/s", "cores": best, "kind": "port",
             "one_thread": legs.get(1), "all_cores": legs.get(ncpu) if ncpu > 1 else None, "usable_cpus": ncpu,
             "logical_cpus": os.cpu_count(), "build": build_flags,
-            "sample": f"{n_steps} Dopri5 steps forward+adjoint of the same {size}x{size} lattice, 1 member; C++ port of the "
+            "sample": f"{n_steps} Dopri5 steps {'forward+adjoint' if adjoint else 'forward only'} of {what or f'the same {size}x{size} lattice'}, 1 member; C++ port of the "
                       f"oracle (OpenMP over blocks), 1 thread and {ncpu} threads, 1 warm-up + median of {repeats} runs each"
                       + ("; " + "; ".join(notes) if notes else "")}
 
@@ -428,10 +627,13 @@ def main():
                     help="where the timed job leaves its gradients: hbm (device pointers; the download is timed after the region and "
                          "reported) | host (pinned views: the D2H copy is inside the timed region)")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the separate 1-stream per-launch measurement")
+    ap.add_argument("--no-launch-bound", action="store_true", help="skip the launch-bound regimes' block (C2 x 1, C3 x 1, C4 x 8 designs)")
+    ap.add_argument("--c2-members", type=int, default=64, help="--workload c2: width of the second, batched leg")
     ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx; strict: exits non-zero if it "
                                                       "does not come up on N distinct GPUs) | socket (rehearsal on one GPU)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
-                    help="c3: 128x128 quads, fixed designs per GPU (weak scaling; the headline).  c4: BASELINE config 4 -- 64 kagome "
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
+                    help="c3: 128x128 quads, fixed designs per GPU (weak scaling; the headline).  c2: BASELINE config 2 -- 32x32 quads, "
+                         "nonlinear ligaments + damping, 10 000 fixed steps, forward only, one member (and --c2-members beside it).  c4: BASELINE config 4 -- 64 kagome "
                          "designs (64x64 cells) in all, sharded over the ranks, forward + design gradient through the problem layer, "
                          "one all-gather of objectives (strong scaling).  c5: BASELINE config 5 -- the multi-input inverse design as "
                          "an ensemble of --c5-members designs in lock-step, --c5-iterations objective evaluations each "
@@ -476,6 +678,8 @@ def main():
     collective = comm_info["collective"]
     if args.workload == "c4":
         return run_c4(args, comm, comm_info, world, rank, local_rank)
+    if args.workload == "c2":
+        return run_c2(args, comm, comm_info, world, rank, local_rank)
     os.environ["DFX_STREAMS"] = str(args.streams)
     K = max(1, args.steps)                      # EXACTLY K steps are timed
     W = max(0, args.warmup)
@@ -545,17 +749,18 @@ def main():
         r1 = execute(fw1, obj1)
         sync()
         w1 = time.perf_counter() - t1
-        f1_us, a1_us = 1e3 * r1["fwd_ms"] / max(1, r1["fwd_launches"]), 1e3 * r1["adj_ms"] / max(1, r1["adj_launches"])
+        # device time per Runge-Kutta stage (a launch each, or one stage of the persistent loop): the sweep's HIP events / stages
+        f1_us, a1_us = 1e3 * r1["fwd_ms"] / (6.0 * K1), 1e3 * r1["adj_ms"] / (6.0 * K1)
         n1u = args.size * args.size
-        stages_per_fwd_launch = 6.0 * K1 / max(1, r1["fwd_launches"] - K1 // SPI - 2)      # 2 when the forward pass runs pair launches
         single = {"members_per_gpu": 1, "steps": K1, "value": K1 * args.size * args.size / w1,
                   "forward_only_value": K1 * args.size * args.size / (r1["fwd_ms"] * 1e-3),
-                  "fwd_launch_us": f1_us, "adj_launch_us": a1_us,
-                  "roofline": {"bound": "hbm", "kernel": "k_adj_stage<nonlinear,contact>", "launch_us": a1_us,
+                  "fwd_stage_us": f1_us, "adj_stage_us": a1_us,
+                  "kernels": {"forward": BUILD_NAMES.get(r1.get("fwd_build")), "adjoint": BUILD_NAMES.get(r1.get("adj_build"))},
+                  "launches": {"forward": r1["fwd_launches"], "adjoint": r1["adj_launches"]},
+                  "roofline": {"bound": "hbm", "kernel": "reverse stage <nonlinear,contact>", "stage_us": a1_us,
                                "achieved": BYTES_ADJ_STAGE * n1u / (a1_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": BYTES_ADJ_STAGE * n1u / (a1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                               "forward_frac": round(stages_per_fwd_launch) * BYTES_FWD_STAGE * n1u / (f1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                               "forward_stages_per_launch": round(stages_per_fwd_launch)},
+                               "forward_frac": BYTES_FWD_STAGE * n1u / (f1_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                   "checkpoint": r1.get("checkpoint"),
                   "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
         fw1.solve_dynamics.engine.close()
@@ -713,6 +918,9 @@ def main():
         line["end_to_end_frac_of_hbm_peak"] = per_step_bytes * total_units_steps / wall / 1e9 / HBM_PEAK_GBS
         if single is not None:
             line["single_system"] = single
+        if world == 1 and adjoint and not args.no_launch_bound:
+            line["launch_bound"] = launch_bound_block(local_rank, sync, single)
+        line["csrc"] = source_ids()
         if world == 1 and adjoint and not args.no_as_written and args.size == 128 and args.as_written_steps > 0:
             line["c3_as_written"] = c3_as_written_leg(args, local_rank, sync, steps=args.as_written_steps)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
@@ -722,17 +930,32 @@ def main():
     comm.close()
 
 
-def csrc_digest():
-    """sha256 over the engine's sources (difflexmm_amd/csrc/*.h, *.hip, sorted by name): what identifies the build a counter file belongs
-    to on the GPU box, where the snapshot has no .git."""
-    import glob
+KERNEL_SOURCES = ("dfx_physics.h", "dfx_plan.h", "dfx_stage.h", "dfx_kernels.h")                 # what the two stage kernels are compiled from
+ENGINE_SOURCES = KERNEL_SOURCES + ("dfx_persist.h", "dfx_persist_api.h", "dfx_pair.h", "dfx_tile.h", "dfx_engine.hip", "dfx_persist.hip", "dfx_comm.hip")
+
+
+def csrc_digest(files=KERNEL_SOURCES):
+    """sha256 over an EXPLICIT list of engine sources (default: the headers the stage kernels are compiled from -- what a counter
+    file of those kernels belongs to), by name and content: identifies the build on the GPU box, where the snapshot has no .git.
+    (Round-4 advice: a glob also hashed whatever else sat in the directory.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "difflexmm_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def source_ids():
+    """What every bench line says about the tree it ran on: digest of the stage kernels' sources, digest of all engine sources, and the
+    commit when the tree has a .git (the GPU box's snapshot has none)."""
+    head = None
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:       # noqa: BLE001
+        pass
+    return {"stage_kernel_sources_sha256": csrc_digest(), "engine_sources_sha256": csrc_digest(ENGINE_SOURCES), "git_head": head}
 
 
 def load_pmc_traffic():

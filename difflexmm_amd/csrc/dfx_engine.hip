@@ -605,11 +605,13 @@ static void persist_shape(const dfx_handle* h, int npb, int nm, int* grid, int* 
   *grid = (int)g;
   *lds = (kPersistLdsBudget / (int)per_cu) & ~1023;
 }
-// launches per segment a solve may be cut into (members that do not fit at once follow in further launches); beyond it the stage launches
-// serve the solve.  1 by default: a launch that fills the chip several times over is what the stage kernels are tuned for.
+// launches per segment a solve may be cut into (members that do not fit at once follow in further launches of the same segment); beyond
+// it the stage launches serve the solve: a launch that fills the chip several times over is what the stage kernels are tuned for.
+// Measured (profiles/r05_persistent_kernels.txt): 8 designs of the 64x64-cell kagome lattice -- forward in one launch 5.3 against 6.9 us
+// per stage, reverse in two launches of 4 designs 8.5 against 10.7 us; 16 x 128x128 cut into 4 + 8 launches: 22 / 34 against 14 / 26 us.
 static int persist_max_chunks() {
   const char* e = getenv("DFX_PERSIST_CHUNKS");
-  return e ? std::max(1, atoi(e)) : 1;
+  return e ? std::max(1, atoi(e)) : 2;
 }
 static bool persist_common_ok(dfx_handle* h, const DevCtx& c) {
   if (!persist_shape_ok(h) || h->adaptive || h->groups.size() != 1) return false;
@@ -1314,7 +1316,9 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     // solves that fit the persistent stage loop (dfx_persist.h) run all their members in ONE launch per segment
     if (!e && problem->streams <= 0 && want > 1 && persist_shape_ok(h)) {
       h->persist_npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
-      if (persist_members_ok(h, persist_members_that_fit(h, dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, h->persist_npb), h->persist_npb))) want = 1;
+      // (both sweeps must fit: a solve whose reverse sweep keeps the stage launches keeps its two member groups too)
+      if (persist_members_ok(h, persist_members_that_fit(h, dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, h->persist_npb), h->persist_npb)) &&
+          persist_members_ok(h, persist_members_that_fit(h, dfx_persist::adj_kernel(h->pl.model, h->pl.contact, h->persist_npb), h->persist_npb))) want = 1;
     }
     int ng = std::max(1, std::min({want, h->pl.batch, kMaxGroups}));
     (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);

@@ -24,6 +24,38 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def bench_extras(objective, steps, nb, mine, world, args):
+    """`roofline` / `cpu_baseline` / `csrc` of the bench line (bench.py --workload c5): device time per Runge-Kutta stage of the LAST
+    evaluation of input 0's engine (HIP events around its sweeps / stages) against the 8 TB/s roofline in algorithmic bytes (SURVEY
+    8(d): 344 B forward, 624 B reverse per unit and stage, quads + contact), and the C++ port of the oracle on the same 24x16 lattice
+    (one member, one input, bounded sample) on this host."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sd = objective.objectives[0].forward.solve_dynamics
+    st, sa = sd.stats, sd.adjoint_stats
+    f_us, a_us = 1e3 * st["kernel_ms"] / (steps * 6), 1e3 * sa["kernel_ms"] / (steps * 6)
+    builds = {"forward": bench.BUILD_NAMES.get(int(st.get("tile_kernels", 0))), "adjoint": bench.BUILD_NAMES.get(int(sa.get("tile_kernels", 0)))}
+    out = {"roofline": bench.stage_roofline("reverse stage <nonlinear,contact>", bench.BYTES_ADJ_STAGE, nb * mine, a_us, kernels=builds,
+                                            members_per_stage=mine, measured_with="HIP events around the reverse sweep of input 0's last "
+                                            "evaluation / (steps x 6 stages), rank 0"),
+           "roofline_forward_kernel": bench.stage_roofline("forward stage <nonlinear,contact>", bench.BYTES_FWD_STAGE, nb * mine, f_us),
+           "csrc": bench.source_ids()}
+    if world == 1 and not args.cpu_port:
+        def make(lib):
+            from difflexmm_amd import problems as P
+            fw = objective.objectives[0].forward
+            fwc = P.QuadsFocusingForward(**{**{k: getattr(fw, k) for k in ("n1_blocks", "n2_blocks", "spacing", "bond_length", "k_stretch", "k_shear",
+                                                "k_rot", "density", "damping", "amplitude", "loading_rate", "input_delay", "n_excited_blocks",
+                                                "loaded_side", "input_shift", "simulation_time", "n_timepoints", "use_contact", "k_contact",
+                                                "min_angle", "cutoff_angle")}, "steps_per_interval": 50, "batch": 1, "_lib": lib})
+            fwc.setup()
+            objc = P.TargetKineticEnergy(fwc, (2, 2), (args.n1 // 6, args.n2 // 5))
+            return fwc, objc, [fwc.geometry.get_design_from_rotated_square(25 * math.pi / 180)]
+        out["cpu_baseline"] = bench.cpu_baseline(0, 0, n_steps=1000, repeats=3, budget_s=30.0, make=make,
+                                                 what=f"the same {args.n1}x{args.n2} lattice, one input")
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--members", type=int, default=32, help="designs in the whole ensemble")
@@ -129,7 +161,7 @@ def main(argv=None):
                     "note": "median of evaluations 2.. of the whole ensemble on rank 0 (forward + reverse sweeps of the three inputs + design maps); "
                             "`value` above also carries the first (allocating) evaluation and the MMA sub-problems between evaluations"},
                 "objective_first": [float(x) for x in first[:8]], "objective_best": [float(x) for x in final[:8]],
-                "objectives_gathered": int(len(final))}), flush=True)
+                "objectives_gathered": int(len(final)), **bench_extras(objective, steps, nb, mine, world, args)}), flush=True)
     if workers is not None:
         workers.close()
     comm.barrier()
