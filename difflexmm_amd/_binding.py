@@ -54,7 +54,7 @@ class dfx_stats(C.Structure):
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid", "dfx_forward_grid_members",
            "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
-           "dfx_device_count", "dfx_version", "dfx_share_checkpoint"]
+           "dfx_device_count", "dfx_version", "dfx_share_checkpoint", "dfx_abi_layout"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
@@ -62,9 +62,31 @@ COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_
 EXPORTS = EXPORTS + COMM_EXPORTS
 
 
+def abi_layout():
+    """sizeof + field offsets of the five public structs as THIS module mirrors them, in the order dfx_abi_layout reports."""
+    out = []
+    for cls in (dfx_special, dfx_problem, dfx_params, dfx_grads, dfx_stats):
+        out.append(C.sizeof(cls))
+        out += [getattr(cls, name).offset for name, _ in cls._fields_]
+    return out
+
+
+def check_abi_layout(lib):
+    """A library whose structs are laid out differently from the ctypes mirrors above would read garbage silently: refuse it."""
+    want = abi_layout()
+    buf = (C.c_int32 * len(want))()
+    lib.dfx_abi_layout.argtypes = [C.POINTER(C.c_int32), C.c_int32]
+    lib.dfx_abi_layout.restype = C.c_int
+    n = lib.dfx_abi_layout(buf, len(want))
+    if n != len(want) or list(buf) != want:
+        raise RuntimeError(f"difflexmm_amd: struct layout of the library ({n} entries: {list(buf)[:n]}) differs from the binding's ({want}); "
+                           "include/dfx.h and difflexmm_amd/_binding.py are out of step")
+
+
 def declare(lib):
     """Attach argument / result types to every entry point of include/dfx.h."""
     H = C.c_void_p
+    check_abi_layout(lib)
     lib.dfx_create.argtypes = [C.POINTER(dfx_problem), C.POINTER(H)]
     lib.dfx_destroy.argtypes = [H]
     if hasattr(lib, "dfx_share_checkpoint"):

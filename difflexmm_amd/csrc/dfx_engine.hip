@@ -18,6 +18,7 @@
 //     accelerations of every step, kept when they fit in HBM) or recomputed by forward launches.
 //
 // The per-ligament physics (dfx_physics.h) is shared with the CPU port of the oracle.
+#define DFX_ABI_LAYOUT_IMPL      // include/dfx.h then carries the body of dfx_abi_layout
 #include <hip/hip_runtime.h>
 
 
@@ -1269,6 +1270,8 @@ int dfx_device_count(void) {
 }
 
 const char* dfx_version(void) { return "dfx-hip-gfx950 0.2.0"; }
+
+int dfx_abi_layout(int32_t* out, int32_t n) { return dfxabi_fill(out, n); }
 
 const char* dfx_last_error(const dfx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

@@ -258,6 +258,12 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy);
 int dfx_device_count(void);
 const char* dfx_version(void);
 
+/* Layout of the five public structs AS THIS LIBRARY WAS COMPILED: for dfx_special, dfx_problem, dfx_params, dfx_grads, dfx_stats in
+ * that order, sizeof followed by offsetof of every field in declaration order -- 5 + 4 + 16 + 9 + 10 + 9 = 53 int32 values.  A binding
+ * that mirrors the structs by hand (difflexmm_amd/_binding.py flattens the ControlParams tree of utils.py:48-163 into them) compares
+ * them with its own before the first call (tests/test_abi.py).  Writes min(n, 53) values, returns 53. */
+int dfx_abi_layout(int32_t* out, int32_t n);
+
 /* ---- multi-GPU: one process per GPU, independent members per rank, ONE collective per evaluation -------------
  * Replaces the reference's pmap over forward inputs + host sum (problems/quads_kinetic_energy_static_tuning.py:454-478) and the
  * sequential list of forward problems of problems/quads_focusing_multi_input.py:66-86.  RCCL over xGMI inside the library;
@@ -286,6 +292,36 @@ int dfx_mem_info(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 int dfx_device_synchronize(int32_t device);
 
 #ifdef __cplusplus
+}
+#endif
+
+#ifdef DFX_ABI_LAYOUT_IMPL   /* the body of dfx_abi_layout, compiled into each library that implements this header */
+#include <stddef.h>
+static inline int dfxabi_fill(int32_t* out, int32_t n) {
+  const int32_t v[] = {
+      (int32_t)sizeof(dfx_special), (int32_t)offsetof(dfx_special, block), (int32_t)offsetof(dfx_special, con_mask),
+      (int32_t)offsetof(dfx_special, con_coef), (int32_t)offsetof(dfx_special, load_coef),
+      (int32_t)sizeof(dfx_problem), (int32_t)offsetof(dfx_problem, n_blocks), (int32_t)offsetof(dfx_problem, n_npb),
+      (int32_t)offsetof(dfx_problem, n_bonds), (int32_t)offsetof(dfx_problem, bonds), (int32_t)offsetof(dfx_problem, bond_model),
+      (int32_t)offsetof(dfx_problem, contact), (int32_t)offsetof(dfx_problem, n_special), (int32_t)offsetof(dfx_problem, special),
+      (int32_t)offsetof(dfx_problem, n_fns), (int32_t)offsetof(dfx_problem, fn_type), (int32_t)offsetof(dfx_problem, batch),
+      (int32_t)offsetof(dfx_problem, tableau), (int32_t)offsetof(dfx_problem, device), (int32_t)offsetof(dfx_problem, fn_table_n),
+      (int32_t)offsetof(dfx_problem, fn_table), (int32_t)offsetof(dfx_problem, streams),
+      (int32_t)sizeof(dfx_params), (int32_t)offsetof(dfx_params, centroid_node_vectors), (int32_t)offsetof(dfx_params, reference_vector),
+      (int32_t)offsetof(dfx_params, k_bond), (int32_t)offsetof(dfx_params, inertia), (int32_t)offsetof(dfx_params, damping),
+      (int32_t)offsetof(dfx_params, void_angle0), (int32_t)offsetof(dfx_params, contact), (int32_t)offsetof(dfx_params, fn_params),
+      (int32_t)offsetof(dfx_params, block_centroids),
+      (int32_t)sizeof(dfx_grads), (int32_t)offsetof(dfx_grads, centroid_node_vectors), (int32_t)offsetof(dfx_grads, reference_vector),
+      (int32_t)offsetof(dfx_grads, k_bond), (int32_t)offsetof(dfx_grads, inertia), (int32_t)offsetof(dfx_grads, damping),
+      (int32_t)offsetof(dfx_grads, void_angle0), (int32_t)offsetof(dfx_grads, contact), (int32_t)offsetof(dfx_grads, fn_params),
+      (int32_t)offsetof(dfx_grads, state0), (int32_t)offsetof(dfx_grads, block_centroids),
+      (int32_t)sizeof(dfx_stats), (int32_t)offsetof(dfx_stats, steps), (int32_t)offsetof(dfx_stats, rhs_evals),
+      (int32_t)offsetof(dfx_stats, launches), (int32_t)offsetof(dfx_stats, kernel_ms), (int32_t)offsetof(dfx_stats, stage_kernel_us),
+      (int32_t)offsetof(dfx_stats, streams), (int32_t)offsetof(dfx_stats, stage_checkpoint), (int32_t)offsetof(dfx_stats, checkpoint_records),
+      (int32_t)offsetof(dfx_stats, tile_kernels)};
+  const int32_t total = (int32_t)(sizeof(v) / sizeof(v[0]));
+  for (int32_t i = 0; i < total && i < n; ++i) out[i] = v[i];
+  return total;
 }
 #endif
 #endif /* DFX_H */

@@ -9,6 +9,7 @@
 // hand-derived instead of obtained by autodiff.  The per-ligament formulas are the ones in
 // difflexmm_amd/csrc/dfx_physics.h (also compiled into the GPU kernels); their independent check is
 // the torch-autograd restatement in oracle/ref_*.py.  Parallelism: OpenMP over blocks.
+#define DFX_ABI_LAYOUT_IMPL
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -716,5 +717,6 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
 
 int dfx_device_count(void) { return 0; }
 const char* dfx_version(void) { return "dfx-cpu-port 0.1.0"; }
+int dfx_abi_layout(int32_t* out, int32_t n) { return dfxabi_fill(out, n); }
 
 }  // extern "C"

@@ -23,6 +23,28 @@ def test_libdfx_exports_every_declared_symbol(hip_lib):
     assert b"gfx950" in hip_lib.dfx_version()
 
 
+def test_struct_layouts_of_header_libraries_and_binding_agree(hip_lib, cpu_lib):
+    """sizeof and every field offset of dfx_special / dfx_problem / dfx_params / dfx_grads / dfx_stats (the ControlParams tree of
+    /root/reference/difflexmm/utils.py:48-163, flattened) as both libraries were compiled, against the hand-written ctypes mirrors:
+    a reordered or resized field fails here (and at load time: declare() refuses such a library) instead of corrupting a solve."""
+    import ctypes as C
+    from difflexmm_amd import _binding as b
+    want = b.abi_layout()
+    assert len(want) == 53
+    for lib in (hip_lib, cpu_lib):
+        buf = (C.c_int32 * 64)()
+        assert lib.dfx_abi_layout(buf, 64) == len(want)
+        assert list(buf)[:len(want)] == want
+    # the count the header documents, and a truncated query
+    small = (C.c_int32 * 3)()
+    assert hip_lib.dfx_abi_layout(small, 3) == 53 and list(small) == want[:3]
+    # a mirror with a field out of place is caught
+    class bad_stats(C.Structure):
+        _fields_ = [("rhs_evals", C.c_int64), ("steps", C.c_int64)] + b.dfx_stats._fields_[2:]
+    assert [getattr(bad_stats, n).offset for n, _ in bad_stats._fields_] == [getattr(b.dfx_stats, n).offset for n, _ in b.dfx_stats._fields_]   # same offsets, other names:
+    assert [n for n, _ in bad_stats._fields_] != [n for n, _ in b.dfx_stats._fields_]                                                           # names are the header's job (test_header_and_binding_agree)
+
+
 def test_cpu_port_exports_the_solver_abi(cpu_lib):
     """The CPU port (test infrastructure) mirrors the solver entry points; the RCCL collective and the device helpers exist in
     the HIP library only."""
