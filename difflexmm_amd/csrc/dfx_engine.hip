@@ -123,7 +123,6 @@ struct dfx_handle {
   DevBuf<double> d_ovf_p, d_ovf_g;             // extra ligaments (general bond lists): parameters, gradient accumulators
   DevBuf<double> d_out_r, d_out_phi, d_out_lam;    // gradients re-laid-out on the device (collect_grads)
   DevBuf<double> d_resp;                           // dfx_response_data outputs
-  bool prelude_done = false;                       // adjoint_kinetic cleared the accumulators in the launch that cleared its cotangents
   bool device_views = false;                       // this call hands out device pointers (dfx_kinetic_value_and_grad_device)
   DevBuf<dfx_special> d_special;
   DevBuf<double> d_p_r, d_p_l, d_p_k, d_p_phi, d_cst, d_inv_m, d_damping, d_l_dict, d_p_c, d_g_c;
@@ -1886,7 +1885,11 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
 }
 
 // reverse sweep with the output cotangents already in h->d_G
-static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_grads* views, dfx_stats* stats, bool kinetic, int n_target) {
+// accumulators_cleared: the caller's prelude launch has already zeroed the gradient accumulators and set the cursors (adjoint_kinetic
+// does it in the launch that clears its cotangents) -- an argument, not handle state: a flag left behind by a call that failed half way
+// made the next sweep skip its zeroing (round-4 advice)
+static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_grads* views, dfx_stats* stats, bool kinetic, int n_target,
+                       bool accumulators_cleared = false) {
   const Plan& pl = h->pl;
   const size_t B = pl.batch;
   const int Tn = (int)h->ts.size();
@@ -1897,8 +1900,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   const auto ta0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   const int nseg = (int)h->segs.size();
-  if (!h->prelude_done && zero_grad_accumulators(h, nullptr, 0, nseg)) return 2;      // (adjoint_kinetic did it together with its own arrays)
-  h->prelude_done = false;
+  if (!accumulators_cleared && zero_grad_accumulators(h, nullptr, 0, nseg)) return 2;
   const double h_last = Tn > 1 ? (h->t_steps.empty() ? (h->ts[Tn - 1] - h->ts[Tn - 2]) / h->spis[Tn - 2]
                                                      : h->t_steps[h->n_total] - h->t_steps[h->n_total - 1]) : 0.0;
   HIP_OK(hipEventRecord(h->ev2, h->stream));
@@ -2056,14 +2058,13 @@ static int adjoint_kinetic(dfx_handle* h, const int32_t* target_blocks, int32_t 
   // one launch: accumulators and cotangents cleared, cursors at the last segment, target blocks in place (zero_grad_accumulators)
   set_grad_wishes(h, want);
   if (zero_grad_accumulators(h, h->d_G.p, B * Tn * nb * 6, (int)h->segs.size(), target_blocks, n_target)) return 2;
-  h->prelude_done = true;
   DevCtx c = make_ctx(h);
   // the objective rides along with the reverse sweep: the kernel stores it into pinned host memory as well (a copy on the stream would be
   // a hop to the copy engine and back in front of the sweep), read after the sweep's final synchronisation
   if (objective) HIP_OK(h->obj_stage.ensure(sizeof(double) * B));
   hipLaunchKernelGGL(k_kinetic, dim3(h->pl.batch), dim3(kThreads), 0, h->stream, c, (const double*)h->d_fields.p,
                      (const int32_t*)h->d_target.p, n_target, h->d_G.p, h->d_obj.p, objective ? reinterpret_cast<double*>(h->obj_stage.p) : (double*)nullptr);
-  if (int rc = run_adjoint(h, want, grads, views, stats, true, n_target)) return rc;
+  if (int rc = run_adjoint(h, want, grads, views, stats, true, n_target, true)) return rc;
   if (objective) memcpy(objective, h->obj_stage.p, sizeof(double) * B);
   return 0;
 }

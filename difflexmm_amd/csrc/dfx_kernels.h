@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dfx_stage.h"
 
 using namespace dfx;
@@ -450,7 +452,11 @@ __device__ __forceinline__ T* late_arg(u32 byte_offset) {
   asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(byte_offset) : "memory");
   return v;
 }
+// (offset inside the kernel-argument segment = offset inside DevCtx: every __global__ function that reaches a DFX_LATE must take DevCtx
+// BY VALUE AS ITS FIRST PARAMETER -- k_adj_stage says so with a static_assert on its own signature)
 #define DFX_LATE(T, field) late_arg<T>((u32)offsetof(DevCtx, field))
+template <class First, class... Rest> struct first_param_is_devctx { static constexpr bool value = std::is_same<First, DevCtx>::value; };
+template <class R, class... A> constexpr bool kernel_takes_devctx_first(R (*)(A...)) { return first_param_is_devctx<A...>::value; }
 
 // uniform bases of member m's parameter arrays
 struct MemberBases {
@@ -1337,6 +1343,8 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
 template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
 __global__ __launch_bounds__(kThreads) DFX_ADJ_OCC void k_adj_stage(DevCtx c, AdjCoef ac, int i, int j, int in_buf, int wbuf_static,
                                                         int local_only, StageCoef rc, int rb) {
+  // the records build fetches its epilogue pointers from the kernel-argument segment at offsetof(DevCtx, field) (late_arg)
+  static_assert(kernel_takes_devctx_first(&k_adj_stage<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF, WT, ISTAGE>), "DevCtx must stay the first kernel argument");
   adj_stage_body<MODEL, CONTACT, BOND_GRADS, REBUILD, NPB, TAB, OVF, WT, ISTAGE>(c, ac, i, j, in_buf, wbuf_static, local_only, rc, rb);
 }
 // The stage-checkpoint build (REBUILD, no per-ligament gradients) sits at 127-131 VGPRs depending on unrelated edits: its own entry

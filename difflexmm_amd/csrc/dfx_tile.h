@@ -109,6 +109,15 @@ struct LigIn {
   double lx, ly, l0, il0, ks, ksh, kr, phi1, phi2, am, ac, kc, sgn;
 };
 // what a ligament lane needs beyond the two node vectors, once the LDS copies are there
+// A wave's LDS operations complete in order, but the COMPILER must be told that the wave-private exchange below is one: a release /
+// acquire pair at wavefront scope around a wave barrier (no instruction: s_barrier stays out of these kernels) keeps it from moving
+// the loads of one phase above the stores of the previous one (round-4 advice: under the HIP memory model the unfenced form is a race).
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int CONTACT>
 __device__ __forceinline__ void lig_resolve(const DevCtx& c, const LigCtx& lc, const MemberBases& B, int m, int lig, int tab, const double2 (*s_rec)[2],
                                             const double2 (*s_dict)[2], int co, int cp, LigIn& L) {
@@ -193,6 +202,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_fwd_tile(DevCtx c, LigCtx l
   double fx = 0.0, fy = 0.0, fth = 0.0, pfx = 0.0, pfy = 0.0, pfth = 0.0;
   if (t.lig_ok && (tab & 1)) {
     LigIn L;
+    wave_lds_fence();
     lig_resolve<CONTACT>(c, lc, B, m, (int)lig, tab, s_rec, s_dict, WaveTile::cell(t.hr, t.hc), WaveTile::cell(t.hr + t.lig_e, t.hc + (t.lig_e ? lc.dc1 : 1)), L);
     BondGrad<double> g;
     BondPartner<double> pg;
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_fwd_tile(DevCtx c, LigCtx l
     }
   }
   { double (*q)[3] = s_con[t.ln]; q[0][0] = fx; q[0][1] = fy; q[0][2] = fth; q[1][0] = pfx; q[1][1] = pfy; q[1][2] = pfth; }
+  wave_lds_fence();
   if (!t.dof_ok) return;
   // ---- block sum of component k: own ligament 0, own ligament 1, from the left, from below (fixed order)
   const double dE = ((s_con[3 * t.blk][0][k] + s_con[3 * t.blk + 1][0][k]) + s_con[t.src_left()][1][k]) + s_con[t.src_below(lc.dc1)][1][k];
@@ -335,6 +346,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_adj_tile(DevCtx c, LigCtx l
   if (t.lig_ok && (tab & 1)) {
     LigIn L;
     const int co = WaveTile::cell(t.hr, t.hc), cp = WaveTile::cell(t.hr + t.lig_e, t.hc + (t.lig_e ? lc.dc1 : 1));
+    wave_lds_fence();
     lig_resolve<CONTACT>(c, lc, B, m, (int)lig, tab, s_rec, s_dict, co, cp, L);
     const BlockRec<Dual> o = seed_rec(L.o, s_w[co][0], s_w[co][1], s_w[co][2]);
     const BlockRec<Dual> p = seed_rec(L.p, s_w[cp][0], s_w[cp][1], s_w[cp][2]);
@@ -366,6 +378,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_adj_tile(DevCtx c, LigCtx l
     }
   }
   { double2 (*q)[3] = s_con[t.ln]; q[0][0] = own[0]; q[0][1] = own[1]; q[0][2] = own[2]; q[1][0] = par[0]; q[1][1] = par[1]; q[1][2] = par[2]; }
+  wave_lds_fence();
   if (!t.dof_ok) return;
   // ---- block sums of component k (fixed order: own ligament 0, own ligament 1, from the left, from below)
   const double2 a0 = s_con[3 * t.blk][0][k], a1 = s_con[3 * t.blk + 1][0][k], a2 = s_con[t.src_left()][1][k], a3 = s_con[t.src_below(lc.dc1)][1][k];

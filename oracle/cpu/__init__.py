@@ -56,15 +56,30 @@ def load_native():
         h.update(flags.encode())
     except Exception:       # noqa: BLE001
         pass
-    so = os.path.join(tempfile.gettempdir(), f"libdfx_cpu_native_{h.hexdigest()[:12]}.so")
+    # a directory only this user can write (round-4 advice: a predictable name in the shared temp directory could be pre-planted by
+    # another local user and would then be loaded and timed), the intermediate file from mkstemp, ownership checked before loading
+    cache = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "difflexmm_amd")
+    try:
+        os.makedirs(cache, mode=0o700, exist_ok=True)
+        st = os.stat(cache)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise PermissionError(cache)
+    except Exception:       # noqa: BLE001 -- no usable home: a fresh private directory for this process
+        cache = tempfile.mkdtemp(prefix="dfx_cpu_native_")
+    so = os.path.join(cache, f"libdfx_cpu_native_{h.hexdigest()[:12]}.so")
     cflags = "-O3 -march=native -std=c++17 -fPIC -fopenmp"
     if not os.path.exists(so):
         try:
-            subprocess.check_call(["g++"] + cflags.split() + ["-Wno-unknown-pragmas", "-shared", "-o", so + ".tmp", srcs[0]],
+            fd, tmp = tempfile.mkstemp(suffix=".so", dir=cache)
+            os.close(fd)
+            subprocess.check_call(["g++"] + cflags.split() + ["-Wno-unknown-pragmas", "-shared", "-o", tmp, srcs[0]],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            os.replace(so + ".tmp", so)
+            os.replace(tmp, so)
         except Exception as e:       # noqa: BLE001
             return None, f"-march=native build failed ({type(e).__name__}): prebuilt x86-64-v3 library used"
+    st = os.stat(so)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        return None, "cached -march=native library is not owned by this user: prebuilt x86-64-v3 library used"
     lib = declare(ctypes.CDLL(so))
     lib._dfx_test_only = True
     return lib, "g++ " + cflags + " (built on this host)"

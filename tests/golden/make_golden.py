@@ -179,6 +179,81 @@ def long_horizon():
         print(lattice, "objective", obj.item(), "contact energy", contact[0], "->", contact[-1], flush=True)
 
 
+def long_horizon_32(steps=2000, n=32, seed=23, cut=42.0, intervals=8):
+    """The same at a size where the engine's size-dependent code runs (round-4 verdict #5): 32 x 32 quads (1 024 blocks: 64 waves, several
+    workgroups, the XCD-banded order, more than one segment), contact engaged everywhere, 2 000 fixed Dopri5 steps.  Two thousand steps
+    of 1 024 blocks do not fit on one autograd tape (33 MB per step), so the gradient is assembled interval by interval: a first pass
+    keeps the state at the start of every interval; the reverse pass re-runs ONE interval on the tape from its stored state (a leaf)
+    and differentiates  L_k = (objective terms of the interval's output) + <state cotangent of the next interval, final state>  with
+    respect to that leaf and the design -- the chain rule written out, still autograd through the unrolled oracle inside an interval."""
+    from oracle import ref_energy as OE, ref_geometry as OG
+    import time
+    c = Case("quads", n, True, True, seed=seed, lib=load(), cutoff_deg=cut)
+    nb = c.geo.n_blocks
+    lv = dict(loading_rate=T64(3000.0), input_delay=T64(1e-5))
+    ts = np.linspace(0.0, 1.5e-6 * steps, intervals + 1)
+    spi = steps // intervals
+    osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi)
+    free = torch.as_tensor(osol.free_DOF_ids, dtype=torch.long)
+    free_l = list(osol.free_DOF_ids)
+    target = np.array([nb // 2 + n // 2 + 1, nb // 2 + n // 2 + 2])
+    cols = [[free_l.index(b * 3 + d) for d in range(3)] for b in target]
+
+    def interval(y_free, k, design):
+        cnv = c.ogeo.centroid_node_vectors(*design)
+        cen = c.ogeo.block_centroids(*design)
+        full = torch.zeros(2, nb * 3, dtype=torch.float64)
+        full = full.index_copy(1, free, y_free)
+        hist, _ = OD.solve_fixed_differentiable(osol, c.ogeo, full.reshape(2, nb, 3), ts[k:k + 2], c.oracle_cp(dict(cnv=cnv, cen=cen, **lv)), spi)
+        inertia = OG.compute_inertia(cnv, 6.18e-9)
+        return hist[1], inertia
+
+    def kinetic(y_free, inertia):
+        e = 0.0
+        for b, cs in zip(target, cols):
+            for d in range(3):
+                e = e + inertia[b, d] * y_free[1, cs[d]] ** 2 / 2
+        return e
+
+    t0 = time.time()
+    design0 = [T64(d) for d in c.design]
+    states = [torch.zeros(2, len(free_l), dtype=torch.float64)]
+    for k in range(intervals):
+        y1, _ = interval(states[-1], k, design0)
+        states.append(y1.detach())
+        print("forward interval", k, time.time() - t0, "s", flush=True)
+    grads = [torch.zeros_like(d) for d in design0]
+    ybar = torch.zeros_like(states[-1])
+    obj = 0.0
+    for k in range(intervals - 1, -1, -1):
+        design = [T64(d, True) for d in c.design]
+        y0 = states[k].clone().requires_grad_(True)
+        y1, inertia = interval(y0, k, design)
+        e = kinetic(y1, inertia)
+        L = e + (ybar * y1).sum()
+        g = torch.autograd.grad(L, [y0] + design)
+        ybar = g[0]
+        for a, b in zip(grads, g[1:]):
+            a += b
+        obj += e.item()
+        print("reverse interval", k, time.time() - t0, "s", flush=True)
+    # (output 0 is the state at rest: its kinetic energy and gradient are zero)
+    cp = c.oracle_cp(lv)
+    fields = osol(np.zeros((2, nb, 3)), ts, cp).detach()
+    for part in (0, 1):
+        for k in range(intervals + 1):
+            a, b = fields.reshape(len(ts), 2, -1)[k, part][free], states[k][part]
+            assert float((a - b).abs().max() / max(float(b.abs().max()), 1e-300)) < 1e-10 or k == 0
+    with torch.no_grad():
+        ce = OE.build_contact_energy(c.bonds)
+        contact = np.array([float(ce(fields[k, 0], cp)) for k in range(len(ts))])
+    keep = np.arange(0, intervals + 1, 2)          # every other output row travels (file size)
+    np.savez_compressed(os.path.join(OUT, "long_horizon_quads32.npz"), timepoints=ts, spi=spi, target=target, seed=seed, n=n, cutoff_deg=cut,
+                        rows=keep, fields=fields.numpy()[keep], objective=obj, contact_energy=contact,
+                        **{f"design_{i}": d for i, d in enumerate(c.design)}, **{f"grad_{i}": a.numpy() for i, a in enumerate(grads)})
+    print("quads32 objective", obj, "contact energy", contact[0], "->", contact[-1], "total", time.time() - t0, "s", flush=True)
+
+
 def pulse_rs_script(n1_cells=20, n2_cells=10, name="pulse_rs"):
     """scripts/pulse_RS.py as written, on the oracle: 20 x 10 cells of rotated squares (40 x 20 blocks) at 0.35 rad, nonlinear
     ligaments (1, 0.33, 0.0075), no constraints, no damping, the sech^2 tanh force pulse on the second column of blocks, the reference's
@@ -219,11 +294,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "long":
         long_horizon()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "long32":
+        long_horizon_32()
+        sys.exit(0)
     rhs_cases()
     adaptive_trajectory()
     focusing_gradient()
     problem_layer()
     long_horizon()
+    long_horizon_32()
     pulse_rs_script()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
