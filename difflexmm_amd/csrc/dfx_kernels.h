@@ -32,7 +32,7 @@ using namespace dfx;
 #define DFX_ADJ_RB_OCC __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
-namespace {
+namespace dfx {    // types and constants the host side's translation units share (everything device-side stays in the anonymous namespace below)
 
 // Index arithmetic inside the stage kernels is 32-bit (one s_mul / v_mad instead of a 64-bit multiply chain per array);
 // dfx_create refuses ensembles whose largest per-handle array would not fit (check_index_range).  The trajectory
@@ -162,6 +162,10 @@ struct DevCtx {
   double* blk_c;          // batch * n_blocks*3    d/d(damping) or null
   double* fn_g;           // batch * n_special*MAX_FNS*FN_PARAMS or null
 };
+
+}  // namespace dfx
+
+namespace {
 
 // ---- quad (4-lane) data movement on DPP: no LDS traffic, no bank conflicts --------------------
 template <int CTRL>

@@ -38,3 +38,13 @@ def hip_lib():
     """The product library; loading it without a GPU is fine, creating a solver is not."""
     from difflexmm_amd._binding import load_library
     return load_library()
+
+
+@pytest.fixture(scope="session")
+def experimental_lib(hip_lib):
+    """The opt-in experiments (two stages per launch on lattice windows, every ligament once on lattice tiles) and the test hook
+    DFX_TEST_FREE_BYTES are compiled into `make -C difflexmm_amd/csrc experimental` only (libdfx_experimental.so), never into the
+    default library: their tests run when DFX_LIBRARY points at such a build and skip otherwise."""
+    if b"experimental" not in hip_lib.dfx_version():
+        pytest.skip("needs a library built with -DDFX_EXPERIMENTAL (make -C difflexmm_amd/csrc experimental; DFX_LIBRARY=difflexmm_amd/libdfx_experimental.so)")
+    return hip_lib

@@ -259,7 +259,7 @@ def test_adaptive_solve_on_member_group_streams_equals_one_stream(hip_lib, monke
     assert np.array_equal(out["1"][3], out["2"][3]) and np.array_equal(out["1"][0], out["2"][0]) and np.abs(out["1"][0]).max() > 0
 
 
-def test_checkpoint_level_survives_low_free_memory_once_allocated(hip_lib, monkeypatch):
+def test_checkpoint_level_survives_low_free_memory_once_allocated(experimental_lib, monkeypatch):
     """Round-2 advice: choose_checkpoint ran its 5 %-of-HBM-free test even for buffers that already existed, so the second solve of a
     loop that nearly fills the device silently dropped from records to segments (3 s launches per step instead of s).  A level whose
     buffers exist must fit; only growth is checked.  DFX_TEST_FREE_BYTES makes the engine believe the device is almost full."""

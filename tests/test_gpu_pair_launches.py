@@ -38,7 +38,7 @@ FAST = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)
 
 
 @pytest.mark.parametrize("lattice,n,rows", [("quads", 37, "16"), ("quads", 37, "8"), ("kagome", 21, "16"), ("quads", 12, "8")])
-def test_pair_launches_equal_stage_launches(hip_lib, lattice, n, rows):
+def test_pair_launches_equal_stage_launches(experimental_lib, lattice, n, rows):
     c = Case(lattice, n, True, True, seed=21, cutoff_deg=42.0 if lattice == "quads" else 125.0)
     c.cp = c.cp._replace(constraint_params=FAST)
     ts = np.linspace(0.0, 3e-4, 4)
@@ -61,7 +61,7 @@ def test_pair_launches_equal_stage_launches(hip_lib, lattice, n, rows):
             assert relerr(out[2][k], ref[2][k]) < 1e-10, (level, k)
 
 
-def test_pair_launches_match_the_oracle(hip_lib):
+def test_pair_launches_match_the_oracle(experimental_lib):
     """20 x 20 quads (2 x 2 windows), contact engaged: fields of a 24-step solve against the oracle's fixed-grid solver."""
     c = Case("quads", 20, True, True, seed=5, cutoff_deg=42.0)
     c.cp = c.cp._replace(constraint_params=FAST)

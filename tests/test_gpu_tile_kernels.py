@@ -38,7 +38,7 @@ def _case(lattice, n, env):
 
 
 @pytest.mark.parametrize("lattice,n", [("quads", 37), ("kagome", 21), ("quads", 12), ("kagome", 7), ("quads", 15)])
-def test_tile_kernels_equal_slot_kernels(hip_lib, lattice, n):
+def test_tile_kernels_equal_slot_kernels(experimental_lib, lattice, n):
     ts = np.linspace(0.0, 3e-4, 4)
     ref_c = _case(lattice, n, {"DFX_TILE": "0"})
     mid = ref_c.geo.n_blocks // 2
@@ -55,7 +55,7 @@ def test_tile_kernels_equal_slot_kernels(hip_lib, lattice, n):
     assert np.abs(ref[2]["centroid_node_vectors"]).max() > 0 and np.abs(ref[2]["void_angle0"]).max() > 0 and ref[1] > 0
 
 
-def test_tile_kernels_match_the_oracle(hip_lib):
+def test_tile_kernels_match_the_oracle(experimental_lib):
     """20 x 20 quads (2 x 3 tiles), contact engaged: fields of a 24-step solve against the oracle's fixed-grid solver."""
     c = _case("quads", 20, {"DFX_TILE": "1"})
     ts = np.linspace(0.0, 2.4e-4, 3)

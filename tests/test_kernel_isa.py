@@ -12,8 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _function(txt, name):
-    i = txt.index("\n" + name + ":")
+def _function(txt, prefix):
+    """Instructions of the kernel whose mangled name starts with `prefix` (the template instance; the parameter types follow)."""
+    m = re.search(r"\n(" + re.escape(prefix) + r"\S*):", txt)
+    assert m, prefix
+    i = m.start()
     body = txt[i:txt.index(".Lfunc_end", i)].split("\n")
     return [l.strip() for l in body if l.strip() and not l.strip().startswith((";", ".", "_")) and not l.strip().endswith(":")]
 
@@ -22,10 +25,10 @@ def _function(txt, name):
 def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     out = tmp_path / "dfx.s"
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(ROOT, "difflexmm_amd", "csrc", "dfx_engine.hip")], stderr=subprocess.DEVNULL)
+                           os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")], stderr=subprocess.DEVNULL)
     txt = out.read_text()
-    fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
-    adj = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi0ELin1EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
+    fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EE")
+    adj = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi0ELin1EE")
     # forward: 5 waves per SIMD are bought with ~100 B/lane of scratch, all of it inside the time-function path that only the lanes of
     # driven blocks execute -- the ligament + contact evaluation (the first ~1000 instructions) must stay free of scratch traffic
     first_spill = next((n for n, x in enumerate(fwd) if x.startswith("scratch_")), len(fwd))
@@ -40,7 +43,7 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
         if x.startswith("s_waitcnt") and "vmcnt" in x:
             break
     assert n_loads >= 20, f"k_fwd_stage: first vmcnt wait after only {n_loads} loads"
-    meta = re.search(r"\.name:\s+_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii.*?\.vgpr_count:\s+(\d+)", txt, re.S)
+    meta = re.search(r"\.name:\s+_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EE.*?\.vgpr_count:\s+(\d+)", txt, re.S)
     assert meta and int(meta.group(1)) <= 102, "k_fwd_stage<nonlinear,contact> no longer fits 5 waves per SIMD"
     # reverse: both builds must keep four waves per SIMD (<= 128 VGPRs); the stage-checkpoint build, pinned to that occupancy, may
     # spill a little (12 B/lane when this was written) but not more
@@ -57,7 +60,7 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     # the builds that read the time functions from the segment's table (fixed-grid solves: the hot ones): the forward kernel has no
     # scratch at all, neither build spills scalar registers in its main path (v_readlane / v_writelane: the first version of the table
     # cost the main path 26 of them per wave, found in the SQ counters)
-    fwd_t = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi0ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
+    fwd_t = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi0ELin1ELi1EE")
     assert not any(x.startswith("scratch_") for x in fwd_t), "k_fwd_stage<nonlinear,contact,4,table> spills"
     assert sum(x.startswith(("v_readlane", "v_writelane")) for x in fwd_t) <= 8, "k_fwd_stage<..., table>: scalar-register spills"
     n_loads = 0
@@ -82,8 +85,8 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     # round 4: the write-through builds (template parameter WT = 1: what 16 x 128x128 launches run) keep the same budgets -- the
     # forward one was lost once already to 30 scalar-register spills in its hot path (profiles/r04_write_through_stores.txt) -- and
     # their stores really carry sc1
-    fwd_w = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELin1ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
-    adj_w = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELin1EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
+    fwd_w = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELin1ELi1EE")
+    adj_w = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELin1EE")
     assert not any(x.startswith("scratch_") for x in fwd_w + adj_w)
     assert sum(x.startswith(("v_readlane", "v_writelane")) for x in fwd_w) <= 8, "k_fwd_stage<..., table, WT>: scalar-register spills"
     # (round 4: the reverse kernel's 17 spilled scalar registers are gone -- its epilogue pointers are fetched late, late_arg -- and
@@ -99,22 +102,52 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     # the per-stage builds of the two (stage index a template parameter: what 16 x 128x128 launches of Dopri5 really run): no scalar spills,
     # no scratch, the register budgets of their generic builds
     for st in range(6):
-        f = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
-        a = _function(txt, f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
+        f = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EE")
+        a = _function(txt, f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EE")
         assert not any(x.startswith("scratch_") for x in f + a), st
         assert sum(x.startswith(("v_readlane", "v_writelane")) for x in f) <= 8 and sum(x.startswith(("v_readlane", "v_writelane")) for x in a) <= 4, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EE")[1] <= 96, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EE")[1] <= 128, st
         # ... and of the packed-triangle mapping (kagome ensembles)
-        f3 = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi1ELi{st}ELi1EEEvNS_6DevCtxENS_9StageCoefEiiiiii")
-        a3 = _function(txt, f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi1ELi{st}EEEvNS_6DevCtxENS_7AdjCoefEiiiiiNS_9StageCoefEi")
+        f3 = _function(txt, f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi1ELi{st}ELi1EE")
+        a3 = _function(txt, f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi1ELi{st}EE")
         assert not any(x.startswith("scratch_") for x in f3 + a3), st
         assert sum(x.startswith(("v_readlane", "v_writelane")) for x in f3) <= 8 and sum(x.startswith(("v_readlane", "v_writelane")) for x in a3) <= 4, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi1ELi{st}ELi1EE")[1] <= 102, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi1ELi{st}EE")[1] <= 128, st
-    # the opt-in tile kernels (dfx_tile.h): no scratch, no workgroup barrier (wave-private tiles: LDS operations of a wave are in order)
-    for nm in ("_ZN12_GLOBAL__N_110k_fwd_tileILi1ELi1EEEvNS_6DevCtxENS_6LigCtxENS_9StageCoefEiiiiii",
-               "_ZN12_GLOBAL__N_110k_adj_tileILi1ELi1EEEvNS_6DevCtxENS_6LigCtxENS_7AdjCoefEiii"):
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_persistent_kernels_fit_their_occupancy(tmp_path):
+    """The persistent stage loop (dfx_persist.hip, compiled without machine-level loop-invariant code motion: dfx_persist_api.h): the
+    forward kernels must fit FOUR workgroups per compute unit (<= 128 VGPRs; with the hoisting on they need 203), the reverse kernels two
+    (<= 256), and neither may touch scratch -- the host sizes its launches by these numbers (persist_wg_per_cu)."""
+    out = tmp_path / "persist.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-S", "--cuda-device-only",
+                           "-o", str(out), os.path.join(ROOT, "difflexmm_amd", "csrc", "dfx_persist.hip")], stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(_ZN12_GLOBAL__N_113k_(fwd|adj)_persist\S*)(.*?)\.vgpr_count:\s+(\d+)", txt, re.S):
+        blk = m.group(3)
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        assert scratch == 0, (m.group(1), scratch)
+        assert int(m.group(4)) <= (128 if m.group(2) == "fwd" else 256), (m.group(1), m.group(4))
+        seen += 1
+    assert seen == 16
+    # every ring access is write-through / past the L1: sc1 on every 16-byte ring store and load, and no plain dwordx4 load in the poll
+    # (forward: publish at the start, re-poison, publish = 3 stores, one poll of 2 loads; reverse: re-poison, publish = 2 stores, one poll)
+    assert len(re.findall(r"global_store_dwordx4 .* sc1", txt)) == 8 * 3 + 8 * 2 and len(re.findall(r"global_load_dwordx4 .* sc1", txt)) == 16 * 2
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) or not os.environ.get("DFX_TEST_EXPERIMENTAL_ISA"), reason="opt-in experiments: set DFX_TEST_EXPERIMENTAL_ISA=1")
+def test_tile_kernels_have_no_scratch_and_no_barrier(tmp_path):
+    """The opt-in tile kernels (dfx_tile.h, -DDFX_EXPERIMENTAL builds only): no scratch, no workgroup barrier (wave-private tiles; the
+    exchange through LDS is ordered by wavefront-scope fences, which emit no instruction)."""
+    out = tmp_path / "exp.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DDFX_EXPERIMENTAL", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")], stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    for nm in ("_ZN12_GLOBAL__N_110k_fwd_tileILi1ELi1EE", "_ZN12_GLOBAL__N_110k_adj_tileILi1ELi1EE"):
         body = _function(txt, nm)
         assert not any(x.startswith("scratch_") for x in body), nm
         assert not any(x.startswith("s_barrier") for x in body), nm
