@@ -27,12 +27,14 @@
 // 128x128 system with 352 fp64 operations per lane, every word of every record equal to the one-launch-per-stage form, also under
 // uneven load, 4 workgroups per compute unit, and with finite garbage in the unpoisoned places.
 //
-// Residency.  All waves of a launch must be resident at once: grid = ceil(waves / 4) workgroups of 256 threads (one wave per SIMD);
-// the launch asks for just enough dynamic LDS that a compute unit admits exactly ceil(grid / CUs) of them (an even spread: one wave
-// per SIMD for one 128x128 system), and the host refuses shapes that do not fit (persist_fits).  Two persistent launches of one
-// process never overlap on the device (a partial residency of both would starve both): the engine chains them through one event
-// (persist_serialize).  Checkpoint stores (records / state / stage accelerations) are plain stores beside the ring, in the layout the
-// stage kernels write, so every reverse path reads them unchanged.
+// Residency.  All waves of a launch must be resident at once: grid = ceil(waves / 4) workgroups of 256 threads (one wave per SIMD),
+// which the dispatcher spreads evenly over the compute units by itself (measured with and without an LDS allocation that would force
+// it: profiles/r05_persistent_stage_mock.txt run 5, profiles/r05_persistent_kernels.txt), and the host refuses shapes whose
+// workgroups per compute unit exceed what the kernel's registers allow (persist_members_that_fit: members beyond it follow in a
+// second launch of the same segment).  Persistent launches of different streams (several engines of one process) overlap only while
+// their needs fit a compute unit together; otherwise the later one queues behind the other stream (engine_launch.hip, launch_persist):
+// two half-resident launches would starve each other.  Checkpoint stores (records / state / stage accelerations) are plain stores
+// beside the ring, in the layout the stage kernels write, so every reverse path reads them unchanged.
 #pragma once
 #include "dfx_persist_api.h"
 

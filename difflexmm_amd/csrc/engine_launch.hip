@@ -270,25 +270,32 @@ void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wb
 }
 
 // ---- the stage loop without kernel boundaries (dfx_persist.h) ---------------------------------------------------------------------
-// Two persistent launches must never share the device: each needs ALL its workgroups resident, and two half-resident launches would
-// wait for each other until their spins give up.  Every persistent launch of the process therefore waits for the one before it
-// (whatever handle or stream issued it) through one event per device.
+// A persistent launch needs ALL its workgroups resident at once; two of them that are each half resident would wait for each other
+// until their spins give up.  Residency is a matter of registers (256-thread workgroups = one wave per SIMD; the dispatcher spreads
+// them evenly by itself: profiles/r05_persistent_stage_mock.txt, run 5), so the process keeps account in SLOTS: a compute unit has
+// kPersistSlots of 128 registers per lane; a workgroup of the forward kernels takes one, of the reverse kernels (<= 256 registers) two;
+// a launch takes  workgroups per compute unit x slots per workgroup.  Launches on ONE stream follow each other anyway; launches on
+// different streams (the engines of a multi-input objective, one host thread each) may overlap while the streams' largest
+// outstanding needs sum to <= kPersistSlots -- otherwise the new launch first waits for everything another stream has queued.
+static const int kPersistSlots = 4;
+struct PersistInflight { hipEvent_t ev; hipStream_t st; int slots; };
 static std::mutex g_persist_mu;
-static hipEvent_t g_persist_tail[64];
-static bool g_persist_tail_on[64];
-static const int kPersistLdsBudget = 150 * 1024;    // of a compute unit's 160 KB: room for the stage kernels' small LDS users next to us
+static std::vector<PersistInflight> g_persist_inflight[64];
+static std::vector<hipEvent_t> g_persist_events[64];        // recycled
 
-// workgroups of `fn` a compute unit can hold at once (registers; 256-thread workgroups = one wave per SIMD each), capped where the
-// residency rule of MI355X_MICROARCH.md ("Residency and cooperative launch") starts to depend on the scalar-register count
-static int persist_wg_per_cu(const void* fn) {
+// slots one workgroup of `fn` takes (by its register allocation); 0: the kernel cannot be launched
+static int persist_wg_slots(const void* fn) {
+  static std::mutex mu;
+  static std::map<const void*, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(fn);
+  if (it != cache.end()) return it->second;
   hipFuncAttributes at;
   if (!fn || hipFuncGetAttributes(&at, fn) != hipSuccess) { (void)hipGetLastError(); return 0; }
   const int alloc = std::max(8, ((at.numRegs + 7) / 8) * 8);
-  int cap = std::min({8, 512 / alloc, 6});
-  if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
-  return cap;
+  const int cap = std::min(kPersistSlots, 512 / alloc);        // workgroups per compute unit the registers allow
+  return cache[fn] = cap <= 0 ? 0 : (kPersistSlots + cap - 1) / cap;
 }
-// which lattices and solves the persistent kernels serve (everything else keeps one launch per stage)
 bool persist_shape_ok(const dfx_handle* h) {
   const Plan& pl = h->pl;
   const char* e = getenv("DFX_PERSIST");
@@ -302,17 +309,18 @@ static int persist_waves_per_member(const dfx_handle* h, int npb) {
 // how many members fit on the chip at once (0: not even one), and the launch shape for `nm` of them
 int persist_members_that_fit(dfx_handle* h, const void* fn, int npb) {
   if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return 0; h->n_cu = v; }
-  const int cap = persist_wg_per_cu(fn);
+  const int wg_slots = persist_wg_slots(fn);
+  int cap = wg_slots ? kPersistSlots / wg_slots : 0;
+  if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
   const long long wpm = persist_waves_per_member(h, npb);
   if (cap <= 0 || wpm <= 0) return 0;
   return (int)std::min<long long>(h->pl.batch, ((long long)cap * h->n_cu * 4) / wpm);
 }
-static void persist_shape(const dfx_handle* h, int npb, int nm, int* grid, int* lds) {
+static void persist_shape(const dfx_handle* h, int npb, int nm, int* grid, int* per_cu) {
   const long long waves = (long long)nm * persist_waves_per_member(h, npb);
   const long long g = (waves + 3) / 4;
-  const long long per_cu = std::max<long long>(1, (g + h->n_cu - 1) / h->n_cu);
   *grid = (int)g;
-  *lds = (kPersistLdsBudget / (int)per_cu) & ~1023;
+  *per_cu = (int)std::max<long long>(1, (g + h->n_cu - 1) / h->n_cu);
 }
 // launches per segment a solve may be cut into (members that do not fit at once follow in further launches of the same segment); beyond
 // it the stage launches serve the solve: a launch that fills the chip several times over is what the stage kernels are tuned for.
@@ -363,16 +371,35 @@ static PersistCoef persist_coef(const Tableau& T) {
   return pc;
 }
 int* persist_give_up_word(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 2; }   // (word 0: non-finite flag, word 1: touched flag)
-// one launch, chained behind the previous persistent launch of the process
-static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void** args, int grid, int lds) {
-  static std::map<const void*, int> lds_set;
+// one launch, admitted by the slot account above
+static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void** args, int grid, int need) {
   std::lock_guard<std::mutex> lk(g_persist_mu);
-  if (lds_set[fn] < lds) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLdsBudget); lds_set[fn] = kPersistLdsBudget; }
   const int d = h->device & 63;
-  if (g_persist_tail_on[d]) (void)hipStreamWaitEvent(st, g_persist_tail[d], 0);
-  else { (void)hipEventCreateWithFlags(&g_persist_tail[d], hipEventDisableTiming); g_persist_tail_on[d] = true; }
-  (void)hipLaunchKernel(fn, dim3(grid), dim3(kPersistThreads), args, lds, st);
-  (void)hipEventRecord(g_persist_tail[d], st);
+  auto& fl = g_persist_inflight[d];
+  for (size_t i = 0; i < fl.size();)          // retire what has finished
+    if (hipEventQuery(fl[i].ev) == hipSuccess) { g_persist_events[d].push_back(fl[i].ev); fl.erase(fl.begin() + i); } else { (void)hipGetLastError(); ++i; }
+  for (;;) {
+    // the other streams' largest outstanding needs (launches of one stream never overlap)
+    std::map<hipStream_t, std::pair<int, size_t>> other;       // stream -> (largest need, index of its latest entry)
+    for (size_t i = 0; i < fl.size(); ++i)
+      if (fl[i].st != st) { auto& o = other[fl[i].st]; o.first = std::max(o.first, fl[i].slots); o.second = i; }
+    int total = need;
+    for (auto& kv : other) total += kv.second.first;
+    if (total <= kPersistSlots || other.empty()) break;
+    // over the budget: queue behind everything the stream whose latest launch is oldest has outstanding, and forget its entries
+    auto victim = other.begin();
+    for (auto it = other.begin(); it != other.end(); ++it) if (it->second.second < victim->second.second) victim = it;
+    (void)hipStreamWaitEvent(st, fl[victim->second.second].ev, 0);
+    const hipStream_t vs = victim->first;
+    for (size_t i = 0; i < fl.size();)
+      if (fl[i].st == vs) { fl[i].st = st; ++i; } else ++i;      // (ordered before us from now on: they count as this stream's)
+  }
+  (void)hipLaunchKernel(fn, dim3(grid), dim3(kPersistThreads), args, 0, st);
+  hipEvent_t ev = nullptr;
+  if (!g_persist_events[d].empty()) { ev = g_persist_events[d].back(); g_persist_events[d].pop_back(); }
+  else (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  (void)hipEventRecord(ev, st);
+  fl.push_back({ev, st, need});
   h->launches++;
 }
 // one segment of the group's members: the first ring places poisoned, then the whole segment in one launch per `per_launch` members
@@ -391,15 +418,15 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     const int cnt = std::min(per, nm - off);
     DevCtx cc = c;
     cc.m0 = c.m0 + off;
-    int grid = 0, lds = 0;
-    persist_shape(h, npb, cnt, &grid, &lds);
+    int grid = 0, per_cu = 0;
+    persist_shape(h, npb, cnt, &grid, &per_cu);
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
     pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
     void* args_f[] = {&cc, &pcf, &pa};
     void* args_r[] = {&cc, &pca, &pa};
-    launch_persist(h, fn, st, reverse ? args_r : args_f, grid, lds);
+    launch_persist(h, fn, st, reverse ? args_r : args_f, grid, per_cu * persist_wg_slots(fn));
   }
 }
 static void launch_fwd_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) { launch_segment_persist(h, c, st, nm, n_steps, false); }

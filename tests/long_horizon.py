@@ -15,8 +15,13 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL_FIELDS, TOL_OBJECTIVE, TOL_GRAD = 1e-9, 1e-9, 1e-8
 
 
-def check(lib, lattice):
+def check(lib, lattice, tol_fields=TOL_FIELDS, tol_objective=TOL_OBJECTIVE, tol_grad=TOL_GRAD):
+    """`lattice`: "quads" (8 x 8, 1 200 steps), "kagome" (4 x 4 cells, 800 steps), or "quads32": 32 x 32 quads, 2 000 steps -- a size
+    at which the engine's size-dependent code runs (several workgroups, XCD-banded order, more than one segment, the persistent loop's
+    ring wrapping 1 500 times); its gradient was assembled interval by interval (make_golden.py long_horizon_32) and every other
+    output row travels."""
     g = np.load(os.path.join(GOLD, f"long_horizon_{lattice}.npz"))
+    lattice = "quads" if lattice == "quads32" else lattice
     c = Case(lattice, int(g["n"]), True, True, seed=int(g["seed"]), lib=lib, cutoff_deg=float(g["cutoff_deg"]))
     design = tuple(g[f"design_{i}"] for i in range(len(c.design)))
     for a, b in zip(design, c.design):
@@ -26,12 +31,14 @@ def check(lib, lattice):
     nb = c.geo.n_blocks
     f = c.solver(np.zeros((2, nb, 3)), g["timepoints"], cp, keep_trajectory=True, steps_per_interval=int(g["spi"]))
     assert c.solver.stats["steps"] == int(g["spi"]) * (len(g["timepoints"]) - 1)
+    if "rows" in g.files:
+        f = f[g["rows"]]
     out = dict(q=relerr(f[:, 0], g["fields"][:, 0]), v=relerr(f[:, 1], g["fields"][:, 1]))
     obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(g["target"].astype(np.int32))
     grads = c.geo.vjp(design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
     out["objective"] = abs(obj - float(g["objective"])) / abs(float(g["objective"]))
     out["grad"] = max(relerr(a, g[f"grad_{i}"]) for i, a in enumerate(grads))
-    assert out["q"] < TOL_FIELDS and out["v"] < TOL_FIELDS, out
-    assert out["objective"] < TOL_OBJECTIVE, out
-    assert out["grad"] < TOL_GRAD, out
+    assert out["q"] < tol_fields and out["v"] < tol_fields, out
+    assert out["objective"] < tol_objective, out
+    assert out["grad"] < tol_grad, out
     return out

@@ -101,3 +101,36 @@ def test_persistent_forward_matches_the_oracle(hip_lib):
     lv = dict(loading_rate=torch.tensor(3000.0, dtype=torch.float64), input_delay=torch.tensor(1e-5, dtype=torch.float64))
     osol = c.oracle_solver(integrator="fixed", steps_per_interval=12)
     assert relerr(fields, osol(np.zeros((2, 400, 3)), ts, c.oracle_cp(lv)).numpy()) < 1e-10
+
+
+def test_concurrent_engines_share_the_chip(hip_lib):
+    """Three engines driven from three host threads at once, as the inputs of a multi-input objective are (problems/
+    quads_focusing_multi_input.py:66-86 evaluates them in turn; here they overlap on three streams): their persistent launches are admitted
+    side by side while their register needs fit a compute unit, and queue behind each other otherwise -- whatever the interleaving,
+    every engine's numbers equal those of the same solve run alone."""
+    import threading
+    cases = [Case("quads", n, True, True, seed=40 + i, cutoff_deg=42.0, batch=b) for i, (n, b) in enumerate(((24, 3), (37, 2), (30, 4)))]
+    ts = np.linspace(0.0, 3e-4, 3)
+    solo = []
+    for c in cases:
+        c.cp = c.cp._replace(constraint_params=FAST)
+        mid = c.geo.n_blocks // 2
+        c.target = np.array([mid + 1, mid + 2], dtype=np.int32)
+        solo.append(_solve(c, ts, 130, c.target, {}))
+        assert solo[-1][3]["tile_kernels"] == 3 and solo[-1][3]["adjoint"]["tile_kernels"] == 3
+    for rep in range(3):
+        out, errs = [None] * len(cases), []
+
+        def work(i):
+            try:
+                out[i] = _solve(cases[i], ts, 130, cases[i].target, {})
+            except Exception as e:       # noqa: BLE001
+                errs.append((i, repr(e)))
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for a, b in zip(out, solo):
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+            for k in b[2]:
+                assert np.array_equal(a[2][k], b[2][k]), k

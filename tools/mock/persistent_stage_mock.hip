@@ -274,7 +274,8 @@ int main(int argc, char** argv) {
   // ---- persistent
   const int wg_per_cu = (grid + n_cu - 1) / n_cu;
   if (wg_per_cu > 8) { printf("too many workgroups to be resident (%d per CU)\n", wg_per_cu); return 1; }
-  const int lds = wg_per_cu == 1 ? 96 * 1024 : (160 * 1024 / wg_per_cu) & ~1023;   // admits exactly wg_per_cu workgroups per compute unit
+  int lds = wg_per_cu == 1 ? 96 * 1024 : (160 * 1024 / wg_per_cu) & ~1023;   // admits exactly wg_per_cu workgroups per compute unit
+  if (getenv("MOCK_LDS")) lds = atoi(getenv("MOCK_LDS"));     // (experiment: does the dispatcher spread workgroups by itself?)
   CK(hipFuncSetAttribute((const void*)k_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   {
     int* cu_count; CK(hipMalloc(&cu_count, 8 * 8 * 32 * 4)); CK(hipMemset(cu_count, 0, 8 * 8 * 32 * 4));
