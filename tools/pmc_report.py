@@ -7,7 +7,8 @@ for d in sys.argv[1:]:
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             n_ = r["Kernel_Name"]
-            k = "fwd" if ("k_fwd_stage" in n_ or "k_fwd_tile" in n_) else "adj" if ("k_adj_stage" in n_ or "k_adj_tile" in n_) else None
+            k = ("fwd_persist" if "k_fwd_persist" in n_ else "adj_persist" if "k_adj_persist" in n_ else
+                 "fwd" if ("k_fwd_stage" in n_ or "k_fwd_tile" in n_) else "adj" if ("k_adj_stage" in n_ or "k_adj_tile" in n_) else None)
             if k:
                 acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in acc.items():
