@@ -674,6 +674,9 @@ def main():
     from difflexmm_amd import _binding as B
     if args.all_ranks_device >= 0:
         local_rank = args.all_ranks_device
+        # several PROCESSES on one GPU: the persistent stage loop needs all workgroups of a launch resident, and the account that keeps
+        # concurrent persistent launches within the chip is per process -- the rehearsal keeps one launch per stage
+        os.environ["DFX_PERSIST"] = "0"
     comm, comm_info = make_comm(args, world, rank, local_rank)
     collective = comm_info["collective"]
     if args.workload == "c4":

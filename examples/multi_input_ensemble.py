@@ -79,6 +79,7 @@ def main(argv=None):
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if args.all_ranks_device >= 0:
         local_rank = args.all_ranks_device
+        os.environ["DFX_PERSIST"] = "0"      # several processes on one GPU: one launch per stage (bench.py says why)
     from difflexmm_amd import problems as P
     from difflexmm_amd import ensemble
     from difflexmm_amd.optimize import MemberWorkers
