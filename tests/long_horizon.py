@@ -31,14 +31,25 @@ def check(lib, lattice, tol_fields=TOL_FIELDS, tol_objective=TOL_OBJECTIVE, tol_
     nb = c.geo.n_blocks
     f = c.solver(np.zeros((2, nb, 3)), g["timepoints"], cp, keep_trajectory=True, steps_per_interval=int(g["spi"]))
     assert c.solver.stats["steps"] == int(g["spi"]) * (len(g["timepoints"]) - 1)
+    row_tol = None
     if "rows" in g.files:
         f = f[g["rows"]]
+        # the golden carries how far the oracle's own two paths (taped interval by interval / tape-free) have drifted apart at every output:
+        # this contact-engaged trajectory amplifies a last-bit difference ~10 x per 250 steps (1.6e-15 after 250 steps, 2.4e-8 after 2 000),
+        # so the bound on the FIELDS follows the row -- 50 x that drift, at least 1e-11 -- while objective and gradient keep the flat bounds
+        row_tol = np.maximum(1e-11, 50.0 * g["oracle_paths_agree"][g["rows"]])
     out = dict(q=relerr(f[:, 0], g["fields"][:, 0]), v=relerr(f[:, 1], g["fields"][:, 1]))
     obj, tree, _ = c.solver.kinetic_energy_value_and_vjp(g["target"].astype(np.int32))
     grads = c.geo.vjp(design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
     out["objective"] = abs(obj - float(g["objective"])) / abs(float(g["objective"]))
     out["grad"] = max(relerr(a, g[f"grad_{i}"]) for i, a in enumerate(grads))
-    assert out["q"] < tol_fields and out["v"] < tol_fields, out
+    if row_tol is not None:
+        for i in range(1, len(row_tol)):
+            rq, rv = relerr(f[i, 0], g["fields"][i, 0]), relerr(f[i, 1], g["fields"][i, 1])
+            out[f"row{int(g['rows'][i])}"] = (rq, rv, float(row_tol[i]))
+            assert rq < row_tol[i] and rv < row_tol[i], out
+    else:
+        assert out["q"] < tol_fields and out["v"] < tol_fields, out
     assert out["objective"] < tol_objective, out
     assert out["grad"] < tol_grad, out
     return out
