@@ -9,9 +9,9 @@ OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
-ARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written"
+ARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written --no-launch-bound"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-PARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written"
+PARGS="bench.py --streams 1 --members $M --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written --no-launch-bound"
 export DFX_DUAL_CHAIN=0
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $PARGS > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python3 $PARGS > /dev/null 2> $OUT/pmc_write.err
