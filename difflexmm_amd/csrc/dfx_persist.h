@@ -283,16 +283,19 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
 
 // ---- reverse: every stage of every step of one segment in one launch --------------------------------------------------------------
 // The records build of k_adj_stage (records or segments checkpoint, no per-ligament gradients) with everything a DOF or a slot owns
-// kept in registers across the segment: lambda, the later stages' Ybar, the node-vector / void-angle / inertia / damping accumulators
-// (one read-modify-write per SEGMENT instead of one per stage: 176 of the launch's 611 B per unit), the ligament's parameters.  What
+// kept on the compute unit across the segment: lambda and the ligament's parameters in registers, the later stages' Ybar and the
+// node-vector / void-angle / inertia / damping accumulators in lane-private LDS (one read-modify-write of the arrays per SEGMENT
+// instead of one per stage: 176 of the launch's 611 B per unit).  What
 // crosses waves is w = Kbar_v / m of the next stage to run, three doubles per block: the ring record is (w_x, w_y | w_theta, 0).
 // The stage records the sweep linearises about come from the checkpoint (plain loads: written by an earlier launch), issued in front
 // of the poll so that the two round trips overlap.  The first stage of a launch reads the partner's w where the previous launch
 // (k_adj_begin, a stage launch, or this kernel) left it -- DevCtx::W -- and the last one leaves its own there, with lambda in LAM and
 // the accumulators in their arrays: segments run by this kernel and by stage launches can alternate.
 
+// (three workgroups per compute unit: 168 registers; the allocator's own choice is 170-172, the limit costs two 8-byte spills of
+// epilogue pointers OUTSIDE the stage loop)
 template <int MODEL, int CONTACT, int NPB>
-__global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, PersistAdjCoef pc, PersistArgs pa) {
+__global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_adj_persist(DevCtx c, PersistAdjCoef pc, PersistArgs pa) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
   if (wave >= pa.waves_per_member * pa.nm) return;
   const int ml = wave / pa.waves_per_member, w = wave - ml * pa.waves_per_member;
@@ -315,19 +318,25 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
   const bool constrained = k < 3 && sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> k) & 1);
   // ---- resident: lambda, accumulators
   double* LAMm = c.LAM + (size_t)((u32)m * nd6);
-  double2 lam = ldg<double2>(LAMm, o_b6);
   const u32 ms = (u32)m * (u32)c.n_slots;
   double* grm = c.g_r + (size_t)(ms * 2);
   double* gpm = c.g_phi + (size_t)ms;
   double* bmm = c.blk_m + (size_t)((u32)m * nd);
   double* bcm = c.blk_c ? c.blk_c + (size_t)((u32)m * nd) : nullptr;
-  double2 r_acc = ldg<double2>(grm, (u32)slot * 16);
-  double p_acc = CONTACT == 1 ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
-  double bm_acc = ldg<double>(bmm, o_dof), bc_acc = bcm ? ldg<double>(bcm, o_dof) : 0.0;
+  // The later stages' Ybar (five (q, v) pairs per DOF) and the four accumulators are touched once or twice per stage: they live in LDS,
+  // one private place per lane (no lane reads another lane's: no barrier, no fence) -- 30 registers less, which is what lets three
+  // workgroups of this kernel share a compute unit (171-198 VGPRs before, two workgroups)
+  __shared__ double2 s_yb[kPersistStages - 1][kPersistThreads];
+  __shared__ double2 s_racc[kPersistThreads];
+  __shared__ double s_acc[3][kPersistThreads];        // void angle, inertia, damping
+  __shared__ double2 s_lam[kPersistThreads];
+  const int tid = (int)threadIdx.x;
+  s_racc[tid] = ldg<double2>(grm, (u32)slot * 16);
+  s_lam[tid] = ldg<double2>(LAMm, o_b6);
+  s_acc[0][tid] = CONTACT == 1 ? ldg<double>(gpm, (u32)slot * 8) : 0.0;
+  s_acc[1][tid] = ldg<double>(bmm, o_dof);
+  s_acc[2][tid] = bcm ? ldg<double>(bcm, o_dof) : 0.0;
   bool phi_any = false;
-  double2 yb[kPersistStages];
-#pragma unroll
-  for (int jj = 0; jj < kPersistStages; ++jj) yb[jj] = make_double2(0.0, 0.0);
   // ---- the ring
   const size_t ring_stride = (size_t)c.batch * c.n_blocks * kPos;
   const u32 r_own = ((u32)m * (u32)c.n_blocks + (u32)b) * (kPos * 8) + 16u * (u32)(k & 1);
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
 #pragma unroll
       for (int jj = 1; jj < kPersistStages; ++jj) {
         const bool on = jj > i && jj < s;
-        const double2 y = on ? yb[jj] : make_double2(0.0, 0.0);
+        const double2 y = on ? s_yb[jj - 1][tid] : make_double2(0.0, 0.0);
         const double cf = i > 0 ? pc.col[i][jj] : 1.0;
         sq += cf * y.x;
         sv += cf * y.y;
@@ -370,6 +379,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
         svc += pc.cur[i][jj] * y.y;
       }
       const double col_s = pc.col[i][s], cur_s = pc.cur[i][s], col_i = pc.col[i][i];
+      const double2 lam = s_lam[tid];
       const double lq = lam.x, lv = lam.y;
       const double w_d = (h * (cur_s * lv + svc)) * invm;
       const double wox = blk_bcast<NPB, 0>(w_d, k), woy = blk_bcast<NPB, 1>(w_d, k), woth = blk_bcast<NPB, 2>(w_d, k);
@@ -391,9 +401,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
           eth += g.sgn * cg.dkap.v;
           d_phi = (info & 1) ? cg.p2.e : cg.p1.e;
         }
-        r_acc = make_double2(r_acc.x - d_rx, r_acc.y - d_ry);
+        const double2 r_old = s_racc[tid];
+        s_racc[tid] = make_double2(r_old.x - d_rx, r_old.y - d_ry);
       }
-      if (CONTACT == 1 && d_phi != 0.0) { p_acc -= d_phi; phi_any = true; }
+      if (CONTACT == 1 && d_phi != 0.0) { s_acc[0][tid] -= d_phi; phi_any = true; }
       const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
       const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
       // ---- DOF epilogue
@@ -403,18 +414,16 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
         if (sidx >= 0) {
           const dfx_special& sp = c.special[sidx];
           const double* ft = fn_tab_row(c, m, j, i);
-          double gp[kMaxFnParams];
           for (int f = 0; f < c.n_fns; ++f) {
             const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
             const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
             if ((coef != 0.0 && c.fn_g) || loaded) {
               const u32 z = lane_zero();
               const double gv = fn_tab_get(ft, f, 0, z);
-              if (coef != 0.0 && c.fn_g) for (int kk = 0; kk < kMaxFnParams; ++kk) gp[kk] = fn_tab_get(ft, f, 2 + kk, z);
               if (loaded) fload += sp.load_coef[k][f] * gv;
               if (coef != 0.0 && c.fn_g) {
                 double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
-                for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * gp[kk]);
+                for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * fn_tab_get(ft, f, 2 + kk, z));
               }
             }
           }
@@ -425,11 +434,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
         if (!constrained) {
           ybq = -hw;
           ybv = kq_in - damp * w_d;
-          bm_acc -= w_d * a_i;
-          bc_acc -= w_d * v_i;
+          s_acc[1][tid] -= w_d * a_i;
+          s_acc[2][tid] -= w_d * v_i;
         }
-#pragma unroll
-        for (int jj = 1; jj < kPersistStages; ++jj) yb[jj] = jj == i ? make_double2(ybq, ybv) : yb[jj];
+        if (i > 0) s_yb[i - 1][tid] = make_double2(ybq, ybv);
         double kv;
         if (i > 0) {
           kv = h * (col_s * lv + col_i * ybv + sv);
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
             nlq += G[b * 6 + k]; nlv += G[b * 6 + 3 + k];
           }
           if (constrained) { nlq = 0.0; nlv = 0.0; }
-          lam = make_double2(nlq, nlv);
+          s_lam[tid] = make_double2(nlq, nlv);
           kv = h_before * col_s * nlv;
         }
         w_next = constrained ? 0.0 : kv * invm;
@@ -457,11 +465,11 @@ __global__ __launch_bounds__(kPersistThreads) void k_adj_persist(DevCtx c, Persi
     }
   }
   // ---- what the segment leaves behind
-  if (info >= 0) stg<double2>(grm, (u32)slot * 16, r_acc);
-  if (CONTACT == 1 && phi_any) { stg<double>(gpm, (u32)slot * 8, p_acc); c.touch[0] = 1; }
+  if (info >= 0) stg<double2>(grm, (u32)slot * 16, s_racc[tid]);
+  if (CONTACT == 1 && phi_any) { stg<double>(gpm, (u32)slot * 8, s_acc[0][tid]); c.touch[0] = 1; }
   if (k < 3) {
-    stg<double2>(LAMm, o_b6, lam);
-    if (!constrained) { stg<double>(bmm, o_dof, bm_acc); if (bcm) stg<double>(bcm, o_dof, bc_acc); }
+    stg<double2>(LAMm, o_b6, s_lam[tid]);
+    if (!constrained) { stg<double>(bmm, o_dof, s_acc[1][tid]); if (bcm) stg<double>(bcm, o_dof, s_acc[2][tid]); }
   }
 }
 

@@ -272,12 +272,13 @@ void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wb
 // ---- the stage loop without kernel boundaries (dfx_persist.h) ---------------------------------------------------------------------
 // A persistent launch needs ALL its workgroups resident at once; two of them that are each half resident would wait for each other
 // until their spins give up.  Residency is a matter of registers (256-thread workgroups = one wave per SIMD; the dispatcher spreads
-// them evenly by itself: profiles/r05_persistent_stage_mock.txt, run 5), so the process keeps account in SLOTS: a compute unit has
-// kPersistSlots of 128 registers per lane; a workgroup of the forward kernels takes one, of the reverse kernels (<= 256 registers) two;
-// a launch takes  workgroups per compute unit x slots per workgroup.  Launches on ONE stream follow each other anyway; launches on
+// them evenly by itself: profiles/r05_persistent_stage_mock.txt, run 5), so the process keeps account in SLOTS of 8 registers per lane
+// (the allocation granule): a SIMD has kPersistSlots = 512 / 8 of them; a workgroup takes what its kernel allocates (forward kernels
+// 104-112 registers: four workgroups per compute unit, reverse kernels 168: three); a launch takes  workgroups per compute unit x slots
+// per workgroup.  Launches on ONE stream follow each other anyway; launches on
 // different streams (the engines of a multi-input objective, one host thread each) may overlap while the streams' largest
 // outstanding needs sum to <= kPersistSlots -- otherwise the new launch first waits for everything another stream has queued.
-static const int kPersistSlots = 4;
+static const int kPersistSlots = 64;
 struct PersistInflight { hipEvent_t ev; hipStream_t st; int slots; };
 static std::mutex g_persist_mu;
 static std::vector<PersistInflight> g_persist_inflight[64];
@@ -293,8 +294,7 @@ static int persist_wg_slots(const void* fn) {
   hipFuncAttributes at;
   if (!fn || hipFuncGetAttributes(&at, fn) != hipSuccess) { (void)hipGetLastError(); return 0; }
   const int alloc = std::max(8, ((at.numRegs + 7) / 8) * 8);
-  const int cap = std::min(kPersistSlots, 512 / alloc);        // workgroups per compute unit the registers allow
-  return cache[fn] = cap <= 0 ? 0 : (kPersistSlots + cap - 1) / cap;
+  return cache[fn] = alloc > 512 ? 0 : alloc / 8;
 }
 bool persist_shape_ok(const dfx_handle* h) {
   const Plan& pl = h->pl;
@@ -310,7 +310,7 @@ static int persist_waves_per_member(const dfx_handle* h, int npb) {
 int persist_members_that_fit(dfx_handle* h, const void* fn, int npb) {
   if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return 0; h->n_cu = v; }
   const int wg_slots = persist_wg_slots(fn);
-  int cap = wg_slots ? kPersistSlots / wg_slots : 0;
+  int cap = wg_slots ? std::min(8, kPersistSlots / wg_slots) : 0;      // (8 waves per SIMD at most)
   if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
   const long long wpm = persist_waves_per_member(h, npb);
   if (cap <= 0 || wpm <= 0) return 0;
@@ -414,8 +414,9 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     for (int jj = 0; jj <= kPersistStages; ++jj) { pca.col[i][jj] = ac.col[jj]; pca.cur[i][jj] = ac.cur[jj]; }
     pca.c[i] = ac.c_i;
   }
-  for (int off = 0; off < nm; off += per) {
-    const int cnt = std::min(per, nm - off);
+  const int n_chunks = (nm + per - 1) / per, even = (nm + n_chunks - 1) / n_chunks;      // members that do not fit at once: equal launches
+  for (int off = 0; off < nm; off += even) {
+    const int cnt = std::min(even, nm - off);
     DevCtx cc = c;
     cc.m0 = c.m0 + off;
     int grid = 0, per_cu = 0;

@@ -151,14 +151,17 @@ def test_c5_ensemble_of_8_designs_in_lock_step(hip_lib):
         assert all(np.abs(a - b).max() < 1e-9 for a, b in zip(x, best[m]))
 
 
-def test_c5_at_width_192_designs_three_inputs_shared_checkpoint(hip_lib):
+def test_c5_at_width_192_designs_three_inputs_shared_checkpoint(hip_lib, monkeypatch):
     """BASELINE config 5 at a width that exercises what the 8-member test cannot (problems/quads_focusing_multi_input.py:43-119 for
     every member): 192 designs x 3 inputs x 2 lock-step evaluations through `run_ensemble_optimization` -- wide enough that every
     engine fills the chip alone, so the inputs take turns and the three engines keep their trajectory checkpoints in ONE shared pool
     (below ~170 members of this lattice the inputs run concurrently, each with its own).  The records level must have been taken (three separate checkpoints
     used to push ensembles of this lattice down to the stages level), and members 3 and 141 must see exactly the numbers they see
-    alone."""
+    alone.  The whole test runs one launch per stage (DFX_PERSIST=0): it compares a member of a wide ensemble with the same design alone bit
+    for bit, which needs the same kernel builds in both -- with the persistent stage loop in play the two would take different forms
+    (tests/test_gpu_persistent.py holds the persistent loop's own member-independence and concurrency checks)."""
     import time
+    monkeypatch.setenv("DFX_PERSIST", "0")
     n = 192
     mi = P.MultiInputTargetKineticEnergy([_fw5(s, sh, batch=n) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
     assert not mi.concurrent_inputs                                  # the inputs take turns: one checkpoint pool
@@ -177,7 +180,6 @@ def test_c5_at_width_192_designs_three_inputs_shared_checkpoint(hip_lib):
     # on the chip at once: DFX_PERSIST is read per solve.  Different builds of the same arithmetic differ in the last digit; a
     # member's numbers must not depend on its NEIGHBOURS.)
     os.environ["DFX_WT"] = "1"
-    os.environ["DFX_PERSIST"] = "0"
     try:
         mi1 = P.MultiInputTargetKineticEnergy([_fw5(s, sh) for s, sh in _INPUTS], (2, 2), (4, 3), weights=(1.0, 1.0, 1.0))
         for m in (3, 141):
@@ -189,7 +191,6 @@ def test_c5_at_width_192_designs_three_inputs_shared_checkpoint(hip_lib):
             assert all(np.array_equal(a, b) for a, b in zip(x, best[m]))
     finally:
         os.environ.pop("DFX_WT")
-        os.environ.pop("DFX_PERSIST")
 
 
 def test_second_solve_with_a_larger_segment_table_on_one_handle(hip_lib, cpu_lib):

@@ -134,3 +134,22 @@ def test_concurrent_engines_share_the_chip(hip_lib):
             assert np.array_equal(a[0], b[0]) and a[1] == b[1]
             for k in b[2]:
                 assert np.array_equal(a[2][k], b[2][k]), k
+
+
+def test_a_member_does_not_depend_on_its_neighbours(hip_lib):
+    """Member 1 of a three-member persistent solve equals the same design solved alone, bit for bit (waves of different members share
+    workgroups and the ring buffer's places; nothing of one member may leak into another)."""
+    c3 = Case("quads", 10, True, True, seed=4, cutoff_deg=42.0, batch=3)
+    c1 = Case("quads", 10, True, True, seed=4, cutoff_deg=42.0, batch=1)
+    ts = np.linspace(0.0, 3e-4, 3)
+    target = np.array([44, 45], dtype=np.int32)
+    cps = [c3.cp._replace(constraint_params=dict(FAST, amplitude=7.5 * (1 + 0.1 * m))) for m in range(3)]
+    f3 = c3.solver(np.zeros((2, 100, 3)), ts, cps, keep_trajectory=True, steps_per_interval=60)
+    assert c3.solver.stats["tile_kernels"] == 3
+    o3, r3 = c3.solver.kinetic_energy_value_and_raw(target)
+    f1 = c1.solver(np.zeros((2, 100, 3)), ts, cps[1], keep_trajectory=True, steps_per_interval=60)
+    o1, r1 = c1.solver.kinetic_energy_value_and_raw(target)
+    assert c1.solver.stats["tile_kernels"] == 3 and c1.solver.adjoint_stats["tile_kernels"] == 3
+    assert np.array_equal(np.asarray(f3)[1], np.asarray(f1)) and float(np.atleast_1d(o3)[1]) == float(np.atleast_1d(o1)[0])
+    for k in r1:
+        assert np.array_equal(np.asarray(r3[k])[1], np.asarray(r1[k]).reshape(np.asarray(r3[k])[1].shape)), k

@@ -120,8 +120,10 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_persistent_kernels_fit_their_occupancy(tmp_path):
     """The persistent stage loop (dfx_persist.hip, compiled without machine-level loop-invariant code motion: dfx_persist_api.h): the
-    forward kernels must fit FOUR workgroups per compute unit (<= 128 VGPRs; with the hoisting on they need 203), the reverse kernels two
-    (<= 256), and neither may touch scratch -- the host sizes its launches by these numbers (persist_wg_per_cu)."""
+    forward kernels must fit FOUR workgroups per compute unit (<= 128 VGPRs; with the hoisting on they need 203), the reverse kernels
+    THREE (<= 168: the later stages' Ybar and the accumulators live in lane-private LDS); the forward kernels touch no scratch, the
+    reverse kernels at most two 8-byte spills and none inside the stage loop -- the host sizes its launches by these numbers
+    (persist_wg_slots)."""
     out = tmp_path / "persist.s"
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-S", "--cuda-device-only",
                            "-o", str(out), os.path.join(ROOT, "difflexmm_amd", "csrc", "dfx_persist.hip")], stderr=subprocess.DEVNULL)
@@ -130,12 +132,17 @@ def test_persistent_kernels_fit_their_occupancy(tmp_path):
     for m in re.finditer(r"\.name:\s+(_ZN12_GLOBAL__N_113k_(fwd|adj)_persist\S*)(.*?)\.vgpr_count:\s+(\d+)", txt, re.S):
         blk = m.group(3)
         scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
-        assert scratch == 0, (m.group(1), scratch)
-        assert int(m.group(4)) <= (128 if m.group(2) == "fwd" else 256), (m.group(1), m.group(4))
+        assert scratch <= (0 if m.group(2) == "fwd" else 32), (m.group(1), scratch)
+        assert int(m.group(4)) <= (128 if m.group(2) == "fwd" else 168), (m.group(1), m.group(4))
         seen += 1
     assert seen == 16
     # every ring access is write-through / past the L1: sc1 on every 16-byte ring store and load, and no plain dwordx4 load in the poll
     # (forward: publish at the start, re-poison, publish = 3 stores, one poll of 2 loads; reverse: re-poison, publish = 2 stores, one poll)
+    # no scratch access between the first and the last ring access of any kernel (i.e. none in the stage loop)
+    for m in re.finditer(r"\n(_ZN12_GLOBAL__N_113k_adj_persist\S*):", txt):
+        body = txt[m.end():txt.index(".Lfunc_end", m.end())]
+        ring = [x.start() for x in re.finditer(r"global_(?:load|store)_dwordx4 .* sc1", body)]
+        assert not re.search(r"scratch_", body[ring[0]:ring[-1]]), m.group(1)
     assert len(re.findall(r"global_store_dwordx4 .* sc1", txt)) == 8 * 3 + 8 * 2 and len(re.findall(r"global_load_dwordx4 .* sc1", txt)) == 16 * 2
 
 
