@@ -197,6 +197,22 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
 #pragma unroll 1
     for (int i = 0; i < s; ++i) {
       {
+        // ---- what does not need the partner's record, in front of the poll (a wave alone on its SIMD has nothing else to do while it
+        // waits): the own half-angle cosine, the Runge-Kutta sums over the EARLIER stages' accelerations, the load of a loaded block
+        o.ch = half_cos(o.th, o.sh);
+        double sv = 0.0, sq = 0.0, fload = 0.0;
+#pragma unroll
+        for (int l = 0; l < kPersistStages - 1; ++l) {
+          const double a_l = l < i ? al[l] : 0.0;         // (the stage kernels add exact zeros for l >= i as well)
+          sv += pc.cv[i][l] * a_l;
+          sq += pc.cq[i][l] * a_l;
+        }
+        if (k < 3 && sidx >= 0 && !constrained) {
+          const dfx_special& sp = c.special[sidx];
+          const double* ft_i = fn_tab_row(c, m, j, i);
+          const u32 z = lane_zero();
+          for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * fn_tab_get(ft_i, f, 0, z);
+        }
         // ---- the partner's record of this stage
         const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
         double pr[4];
@@ -205,7 +221,6 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
         BlockRec<double> p;
         p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];
         p.ch = half_cos(p.th, p.sh);
-        o.ch = half_cos(o.th, o.sh);
         // ---- ligament + contact of this slot (k_fwd_stage's arithmetic)
         double fx = 0.0, fy = 0.0, fth = 0.0;
         if (info >= 0) {
@@ -225,24 +240,13 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
         // ---- DOF epilogue
         double qnext = 0.0, vnext = 0.0;
         if (k < 3) {
-          double fload = 0.0;
-          if (sidx >= 0 && !constrained) {
-            const dfx_special& sp = c.special[sidx];
-            const double* ft_i = fn_tab_row(c, m, j, i);
-            const u32 z = lane_zero();
-            for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * fn_tab_get(ft_i, f, 0, z);
-          }
           const double a = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
           if (Am && i < s - 1) stg<double>(Am + (size_t)i * nd, o_dof, a);
-          // the stage kernels sum the earlier stages' terms in order and the own term last; the rows are zero beyond the diagonal, so the
-          // same sum runs over the whole row here (exact zeros added behind the own term)
-          double sv = 0.0, sq = 0.0;
+          // (the stage kernels' order: the earlier stages' terms first -- summed above --, the own term last)
+          sv += pc.cv[i][i] * a;
+          sq += pc.cq[i][i] * a;
 #pragma unroll
-          for (int l = 0; l < kPersistStages; ++l) {
-            al[l] = l == i ? a : al[l];
-            sv += pc.cv[i][l] * al[l];
-            sq += pc.cq[i][l] * al[l];
-          }
+          for (int l = 0; l < kPersistStages; ++l) al[l] = l == i ? a : al[l];
           qnext = qn + h * (pc.c[i + 1] * vn + h * sq);
           vnext = vn + h * sv;
           if (constrained) {
@@ -355,18 +359,8 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       const double2 o0 = ldg<double2>(POSin, (u32)b * (kPos * 8)), o1 = ldg<double2>(POSin, (u32)b * (kPos * 8) + 16);
       const double2 q0 = ldg<double2>(POSin, (u32)(pslot >> 2) * (kPos * 8)), q1 = ldg<double2>(POSin, (u32)(pslot >> 2) * (kPos * 8) + 16);
       const double v_i = ldg<double>(POSin + (size_t)c.n_blocks * kPos, o_dof);
-      double wp[4];
-      if (t_ord == 0) {
-        const double* Win = c.W + (size_t)(((u32)m * 2 + (u32)win) * nd);
-        const u32 pb = (u32)(pslot >> 2) * 24;
-        const double2 wxy = ldg<double2>(Win, pb);
-        wp[0] = wxy.x; wp[1] = wxy.y; wp[2] = ldg<double>(Win, pb + 16);
-      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up)) return;
-      if (k < 2 && t_ord + kPAhead < total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
-      BlockRec<double> o, p;
-      o.x = o0.x; o.y = o0.y; o.th = o1.x; o.sh = o1.y; o.ch = half_cos(o.th, o.sh);
-      p.x = q0.x; p.y = q0.y; p.th = q1.x; p.sh = q1.y; p.ch = half_cos(p.th, p.sh);
-      // ---- Kbar sums over the later stages' Ybar (k_adj_stage, records build)
+      // ---- Kbar sums over the later stages' Ybar, the own w and its broadcasts (k_adj_stage, records build): none of it needs the
+      // partner's w or the records still in flight -- in front of the poll
       double sq = 0.0, sv = 0.0, sqc = 0.0, svc = 0.0;
 #pragma unroll
       for (int jj = 1; jj < kPersistStages; ++jj) {
@@ -383,6 +377,17 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       const double lq = lam.x, lv = lam.y;
       const double w_d = (h * (cur_s * lv + svc)) * invm;
       const double wox = blk_bcast<NPB, 0>(w_d, k), woy = blk_bcast<NPB, 1>(w_d, k), woth = blk_bcast<NPB, 2>(w_d, k);
+      double wp[4];
+      if (t_ord == 0) {
+        const double* Win = c.W + (size_t)(((u32)m * 2 + (u32)win) * nd);
+        const u32 pb = (u32)(pslot >> 2) * 24;
+        const double2 wxy = ldg<double2>(Win, pb);
+        wp[0] = wxy.x; wp[1] = wxy.y; wp[2] = ldg<double>(Win, pb + 16);
+      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up)) return;
+      if (k < 2 && t_ord + kPAhead < total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
+      BlockRec<double> o, p;
+      o.x = o0.x; o.y = o0.y; o.th = o1.x; o.sh = o1.y; o.ch = half_cos(o.th, o.sh);
+      p.x = q0.x; p.y = q0.y; p.th = q1.x; p.sh = q1.y; p.ch = half_cos(p.th, p.sh);
       // ---- Hessian-vector product + mixed parameter derivatives of this slot
       double hx = 0.0, hy = 0.0, hth = 0.0, ex = 0.0, ey = 0.0, eth = 0.0, d_rx = 0.0, d_ry = 0.0, d_phi = 0.0;
       if (info >= 0) {
