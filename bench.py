@@ -740,7 +740,10 @@ def main():
             os.environ["DFX_CHECKPOINT"] = timed_level
     single = None
     if rank == 0 and world == 1 and args.members > 1 and adjoint and not args.no_single:
-        # the same config with ONE design per GPU (launch-bound: one wave per SIMD), for reference
+        # the same config with ONE design per GPU (launch-bound: one wave per SIMD), for reference.  The engine chooses its checkpoint
+        # level itself here (the level pinned above is the 16-member job's: a 5 000-step default run pins "stages", at which one member's
+        # reverse sweep would keep the stage launches although its records fit)
+        pinned_level = os.environ.pop("DFX_CHECKPOINT", None)
         fw1, obj1, des1 = c3_problem(args.size, 3, 1, device=local_rank, **prob)
         K1 = min(max(K, 250), 2500)
         fw1.solve_dynamics.engine.reserve(K1, K1 // SPI + 2, keep_trajectory=True)
@@ -768,6 +771,8 @@ def main():
                   "device_ms": {"forward": r1["fwd_ms"], "adjoint": r1["adj_ms"]}}
         fw1.solve_dynamics.engine.close()
         del fw1, obj1, r1
+        if pinned_level is not None:
+            os.environ["DFX_CHECKPOINT"] = pinned_level
     fw, obj, designs = c3_problem(args.size, 3 + 1000 * rank, args.members, device=local_rank, **prob)
     device_outputs = adjoint and args.outputs == "hbm" and hasattr(fw.solve_dynamics.engine.lib, "dfx_kinetic_value_and_grad_device")
     fw.solve_dynamics.engine.reserve(max(K, W), max(K, W) // SPI + 2, keep_trajectory=adjoint)

@@ -24,7 +24,7 @@ def _function(txt, prefix):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     out = tmp_path / "dfx.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out),
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")], stderr=subprocess.DEVNULL)
     txt = out.read_text()
     fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EE")
@@ -151,7 +151,7 @@ def test_tile_kernels_have_no_scratch_and_no_barrier(tmp_path):
     """The opt-in tile kernels (dfx_tile.h, -DDFX_EXPERIMENTAL builds only): no scratch, no workgroup barrier (wave-private tiles; the
     exchange through LDS is ordered by wavefront-scope fences, which emit no instruction)."""
     out = tmp_path / "exp.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DDFX_EXPERIMENTAL", "-S", "--cuda-device-only", "-o", str(out),
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-DDFX_EXPERIMENTAL", "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")], stderr=subprocess.DEVNULL)
     txt = out.read_text()
     for nm in ("_ZN12_GLOBAL__N_110k_fwd_tileILi1ELi1EE", "_ZN12_GLOBAL__N_110k_adj_tileILi1ELi1EE"):
