@@ -249,6 +249,27 @@ def _launch_bound_legs(out, device, sync, single, c4_steps, c2_steps):
         out["c3_1_member"] = {"lattice": "128x128 quads + contact, forward + adjoint", "steps": single["steps"],
                               "fwd_stage_us": single["fwd_stage_us"], "adj_stage_us": single["adj_stage_us"], "value": single["value"],
                               "fwd_frac": single["roofline"]["forward_frac"], "adj_frac": single["roofline"]["frac"], "kernels": single["kernels"]}
+    if single is not None:
+        # ... and the same single design over the WHOLE horizon of C3 as written (50 000 steps, pulse delayed by 0.1/f, target at (21, 25)):
+        # what a user of the reference runs.  Its 275 GB of stage records do not fit next to everything else, so the engine
+        # takes the segments level (every output interval integrated twice, both sweeps in the persistent loop)
+        t_d = 0.1 / FREQ
+        fwf, objf, desf = c3_problem(128, 3, 1, device=device, input_delay=t_d, target_shift=(128 // 6, 128 // 5))
+        fwf.solve_dynamics.engine.reserve(50000, 50000 // SPI + 2, keep_trajectory=True)
+        prepare(fwf, desf, 2 * SPI, t_start=t_d)
+        execute(fwf, objf)
+        prepare(fwf, desf, 50000)
+        sync()
+        tf = time.perf_counter()
+        rf = execute(fwf, objf)
+        sync()
+        wf = time.perf_counter() - tf
+        out["c3_1_member_whole_horizon"] = {"lattice": "128x128 quads + contact, ONE design, 50 000 steps as C3 is written, forward + adjoint",
+                                            "value": 50000 * 16384 / wf, "wall_s": wf, "checkpoint": rf.get("checkpoint"),
+                                            "device_ms": {"forward": rf["fwd_ms"], "adjoint": rf["adj_ms"]},
+                                            "kernels": {"forward": BUILD_NAMES.get(rf.get("fwd_build")), "adjoint": BUILD_NAMES.get(rf.get("adj_build"))},
+                                            "objective": float(np.atleast_1d(rf["objective"])[0]), "grad_norm": grad_norm(rf)}
+        fwf.solve_dynamics.engine.close()
     fw4, obj4, K4 = c4_problem(8, c4_steps, device=device)
     designs4 = []
     for seed in range(100, 108):
@@ -705,6 +726,10 @@ def main():
             level = ("records" if 432.0 * (n_ck + 1) * units < room else
                      "stages" if (72.0 * (n_ck + 1) + 120.0 * n_ck) * units < room else
                      "state" if 72.0 * (n_ck + 1) * units < room else "segments")
+            # where the persistent stage loop serves the job (its waves fit on the chip in at most two launches: 3 reverse workgroups of
+            # 4 waves on each of 256 CUs) the engine goes from records straight to segments (engine_forward.hip, choose_checkpoint)
+            if level != "records" and args.members * ((args.size * args.size + 15) // 16) <= 2 * 3 * 256 * 4:
+                level = "segments"
             level = ["records", "stages", "state", "segments"][int(comm.all_reduce(
                 [float(["records", "stages", "state", "segments"].index(level))], "max")[0])]      # same kernels on every rank
             os.environ["DFX_CHECKPOINT"] = level

@@ -202,6 +202,7 @@ void launch_fwd(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int ou
 void launch_adj(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only);
 void launch_adj(dfx_handle* h, const DevCtx& c, int i, int j, int in_buf, int wbuf, int local_only);
 bool persist_shape_ok(const dfx_handle* h);
+bool persist_would_serve(dfx_handle* h);
 int persist_members_that_fit(dfx_handle* h, const void* fn, int npb);
 bool persist_members_ok(const dfx_handle* h, int per_launch);
 void persist_plan(dfx_handle* h, const DevCtx& c);

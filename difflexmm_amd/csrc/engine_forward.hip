@@ -71,7 +71,12 @@ int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_s
     // Round 2 kept small lattices at the stages level because THREE engines of a multi-input objective each allocated a 50 - 130 GB
     // checkpoint; engines whose inputs run in turn now share one (dfx_share_checkpoint), and a level that does not fit next to what
     // other handles hold falls back by itself.
+    // Where the persistent stage loop serves the solve (dfx_persist.h) and the records do not fit, the segments level comes next: its
+    // forward re-run is one cheap persistent launch per segment and its reverse sweep reads records, i.e. stays persistent too -- the
+    // stages / state levels would put the reverse sweep back on one launch per stage (one 128x128 design over the whole 50 000 steps:
+    // 7.7 us per stage pair against 9.4)
     if (fits(grow(want_rec, have_t))) mode = kCkRecords;
+    else if (persist_would_serve(h) && fits(grow(want_seg, have_t))) mode = kCkSegments;
     else if (fits(grow(want_state, have_t) + grow(want_ad, have_a))) mode = kCkStages;
     else if (fits(grow(want_state, have_t))) mode = kCkState;
     else mode = kCkSegments;

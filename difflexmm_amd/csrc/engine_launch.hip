@@ -340,6 +340,13 @@ static bool persist_common_ok(dfx_handle* h, const DevCtx& c) {
 bool persist_members_ok(const dfx_handle* h, int per_launch) {
   return per_launch > 0 && (h->pl.batch + per_launch - 1) / per_launch <= persist_max_chunks();
 }
+// would both sweeps of a fixed-grid solve of this handle run the persistent loop?  (asked before the context exists: the checkpoint choice)
+bool persist_would_serve(dfx_handle* h) {
+  if (!persist_shape_ok(h) || h->adaptive || h->groups.size() != 1) return false;
+  const int npb = (h->pl.n_npb == 3 && pack3(h)) ? 3 : 4;
+  return persist_members_ok(h, persist_members_that_fit(h, dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, npb), npb)) &&
+         persist_members_ok(h, persist_members_that_fit(h, dfx_persist::adj_kernel(h->pl.model, h->pl.contact, npb), npb));
+}
 // decided per solve, after the context is known
 void persist_plan(dfx_handle* h, const DevCtx& c) {
   h->persist_fwd = false;
