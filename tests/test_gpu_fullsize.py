@@ -275,6 +275,16 @@ def test_checkpoint_level_survives_low_free_memory_once_allocated(experimental_l
     c.solver(y0, ts, c.cp, keep_trajectory=True, steps_per_interval=10)
     assert c.solver.stats["checkpoint_records"] == 1                       # same level: nothing had to grow
     c.solver(y0, np.linspace(0.0, 4e-4, 5), c.cp, keep_trajectory=True, steps_per_interval=10)
-    # twice the steps: the records level would have to GROW and nothing is free -- the solve drops to the richest level that fits
-    # the buffer it already has (the step states of 40 steps fit where the records of 20 were)
-    assert c.solver.stats["checkpoint_records"] == 0 and c.solver.stats["stage_checkpoint"] == 0
+    # twice the steps: the records level would have to GROW and nothing is free -- the solve drops to the next level that fits the
+    # buffer it already has.  Since round 5 that is the segments level where the persistent stage loop serves the solve (the records
+    # of ONE interval fit where those of 20 steps were; both sweeps stay persistent) ...
+    assert c.solver.stats["checkpoint_records"] == 2 and c.solver.stats["tile_kernels"] == 3
+    # ... and, with one launch per stage, the step states of 40 steps (they fit there too)
+    monkeypatch.setenv("DFX_PERSIST", "0")
+    c2 = Case("quads", 16, True, True, seed=2, cutoff_deg=42.0)
+    c2.cp = c.cp
+    monkeypatch.delenv("DFX_TEST_FREE_BYTES")
+    c2.solver(y0, ts, c2.cp, keep_trajectory=True, steps_per_interval=10)
+    monkeypatch.setenv("DFX_TEST_FREE_BYTES", "1024")
+    c2.solver(y0, np.linspace(0.0, 4e-4, 5), c2.cp, keep_trajectory=True, steps_per_interval=10)
+    assert c2.solver.stats["checkpoint_records"] == 0 and c2.solver.stats["stage_checkpoint"] == 0
