@@ -144,9 +144,13 @@ int dfx_destroy(dfx_handle* h) {
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();
   h->d_tmp.release(); h->d_obj.release(); h->d_target.release(); h->stage.release(); h->obj_stage.release(); h->flag_stage.release();
-  for (auto& gr : h->groups) { for (auto e : gr.ev_a) (void)hipEventDestroy(e); for (auto e
-      : gr.ev_b) (void)hipEventDestroy(e); if (gr.stream2) (void)hipStreamDestroy(gr.stream2); if (gr.done) (void)hipEventDestroy(gr.done); if (gr.stream
-      && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream); }
+  for (auto& gr : h->groups) {
+    for (auto e : gr.ev_a) (void)hipEventDestroy(e);
+    for (auto e : gr.ev_b) (void)hipEventDestroy(e);
+    if (gr.stream2) (void)hipStreamDestroy(gr.stream2);
+    if (gr.done) (void)hipEventDestroy(gr.done);
+    if (gr.stream && gr.stream != h->stream) (void)hipStreamDestroy(gr.stream);
+  }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

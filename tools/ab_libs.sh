@@ -1,8 +1,20 @@
 #!/bin/bash
-# usage: tools/ab_libs.sh libA.so libB.so ... -- A/B of engine builds on one box: per-launch leg (1 stream) and the timed job (2 streams), each
-# library twice, interleaved (DFX_LIBRARY selects the build; every one must be a gfx950 engine)
-for rep in 1 2; do
-  for lib in "$@"; do
-    DFX_LIBRARY=$PWD/$lib timeout 300 python bench.py --steps ${STEPS:-250} --warmup 50 --no-cpu-baseline --no-as-written 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); a=d['roofline']; r=d['roofline_forward_kernel']; s=d.get('single_system',{}); print('$lib rep $rep value %.4e fwd_only %.4e fwd launch %.2f us adj launch %.2f us single %.3e'%(d['value'],d['forward_only_value'],r['launch_us'],a['launch_us'],s.get('value',0)))"
+# usage (GPU box): tools/scratch/ab_libs.sh OUTFILE lib1 lib2 ...   ("default" = the product library)
+OUT=$1; shift
+A1="bench.py --streams 1 --members 16 --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written --no-launch-bound"
+A2="bench.py --steps 250 --warmup 250 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written --no-launch-bound"
+for rep in 1 2 3; do
+for lib in "$@"; do
+  if [ "$lib" = default ]; then unset DFX_LIBRARY; else export DFX_LIBRARY=$PWD/variants/libdfx_$lib.so; fi
+  for mode in 1 2; do
+    if [ $mode = 1 ]; then A=$A1; else A=$A2; fi
+    timeout 300 python $A 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+dm=d['device_ms']
+print('$lib', 'streams', d['config']['concurrent_streams'], 'value %.4e'%d['value'], 'fwd %.2f adj %.2f ms'%(dm['forward'],dm['adjoint']), 'level', d['config']['checkpoint'])
+" >> $OUT
   done
 done
+done
+cat $OUT
