@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/scratch/ab_libs.sh OUTFILE lib1 lib2 ...   ("default" = the product library)
+# usage (GPU box): tools/ab_libs.sh OUTFILE name1 name2 ...   -- A/B of engine builds on one box, three repetitions, interleaved:
+# "default" = the product library, NAME = variants/libdfx_NAME.so (through DFX_LIBRARY); per build the one-stream leg and the
+# two-stream job: value, device time of the forward pass and of the reverse sweep
 OUT=$1; shift
 A1="bench.py --streams 1 --members 16 --steps 250 --warmup 0 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written --no-launch-bound"
 A2="bench.py --steps 250 --warmup 250 --no-cpu-baseline --no-single --no-roofline-leg --no-as-written --no-launch-bound"
