@@ -8,7 +8,8 @@
 // /root/reference/difflexmm/dynamics.py:166.
 //
 // How.  A wave owns its 16 (20: packed triangles) blocks for a whole segment of <= 256 steps: parameters, step state and the stage
-// accelerations stay in registers.  What the NEXT stage of a neighbouring wave needs is the 32-byte stage record of a block (x, y, theta,
+// accelerations stay in registers (reverse loop: lambda, the Ybar history and the gradient accumulators in lane-private LDS words, which
+// is what lets three of its workgroups share a compute unit).  What the NEXT stage of a neighbouring wave needs is the 32-byte stage record of a block (x, y, theta,
 // sin theta/2) -- nothing else crosses waves, and a wave has <= 4 neighbour waves on a lattice.  Hand-off (MI355X_MICROARCH.md,
 // "Valid forms", R2: the data is the flag):
 //   * records travel through a RING of kPRing places per member, [place][member][block][4 doubles]; the record of stage ordinal t of a
