@@ -231,7 +231,11 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
               h->ck->traj.n * 8e-9, h->ck->AD.n * 8e-9, h->ck->users);
     if (mode == -2) return 1;
     if (mode < 0) {
-      h->err = "forward: cannot allocate the trajectory checkpoint (" + std::to_string((B * (h->n_total + 1) * rec * 8) >> 20) + " MiB)";
+      // (the last level tried is the segments level: the stage records of ONE output interval of all members)
+      h->err = "forward: cannot allocate the trajectory checkpoint: even its smallest form, the stage records of one output interval of all members ("
+               + std::to_string((B * ((size_t)max_spi * h->pl.tab.s + 1) * rec * 8) >> 20) + " MiB), does not fit the device next to what is "
+               "allocated -- integrate fewer members per engine call (the problem layer runs a longer list of designs in calls of `batch`) or "
+               "ask for more output times";
       return 2;
     }
     h->have_traj = true;

@@ -190,3 +190,24 @@ def check_recorded_input_signal(lib):
     assert v > 0 and abs(an - fd) < 1e-5 * abs(fd), (an, fd)
     with np.testing.assert_raises(TypeError):
         fw.setup(excited_blocks_fn=lambda t: 0.0)
+
+
+def check_more_designs_than_batch(lib):
+    """A list of designs longer than the engine's ``batch`` runs in consecutive engine calls (config 4 as written on one GPU: 64 designs whose
+    smallest checkpoint does not fit at once): values and gradients equal those of one design at a time, in order."""
+    fw2 = P.QuadsFocusingForward(n1_blocks=N1, n2_blocks=N2, damping=damping(), loaded_side="left", input_shift=0, steps_per_interval=SPI,
+                                 batch=2, _lib=lib, **KW)
+    fw1, _, x = quads_forward(lib)
+    rng = np.random.default_rng(23)
+    designs = [tuple(a + rng.uniform(-0.1, 0.1, a.shape) for a in x) for _ in range(4)]
+    o2, o1 = P.TargetKineticEnergy(fw2, (2, 2), (1, 0)), P.TargetKineticEnergy(fw1, (2, 2), (1, 0))
+    v, g = o2.value_and_grad(designs)
+    assert v.shape == (4,) and len(g) == 4 and len(set(np.round(v / v.max(), 9))) == 4
+    for m, d in enumerate(designs):
+        v1, g1 = o1.value_and_grad(d)
+        assert abs(v[m] - v1) <= 1e-13 * abs(v1)
+        for a, b in zip(g[m], g1):
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    # a length that is not a multiple of the batch is still refused by the solver
+    with np.testing.assert_raises(Exception):
+        o2.value_and_grad(designs[:3])

@@ -20,3 +20,7 @@ def test_reference_design_cpu_port(cpu_lib):
 
 def test_recorded_input_signal_cpu_port(cpu_lib):
     C.check_recorded_input_signal(cpu_lib)
+
+
+def test_more_designs_than_batch_cpu_port(cpu_lib):
+    C.check_more_designs_than_batch(cpu_lib)

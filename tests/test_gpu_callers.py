@@ -20,3 +20,7 @@ def test_reference_design_hip(hip_lib):
 
 def test_recorded_input_signal_hip(hip_lib):
     C.check_recorded_input_signal(None)
+
+
+def test_more_designs_than_batch_hip(hip_lib):
+    C.check_more_designs_than_batch(None)

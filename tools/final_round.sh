@@ -8,6 +8,7 @@ tools/profile_round.sh $TAG 16 > $OUT/profile_round.log 2>&1
 timeout 900 python bench.py --workload c5 > $OUT/bench_c5_256_designs.json 2> $OUT/bench_c5.err
 timeout 600 python bench.py --workload c4 --steps 4000 --warmup 1 > $OUT/bench_c4_64_designs.json 2> $OUT/bench_c4.err
 timeout 600 python bench.py --workload c2 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+timeout 900 python bench.py --workload c4 --steps 75000 > $OUT/bench_c4_64_designs_full_horizon.json 2> $OUT/bench_c4_full.err      # config 4 as written: 75 000 steps (two engine calls of 32 designs on one GPU)
 timeout 600 python bench.py --workload c5 --c5-members 32 --c5-iterations 4 --no-cpu-baseline > $OUT/bench_c5_32_designs.json 2> $OUT/bench_c5_32.err
 for a in "quads 128 1 400" "quads 128 2 400" "quads 128 4 400" "kagome 64 8 400" "quads 64 8 400" "quads 32 1 2000 0 0" "quads 32 64 1000 0 0"; do timeout 300 python tools/persist_probe.py $a; done > $OUT/persist_probe.txt 2>/dev/null
 timeout 600 python tools/c4_problem_timing.py 8 4000 > $OUT/c4_8_designs.txt 2>&1
