@@ -90,12 +90,24 @@ int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_s
     return m;
   };
   if (mode == kCkSegments) {
-    if (h->ck->traj.ensure(want_seg) != hipSuccess) { (void)hipGetLastError(); return done(-1); }
+    if (h->ck->traj.ensure(want_seg) != hipSuccess) {
+      (void)hipGetLastError();
+      h->err = "forward: cannot allocate the trajectory checkpoint: even its smallest form, the stage records of one output interval of all members ("
+               + std::to_string((want_seg * sizeof(double)) >> 20) + " MiB), does not fit the device next to what is allocated -- integrate fewer members "
+               "per engine call (the problem layer runs a longer list of designs in calls of `batch`) or ask for more output times";
+      return done(-1);
+    }
     return done(mode);
   }
   // allocate; a failed allocation falls back one level (forced modes included: the solve still runs)
   if (mode == kCkRecords && h->ck->traj.ensure(want_rec) != hipSuccess) { (void)hipGetLastError(); mode = kCkStages; }
-  if (mode != kCkRecords && h->ck->traj.ensure(want_state) != hipSuccess) { (void)hipGetLastError(); return done(-1); }
+  if (mode != kCkRecords && h->ck->traj.ensure(want_state) != hipSuccess) {
+    (void)hipGetLastError();
+    // (the free-memory query said it would fit: another process, or another thread of this one, took the memory in between)
+    h->err = "forward: cannot allocate the trajectory checkpoint (the step states of all members: " + std::to_string((want_state * sizeof(double)) >> 20)
+             + " MiB) although the device reported enough free memory a moment ago -- is another process allocating on this GPU?";
+    return done(-1);
+  }
   if (mode == kCkStages && h->ck->AD.ensure(want_ad) != hipSuccess) { (void)hipGetLastError(); mode = kCkState; }
   return done(mode);
 }
@@ -231,11 +243,6 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
               h->ck->traj.n * 8e-9, h->ck->AD.n * 8e-9, h->ck->users);
     if (mode == -2) return 1;
     if (mode < 0) {
-      // (the last level tried is the segments level: the stage records of ONE output interval of all members)
-      h->err = "forward: cannot allocate the trajectory checkpoint: even its smallest form, the stage records of one output interval of all members ("
-               + std::to_string((B * ((size_t)max_spi * h->pl.tab.s + 1) * rec * 8) >> 20) + " MiB), does not fit the device next to what is "
-               "allocated -- integrate fewer members per engine call (the problem layer runs a longer list of designs in calls of `batch`) or "
-               "ask for more output times";
       return 2;
     }
     h->have_traj = true;
