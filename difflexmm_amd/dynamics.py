@@ -218,6 +218,7 @@ class DynamicSolver:
                 s0 = np.broadcast_to(s0, (self.batch,) + s0.shape)
             fields, stats = self.engine.forward(s0, timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times, want_fields=want_fields)
             self._last = (cps, flats, np.asarray(timepoints, dtype=float))
+            self._last_fields = fields
             self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control="fixed")
             if fields is None:
                 return None
@@ -240,6 +241,7 @@ class DynamicSolver:
         fields, stats = self.engine.forward(state0, timepoints, spi, keep_trajectory=keep_trajectory, step_times=step_times,
                                             want_fields=want_fields)
         self._last = (cps, flats, np.asarray(timepoints, dtype=float))
+        self._last_fields = fields
         self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control=control)
         if fields is None:
             return None
@@ -257,6 +259,7 @@ class DynamicSolver:
         grads, stats = self.engine.adjoint(fb)
         self.adjoint_stats = stats
         trees, s0 = self._unflatten_grads(grads, fb)
+        self._last_state0_bar = s0
         # cotangents on the OUTPUTS of prescribed DOFs feed the constraint parameters directly:
         # fields[k, 0, dof] = c_dof(t_k; p), fields[k, 1, dof] = dc_dof/dt(t_k; p)   (dynamics.py:132-134, 169-182)
         if len(self.constrained_pairs) and self.con_terms:
@@ -281,6 +284,57 @@ class DynamicSolver:
                             g5 += wv[k] * term.param_partials(float(t), p, "rate")
                     term.scatter_grad(g5, tree.constraint_params, cp.constraint_params)
         return trees, s0
+
+    def timepoints_vjp(self, fields_bar):
+        """Cotangent of ``timepoints`` for the cotangent ``fields_bar`` of the last solve -- what ``jax.grad`` through the reference's
+        ``solve_dynamics`` returns for its ``timepoints`` argument (dynamics.py:138-148; jax.experimental.ode._odeint_rev, restated in
+        oracle/ref_adjoint.py).  Call after ``vjp(fields_bar)`` (its state0 cotangent is used).  With f = (v, a) the right-hand side on the
+        free DOFs and (c', c'') the rates of the prescribed ones:
+
+            ts_bar[i] = fields_bar[i] . d fields[i] / d t_i = g_i . f(y_i, t_i)        i >= 1   (moving a measurement time)
+            ts_bar[0] = -lambda(t_0+) . f(y_0, t_0)  (+ g_0 . (c', c'') on prescribed DOFs),  lambda(t_0+) = state0_bar - g_0 on the free DOFs
+
+        (the second line is the closed form of _odeint_rev's ``t0_bar``: d/dt (lambda . f) = lambda . df/dt between outputs and lambda jumps by
+        g_i at t_i, so  -sum_i g_i . f_i + int lambda . df/dt dt = -lambda(t_0+) . f_0).  These are the derivatives of the CONTINUOUS solution:
+        on a fixed grid they differ from the derivative of the discrete map by the integrator's truncation error, like the reference's own.
+        One right-hand-side evaluation per output time (the engine's ``dfx_rhs`` hook).  Returns (T,) or (batch, T)."""
+        if self._last is None or getattr(self, "_last_fields", None) is None or getattr(self, "_last_state0_bar", None) is None:
+            raise RuntimeError("timepoints_vjp: solve with keep_trajectory=True (fields returned), then call vjp(fields_bar) first")
+        cps, flats, ts = self._last
+        B, nb = self.batch, self.n_blocks
+        fb = np.asarray(fields_bar, dtype=float).reshape(B, -1, 2, nb * 3)
+        fields = np.asarray(self._last_fields, dtype=float).reshape(B, -1, 2, nb * 3)
+        s0b = np.asarray(self._last_state0_bar, dtype=float).reshape(B, 2, nb * 3)
+        T = fields.shape[1]
+        tsm = np.broadcast_to(ts, (B, T)) if ts.ndim == 1 else ts
+        con = self.constrained_pairs[:, 0] * 3 + self.constrained_pairs[:, 1] if len(self.constrained_pairs) else np.zeros(0, dtype=np.int64)
+        n_con = len(con)
+        out = np.zeros((B, T))
+        for i in range(T):
+            # members that share this output time are evaluated in one call (one time for all of them unless timepoints has a row per member)
+            for t in np.unique(tsm[:, i]):
+                rows = np.nonzero(tsm[:, i] == t)[0]
+                dy = self.engine.rhs(fields[:, i].reshape(B, 2, nb, 3), float(t)).reshape(B, 2, nb * 3)
+                for m in rows:
+                    rate = dy[m].copy()                           # (v, a) on the free DOFs, zeros on the prescribed ones
+                    if n_con:
+                        rate[0, con] = fields[m, i, 1, con]       # c'(t): the prescribed velocity is what the output holds
+                        acc = np.zeros(n_con)
+                        for term in self.con_terms:
+                            p = term.resolve(cps[m].constraint_params)
+                            h = 1e-4 * max(float(np.ptp(tsm[m])), 1e-300)      # (central difference of the rate, in the scale of the horizon)
+                            acc += _bcast(term.vector, n_con) * (term.rate(float(t) + h, p) - term.rate(float(t) - h, p)) / (2 * h)
+                        rate[1, con] = acc                        # c''(t)
+                    g = fb[m, i]
+                    if i == 0:
+                        lam = s0b[m] - g
+                        lam[:, con] = 0.0
+                        out[m, 0] = -float(np.vdot(lam, rate))
+                        if n_con:
+                            out[m, 0] += float(np.vdot(g[:, con], rate[:, con]))
+                    else:
+                        out[m, i] = float(np.vdot(g, rate))
+        return out[0] if (B == 1 and ts.ndim == 1) else out
 
     def vjp_raw(self, fields_bar, which=("centroid_node_vectors", "void_angle0", "inertia")):
         """Reverse sweep for a cotangent of the fields, returning the engine's raw gradient arrays (batch-leading) of the requested
