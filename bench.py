@@ -977,9 +977,9 @@ def main():
     comm.close()
 
 
-KERNEL_SOURCES = ("dfx_physics.h", "dfx_plan.h", "dfx_stage.h", "dfx_kernels.h")                 # what the two stage kernels are compiled from
+KERNEL_SOURCES = ("dfx_physics.h", "dfx_plan.h", "dfx_stage.h", "dfx_kernels.h", "stage_builds_adj.hip")   # what the two stage kernels are compiled from
 ENGINE_SOURCES = KERNEL_SOURCES + ("dfx_persist.h", "dfx_persist_api.h", "dfx_engine.h", "engine_launch.hip", "engine_forward.hip", "engine_adaptive.hip",
-                                  "engine_reverse.hip", "engine_abi.hip", "dfx_persist.hip", "dfx_comm.hip")
+                                  "engine_reverse.hip", "engine_abi.hip", "dfx_persist.hip", "dfx_comm.hip", "Makefile")
 
 
 def csrc_digest(files=KERNEL_SOURCES):

@@ -145,16 +145,17 @@ static bool launch_fwd_hot(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 
   }
   return false;
 }
+// the reverse per-stage builds live in a translation unit of their own (stage_builds_adj.hip: compiled with its own scheduling strategy)
+namespace dfx_hot {
+bool launch_adj_stage_build(int model, int contact, int npb, hipStream_t st, dim3 grid, const DevCtx& c, const AdjCoef& acf, int i, int j, int in_buf, int wbuf,
+                            int local_only, const StageCoef& rc, int rb);
+}
 template <int MODEL, int CONTACT, int NPB>
 static bool launch_adj_hot(dfx_handle* h, const DevCtx& c, hipStream_t st, dim3 grid, int i, int j, int in_buf, int wbuf, int local_only, const StageCoef& rc,
     int rb) {
   if constexpr ((MODEL == kNonlinear || MODEL == kLinearized) && CONTACT != 2) {
     if (!h->wt || !h->stage_builds || !(c.k_uniform && c.l_dict_on && c.l_dict_lds && c.damping_uniform && !c.t_steps)) return false;
-    const AdjCoef acf = adj_coef(h->pl.tab, i);
-#define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, NPB, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, \
-    wbuf, local_only, rc, rb); return true;
-    switch (i) { DFX_ADJ_I(0) DFX_ADJ_I(1) DFX_ADJ_I(2) DFX_ADJ_I(3) DFX_ADJ_I(4) DFX_ADJ_I(5) default: break; }
-#undef DFX_ADJ_I
+    return dfx_hot::launch_adj_stage_build(MODEL, CONTACT, NPB, st, grid, c, adj_coef(h->pl.tab, i), i, j, in_buf, wbuf, local_only, rc, rb);
   }
   return false;
 }

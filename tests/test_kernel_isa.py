@@ -27,6 +27,20 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")], stderr=subprocess.DEVNULL)
     txt = out.read_text()
+    # the per-stage builds of the reverse kernel: a translation unit of their own with its own flags (the Makefile's ADJFLAGS, read from
+    # there so that the guard compiles what the library does)
+    import shlex
+    mk = open(os.path.join(ROOT, "difflexmm_amd", "csrc", "Makefile")).read()
+    adjflags = shlex.split(re.search(r"^ADJFLAGS = (.*)$", mk, re.M).group(1))
+    assert "max-ilp" in " ".join(adjflags) and any("amdgpu_waves_per_eu(4)" in a for a in adjflags), adjflags
+    out2 = tmp_path / "dfx_adj.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm"] + adjflags +
+                          ["-S", "--cuda-device-only", "-o", str(out2), os.path.join(ROOT, "difflexmm_amd", "csrc", "stage_builds_adj.hip")],
+                          stderr=subprocess.DEVNULL)
+    txt_adj = out2.read_text()
+    assert "k_fwd_stage" not in txt_adj and "k_adj_stage_rb" not in txt_adj      # nothing but the reverse per-stage builds is compiled with those flags
+    assert "k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi0EE" not in txt          # ... and they are compiled nowhere else
+    txt = txt + "\n" + txt_adj
     fwd = _function(txt, "_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi0ELi0ELi0ELin1ELi1EE")
     adj = _function(txt, "_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi0ELin1EE")
     # forward: 5 waves per SIMD are bought with ~100 B/lane of scratch, all of it inside the time-function path that only the lanes of

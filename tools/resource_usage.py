@@ -8,9 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pats = sys.argv[1:] or ["k_fwd_stageILi1ELi1E", "k_adj_stageILi1ELi1ELi0ELi0E", "k_adj_stage_rbILi1ELi1E", "k_fwd_pairILi1ELi1E", "k_adj_pairILi1ELi1E"]
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-Rpass-analysis=kernel-resource-usage",
-                      "-c", "-o", "/dev/null", os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")] + os.environ.get("DFX_EXTRA_FLAGS", "").split(),
-                     capture_output=True, text=True).stderr
+import shlex
+BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null"]
+EXTRA = os.environ.get("DFX_EXTRA_FLAGS", "").split()
+CSRC = os.path.join(ROOT, "difflexmm_amd", "csrc")
+# the per-stage builds of the reverse kernel are a translation unit of their own with the Makefile's ADJFLAGS
+ADJ = shlex.split(re.search(r"^ADJFLAGS = (.*)$", open(os.path.join(CSRC, "Makefile")).read(), re.M).group(1))
+out = subprocess.run(BASE + [os.path.join(CSRC, "engine_launch.hip")] + EXTRA, capture_output=True, text=True).stderr
+out += subprocess.run(BASE + ADJ + [os.path.join(CSRC, "stage_builds_adj.hip")] + EXTRA, capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
