@@ -4,7 +4,8 @@
 //   engine_adaptive.hip  the reference's adaptive odeint semantics
 //   engine_reverse.hip   reverse sweep, gradient collection, objectives
 //   engine_abi.hip       create / destroy / set_params / reserve, test hooks, post-processing, downloads
-// The kernels live in dfx_kernels.h (stage kernels: instantiated by engine_launch.hip, the reverse per-stage builds by stage_builds_adj.hip) and dfx_persist.hip.
+// The kernels live in dfx_kernels.h (stage kernels: instantiated by engine_launch.hip, the reverse per-stage builds by stage_builds_adj.hip)
+// and dfx_persist.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -15,7 +15,8 @@
 namespace dfx_hot {
 
 template <int MODEL, int CONTACT, int NPB>
-static bool adj_t(hipStream_t st, dim3 grid, const DevCtx& c, const AdjCoef& acf, int i, int j, int in_buf, int wbuf, int local_only, const StageCoef& rc, int rb) {
+static bool adj_t(hipStream_t st, dim3 grid, const DevCtx& c, const AdjCoef& acf, int i, int j, int in_buf, int wbuf, int local_only,
+                  const StageCoef& rc, int rb) {
 #define DFX_ADJ_I(I) case I: hipLaunchKernelGGL((k_adj_stage<MODEL, CONTACT, 0, 0, NPB, 1, 0, 1, I>), grid, dim3(kThreads), 0, st, c, acf, i, j, in_buf, \
     wbuf, local_only, rc, rb); return true;
   switch (i) { DFX_ADJ_I(0) DFX_ADJ_I(1) DFX_ADJ_I(2) DFX_ADJ_I(3) DFX_ADJ_I(4) DFX_ADJ_I(5) default: break; }
@@ -23,8 +24,8 @@ static bool adj_t(hipStream_t st, dim3 grid, const DevCtx& c, const AdjCoef& acf
   return false;
 }
 template <int MODEL, int CONTACT>
-static bool adj_n(int npb, hipStream_t st, dim3 grid, const DevCtx& c, const AdjCoef& acf, int i, int j, int in_buf, int wbuf, int local_only, const StageCoef& rc,
-                  int rb) {
+static bool adj_n(int npb, hipStream_t st, dim3 grid, const DevCtx& c, const AdjCoef& acf, int i, int j, int in_buf, int wbuf, int local_only,
+                  const StageCoef& rc, int rb) {
   return npb == 3 ? adj_t<MODEL, CONTACT, 3>(st, grid, c, acf, i, j, in_buf, wbuf, local_only, rc, rb)
                   : adj_t<MODEL, CONTACT, 4>(st, grid, c, acf, i, j, in_buf, wbuf, local_only, rc, rb);
 }
