@@ -330,9 +330,14 @@ class Geometry:
         cnv, cen = self._centre(self.reference_node_vectors(*design))
         return self.reference_points() + cen, cnv
 
-    def _centre_vjp(self, ref, cnv_bar, centroid_bar):
+    def _centre_vjp(self, ref, cnv_bar, centroid_bar, props_bar=None):
+        """props_bar = (area_bar, polar_moment_bar) of the centred polygons, folded into the same polygon pass: area and polar moment about the
+        centroid do not change under translation, so their vertex derivatives on ``ref`` are those on ``ref - centroid`` and sum to zero over
+        a polygon (no contribution to the centroid's cotangent) -- one pass per design instead of two (compute_inertia_vjp + this)."""
         g = (centroid_bar if centroid_bar is not None else 0.0) - cnv_bar.sum(1)   # cotangent of the centroid
-        return cnv_bar + polygon_props_vjp(ref, cen_bar=g)
+        if props_bar is None:
+            return cnv_bar + polygon_props_vjp(ref, cen_bar=g)
+        return cnv_bar + polygon_props_vjp(ref, area_bar=props_bar[0], cen_bar=g, ip_bar=props_bar[1])
 
 
 def _square_grid(n1, n2):
@@ -388,10 +393,10 @@ class QuadGeometry(Geometry):
     def reference_bond_vectors(self):
         return _quad_ref_vectors(self.n1_blocks, self.n2_blocks, self.bond_length)
 
-    def vjp(self, design, cnv_bar, centroid_bar=None):
-        """Cotangents of (centroid_node_vectors, block_centroids) -> cotangents of the design tuple."""
+    def vjp(self, design, cnv_bar, centroid_bar=None, props_bar=None):
+        """Cotangents of (centroid_node_vectors, block_centroids[, (area, polar moment)]) -> cotangents of the design tuple."""
         hs, vs = design
-        ref_bar = self._centre_vjp(self.reference_node_vectors(hs, vs), cnv_bar, centroid_bar)
+        ref_bar = self._centre_vjp(self.reference_node_vectors(hs, vs), cnv_bar, centroid_bar, props_bar)
         n1, n2 = self._n1s, self._n2s
         hb = np.zeros(self.design_shapes()[0]); vb = np.zeros(self.design_shapes()[1])
         np.add.at(hb, (n1 + 1, n2), ref_bar[:, 0]); np.add.at(vb, (n1, n2 + 1), ref_bar[:, 1])
@@ -496,8 +501,8 @@ class KagomeGeometry(Geometry):
         return np.concatenate([np.tile(self._ri, (n1c * n2c, 1)), np.tile(self._r1, (n1c * (n2c - 1), 1)),
                                np.tile(self._r2, ((n1c - 1) * n2c, 1))])
 
-    def vjp(self, design, cnv_bar, centroid_bar=None):
-        ref_bar = self._centre_vjp(self.reference_node_vectors(*design), cnv_bar, centroid_bar)
+    def vjp(self, design, cnv_bar, centroid_bar=None, props_bar=None):
+        ref_bar = self._centre_vjp(self.reference_node_vectors(*design), cnv_bar, centroid_bar, props_bar)
         n1, n2 = self.n1_cells, self.n2_cells
         cells = ref_bar.reshape(n2, n1, 2, 3, 2).transpose(1, 0, 2, 3, 4)        # (n1, n2, 2, 3, 2)
         s1b, s2b, s3b = (np.zeros(s) for s in self.design_shapes())

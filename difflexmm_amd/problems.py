@@ -714,8 +714,11 @@ def design_gradients(fw, designs, raw):
         # (contacts are rare: an identically zero cotangent -- the engine hands out a view of a zero buffer then -- maps to exact zeros)
         if "void_angle0" in raw and np.any(raw["void_angle0"][m]):
             cnv_bar += void_angles0_vjp(cnv, bonds, raw["void_angle0"][m])
-        cnv_bar += compute_inertia_vjp(cnv, fw.density, raw["inertia"][m])[0]
-        grads.append(geo.vjp(d, cnv_bar, raw["block_centroids"][m] if "block_centroids" in raw else None))
+        # inertia = density * (area, area, polar moment about the centroid): its cotangent rides on the lattice map's own polygon pass
+        ib = np.asarray(raw["inertia"][m], dtype=float)
+        rho = np.broadcast_to(np.asarray(fw.density, dtype=float), ib.shape[:1])
+        grads.append(geo.vjp(d, cnv_bar, raw["block_centroids"][m] if "block_centroids" in raw else None,
+                             props_bar=(rho * (ib[:, 0] + ib[:, 1]), rho * ib[:, 2])))
     return grads
 
 
