@@ -21,6 +21,27 @@ def _function(txt, prefix):
     return [l.strip() for l in body if l.strip() and not l.strip().startswith((";", ".", "_")) and not l.strip().endswith(":")]
 
 
+def _schedule_fingerprint(instrs):
+    """sha256 of a kernel's instruction SEQUENCE with register numbers and labels taken out: equal for two compilations that differ in
+    register allocation only, different as soon as the machine scheduler orders the same instructions differently."""
+    import hashlib
+    norm = []
+    for x in instrs:
+        x = re.sub(r";.*$", "", x)
+        x = re.sub(r"\.LBB\d+_\d+", ".LBB", x)
+        x = re.sub(r"\b[vsa]\[\d+:\d+\]", "R", x)
+        x = re.sub(r"\b[vsa]\d+\b", "r", x)
+        norm.append(" ".join(x.split()))
+    return hashlib.sha256("\n".join(norm).encode()).hexdigest()[:16]
+
+
+FINGERPRINTS = os.path.join(ROOT, "tests", "golden", "schedule_fingerprints.json")
+
+
+def _toolchain():
+    return subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()[1].strip()
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
     out = tmp_path / "dfx.s"
@@ -129,6 +150,22 @@ def test_stage_kernels_keep_their_spills_off_the_hot_path(tmp_path):
         assert sum(x.startswith(("v_readlane", "v_writelane")) for x in f3) <= 8 and sum(x.startswith(("v_readlane", "v_writelane")) for x in a3) <= 4, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi3ELi1ELi0ELi1ELi{st}ELi1EE")[1] <= 102, st
         assert meta_of(f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi3ELi1ELi0ELi1ELi{st}EE")[1] <= 128, st
+    # The SCHEDULE of the launches that fill the chip.  Round 5 lost 3 % on the reverse kernel without a line of it changing: the machine
+    # scheduler's order for one kernel depends on what else is compiled in its module, and moving the experiments out of the library moved
+    # it (profiles/r05_reverse_stage_schedule.txt).  The fingerprints below are the schedules the committed measurements were taken with
+    # (same toolchain only).  If this fails after an edit that was not meant to touch these kernels: measure (tools/ab_libs.sh) before
+    # accepting -- then refresh with DFX_UPDATE_FINGERPRINTS=1.
+    import json
+    names = {f"adj_stage{st}": f"_ZN12_GLOBAL__N_111k_adj_stageILi1ELi1ELi0ELi0ELi4ELi1ELi0ELi1ELi{st}EE" for st in range(6)}
+    names.update({f"fwd_stage{st}": f"_ZN12_GLOBAL__N_111k_fwd_stageILi1ELi1ELi4ELi1ELi0ELi1ELi{st}ELi1EE" for st in range(6)})
+    now = {"toolchain": _toolchain(), "kernels": {k: _schedule_fingerprint(_function(txt, v)) for k, v in names.items()}}
+    if os.environ.get("DFX_UPDATE_FINGERPRINTS"):
+        json.dump(now, open(FINGERPRINTS, "w"), indent=1, sort_keys=True)
+    want = json.load(open(FINGERPRINTS))
+    if want["toolchain"] != now["toolchain"]:
+        pytest.skip(f"schedule fingerprints were taken with {want['toolchain']!r}, this is {now['toolchain']!r}")
+    changed = sorted(k for k in names if want["kernels"].get(k) != now["kernels"][k])
+    assert not changed, f"the compiler now schedules {changed} differently from the build the committed measurements were taken with"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
