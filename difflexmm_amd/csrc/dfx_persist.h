@@ -9,8 +9,8 @@
 //
 // How.  A wave owns its 16 (20: packed triangles) blocks for a whole segment of <= 256 steps: parameters, step state and the stage
 // accelerations stay in registers (reverse loop: lambda, the Ybar history and the gradient accumulators in lane-private LDS words, which
-// is what lets three of its workgroups share a compute unit).  What the NEXT stage of a neighbouring wave needs is the 32-byte stage record of a block (x, y, theta,
-// sin theta/2) -- nothing else crosses waves, and a wave has <= 4 neighbour waves on a lattice.  Hand-off (MI355X_MICROARCH.md,
+// is what lets three of its workgroups share a compute unit).  What the NEXT stage of a neighbouring wave needs is the 32-byte stage record of
+// a block (x, y, theta, sin theta/2) -- nothing else crosses waves, and a wave has <= 4 neighbour waves on a lattice.  Hand-off (MI355X_MICROARCH.md,
 // "Valid forms", R2: the data is the flag):
 //   * records travel through a RING of kPRing places per member, [place][member][block][4 doubles]; the record of stage ordinal t of a
 //     launch lives in place t % kPRing;
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
             const double* ft_n = fn_tab_row(c, m, j, i + 1);
             const u32 z = lane_zero();
             qnext = 0.0; vnext = 0.0;
-            for (int f = 0; f < c.n_fns; ++f) { qnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 0, z); vnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 1, z); }
+            for (int f = 0; f < c.n_fns; ++f) {
+              qnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 0, z);
+              vnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 1, z);
+            }
           }
         }
         // ---- the next stage record: into the ring for the neighbours, into the checkpoint for the reverse sweep
