@@ -17,6 +17,13 @@ pytestmark = pytest.mark.gpu
 EXACT = "nocontract" in os.environ.get("DFX_LIBRARY", "")
 
 
+@pytest.fixture(autouse=True)
+def _persistent_loop_not_switched_off(monkeypatch):
+    """These tests are about the persistent loop: a suite run with DFX_PERSIST=0 (everything else on one launch per stage) must not switch
+    it off underneath them; the arms that want stage launches set DFX_PERSIST=0 themselves."""
+    monkeypatch.delenv("DFX_PERSIST", raising=False)
+
+
 def same(a, b, tol):
     return np.array_equal(a, b) if EXACT else relerr(a, b) < tol
 
