@@ -122,7 +122,7 @@ struct dfx_handle {
   bool adaptive = false;
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
-  DevBuf<double> d_POS, d_VEL, d_A, d_state0, d_fields, d_fn_tab;
+  DevBuf<double> d_POS, d_VEL, d_A, d_state0, d_fields, d_fn_tab, d_restart;
   DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_m, d_blk_c, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
@@ -133,6 +133,8 @@ struct dfx_handle {
   DevBuf<double> d_acc_times, d_tsteps;
   bool dense = false;              // the last fixed-grid forward kept the stage checkpoint (stage accelerations of every step)
   bool segments = false;           // ... or nothing but the outputs: the reverse sweep re-runs one output interval at a time (records level inside it)
+  long long seg_chunk = 0;         // segments level: stage records of at most this many steps are resident (0: a whole output interval); longer intervals are
+                                   // re-run in pieces from restart states that one more record-free pass over the interval leaves in d_restart
   std::vector<int> seg_first, seg_last;   // first / last segment of every output interval
   bool records = false;            // ... or the records checkpoint (every stage record of every step): no rebuild, no recompute
   std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps); one grid, or one per member (ts_stride = n_total + 1)

@@ -44,7 +44,8 @@ int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_s
       warned = true;
     }
   } else if (const char* e2 = getenv("DFX_STAGE_CHECKPOINT")) forced = e2[0] != '0' ? kCkStages : kCkState;
-  const size_t want_seg = B * ((size_t)std::max<long long>(max_interval_steps, 1) * pl.tab.s + 1) * rec;
+  size_t want_seg = B * ((size_t)std::max<long long>(max_interval_steps, 1) * pl.tab.s + 1) * rec;
+  h->seg_chunk = 0;
   // the kernels address trajectory records by a 32-bit ordinal ((step * records per step + record) * members + member; at the segments
   // level the step is the global one against a shifted base): 2^32 records are 44 million Dopri5 steps of 16 members
   if ((double)B * ((double)N * pl.tab.s + 1.0) >= 4294967296.0) {
@@ -90,11 +91,28 @@ int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_s
     return m;
   };
   if (mode == kCkSegments) {
+    // An output interval whose stage records do not fit (few output times, many steps between them, many members) is re-run in pieces of
+    // whole graph segments (kMaxGraphSteps steps): the reverse sweep first runs the interval once more without records to leave restart
+    // states at the piece boundaries (run_adjoint).  The piece: as long as fits next to what is allocated, at least one segment.
+    // DFX_SEG_CHUNK_STEPS=n forces pieces of n steps (tests).
+    long long piece = 0;
+    if (const char* e = getenv("DFX_SEG_CHUNK_STEPS")) piece = std::max<long long>(kMaxGraphSteps, (atoll(e) / kMaxGraphSteps) * kMaxGraphSteps);
+    else if (!fits(grow(want_seg, have_t)) && max_interval_steps > kMaxGraphSteps) {
+      (void)fits(1);       // (queries the free memory if nothing has yet)
+      const size_t free_now = dfx_test_free_bytes ? std::min<size_t>(free_b, dfx_test_free_bytes) : free_b;
+      const size_t budget = free_now > total_b / 20 ? (free_now - total_b / 20) / sizeof(double) + have_t : have_t;
+      const long long can = (long long)(budget / (B * rec) > 1 ? (budget / (B * rec) - 1) / pl.tab.s : 0);
+      piece = std::max<long long>(kMaxGraphSteps, (can / kMaxGraphSteps) * kMaxGraphSteps);
+    }
+    if (piece > 0 && piece < max_interval_steps) {
+      h->seg_chunk = piece;
+      want_seg = B * ((size_t)piece * pl.tab.s + 1) * rec;
+    }
     if (h->ck->traj.ensure(want_seg) != hipSuccess) {
       (void)hipGetLastError();
-      h->err = "forward: cannot allocate the trajectory checkpoint: even its smallest form, the stage records of one output interval of all members ("
-               + std::to_string((want_seg * sizeof(double)) >> 20) + " MiB), does not fit the device next to what is allocated -- integrate fewer members "
-               "per engine call (the problem layer runs a longer list of designs in calls of `batch`) or ask for more output times";
+      h->err = "forward: cannot allocate the trajectory checkpoint: even its smallest form, the stage records of " + std::to_string(kMaxGraphSteps)
+               + " steps of all members (" + std::to_string((want_seg * sizeof(double)) >> 20) + " MiB), does not fit the device next to what is "
+               "allocated -- integrate fewer members per engine call (the problem layer runs a longer list of designs in calls of `batch`)";
       return done(-1);
     }
     return done(mode);

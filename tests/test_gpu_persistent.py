@@ -160,3 +160,27 @@ def test_a_member_does_not_depend_on_its_neighbours(hip_lib):
     assert np.array_equal(np.asarray(f3)[1], np.asarray(f1)) and float(np.atleast_1d(o3)[1]) == float(np.atleast_1d(o1)[0])
     for k in r1:
         assert np.array_equal(np.asarray(r3[k])[1], np.asarray(r1[k]).reshape(np.asarray(r3[k])[1].shape)), k
+
+
+@pytest.mark.parametrize("persist", ["0", "1"])
+def test_segments_level_in_pieces_equals_whole_intervals(hip_lib, persist):
+    """An output interval whose stage records do not fit the device is re-run in pieces of whole graph segments from restart states that one
+    more record-free pass over the interval leaves behind (choose_checkpoint / run_adjoint; forced here with DFX_SEG_CHUNK_STEPS).  A restart
+    from a step's state is exact, so fields, objective and every gradient equal the unpieced segments level bit for bit -- with stage
+    launches and with the persistent loop -- and the records level to rounding.  600 and 300 steps per interval: pieces of 256 + 256 + 88 and
+    256 + 44 steps; three members in two groups."""
+    c = Case("quads", 10, True, True, seed=4, cutoff_deg=42.0, batch=3)
+    c.cp = c.cp._replace(constraint_params=FAST)
+    ts = np.array([0.0, 4e-4, 6e-4])
+    target = np.array([44, 45], dtype=np.int32)
+    spi = [600, 300]
+    whole = _solve(c, ts, spi, target, {"DFX_PERSIST": persist, "DFX_CHECKPOINT": "segments"})
+    parts = _solve(c, ts, spi, target, {"DFX_PERSIST": persist, "DFX_CHECKPOINT": "segments", "DFX_SEG_CHUNK_STEPS": "256"})
+    recs = _solve(c, ts, spi, target, {"DFX_PERSIST": persist, "DFX_CHECKPOINT": "records"})
+    assert whole[3]["adjoint"]["checkpoint_records"] == 2 and parts[3]["adjoint"]["checkpoint_records"] == 2
+    assert parts[3]["adjoint"]["launches"] > whole[3]["adjoint"]["launches"]            # the record-free pass and the restarts really ran
+    assert np.array_equal(parts[0], whole[0]) and parts[1] == whole[1]
+    for k in whole[2]:
+        assert np.array_equal(parts[2][k], whole[2][k]), k
+        assert relerr(parts[2][k], recs[2][k]) < 1e-10, k
+    assert whole[1] > 0 and np.abs(whole[2]["centroid_node_vectors"]).max() > 0
