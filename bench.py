@@ -384,15 +384,11 @@ def run_c4(args, comm, comm_info, world, rank, local_rank):
     members = C4_DESIGNS // world
     K = max(40, args.steps - args.steps % 40)
     lo, hi = ensemble.shard_bounds(C4_DESIGNS, rank, world)
-    # designs per engine call: all of this rank's, unless the stage records of one output interval of that many members do not fit the
-    # device (the full 75 000-step horizon with 64 designs on ONE GPU: 385 GB) -- then half as many per call, the calls one after the
-    # other (TargetKineticEnergy.value_and_grad).  The engine would take all 64 in one call and re-run every interval in pieces from
-    # restart states (three forward passes + one reverse instead of two + one): 6.5e8 against 7.6e8 for two calls of 32.
+    # designs per engine call: all of this rank's.  (The full 75 000-step horizon with 64 designs on ONE GPU: the stage records of one
+    # output interval are 385 GB -- the engine re-runs such an interval in pieces from restart states its forward pass leaves behind, at no
+    # extra cost: 7.65e8 in one call, the same as two calls of 32.  Should an engine still refuse a width, half as many designs per call,
+    # the calls one after the other: TargetKineticEnergy.value_and_grad.)
     per_call = members
-    free_b, total_b = B.mem_info(local_rank)
-    spi_full = max(1, K // 40)
-    while per_call % 2 == 0 and per_call * (spi_full * 7 + 1) * (2 * 64 * 64) * 7 * 8 + total_b // 20 > free_b:
-        per_call //= 2
     while True:
         fw, obj, K = c4_problem(per_call, K, device=local_rank)
         designs = []

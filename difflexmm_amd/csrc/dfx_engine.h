@@ -134,8 +134,13 @@ struct dfx_handle {
   bool dense = false;              // the last fixed-grid forward kept the stage checkpoint (stage accelerations of every step)
   bool segments = false;           // ... or nothing but the outputs: the reverse sweep re-runs one output interval at a time (records level inside it)
   long long seg_chunk = 0;         // segments level: stage records of at most this many steps are resident (0: a whole output interval); longer intervals are
-                                   // re-run in pieces from restart states that one more record-free pass over the interval leaves in d_restart
+                                   // re-run in pieces from restart states that the forward pass leaves in d_restart (pieces, below)
   std::vector<int> seg_first, seg_last;   // first / last segment of every output interval
+  // segments level with seg_chunk > 0: the pieces of every interval (runs of segments whose stage records are resident together) and, for every
+  // piece that does not start its interval, the row of d_restart ([member][row][q | v]) the forward pass leaves its start state in
+  struct Piece { int first, last, interval, row; };
+  std::vector<Piece> pieces;
+  int n_restart_rows = 0;
   bool records = false;            // ... or the records checkpoint (every stage record of every step): no rebuild, no recompute
   std::vector<double> t_steps;     // caller-chosen step boundaries (empty: equal steps); one grid, or one per member (ts_stride = n_total + 1)
   long long ts_stride = 0;

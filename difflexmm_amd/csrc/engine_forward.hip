@@ -92,8 +92,8 @@ int choose_checkpoint(dfx_handle* h, long long n_steps, long long max_interval_s
   };
   if (mode == kCkSegments) {
     // An output interval whose stage records do not fit (few output times, many steps between them, many members) is re-run in pieces of
-    // whole graph segments (kMaxGraphSteps steps): the reverse sweep first runs the interval once more without records to leave restart
-    // states at the piece boundaries (run_adjoint).  The piece: as long as fits next to what is allocated, at least one segment.
+    // whole graph segments (kMaxGraphSteps steps): this forward pass leaves a restart state at every piece boundary (below), the reverse
+    // sweep re-runs and reverses piece by piece (run_adjoint).  The piece: as long as fits next to what is allocated, at least one segment.
     // DFX_SEG_CHUNK_STEPS=n forces pieces of n steps (tests).
     long long piece = 0;
     if (const char* e = getenv("DFX_SEG_CHUNK_STEPS")) piece = std::max<long long>(kMaxGraphSteps, (atoll(e) / kMaxGraphSteps) * kMaxGraphSteps);
@@ -273,6 +273,19 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   h->seg_first.assign(std::max(0, Tn - 1), 0); h->seg_last.assign(std::max(0, Tn - 1), -1);
   for (int si = (int)h->segs.size() - 1; si >= 0; --si) h->seg_first[h->segs[si].interval] = si;
   for (int si = 0; si < (int)h->segs.size(); ++si) h->seg_last[h->segs[si].interval] = si;
+  // pieces of the segments level (one per interval unless seg_chunk cuts it) and their restart rows
+  h->pieces.clear();
+  h->n_restart_rows = 0;
+  if (h->have_traj && h->segments)
+    for (int k = 0; k + 1 < Tn; ++k)
+      for (int si = h->seg_first[k]; si <= h->seg_last[k];) {
+        int last = si;
+        long long n = h->segs[si].n_steps;
+        while (last + 1 <= h->seg_last[k] && (h->seg_chunk == 0 || n + h->segs[last + 1].n_steps <= h->seg_chunk)) n += h->segs[++last].n_steps;
+        h->pieces.push_back({si, last, k, si == h->seg_first[k] ? -1 : h->n_restart_rows++});
+        si = last + 1;
+      }
+  if (h->n_restart_rows) HIP_OK(h->d_restart.ensure(B * (size_t)h->n_restart_rows * nb * 6));
   HIP_OK(h->d_segs.ensure(std::max<size_t>(1, h->segs.size())));
   if (!h->segs.empty())
     HIP_OK(hipMemcpyAsync(h->d_segs.p, h->segs.data(), sizeof(Seg) * h->segs.size(), hipMemcpyHostToDevice, h->stream));
@@ -312,11 +325,22 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
   const bool eager = solve_is_eager(h) || h->segments || h->persist_fwd;      // (a persistent segment is three launches: nothing to replay)
+  size_t next_piece = 0;
   for (size_t si = 0; si < h->segs.size(); ++si) {
     const Seg& sg = h->segs[si];
+    while (next_piece < h->pieces.size() && h->pieces[next_piece].first <= (int)si) ++next_piece;      // the first piece that starts after this segment
     if (eager) enqueue_interleaved(h, c, sg.n_steps, 0);
     for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
       if (!eager) if (int rc = run_segment(h, c, gi, sg.n_steps, 0)) return rc;
+      if (next_piece < h->pieces.size() && h->pieces[next_piece].row >= 0 && h->pieces[next_piece].first == (int)si + 1) {
+        // segments level, an interval in pieces: the state the NEXT piece starts from, for the reverse sweep's re-run of that piece
+        const Group& gr = h->groups[gi];
+        DevCtx cs = group_ctx(h, c, gi);
+        cs.n_timepoints = h->n_restart_rows;           // k_snapshot's row stride
+        hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, cs, h->d_restart.p, h->pieces[next_piece].row, bad_flag,
+                           pair_state_buf(h, h->segs[si + 1].base_step), (long long)h->segs[si + 1].base_step);
+        h->launches++;
+      }
       if (sg.j0 + sg.n_steps == h->spis[sg.interval]) {   // buffer 0 holds the state at the end of the interval
         const Group& gr = h->groups[gi];
         // end of the interval: the state is in buffer 0, or (records checkpoint) only in the trajectory

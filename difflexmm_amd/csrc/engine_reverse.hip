@@ -299,64 +299,31 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     // output intervals backwards: records of interval k rebuilt by re-running its forward pass from the resident output row k
     // (bit-identical to the first pass: same state, same arithmetic), then its reverse stages read them
     const size_t nb6 = (size_t)pl.n_blocks * 6;
-    const dim3 g3((unsigned)((pl.n_blocks * 3 + kThreads - 1) / kThreads), 1);
-    int* const bad_flag = reinterpret_cast<int*>(h->flag_stage.p);
-    // (re)start every member group at the first step of segment si from a state row: buffer 0 and, with records, record 0 of that step
-    auto restart = [&](const DevCtx& cc, const double* rows, long long row_stride, int si, bool with_records) {
+    // (re)start every member group at the first step of segment si from a state row: stage buffer 0 and record 0 of that step
+    auto restart = [&](const DevCtx& cc, const double* rows, long long row_stride, int si) {
       const Seg& s0 = h->segs[si];
       for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
         const Group& gr = h->groups[gi];
         const DevCtx cg = group_ctx(h, cc, gi);
-        hipLaunchKernelGGL(k_init, slot_grid(h, gr), dim3(kThreads), 0, gr.stream, cg, rows, s0.t_interval + s0.j0 * s0.h, 0, row_stride, (long long)s0.base_step);
-        h->launches++;
-        if (with_records) {
-          hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)(((size_t)pl.n_blocks * kStep + kThreads - 1) / kThreads), (unsigned)gr.nm), dim3(kThreads), 0,
-                             gr.stream, cg, (long long)s0.base_step);
-          h->launches++;
-        }
+        hipLaunchKernelGGL(k_init, slot_grid(h, gr), dim3(kThreads), 0, gr.stream, cg, rows, s0.t_interval + s0.j0 * s0.h, 0, row_stride,
+                           (long long)s0.base_step);
+        hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)(((size_t)pl.n_blocks * kStep + kThreads - 1) / kThreads), (unsigned)gr.nm), dim3(kThreads), 0,
+                           gr.stream, cg, (long long)s0.base_step);
+        h->launches += 2;
       }
     };
-    for (int k = Tn - 2; k >= 0; --k) {
-      // pieces of the interval whose stage records are resident together: the whole interval, or runs of graph segments of <= seg_chunk steps
-      std::vector<std::pair<int, int>> pieces;
-      for (int si = h->seg_first[k]; si <= h->seg_last[k];) {
-        int last = si;
-        long long n = h->segs[si].n_steps;
-        while (last + 1 <= h->seg_last[k] && (h->seg_chunk == 0 || n + h->segs[last + 1].n_steps <= h->seg_chunk)) n += h->segs[++last].n_steps;
-        pieces.push_back({si, last});
-        si = last + 1;
-      }
-      const int np = (int)pieces.size();
-      if (np > 1) {
-        // one more pass over the interval WITHOUT records (what the forward pass of this level does) leaves the state at the start of every
-        // later piece in d_restart: [member][piece][q | v].  A restart from such a row is exact: the state of a step is all a step starts from.
-        HIP_OK(h->d_restart.ensure(B * (size_t)np * nb6));
-        DevCtx ca = c;
-        ca.traj = nullptr; ca.rps = 1;
-        restart(ca, h->d_fields.p + (size_t)k * nb6, (long long)((size_t)Tn * nb6), pieces[0].first, false);
-        DevCtx cs = ca;
-        cs.n_timepoints = np;          // k_snapshot's row stride
-        for (int pi = 0; pi + 1 < np; ++pi) {
-          for (int si = pieces[pi].first; si <= pieces[pi].second; ++si) enqueue_interleaved(h, ca, h->segs[si].n_steps, 0, si);
-          for (int gi = 0; gi < (int)h->groups.size(); ++gi) {
-            const Group& gr = h->groups[gi];
-            hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, cs, gi), h->d_restart.p, pi + 1, bad_flag,
-                               pair_state_buf(h, h->segs[pieces[pi + 1].first].base_step), (long long)h->segs[pieces[pi + 1].first].base_step);
-            h->launches++;
-          }
-        }
-      }
-      for (int pi = np - 1; pi >= 0; --pi) {
-        // the buffer holds the records of THIS piece only: shift the base so that the kernels keep indexing by the global step
-        // (a per-interval offset inside the kernels cost the forward kernel two hot-path spills: profiles/r02_fwd_spill_regression.txt)
-        c.traj = h->ck->traj.p - (size_t)h->segs[pieces[pi].first].base_step * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
-        // records of the piece rebuilt by re-running its forward pass from the resident output row k / the restart state (bit-identical to
-        // the first pass: same state, same arithmetic), then its reverse stages read them
-        if (pi == 0) restart(c, h->d_fields.p + (size_t)k * nb6, (long long)((size_t)Tn * nb6), pieces[0].first, true);
-        else restart(c, h->d_restart.p + (size_t)pi * nb6, (long long)((size_t)np * nb6), pieces[pi].first, true);
-        for (int si = pieces[pi].first; si <= pieces[pi].second; ++si) enqueue_interleaved(h, c, h->segs[si].n_steps, 0, si);
-        for (int si = pieces[pi].second; si >= pieces[pi].first; --si) enqueue_interleaved(h, c, h->segs[si].n_steps, 1, si);
-      }
+    // the pieces backwards (one per output interval unless seg_chunk cuts it: engine_forward.hip).  The buffer holds the records of ONE piece:
+    // its base is shifted so that the kernels keep indexing by the global step (a per-interval offset inside the kernels cost the forward
+    // kernel two hot-path spills: profiles/r02_fwd_spill_regression.txt).  The records of a piece are rebuilt by re-running its forward pass
+    // from the resident output row of its interval, or from the restart row the forward pass left (bit-identical to the first pass: a step
+    // starts from nothing but its state, same arithmetic), then its reverse stages read them.
+    for (int pi = (int)h->pieces.size() - 1; pi >= 0; --pi) {
+      const dfx_handle::Piece& pc = h->pieces[pi];
+      c.traj = h->ck->traj.p - (size_t)h->segs[pc.first].base_step * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
+      if (pc.row < 0) restart(c, h->d_fields.p + (size_t)pc.interval * nb6, (long long)((size_t)Tn * nb6), pc.first);
+      else restart(c, h->d_restart.p + (size_t)pc.row * nb6, (long long)((size_t)h->n_restart_rows * nb6), pc.first);
+      for (int si = pc.first; si <= pc.last; ++si) enqueue_interleaved(h, c, h->segs[si].n_steps, 0, si);
+      for (int si = pc.last; si >= pc.first; --si) enqueue_interleaved(h, c, h->segs[si].n_steps, 1, si);
     }
   } else
   for (int si = nseg - 1; si >= 0; --si) {

@@ -164,8 +164,8 @@ def test_a_member_does_not_depend_on_its_neighbours(hip_lib):
 
 @pytest.mark.parametrize("persist", ["0", "1"])
 def test_segments_level_in_pieces_equals_whole_intervals(hip_lib, persist):
-    """An output interval whose stage records do not fit the device is re-run in pieces of whole graph segments from restart states that one
-    more record-free pass over the interval leaves behind (choose_checkpoint / run_adjoint; forced here with DFX_SEG_CHUNK_STEPS).  A restart
+    """An output interval whose stage records do not fit the device is cut into pieces of whole graph segments, each re-run from a restart state
+    the forward pass keeps (choose_checkpoint / forward_grid_impl / run_adjoint; forced here with DFX_SEG_CHUNK_STEPS).  A restart
     from a step's state is exact, so fields, objective and every gradient equal the unpieced segments level bit for bit -- with stage
     launches and with the persistent loop -- and the records level to rounding.  600 and 300 steps per interval: pieces of 256 + 256 + 88 and
     256 + 44 steps; three members in two groups."""
@@ -178,7 +178,7 @@ def test_segments_level_in_pieces_equals_whole_intervals(hip_lib, persist):
     parts = _solve(c, ts, spi, target, {"DFX_PERSIST": persist, "DFX_CHECKPOINT": "segments", "DFX_SEG_CHUNK_STEPS": "256"})
     recs = _solve(c, ts, spi, target, {"DFX_PERSIST": persist, "DFX_CHECKPOINT": "records"})
     assert whole[3]["adjoint"]["checkpoint_records"] == 2 and parts[3]["adjoint"]["checkpoint_records"] == 2
-    assert parts[3]["adjoint"]["launches"] > whole[3]["adjoint"]["launches"]            # the record-free pass and the restarts really ran
+    assert parts[3]["adjoint"]["launches"] > whole[3]["adjoint"]["launches"]            # the restarts of the later pieces really ran
     assert np.array_equal(parts[0], whole[0]) and parts[1] == whole[1]
     for k in whole[2]:
         assert np.array_equal(parts[2][k], whole[2][k]), k
