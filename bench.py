@@ -522,6 +522,150 @@ def run_c2(args, comm, comm_info, world, rank, local_rank):
     comm.close()
 
 
+PAPER_UNITS = 24 * 16
+
+
+def paper_problem(members, device=0, lib=None, angle_deg=35.0):
+    """The reference's OWN call (round-5 verdict #1): the lattice, constants and tolerances of the notebooks (24 x 16 quads, spacing 15 mm,
+    hinge 0.15 spacing, k = 120 / 1.19 / 1.5, contact -15 / -10 deg, pulse 0.5 spacing at 30 Hz delayed by 0.1 / f, 200 outputs over 2 / f,
+    `odeint(rtol=1e-8, atol=1e-4)` -- problems/quads_focusing.py:73-74 with the notebook's atol; tests/notebook_kat.py pins this very
+    problem to two numbers the reference printed), objective = kinetic energy of a 2 x 2 target (problems/quads_focusing.py:432-471),
+    value + gradient w.r.t. the design.  Member 0 is the notebook's initial design (rotated squares at 35 degrees), the others perturb it."""
+    from difflexmm_amd.problems import QuadsFocusingForward, TargetKineticEnergy
+    n1, n2, spacing = 24, 16, 15.0
+    rho, ks, ksh, kr = 6.18e-9, 120.0, 1.19, 1.5
+    damping = 0.0186 * np.array([2 * math.sqrt(0.36125 * rho * spacing ** 2 * ksh)] * 2 +
+                                [2 * math.sqrt(0.02175026 * rho * spacing ** 4 * kr)]) * np.ones((n1 * n2, 1))
+    fw = QuadsFocusingForward(n1_blocks=n1, n2_blocks=n2, spacing=spacing, bond_length=0.15 * spacing, k_stretch=ks, k_shear=ksh, k_rot=kr,
+                              density=rho, damping=damping, use_contact=True, k_contact=kr, min_angle=-15 * math.pi / 180,
+                              cutoff_angle=-10 * math.pi / 180, amplitude=0.5 * spacing, loading_rate=FREQ, input_delay=0.1 / FREQ,
+                              n_excited_blocks=2, loaded_side="left", input_shift=0, simulation_time=2 / FREQ, n_timepoints=200,
+                              atol=1e-4, rtol=1e-8, batch=members, device=device, _lib=lib)
+    obj = TargetKineticEnergy(fw, (2, 2), (5, 3))
+    base = fw.geometry.get_design_from_rotated_square(angle_deg * math.pi / 180)
+    designs = [tuple(np.array(b) for b in base)]
+    for m in range(1, members):
+        rng = np.random.default_rng(1000 + m)
+        designs.append(tuple(b + rng.uniform(-0.02 * spacing, 0.02 * spacing, b.shape) for b in base))
+    return fw, obj, designs
+
+
+def paper_eval(fw, obj):
+    """objective + raw gradient of the designs `prepare` left on the device: what `jit(value_and_grad(objective))` is in the reference."""
+    sd = fw.solve_dynamics
+    sd.solve_resident(fw.state0, fw.timepoints, keep_trajectory=True, want_fields=False)
+    vals, raw = sd.kinetic_energy_value_and_raw(obj.target_blocks)
+    st, ast, ad = sd.stats, sd.adjoint_stats, getattr(sd, "adaptive_stats", None)
+    two_pass = st.get("step_control") == "adaptive-grid"
+    counts = sd.engine.adaptive_step_counts() if hasattr(sd.engine, "adaptive_step_counts") else None
+    info = {"forward_passes": 2 if two_pass else 1,
+            "attempts_max": int(((ad if two_pass else st)["rhs_evals"] - 2) // 6),
+            "accepted_per_member": [int(x) for x in counts.sum(1)] if counts is not None else None,
+            "reverse_steps": int(ast["steps"]),
+            "device_ms": {"adaptive_forward": float((ad if two_pass else st)["kernel_ms"]), "frozen_grid_forward": float(st["kernel_ms"]) if two_pass else 0.0,
+                          "reverse": float(ast["kernel_ms"])},
+            "launches": {"adaptive_forward": int((ad if two_pass else st)["launches"]), "frozen_grid_forward": int(st["launches"]) if two_pass else 0,
+                         "reverse": int(ast["launches"])},
+            "kernels": {"adaptive_forward": (ad if two_pass else st).get("tile_kernels", 0), "reverse": ast.get("tile_kernels", 0)}}
+    return np.asarray(vals, dtype=float), raw, info
+
+
+def run_paper(args, comm, comm_info, world, rank, local_rank):
+    """`--workload paper`: one "step" of this workload is ONE whole evaluation (objective + gradient) of the paper's problem with the
+    reference's own integrator settings; `--steps K` evaluations are timed after `--warmup W` (defaults 5 / 1).  Two widths: ONE design
+    (the reference's call) and `--paper-members` designs side by side (weak scaling over ranks: every rank its own designs)."""
+    from difflexmm_amd import _binding as B
+    K = 5 if args.steps == 5000 else max(1, args.steps)
+    W = 1 if args.warmup == 250 else max(0, args.warmup)
+
+    def sync():
+        B.device_synchronize(local_rank)
+
+    legs = {}
+    for name, members in (("one_design", 1), ("batched", max(1, args.paper_members))):
+        fw, obj, designs = paper_problem(members, device=local_rank)
+        sd = fw.solve_dynamics
+        t0 = time.perf_counter()
+        sd.prepare([fw.control_params(d) for d in designs])
+        prep_ms = 1e3 * (time.perf_counter() - t0)
+        for _ in range(W):
+            paper_eval(fw, obj)
+        sync(); comm.barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            vals, raw, info = paper_eval(fw, obj)
+        sync(); comm.barrier(); sync()
+        wall = float(comm.all_reduce([time.perf_counter() - t0], "max")[0]) / K
+        acc = info["accepted_per_member"] or [info["reverse_steps"]] * members
+        unit_steps = PAPER_UNITS * float(sum(acc))
+        dms = info["device_ms"]
+        stage_us_fwd = 1e3 * dms["adaptive_forward"] / max(1, info["attempts_max"] * 6)
+        stage_us_rev = 1e3 * dms["reverse"] / max(1, info["reverse_steps"] * 6)
+        legs[name] = dict(info, members_per_gpu=members, value=unit_steps * world / wall, wall_ms_per_evaluation=1e3 * wall, host_prepare_ms=prep_ms,
+                          device_only_value=unit_steps * world / (1e-3 * sum(dms.values())),
+                          objective=[float(x) for x in vals[:4]],
+                          grad_norm=float(np.sqrt(sum(float(np.vdot(a, a)) for a in raw.values()))),
+                          us_per_stage={"adaptive_forward_attempt": stage_us_fwd, "reverse": stage_us_rev},
+                          roofline=stage_roofline("reverse stage <nonlinear,contact>", BYTES_ADJ_STAGE, PAPER_UNITS * members, stage_us_rev,
+                                                  kernels=BUILD_NAMES.get(int(info["kernels"]["reverse"])), members_per_stage=members,
+                                                  measured_with="HIP events around the reverse sweep / (steps x 6 stages)"),
+                          roofline_forward=stage_roofline("adaptive forward stage <nonlinear,contact>", BYTES_FWD_STAGE, PAPER_UNITS * members,
+                                                          stage_us_fwd, kernels=BUILD_NAMES.get(int(info["kernels"]["adaptive_forward"])),
+                                                          measured_with="HIP events around the adaptive pass / (attempts x 6 evaluations): controller, "
+                                                                        "error norm and dense output included"))
+        sd.engine.close()
+    if rank == 0:
+        one = legs["one_design"]
+        line = {"metric": "timesteps*rigid-units/s (adaptive forward + gradient, accepted steps)", "value": one["value"], "unit": "timesteps*units/s",
+                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": one["wall_ms_per_evaluation"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "paper: 24x16 quads (384 units), nonlinear ligaments + damping + angle contact, delayed pulse, 200 outputs over 2/f, "
+                                       "adaptive Dopri5 rtol=1e-8 atol=1e-4 (jax.experimental.ode semantics), objective + design-reaching gradient; "
+                                       "one step of this workload = one whole evaluation; value counts ACCEPTED steps x units",
+                           "members_per_gpu": 1, "collective": comm_info["collective"], "ranks_seen": comm_info.get("ranks_seen")},
+                "roofline": one["roofline"], "one_design": one, "batched": legs["batched"], "csrc": source_ids()}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = paper_cpu_baseline()
+        print(json.dumps(line), flush=True)
+    comm.barrier()
+    comm.close()
+
+
+def paper_cpu_baseline(repeats=5):
+    """The C++ port of the oracle on the same evaluation, one design: adaptive pass + reverse sweep (on the frozen grid: the port has no
+    dense-output adjoint), all usable cores and one thread, median of `repeats` after one warm-up."""
+    import ctypes
+    from oracle.cpu import load, load_native
+    lib, build_flags = load_native()
+    if lib is None:
+        lib, build_flags = load(), build_flags + " (oracle/cpu/Makefile)"
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    fw, obj, designs = paper_problem(1, lib=lib)
+    fw.solve_dynamics.prepare([fw.control_params(d) for d in designs])
+    ncpu = usable_cpus()
+    legs = {}
+    for nt in ([1, ncpu] if gomp is not None and ncpu > 1 else [1]):
+        if gomp is not None:
+            gomp.omp_set_num_threads(nt)
+        paper_eval(fw, obj)
+        times = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            _, _, info = paper_eval(fw, obj)
+            times.append(time.perf_counter() - t0)
+        acc = info["accepted_per_member"] or [info["reverse_steps"]]
+        legs[nt] = PAPER_UNITS * float(sum(acc)) / float(np.median(times))
+    best = max(legs, key=legs.get)
+    return {"value": legs[best], "unit": "timesteps*units/s", "cores": best, "kind": "port", "one_thread": legs.get(1),
+            "all_cores": legs.get(ncpu) if ncpu > 1 else None, "usable_cpus": ncpu, "build": build_flags,
+            "sample": f"the whole evaluation (adaptive forward, {info['forward_passes']} forward pass(es), reverse sweep) of one design of the same "
+                      f"24x16 lattice; C++ port of the oracle, 1 thread and {ncpu} threads, 1 warm-up + median of {repeats} runs each"}
+
+
 def usable_cpus():
     """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host is
     often granted a handful; spinning 256 OpenMP threads on them takes minutes per step)."""
@@ -667,7 +811,8 @@ def main():
     ap.add_argument("--c2-members", type=int, default=64, help="--workload c2: width of the second, batched leg")
     ap.add_argument("--backend", default="rccl", help="collective of the N>1 run: rccl (inside libdfx; strict: exits non-zero if it "
                                                       "does not come up on N distinct GPUs) | socket (rehearsal on one GPU)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
+    ap.add_argument("--paper-members", type=int, default=32, help="--workload paper: width of the second, batched leg")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5", "paper"],
                     help="c3: 128x128 quads, fixed designs per GPU (weak scaling; the headline).  c2: BASELINE config 2 -- 32x32 quads, "
                          "nonlinear ligaments + damping, 10 000 fixed steps, forward only, one member (and --c2-members beside it).  c4: BASELINE config 4 -- 64 kagome "
                          "designs (64x64 cells) in all, sharded over the ranks, forward + design gradient through the problem layer, "
@@ -719,6 +864,8 @@ def main():
         return run_c4(args, comm, comm_info, world, rank, local_rank)
     if args.workload == "c2":
         return run_c2(args, comm, comm_info, world, rank, local_rank)
+    if args.workload == "paper":
+        return run_paper(args, comm, comm_info, world, rank, local_rank)
     os.environ["DFX_STREAMS"] = str(args.streams)
     K = max(1, args.steps)                      # EXACTLY K steps are timed
     W = max(0, args.warmup)

@@ -201,12 +201,29 @@ class DynamicSolver:
         return spis, grid
 
     # -- solve -----------------------------------------------------------------------------------------
-    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None, step_times=None,
-                 want_fields=True):
+    def prepare(self, control_params):
+        """Host side of a solve: ``ControlParams`` -> flattened arrays -> device (``dfx_set_params``).  After it the inputs of
+        :meth:`solve_resident` are resident in HBM."""
         cps = self._members(control_params)
-        self.solve_count += 1
         flats = [self._flatten(cp) for cp in cps]
         self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
+        self._prepared = (cps, flats)
+        return cps, flats
+
+    def __call__(self, state0, timepoints, control_params, keep_trajectory=False, steps_per_interval=None, step_times=None,
+                 want_fields=True):
+        self.prepare(control_params)
+        fields = self.solve_resident(state0, timepoints, keep_trajectory=keep_trajectory, steps_per_interval=steps_per_interval,
+                                     step_times=step_times, want_fields=want_fields)
+        if fields is None:
+            return None
+        # one ControlParams (not a list) and batch 1 -> no leading member axis
+        return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
+
+    def solve_resident(self, state0, timepoints, keep_trajectory=False, steps_per_interval=None, step_times=None, want_fields=True):
+        """The solve on the parameters :meth:`prepare` left on the device; returns the fields with their leading member axis (or None)."""
+        cps, flats = self._prepared
+        self.solve_count += 1
         spi = steps_per_interval if steps_per_interval is not None else self.steps_per_interval
         if np.ndim(timepoints) == 2:
             # one row of output times per member (same number of outputs and of steps per interval: the members advance in the same
@@ -220,10 +237,7 @@ class DynamicSolver:
             self._last = (cps, flats, np.asarray(timepoints, dtype=float))
             self._last_fields = fields
             self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control="fixed")
-            if fields is None:
-                return None
-            # same convention as the common path: one ControlParams (not a list) and batch 1 -> no leading member axis
-            return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
+            return fields
         state0 = np.asarray(state0, dtype=float)
         if state0.ndim == 3:
             state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
@@ -232,7 +246,7 @@ class DynamicSolver:
             fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol)
             self._last = None
             self.stats = dict(stats, steps_per_interval=None, step_control="adaptive")
-            return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
+            return fields
         control = "fixed"
         if spi is None:   # the reverse sweep needs a fixed grid: freeze the one the adaptive controller chooses
             spi, step_times = self.adaptive_grid(state0, timepoints, flats)
@@ -243,9 +257,7 @@ class DynamicSolver:
         self._last = (cps, flats, np.asarray(timepoints, dtype=float))
         self._last_fields = fields
         self.stats = dict(stats, steps_per_interval=spi, step_times=step_times, step_control=control)
-        if fields is None:
-            return None
-        return fields[0] if self.batch == 1 and not isinstance(control_params, (list,)) else fields
+        return fields
 
     # -- reverse mode ------------------------------------------------------------------------------------
     def vjp(self, fields_bar):
