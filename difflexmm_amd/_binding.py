@@ -101,6 +101,9 @@ def declare(lib):
     lib.dfx_adaptive_step_counts.argtypes = [H, _ip]
     lib.dfx_adaptive_step_times.argtypes = [H, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]
     lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
+    if hasattr(lib, "dfx_forward_adaptive_keep"):
+        lib.dfx_forward_adaptive_keep.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int32, _dp, C.POINTER(dfx_stats)]
+        lib.dfx_forward_adaptive_keep.restype = C.c_int
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
     lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
@@ -337,18 +340,29 @@ class Engine:
         self._check(self.lib.dfx_adaptive_step_times(self._h, int(member), _ptr(out), n.value, C.byref(n)), "dfx_adaptive_step_times")
         return out
 
-    def forward_adaptive(self, state0, timepoints, rtol, atol, max_attempts=10_000_000):
-        """Adaptive Dormand-Prince with the reference's odeint semantics (forward only)."""
+    def forward_adaptive(self, state0, timepoints, rtol, atol, max_attempts=10_000_000, keep_trajectory=False, want_fields=True):
+        """Adaptive Dormand-Prince with the reference's odeint semantics.  ``keep_trajectory``: the accepted steps are kept for the
+        reverse sweep (``adjoint`` / ``kinetic_value_and_grad`` afterwards: the dense-output discrete adjoint of this very solve)."""
         B, nb = self.batch, self.n_blocks
         state0 = _f64(state0, (B, 2, nb, 3)) if state0 is not None else None        # None: every member starts at rest
         ts = _f64(timepoints)
         T = len(ts)
-        fields = np.empty((B, T, 2, nb, 3))
+        fields = np.empty((B, T, 2, nb, 3)) if want_fields else None
         st = dfx_stats()
-        self._check(self.lib.dfx_forward_adaptive(self._h, _ptr(state0), _ptr(ts), T, float(rtol), float(atol),
-                                                  int(max_attempts), _ptr(fields), C.byref(st)), "dfx_forward_adaptive")
+        if keep_trajectory or not want_fields:
+            if not self.can_keep_adaptive:
+                raise RuntimeError("this library has no dfx_forward_adaptive_keep")
+            self._check(self.lib.dfx_forward_adaptive_keep(self._h, _ptr(state0), _ptr(ts), T, float(rtol), float(atol), int(max_attempts),
+                                                           1 if keep_trajectory else 0, _ptr(fields), C.byref(st)), "dfx_forward_adaptive_keep")
+        else:
+            self._check(self.lib.dfx_forward_adaptive(self._h, _ptr(state0), _ptr(ts), T, float(rtol), float(atol),
+                                                      int(max_attempts), _ptr(fields), C.byref(st)), "dfx_forward_adaptive")
         self.n_timepoints = T
         return fields, _stats(st)
+
+    @property
+    def can_keep_adaptive(self):
+        return hasattr(self.lib, "dfx_forward_adaptive_keep")
 
     def _grads(self, which):
         sh = self.shapes()

@@ -667,4 +667,16 @@ DFX_HD double dopri_dense(double y0, double y1, double ymid, double dy0, double 
   return (((a * r + b) * r + c) * r + dt * dy0) * r + y0;
 }
 
+
+// The same dense output as weights of the stage slopes: out(r) = y0 + dt sum_j B_j(r) k_j, j = 0..6 (k_6 = f(y1), the FSAL slope), with
+// y1 = y0 + dt sum_j b_j k_j and y_mid = y0 + dt sum_j cm_j k_j put into the quartic above.  What the reverse sweep of an adaptive solve
+// needs: the cotangent g of an output inside a step adds dt B_j(r) g to Kbar_j and g to lambda at the start of the step.
+DFX_HD void dopri_dense_weights(double r, const double* b /* 7: solution weights */, const double* cm /* 7 */, double* B /* 7 */) {
+  const double r2 = r * r, r3 = r2 * r, r4 = r3 * r;
+  const double w1 = -8.0 * r4 + 14.0 * r3 - 5.0 * r2, wm = 16.0 * r4 - 32.0 * r3 + 16.0 * r2;
+  for (int j = 0; j < 7; ++j) B[j] = w1 * b[j] + wm * cm[j];
+  B[0] += -2.0 * r4 + 5.0 * r3 - 4.0 * r2 + r;
+  B[6] += 2.0 * r4 - 3.0 * r3 + r2;
+}
+
 }  // namespace dfx

@@ -285,6 +285,10 @@ struct AdjStage {
   int i;
   int local_only;       // 1: only Ybar_i + parameter accumulators (dfx_rhs_vjp test hook)
   double t_i, h, h_prev;  // h_prev: step size of the step that the NEXT reverse launch belongs to
+  // dense-output adjoint (the adaptive solve's outputs are interpolated inside a step: dfx_forward_adaptive_keep): what the outputs
+  // inside this step (and, through the FSAL slope, inside the previous one) add to the Kbar this launch hands on, already scaled by the
+  // step size -- (n_blocks*6: q(3) v(3) per block) or null
+  const double* src = nullptr;
 };
 
 // Local part of the reverse DOF work: Ybar of this DOF and the parameter accumulators.
@@ -362,6 +366,7 @@ DFX_HD void adj_dof(const Tables& tb, const Tableau& T, const AdjStage& st, cons
     kq = st.h_prev * bw * lq;
     kv = st.h_prev * bw * lv;
   }
+  if (st.src && !constrained) { kq += st.src[b * 6 + d]; kv += st.src[b * 6 + 3 + d]; }
   st.KQ_out[dof] = kq;
   st.W_out[dof] = constrained ? 0.0 : kv * tb.inv_m[dof];
 }

@@ -15,6 +15,7 @@ Differences that are inherent to running inside hand-written kernels (all keywor
     ``difflexmm_amd.loading`` (declarative specs), otherwise ``TypeError`` at setup;
   * ``batch=B`` integrates B members (list of B ``ControlParams``) side by side.
 """
+import os
 from typing import Optional
 
 import numpy as np
@@ -248,6 +249,15 @@ class DynamicSolver:
             self.stats = dict(stats, steps_per_interval=None, step_control="adaptive")
             return fields
         control = "fixed"
+        if spi is None and self.grid_refine == 1 and self.engine.can_keep_adaptive and os.environ.get("DFX_ADAPTIVE_RECORDS", "1") != "0":
+            # the reference's call, differentiable as it stands: the adaptive pass keeps its accepted steps and the reverse sweep is their
+            # exact discrete adjoint, output cotangents entering through the dense output -- one forward pass, one reverse sweep, and the
+            # gradient belongs to exactly the fields returned (dfx_forward_adaptive_keep; DFX_ADAPTIVE_RECORDS=0: the frozen grid below)
+            fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol, keep_trajectory=True, want_fields=want_fields)
+            self._last = (cps, flats, np.asarray(timepoints, dtype=float))
+            self._last_fields = fields
+            self.stats = dict(stats, steps_per_interval=None, step_times=None, step_control="adaptive-records")
+            return fields
         if spi is None:   # the reverse sweep needs a fixed grid: freeze the one the adaptive controller chooses
             spi, step_times = self.adaptive_grid(state0, timepoints, flats)
             control = "adaptive-grid"

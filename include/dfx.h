@@ -192,6 +192,18 @@ int dfx_forward_grid_members(dfx_handle* h, const double* state0, const double* 
 int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                          double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats);
 
+/* The same solve, keeping what the reverse sweep needs (keep_trajectory != 0): the stage records of every ACCEPTED step (a rejected
+ * attempt's records are overwritten in place), every member's own step boundaries, and for every output the step it was interpolated in.
+ * dfx_adjoint / dfx_adjoint_kinetic / dfx_kinetic_value_and_grad[_device] then run the exact discrete adjoint of THIS solve with its step
+ * sizes frozen -- the outputs' cotangents enter through the quartic dense output (an output at relative position r of step n adds g to
+ * lambda_n and h_n B_j(r) g to the cotangent of stage slope j; the FSAL slope's share joins the first slope of the next step) -- so that
+ * value_and_grad of the reference's default call, jit(value_and_grad(objective)) over odeint at dynamics.py:166, is ONE forward pass and
+ * ONE reverse sweep here, and the gradient is the derivative of exactly the fields that were returned (neither the accept / reject
+ * decisions nor the step sizes are differentiated; nor does the reference's continuous adjoint, jax.experimental.ode._odeint_rev).
+ * fields may be NULL (they stay on the device).  keep_trajectory == 0: dfx_forward_adaptive. */
+int dfx_forward_adaptive_keep(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                              double rtol, double atol, int64_t max_attempts, int32_t keep_trajectory, double* fields, dfx_stats* stats);
+
 /* Accepted steps of the last dfx_forward_adaptive per member and output interval: counts (batch, n_timepoints - 1);
  * a step is counted in the interval that contains its start. */
 int dfx_adaptive_step_counts(dfx_handle* h, int32_t* counts);

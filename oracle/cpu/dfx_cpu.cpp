@@ -44,6 +44,11 @@ struct dfx_handle {
   bool have_traj = false;
   std::vector<double> view_store[10];  // dfx_kinetic_value_and_grad: arrays behind the returned views
   std::vector<double> zero_state;
+  // dfx_forward_adaptive_keep: the accepted steps of every member -- step states (records), step boundaries (t_0 .. t_N), and for every
+  // output the step it lies in (-1: before the first step) with its relative position inside that step
+  bool adaptive_rec = false;
+  std::vector<std::vector<double>> a_traj, a_tsteps, a_theta;
+  std::vector<std::vector<int>> a_out_step;
 };
 
 static Tables member_tables(const dfx_handle* h, int m) {
@@ -206,6 +211,7 @@ static int forward_grid_impl(dfx_handle* h, const double* state0, const double* 
   h->n_tp = Tn;
   const double* timepoints_all = timepoints;
   h->have_traj = keep_trajectory != 0;
+  h->adaptive_rec = false;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
   if (keep_trajectory) h->traj.assign((size_t)B * (N + 1) * rec, 0.0);
   std::vector<double> Ybuf(2 * rec), Sbuf(2 * rec), A((size_t)T.s * nb * 3);
@@ -280,8 +286,8 @@ struct AdaptiveMember {
 };
 }  // namespace
 
-extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
-                                    double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats) {
+static int forward_adaptive_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                 double rtol, double atol, int64_t max_attempts, int keep, double* fields, dfx_stats* stats) {
   if (!h->have_params) { h->err = "forward_adaptive: set_params first"; return 1; }
   if (n_timepoints < 1) { h->err = "forward_adaptive: need >= 1 timepoint"; return 1; }
   const Plan& pl = h->pl;
@@ -291,9 +297,12 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
   h->ts.assign(timepoints, timepoints + Tn);
   h->n_tp = Tn; h->tp_stride = 0; h->ts_stride = 0;
   h->have_traj = false;
+  h->adaptive_rec = false;
   h->fields.assign((size_t)B * Tn * nb * 6, 0.0);
   h->step_counts.assign((size_t)B * std::max(0, Tn - 1), 0);
   h->acc_times.assign(B, {});
+  h->a_traj.assign(keep ? B : 0, {}); h->a_tsteps.assign(keep ? B : 0, {}); h->a_theta.assign(keep ? B : 0, {}); h->a_out_step.assign(keep ? B : 0, {});
+  const auto t_begin = std::chrono::steady_clock::now();
   int64_t max_acc = 0, max_try = 0;
   for (int m = 0; m < B; ++m) {
     Tables tb = member_tables(h, m);
@@ -313,6 +322,14 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
     double t = timepoints[0];
     M.rhs(q.data(), v.data(), t, kq.data(), kv.data());
     write_out(0, q.data(), v.data());
+    auto keep_state = [&]() {       // the record of the current state (constrained DOFs at c(t)): what the reverse sweep restarts a step from
+      std::vector<double> y(2 * (size_t)nd), S((size_t)nb * kRec);
+      memcpy(y.data(), q.data(), sizeof(double) * nd); memcpy(y.data() + nd, v.data(), sizeof(double) * nd);
+      for (int b = 0; b < nb; ++b) for (int d = 0; d < 3; ++d) init_dof(tb, y.data(), t, S.data(), b, d);
+      h->a_traj[m].insert(h->a_traj[m].end(), S.begin(), S.end());
+      h->a_tsteps[m].push_back(t);
+    };
+    if (keep) { keep_state(); h->a_theta[m].assign(Tn, 0.0); h->a_out_step[m].assign(Tn, -1); }
     // initial step (Hairer II.4 as restated by jax, order 4)
     double d0 = 0, d1 = 0, d2 = 0;
     for (int i = 0; i < nd; ++i) if (!M.con[i]) {
@@ -379,6 +396,7 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
           ++n_acc;
           ++h->step_counts[(size_t)m * (Tn - 1) + (k - 1)];   // the interval that contains the start of the step
           h->acc_times[m].push_back(t);
+          if (keep) keep_state();
         }
         dt = dt_new;
       }
@@ -389,6 +407,7 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
           yv[x] = dopri_dense(sv0[x], sv1[x], smv[x], f0v[x], f1v[x], h_acc, r);
         }
         write_out(k, yq.data(), yv.data());
+        if (keep) { h->a_theta[m][k] = r; h->a_out_step[m][k] = (int)n_acc - 1; }
       } else {
         write_out(k, q.data(), v.data());
       }
@@ -396,15 +415,147 @@ extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const d
     max_acc = std::max(max_acc, n_acc); max_try = std::max(max_try, n_try);
   }
   if (fields) memcpy(fields, h->fields.data(), sizeof(double) * h->fields.size());
-  if (stats) { memset(stats, 0, sizeof(*stats)); stats->steps = max_acc; stats->rhs_evals = 6 * max_try + 2; }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats)); stats->steps = max_acc; stats->rhs_evals = 6 * max_try + 2;
+    stats->kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    stats->checkpoint_records = keep ? 1 : 0;
+  }
+  if (keep) { h->adaptive_rec = true; h->have_traj = true; }
   return 0;
+}
+
+extern "C" int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                    double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats) {
+  return forward_adaptive_impl(h, state0, timepoints, n_timepoints, rtol, atol, max_attempts, 0, fields, stats);
+}
+extern "C" int dfx_forward_adaptive_keep(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                         double rtol, double atol, int64_t max_attempts, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
+  return forward_adaptive_impl(h, state0, timepoints, n_timepoints, rtol, atol, max_attempts, keep_trajectory != 0, fields, stats);
 }
 
 extern "C" {
 
+// Reverse sweep of an adaptive solve that kept its accepted steps (dfx_forward_adaptive_keep): the exact discrete adjoint of those steps with
+// the step sizes frozen -- the outputs are interpolated INSIDE steps (jax's quartic dense output), so their cotangents enter through the
+// stage slopes: an output at relative position r of step n adds g to lambda_n and h_n B_j(r) g to Kbar_j (dopri_dense_weights); the
+// seventh slope k_6 = f(y_{n+1}) is the first slope of step n + 1 (FSAL), so its share joins Kbar_0 of that step -- or, after the last
+// step, one extra Hessian-vector product at the final state.
+static int run_adjoint_dense(dfx_handle* h, const std::vector<double>& Gall, dfx_grads* grads, dfx_stats* stats) {
+  const Plan& pl = h->pl;
+  const Tableau& T = pl.tab;
+  const Dopri D = make_dopri();
+  const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp;
+  const size_t rec = (size_t)nb * kRec;
+  if (T.s != 6) { h->err = "adjoint: the adaptive solve is defined for the dopri5 tableau"; return 1; }
+  auto t_begin = std::chrono::steady_clock::now();
+  const int nsp = pl.n_special > 0 ? pl.n_special : 1;
+  std::vector<double> slot_g((size_t)B * pl.n_slots * kSlotGrads, 0.0), blk_g((size_t)B * nb * 6, 0.0),
+      fn_g((size_t)B * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, 0.0), cen_g((size_t)B * nb * 2, 0.0),
+      ovf_g((size_t)B * pl.n_ovf * kOvfGrads + 1, 0.0);
+  std::vector<double> Sst((size_t)T.s * rec), A((size_t)T.s * nb * 3), YB((size_t)T.s * nb * 6), LAM((size_t)nb * 6),
+      W(2 * (size_t)nb * 3), KQ(2 * (size_t)nb * 3), src((size_t)nb * 6), gsum((size_t)nb * 6);
+  int64_t max_steps = 0;
+  for (int m = 0; m < B; ++m) {
+    Tables tb = member_tables(h, m);
+    GradAcc acc{slot_g.data() + (size_t)m * pl.n_slots * kSlotGrads, blk_g.data() + (size_t)m * nb * 6,
+                fn_g.data() + (size_t)m * nsp * DFX_MAX_FNS * DFX_FN_PARAMS, cen_g.data() + (size_t)m * nb * 2,
+                ovf_g.data() + (size_t)m * pl.n_ovf * kOvfGrads};
+    const std::vector<double>& tst = h->a_tsteps[m];
+    const int64_t N = (int64_t)tst.size() - 1;
+    max_steps = std::max(max_steps, N);
+    const double* tr = h->a_traj[m].data();
+    const double* G = Gall.data() + (size_t)m * Tn * nb * 6;
+    // outputs of every step, with their slope weights
+    std::vector<std::vector<int>> outs((size_t)std::max<int64_t>(N, 0) + 1);
+    std::vector<double> Bw((size_t)Tn * 7, 0.0);
+    for (int k = 1; k < Tn; ++k) {
+      const int n = h->a_out_step[m][k];
+      if (n >= 0) { outs[n].push_back(k); dopri_dense_weights(h->a_theta[m][k], D.a[6], D.cm, Bw.data() + (size_t)k * 7); }
+    }
+    // sum over the outputs of step n of  scale * B_j g  (j < 0: of g itself), into `dst`
+    auto add_outputs = [&](int64_t n, int j, double scale, std::vector<double>& dst) {
+      if (n < 0 || n >= N) return;
+      for (int k : outs[n]) {
+        const double w = j < 0 ? scale : scale * Bw[(size_t)k * 7 + j];
+        const double* g = G + (size_t)k * nb * 6;
+        for (size_t x = 0; x < (size_t)nb * 6; ++x) dst[x] += w * g[x];
+      }
+    };
+    auto hstep = [&](int64_t n) { return (n >= 0 && n < N) ? tst[n + 1] - tst[n] : 0.0; };
+    int cur = 0;
+    std::fill(LAM.begin(), LAM.end(), 0.0);
+    std::fill(YB.begin(), YB.end(), 0.0);
+    // Kbar of the extra evaluation at the final state: h_{N-1} B_6 g of the outputs inside the last step
+    std::fill(src.begin(), src.end(), 0.0);
+    add_outputs(N - 1, 6, hstep(N - 1), src);
+    for (int b = 0; b < nb; ++b)
+      for (int d = 0; d < 3; ++d) {
+        const int sidx = tb.block_special[b];
+        const bool con = sidx >= 0 && ((tb.special[sidx].con_mask >> d) & 1);
+        KQ[(size_t)cur * nb * 3 + b * 3 + d] = con ? 0.0 : src[b * 6 + d];
+        W[(size_t)cur * nb * 3 + b * 3 + d] = con ? 0.0 : src[b * 6 + 3 + d] * tb.inv_m[b * 3 + d];
+      }
+    for (int64_t n = N; n >= 0; --n) {
+      const double t = tst[n], hh = hstep(n);
+      const double* Y = tr + (size_t)n * rec;
+      const int i_hi = n == N ? 0 : T.s - 1;            // n == N: only the evaluation at the final state (a step of size zero)
+      for (int i = 0; i <= i_hi; ++i) {       // stage records and accelerations of step n, recomputed from its state
+        FwdStage st;
+        st.S_in = i == 0 ? Y : Sst.data() + (size_t)i * rec;
+        st.S_out = i == i_hi ? nullptr : Sst.data() + (size_t)(i + 1) * rec;
+        st.Y = Y; st.A = A.data(); st.i = i; st.h = hh;
+        st.t_i = t + T.c[i] * hh; st.t_next = t + T.c[i + 1] * hh;
+        fwd_stage(tb, T, st);
+      }
+      for (int i = i_hi; i >= 0; --i) {
+        std::fill(src.begin(), src.end(), 0.0);
+        const double* Gadd = nullptr;
+        if (i > 0) {
+          add_outputs(n, i - 1, hh, src);                                  // Kbar_{i-1} of this step
+          if (i == 1) add_outputs(n - 1, 6, hstep(n - 1), src);            // ... and the FSAL slope of the previous one
+        } else {
+          add_outputs(n - 1, T.s - 1, hstep(n - 1), src);                  // Kbar_{s-1} of the previous step
+          std::fill(gsum.begin(), gsum.end(), 0.0);
+          add_outputs(n, -1, 1.0, gsum);                                   // lambda_n += g of the outputs inside this step
+          if (n == 0) for (size_t x = 0; x < (size_t)nb * 6; ++x) gsum[x] += G[x];      // ... and of the initial state (row 0) and of
+          for (int k = 1; k < Tn; ++k)                                                  // outputs produced before any step
+            if (n == 0 && h->a_out_step[m][k] < 0) for (size_t x = 0; x < (size_t)nb * 6; ++x) gsum[x] += G[(size_t)k * nb * 6 + x];
+          Gadd = gsum.data();
+        }
+        AdjStage st;
+        st.S = i == 0 ? Y : Sst.data() + (size_t)i * rec;
+        st.A = A.data();
+        st.W = W.data() + (size_t)cur * nb * 3; st.KQ = KQ.data() + (size_t)cur * nb * 3;
+        st.W_out = W.data() + (size_t)(1 - cur) * nb * 3; st.KQ_out = KQ.data() + (size_t)(1 - cur) * nb * 3;
+        st.YB = YB.data(); st.LAM = LAM.data();
+        st.G = Gadd; st.src = src.data();
+        st.i = i; st.local_only = 0; st.t_i = t + T.c[i] * hh; st.h = hh; st.h_prev = hstep(n - 1);
+        adj_stage(tb, T, st, acc);
+        cur = 1 - cur;
+      }
+      if (n == N) std::fill(YB.begin(), YB.end(), 0.0);      // (the zero-size step's Ybar_0 has been summed into lambda_N)
+    }
+    if (grads && grads->state0)
+      for (int b = 0; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) {
+          grads->state0[(size_t)m * nb * 6 + b * 3 + d] = LAM[b * 6 + d];
+          grads->state0[(size_t)m * nb * 6 + nb * 3 + b * 3 + d] = LAM[b * 6 + 3 + d];
+        }
+  }
+  if (grads) unpack_grads(pl, slot_g, blk_g, fn_g, h->pp.inv_m, grads, &ovf_g);
+  if (grads && grads->block_centroids) memcpy(grads->block_centroids, cen_g.data(), sizeof(double) * cen_g.size());
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->steps = max_steps; stats->rhs_evals = max_steps * T.s; stats->checkpoint_records = 1;
+    stats->kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return 0;
+}
+
 static int run_adjoint(dfx_handle* h, const std::vector<double>& Gall /* batch*T*nb*6 [q(3) v(3)] per block */,
                        dfx_grads* grads, dfx_stats* stats) {
   if (!h->have_traj) { h->err = "adjoint: run forward with keep_trajectory=1 first"; return 1; }
+  if (h->adaptive_rec) return run_adjoint_dense(h, Gall, grads, stats);
   const Plan& pl = h->pl;
   const Tableau& T = pl.tab;
   const int nb = pl.n_blocks, B = pl.batch, Tn = h->n_tp;

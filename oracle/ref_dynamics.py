@@ -210,6 +210,49 @@ def solve_fixed_differentiable(solver, geometry, state0, timepoints, control_par
     return torch.stack(out), inertia
 
 
+def solve_adaptive_replay_differentiable(solver, geometry, state0, timepoints, control_params, step_times):
+    """The adaptive solve replayed on the autograd tape with its accepted step boundaries ``step_times`` (t_0 .. t_N, t_N >= the last
+    output time) frozen: Dormand-Prince steps that are NOT clipped to the output times, outputs from jax's quartic dense output
+    (``interp_fit_dopri`` + ``polyval``, jax.experimental.ode at the pinned 0.4.8) -- exactly the arithmetic of ``ref_ode.odeint`` for the
+    decisions its controller took.  ``torch.autograd`` through the result is the exact derivative of the returned outputs with the step
+    sizes held fixed: what the engine's dense-output discrete adjoint must reproduce (it differentiates neither the accept / reject
+    decisions nor the step sizes; nor does the reference's continuous adjoint).  Returns (T, 2, n_free) and the reduced inertia."""
+    free_t = torch.as_tensor(solver.free_DOF_ids, dtype=torch.long)
+    ts = np.asarray(timepoints, dtype=np.float64)
+    st = np.asarray(step_times, dtype=np.float64)
+    y = _t(state0).reshape(2, -1)[:, free_t]
+    inertia = solver.reduced_inertia(control_params)
+    A, CS, CM = ref_ode.BETA, ref_ode.C_SOL, ref_ode.C_MID
+
+    def f(s, t):
+        return solver.rhs(s, t, control_params, inertia, create_graph=True)
+
+    out = [y]
+    k1 = f(y, float(st[0]))
+    i_out = 1
+    for n in range(len(st) - 1):
+        t, h = float(st[n]), float(st[n + 1] - st[n])
+        ks = [k1]
+        for i in range(1, 7):
+            yi = y + h * sum(A[i - 1, j] * ks[j] for j in range(i))
+            ks.append(f(yi, t + h * ref_ode.ALPHA[i - 1]))
+        y1 = y + h * sum(CS[j] * ks[j] for j in range(7))
+        if i_out < len(ts) and ts[i_out] <= st[n + 1]:
+            ymid = y + h * sum(CM[j] * ks[j] for j in range(7))
+            dy0, dy1 = ks[0], ks[6]
+            a = -2.0 * h * dy0 + 2.0 * h * dy1 - 8.0 * y - 8.0 * y1 + 16.0 * ymid
+            b = 5.0 * h * dy0 - 3.0 * h * dy1 + 18.0 * y + 14.0 * y1 - 32.0 * ymid
+            c = -4.0 * h * dy0 + h * dy1 - 11.0 * y - 5.0 * y1 + 16.0 * ymid
+            while i_out < len(ts) and ts[i_out] <= st[n + 1]:
+                r = (ts[i_out] - st[n]) / (st[n + 1] - st[n])
+                out.append((((a * r + b) * r + c) * r + h * dy0) * r + y)
+                i_out += 1
+        y, k1 = y1, ks[6]
+    if i_out != len(ts):
+        raise ValueError("step_times do not reach the last output time")
+    return torch.stack(out), inertia
+
+
 def linear_mode_analysis(displacement, geometry, energy_fn, control_params, constrained_block_DOF_pairs=()):
     """dynamics.py:189-245: eigenvalues / eigenmodes of K q = w^2 M q around ``displacement``; K = Hessian of the constrained energy
     w.r.t. the free DOFs (autograd, where the reference calls ``jax.hessian``), generalised problem by ``scipy.linalg.eigh`` as in the

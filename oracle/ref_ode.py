@@ -91,6 +91,7 @@ def odeint(func, y0, ts, rtol=1.4e-8, atol=1.4e-8, mxstep=np.inf, hmax=np.inf, s
     coeff = np.stack([y0] * 5)
     out = [y0]
     n_try = n_acc = 0
+    acc_times = [float(ts[0])]
     for target in ts[1:]:
         i = 0
         while t < target and i < mxstep and dt > 0:
@@ -103,12 +104,13 @@ def odeint(func, y0, ts, rtol=1.4e-8, atol=1.4e-8, mxstep=np.inf, hmax=np.inf, s
                 coeff = interp_fit_dopri(y, y1, k, dt)
                 y, f, last_t, t = y1, f1, t, t + dt
                 n_acc += 1
+                acc_times.append(float(t))
             dt = new_dt
         rel = (target - last_t) / (t - last_t)
         out.append(np.polyval(coeff, rel) if coeff.ndim == 1 else
                    ((((coeff[0] * rel + coeff[1]) * rel + coeff[2]) * rel + coeff[3]) * rel + coeff[4]))
     if stats is not None:
-        stats.update(attempted=n_try, accepted=n_acc)
+        stats.update(attempted=n_try, accepted=n_acc, step_times=np.array(acc_times))
     return np.stack(out)
 
 

@@ -116,6 +116,61 @@ def check_trajectory_and_adjoint(lib, lattice, n, integrator, nonlinear=True, co
     return errs
 
 
+def check_adaptive_records_adjoint(lib, lattice="quads", n=4, nonlinear=True, contact=True, seed=9, n_out=61, rtol=1e-5, atol=1e-5, horizon=3e-4,
+                                   batch=1):
+    """The reference's default call made differentiable as it stands (``dfx_forward_adaptive_keep``): adaptive Dormand-Prince with jax's
+    controller, outputs interpolated inside the steps, and the reverse sweep = the exact discrete adjoint of THAT solve, output cotangents
+    entering through the quartic dense output.  Checked against the oracle's ``odeint`` restatement (forward, accepted step boundaries)
+    and against ``torch.autograd`` through the oracle's replay of the same accepted steps with jax's dense-output formulas
+    (``solve_adaptive_replay_differentiable``).  The tolerances are chosen so that steps hold none, one and several outputs."""
+    cut = (125.0 if lattice == "kagome" else 42.0)
+    c = Case(lattice, n, nonlinear, contact, seed=seed, lib=lib, cutoff_deg=cut, batch=batch)
+    fast = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)
+    c.cp = c.cp._replace(constraint_params=fast)
+    ts = np.linspace(0, horizon, n_out)
+    s = c.solver
+    s.rtol, s.atol = rtol, atol
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    out = s(y0, ts, [c.cp] * batch if batch > 1 else c.cp, keep_trajectory=True)
+    assert s.stats["step_control"] == "adaptive-records", s.stats["step_control"]
+    fields = out[0] if batch > 1 else out
+    osol = c.oracle_solver(integrator="adaptive", rtol=rtol, atol=atol)
+    lv = dict(loading_rate=T64(3000.0), input_delay=T64(1e-5))
+    of = osol(y0, ts, c.oracle_cp(lv)).numpy()
+    st = osol.stats["step_times"]
+    e_fwd = relerr(fields, of)
+    assert e_fwd < 1e-9, ("adaptive forward", e_fwd)
+    mine_t = s.engine.adaptive_step_times(0)
+    # (the controller amplifies rounding: the error estimate is a difference of nearly equal numbers, so two correct implementations
+    # agree on the step boundaries to ~1e-8, not to 1e-15; the decisions -- how many steps, which attempts fail -- are the same)
+    assert len(mine_t) == len(st) - 1 and relerr(mine_t, st[1:]) < 1e-6, (len(mine_t), len(st) - 1)
+    st = np.concatenate([ts[:1], mine_t])                  # the replay below freezes the steps the ENGINE took
+    per_step = np.histogram(ts[1:], bins=st)[0]
+    assert per_step.max() >= 2 and (per_step == 0).any() and (per_step == 1).any(), per_step      # the three kinds of step
+    fb = c.rng.normal(size=fields.shape)
+    fb.reshape(len(ts), 2, -1)[:, :, s.constrained_DOF_ids] = 0.0
+    trees, s0s = s.vjp(np.stack([fb] * batch) if batch > 1 else fb)
+    tree, s0 = (trees[0], s0s[0]) if batch > 1 else (trees, s0s)
+    design = [T64(d, True) for d in c.design]
+    cnv, cen = c.ogeo.centroid_node_vectors(*design), c.ogeo.block_centroids(*design)
+    amp, y0t = T64(7.5, True), T64(y0, True)
+    free = osol.free_DOF_ids
+    hist, _ = OD.solve_adaptive_replay_differentiable(osol, c.ogeo, y0t, ts, c.oracle_cp(dict(cnv=cnv, cen=cen, amplitude=amp, **lv)), st)
+    assert relerr(hist.detach().numpy(), fields.reshape(len(ts), 2, -1)[:, :, free]) < 1e-11    # the replay IS the engine's adaptive solve
+    L = (hist * T64(fb.reshape(len(ts), 2, -1)[:, :, free])).sum()
+    gr = torch.autograd.grad(L, design + [amp, y0t])
+    mine = c.geo.vjp(c.design, tree.geometrical_params.centroid_node_vectors, tree.geometrical_params.block_centroids)
+    errs = {"fwd": e_fwd, "steps": len(st) - 1, "outputs_per_step_max": int(per_step.max())}
+    for i, (a, b) in enumerate(zip(mine, gr)):
+        errs[f"design{i}"] = relerr(a, b.numpy())
+    errs["amplitude"] = abs(tree.constraint_params["amplitude"] - gr[len(design)].item()) / abs(gr[len(design)].item())
+    errs["state0"] = relerr(s0.reshape(2, -1)[:, free], gr[-1].numpy().reshape(2, -1)[:, free])
+    for k, v in errs.items():
+        if k not in ("steps", "outputs_per_step_max"):
+            assert v < RTOL_GRAD, (lattice, "adaptive records", k, v)
+    return errs
+
+
 def torch_table(times, values, vector):
     """Oracle twin of loading.Table: amplitude * interp(t - input_delay; times, values) (jnp.interp semantics)."""
     T, Y = np.asarray(times, dtype=float), np.asarray(values, dtype=float)

@@ -67,8 +67,17 @@ def test_step_times_are_validated(cpu_lib):
         c.solver(y0, ts, c.cp, steps_per_interval=[2, 1], step_times=[0.0, 0.5e-4, 1.1e-4, 2e-4])
 
 
-def test_adaptive_grid_makes_the_default_solve_differentiable(cpu_lib):
-    """keep_trajectory=True without a grid: the step boundaries the adaptive controller accepted (plus the output times)
+@pytest.mark.parametrize("kw", [dict(), dict(lattice="kagome", n=3, n_out=121), dict(batch=2, contact=False, nonlinear=False)],
+                         ids=["quads-contact", "kagome-contact", "linearized-batch2"])
+def test_adaptive_solve_is_differentiable_as_it_stands(cpu_lib, kw):
+    """keep_trajectory=True without a grid (the reference's default call under jax.grad, dynamics.py:166): ONE adaptive pass that keeps its
+    accepted steps + the dense-output discrete adjoint, against autograd through the oracle's replay of the same steps."""
+    parity.check_adaptive_records_adjoint(cpu_lib, **kw)
+
+
+def test_adaptive_grid_makes_the_default_solve_differentiable(cpu_lib, monkeypatch):
+    """keep_trajectory=True without a grid, the two-pass form (DFX_ADAPTIVE_RECORDS=0; the only form before round 6, and what
+    ``grid_refine > 1`` still uses): the step boundaries the adaptive controller accepted (plus the output times)
     become the fixed grid (dfx_adaptive_step_times -> dfx_forward_grid); the result stays within the controller's
     tolerance of the adaptive solve and vjp is the exact gradient of the frozen-grid solve (finite differences of it)."""
     from .common import Case
@@ -77,6 +86,7 @@ def test_adaptive_grid_makes_the_default_solve_differentiable(cpu_lib):
     ts = np.array([0.0, 0.5e-4, 1.0e-4, 2.5e-4, 3.0e-4])
     y0 = c.random_state(0.05, 0.02, 5.0)
     s = c.solver
+    monkeypatch.setenv("DFX_ADAPTIVE_RECORDS", "0")
     adaptive = s(y0, ts, cp)
     counts = s.engine.adaptive_step_counts()
     times = s.engine.adaptive_step_times(0)

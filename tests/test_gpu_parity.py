@@ -185,7 +185,7 @@ def test_grid_with_caller_chosen_step_boundaries(hip_lib, lattice, n, integrator
     parity.check_trajectory_and_adjoint(None, lattice, n, integrator, spi=np.array([3, 7, 2, 5]), own_step_times=True)
 
 
-def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib):
+def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib, monkeypatch):
     """keep_trajectory=True without a grid: freeze the adaptive controller's accepted step boundaries, then forward +
     reverse on that grid.  The frozen solve stays within the tolerance of the adaptive one; on the SAME grid the CPU port
     gives the same fields and gradient; the CPU port's own controller picks the same grid up to the rounding
@@ -196,6 +196,7 @@ def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib):
         return c, cps, c.random_state(0.05, 0.02, 5.0)
 
     ts = np.array([0.0, 0.5e-4, 1.0e-4, 2.5e-4, 3.0e-4])
+    monkeypatch.setenv("DFX_ADAPTIVE_RECORDS", "0")       # the two-pass form (what grid_refine > 1 uses)
     c, cps, y0 = case(None)
     s = c.solver
     adaptive = s(y0, ts, cps)

@@ -504,12 +504,13 @@ def test_to_data_and_from_data_round_trip(cpu_lib):
     assert len(opt.to_data().design_values) == 1
 
 
-def test_grid_refine_brings_the_frozen_grid_gradient_closer_to_exact(cpu_lib):
+def test_grid_refine_brings_the_frozen_grid_gradient_closer_to_exact(cpu_lib, monkeypatch):
     """`grid_refine = k` (setup_dynamic_solver / the forward problems): every step of the grid frozen from the adaptive controller is
     split into k before the reverse sweep differentiates it.  At the paper's loose tolerances (atol = 1e-4) the default grid's gradient is
     further from the exact one than the reference's continuous adjoint; k = 2 brings it closer at twice the steps
     (python -m tests.adjoint_semantics: 6.9e-3 -> 2.2e-5 on the paper lattice).  Here: 10 x 6 quads, exact = rtol = atol = 1e-11."""
     from tests.adjoint_semantics import paper_problem, relerr as rel
+    monkeypatch.setenv("DFX_ADAPTIVE_RECORDS", "0")        # the frozen grid at k = 1 too (the default keeps the adaptive pass's own records)
     res = {}
     for key, (rtol, atol, k) in {"loose": (1e-8, 1e-4, 1), "refined": (1e-8, 1e-4, 2), "exact": (1e-11, 1e-11, 1)}.items():
         fw = paper_problem(10, 6, 6, rtol, atol, cpu_lib, grid_refine=k)
