@@ -52,7 +52,7 @@ class dfx_stats(C.Structure):
 
 
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid", "dfx_forward_grid_members",
-           "dfx_forward_adaptive", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
+           "dfx_forward_adaptive", "dfx_forward_adaptive_keep", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version", "dfx_share_checkpoint", "dfx_abi_layout"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
@@ -101,9 +101,7 @@ def declare(lib):
     lib.dfx_adaptive_step_counts.argtypes = [H, _ip]
     lib.dfx_adaptive_step_times.argtypes = [H, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]
     lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
-    if hasattr(lib, "dfx_forward_adaptive_keep"):
-        lib.dfx_forward_adaptive_keep.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int32, _dp, C.POINTER(dfx_stats)]
-        lib.dfx_forward_adaptive_keep.restype = C.c_int
+    lib.dfx_forward_adaptive_keep.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int32, _dp, C.POINTER(dfx_stats)]
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
     lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]

@@ -3,6 +3,7 @@
 //   engine_forward.hip   fixed-grid forward solve, checkpoint levels, segments
 //   engine_adaptive.hip  the reference's adaptive odeint semantics
 //   engine_reverse.hip   reverse sweep, gradient collection, objectives
+//   engine_dense.hip     reverse sweep of an adaptive solve that kept its accepted steps (dense-output discrete adjoint)
 //   engine_abi.hip       create / destroy / set_params / reserve, test hooks, post-processing, downloads
 // The kernels live in dfx_kernels.h (stage kernels: instantiated by engine_launch.hip, the reverse per-stage builds by stage_builds_adj.hip)
 // and dfx_persist.hip.
@@ -146,6 +147,12 @@ struct dfx_handle {
   long long ts_stride = 0;
   std::vector<long long> accepted_per_member;
   bool have_adaptive_record = false;
+  // dfx_forward_adaptive_keep: the last forward pass was an adaptive solve that kept its accepted steps (stage records in the trajectory
+  // checkpoint at the records level, every member's own count) -- the reverse sweep is run_adjoint_dense (dfx_dense.h)
+  bool adaptive_records = false;
+  long long a_cap = 0, a_stride = 0, a_nmax = 0;      // steps the buffers hold per member, row stride of t_steps / out_ptr, largest N_m
+  DevBuf<int> d_out_ptr, d_nacc;
+  DevBuf<double> d_theta, d_dw;
   long long n_total = 0;
   std::map<std::pair<int, int>, hipGraphExec_t> graphs;
   // what the cached graphs have baked in: every kernel argument (the DevCtx passed by value) and the addresses the tick node
@@ -154,7 +161,7 @@ struct dfx_handle {
   bool graph_ctx_valid = false;
   // the adaptive controller's graph of 32 attempts (small lattices only), valid for the arguments it was captured with
   hipGraphExec_t adaptive_exec = nullptr;
-  struct AdaptiveKey { DevCtx ctx; int n_timepoints; int n_partials; double two_n_free; } adaptive_key;
+  struct AdaptiveKey { DevCtx ctx; int n_timepoints; int n_partials; double two_n_free; int keep, pad; AdaptRec ar; } adaptive_key;
   long long launches = 0;
   // two stages per launch on lattice windows (dfx_pair.h): the row length found at create, or tiling_ok = false
 #ifdef DFX_EXPERIMENTAL
@@ -197,6 +204,8 @@ dim3 slot_grid(const dfx_handle* h);
 dim3 slot_grid(const dfx_handle* h, const Group& g);
 DevCtx group_ctx(const dfx_handle* h, const DevCtx& c, int gi);
 StageCoef stage_coef(const Tableau& T, int i);
+AdjCoef adj_coef(const Tableau& T, int i);
+void launch_fn_table(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps);
 void setup_tiling(dfx_handle* h);
 void pair_plan(dfx_handle* h, const DevCtx& c);
 void setup_lig(dfx_handle* h);
@@ -229,6 +238,8 @@ int ensure_work_buffers(dfx_handle* h);
 int finish_forward(dfx_handle* h, dfx_stats* stats);
 int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints, const int32_t* steps_per_interval,
     const double* step_times, int32_t keep_trajectory, double* fields, dfx_stats* stats, bool per_member);
+// engine_dense.hip: the reverse sweep of an adaptive solve that kept its accepted steps
+int run_adjoint_dense(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_grads* views, dfx_stats* stats, bool kinetic, int n_target);
 // engine_reverse.hip
 int ensure_adjoint_buffers(dfx_handle* h);
 int zero_grad_accumulators(dfx_handle* h, double* extra = nullptr, size_t n_extra = 0, int cursor_value = -1, const int32_t* targets = nullptr,

@@ -88,6 +88,28 @@ struct AdjCoef {
   double c_i;
 };
 
+// The adaptive solve that keeps its accepted steps for the reverse sweep (dfx_forward_adaptive_keep): what the controller records per
+// member beside the stage records it leaves in the trajectory checkpoint (record r of step n of member m, n = the member's own count of
+// accepted steps), and what the reverse stage reads to send the outputs' cotangents through the dense output:
+//   t_steps[m][n]   start of step n (n = 0 .. N_m), and once more at N_m + 1: the "step of size zero" whose only launch is the extra
+//                   evaluation at the final state (the FSAL slope of the last step)
+//   out_ptr[m][n]   first output that lies inside step n or later: the outputs inside step n are [out_ptr[n], out_ptr[n+1])
+//   theta[m][k]     relative position of output k inside its step;  dw[m][k][0..6] = the weights B_j(theta) of the stage slopes
+//                   (dopri_dense_weights; k_dense_weights fills them before a sweep)
+struct AdaptRec {
+  double* t_steps;       // batch * stride
+  int* out_ptr;          // batch * stride
+  double* theta;         // batch * n_out
+  long long stride;
+};
+struct DenseCtx {
+  const int* out_ptr;    // batch * stride
+  const double* dw;      // batch * n_out * 8
+  const int* n_acc;      // batch: accepted steps N_m
+  long long stride;
+  int n_out, pad;
+};
+
 struct DevCtx {
   int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member
@@ -695,7 +717,9 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg
   if (c.clock) {          // adaptive: this member's own time and step
     const Clock ck = c.clock[m];
     if (ck.state | ck.fin_next) return;
-    sg.t_interval = ck.t; sg.h = ck.h; sg.j0 = 0; sg.base_step = 0; j = 0;
+    // (records kept for the reverse sweep -- dfx_forward_adaptive_keep: the attempt works in the records of step `accepted` of the
+    // trajectory checkpoint; a rejected attempt's records are overwritten by the next one)
+    sg.t_interval = ck.t; sg.h = ck.h; sg.j0 = 0; sg.base_step = (c.traj && c.rps > 1) ? ck.accepted : 0; j = 0;
   }
   const long long n = sg.base_step + j;
   const u32 nd = (u32)c.n_blocks * 3;
@@ -859,7 +883,7 @@ __global__ __launch_bounds__(kThreads) DFX_FWD_OCC void k_fwd_stage(DevCtx c_arg
 
 // ---- adaptive step control (jax.experimental.ode semantics) --------------------------------------
 // one workgroup per member: reduce the per-wave partials in a fixed order, decide, advance the clock
-__global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, double two_n_free, int n_timepoints) {
+__global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, double two_n_free, int n_timepoints, AdaptRec ar) {
   const int m = blockIdx.x + c.m0;
   __shared__ double red[kThreads];
   double acc = 0.0;
@@ -887,6 +911,14 @@ __global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, 
     while (ck.out_idx < n_timepoints && c.ts_dev[ck.out_idx] <= ck.t) ck.out_idx++;
     ck.out_hi = ck.out_idx;
     if (ck.out_idx >= n_timepoints) ck.fin_next = 1;
+    if (ar.t_steps) {       // step n = accepted - 1 is [t_last, t]; the entries of n + 2 stand for the zero-size step after the last one
+      const long long n = ck.accepted - 1;
+      double* ts = ar.t_steps + (size_t)m * ar.stride;
+      int* op = ar.out_ptr + (size_t)m * ar.stride;
+      ts[n + 1] = ck.t; ts[n + 2] = ck.t;
+      op[n] = ck.out_lo; op[n + 1] = ck.out_hi; op[n + 2] = ck.out_hi;
+      for (int kk = ck.out_lo; kk < ck.out_hi; ++kk) ar.theta[(size_t)m * n_timepoints + kk] = (c.ts_dev[kk] - ck.t_last) / (ck.t - ck.t_last);
+    }
   }
   ck.h = h_new;
   if (!(h_new > 0.0)) ck.state = 3;
@@ -897,7 +929,10 @@ __global__ __launch_bounds__(kThreads) void k_control(DevCtx c, int n_partials, 
 // stage-1 record of the next attempt with the new step size.  cm / cma: mid-point weights (velocity / position form).
 struct DenseCoef { double cm[7], cma[7]; double a10; };
 
-__global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, int n_timepoints) {
+//   recs: the step state, the candidate and the stage records live in the trajectory checkpoint (dfx_forward_adaptive_keep): y_n = record 0
+//   of step n, the candidate y1 = record 6 of step n = record 0 of step n + 1 (nothing to copy on accept), stage-1 record of the next
+//   attempt = record 1 of the step it attempts
+__global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, int n_timepoints, int recs) {
   const int m = blockIdx.y + c.m0;
   const int slot = logical_wg(blockIdx.x, c.n_wg) * kThreads + threadIdx.x;
   if (slot >= c.n_slots) return;
@@ -906,10 +941,11 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
   const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
   const size_t nd = (size_t)c.n_blocks * 3;
   const int dof = b * 3 + kd;
-  double* POS0 = c.POS + ((size_t)m * c.nbuf + 0) * c.n_blocks * kPos + (size_t)b * kPos;
-  double* VEL0 = c.VEL + ((size_t)m * c.nbuf + 0) * nd;
-  const double* POS3 = c.POS + ((size_t)m * c.nbuf + 3) * c.n_blocks * kPos + (size_t)b * kPos;
-  const double* VEL3 = c.VEL + ((size_t)m * c.nbuf + 3) * nd;
+  const long long n_new = ck.accepted, n_old = ck.accepted - (ck.accept ? 1 : 0);
+  double* POS0 = recs ? traj_rec(c, m, -1, n_old) + (size_t)b * kPos : c.POS + ((size_t)m * c.nbuf + 0) * c.n_blocks * kPos + (size_t)b * kPos;
+  double* VEL0 = recs ? traj_rec(c, m, -1, n_old) + (size_t)c.n_blocks * kPos : c.VEL + ((size_t)m * c.nbuf + 0) * nd;
+  const double* POS3 = recs ? traj_rec(c, m, -7, n_old) + (size_t)b * kPos : c.POS + ((size_t)m * c.nbuf + 3) * c.n_blocks * kPos + (size_t)b * kPos;
+  const double* VEL3 = recs ? traj_rec(c, m, -7, n_old) + (size_t)c.n_blocks * kPos : c.VEL + ((size_t)m * c.nbuf + 3) * nd;
   double* Am = c.A + (size_t)m * (c.s + 1) * nd;
   double qn = POS0[kd], vn = VEL0[dof], a0 = Am[dof];
   const int sidx = c.block_special[b];
@@ -933,8 +969,10 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
     }
     // commit
     if (k < 3) {
-      if (k < 2) *reinterpret_cast<double2*>(POS0 + 2 * k) = *reinterpret_cast<const double2*>(POS3 + 2 * k);
-      VEL0[dof] = v1;
+      if (!recs) {
+        if (k < 2) *reinterpret_cast<double2*>(POS0 + 2 * k) = *reinterpret_cast<const double2*>(POS3 + 2 * k);
+        VEL0[dof] = v1;
+      }
       Am[dof] = a6;
     }
     qn = q1; vn = v1; a0 = a6;
@@ -947,8 +985,10 @@ __global__ __launch_bounds__(kThreads) void k_prepare(DevCtx c, DenseCoef dc, in
   fast_sincos(0.5 * th2, &sn, &cs);
   const double2 chunk = k == 0 ? make_double2(qnext, y1) : make_double2(th2, sn);
   if (k < 3) {
-    if (k < 2) *reinterpret_cast<double2*>(c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos + (size_t)b * kPos + 2 * k) = chunk;
-    c.VEL[((size_t)m * c.nbuf + 1) * nd + dof] = vnext;
+    double* P1 = recs ? traj_rec(c, m, -2, n_new) : c.POS + ((size_t)m * c.nbuf + 1) * c.n_blocks * kPos;
+    double* V1 = recs ? traj_rec(c, m, -2, n_new) + (size_t)c.n_blocks * kPos : c.VEL + ((size_t)m * c.nbuf + 1) * nd;
+    if (k < 2) *reinterpret_cast<double2*>(P1 + (size_t)b * kPos + 2 * k) = chunk;
+    V1[dof] = vnext;
   }
 }
 
@@ -1073,12 +1113,16 @@ __global__ __launch_bounds__(kThreads) void k_rebuild_first(DevCtx c, StageCoef 
 //   wbuf_static: >= 0 selects the (w, kbar_q) input buffer (test hook); -1: parity of the stage ordinal
 //   BOND_GRADS: also accumulate d/d(reference vector, stiffnesses, contact constants) (only when the caller asks for them:
 //   a compile-time switch, the dual parts of those derivatives are dead code otherwise)
-template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1>
+template <int MODEL, int CONTACT, int BOND_GRADS, int REBUILD, int NPB = 4, int TAB = 0, int OVF = 0, int WT = 0, int ISTAGE = -1, int DENSE = 0>
 //   REBUILD (compile-time: the rebuild code and its registers exist only in the stage-checkpoint build), rb > 0: after its own work the launch rebuilds stage record rb -- of the same step when i >= 2
 //   (rb = i - 1, read by the next reverse launch), of the previous step when i == 0 (rb = s - 1); rc = stage_coef(rb - 1)
 //   NPB: lanes per block (lane_pos); the packed mapping exists for the records build only
+//   DENSE: the reverse stage of an adaptive solve that kept its accepted steps (dfx_forward_adaptive_keep; builds of their own, the others
+//   carry none of it): every member has its own number of steps N_m (a launch beyond a member's last step returns at once; the launch
+//   (N_m, 0) is the extra evaluation at the final state: a step of size zero), and the cotangents of the outputs enter through the dense
+//   output -- an output inside step n adds g to lambda_n and h_n B_j g to Kbar_j, the FSAL slope's share (j = 6) joins Kbar_0 of step n + 1
 __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoef& ac, int i_arg, int j, int in_buf, int wbuf_static,
-                                               int local_only, const StageCoef& rc, int rb) {
+                                               int local_only, const StageCoef& rc, int rb, const DenseCtx& dn = DenseCtx{}) {
   // ISTAGE: see k_fwd_stage.  The per-stage builds take the stage index and the PARAMETER shape (uniform stiffnesses / damping, LDS
   // dictionary, equal steps) as constants -- launch 29.7 -> 29.1 us, 112 VGPRs -- but not the buffer / mode arguments: with those
   // folded as well (in_buf, local_only, wbuf, rb, AD, clock) three variants measured 0.6 - 1.5 us SLOWER although they shed more
@@ -1094,6 +1138,10 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
   const int b = slot >> 2, k = slot & 3, kd = k < 3 ? k : 2;
   const Seg sg = *c.cur;
   const long long n = sg.base_step + j;
+  if constexpr (DENSE) {
+    const long long n_m = dn.n_acc[m];
+    if (n > n_m || (n == n_m && i > 0)) return;
+  }
   // the reverse sweep visits forward ordinals n*s+i in decreasing order, so the buffer parity alternates
   const int win = wbuf_static >= 0 ? wbuf_static : (int)((n * c.s + i) & 1);
   const u32 nd = (u32)c.n_blocks * 3, nd6 = (u32)c.n_blocks * 6;
@@ -1158,6 +1206,49 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
         sq += cf * yq[jj];
         sv += cf * yv[jj];
       }
+    }
+  }
+  // ---- dense output (DENSE builds): what the outputs inside this step and inside the previous one add to the Kbar of this stage
+  // (`own`: the records build recomputes its own Kbar), to the Kbar this launch hands on (`nxt`), and to lambda_n (`gs`, i == 0) --
+  // already scaled by the step sizes; zero on constrained DOFs
+  double e_own_q = 0.0, e_own_v = 0.0, e_nxt_q = 0.0, e_nxt_v = 0.0, gs_q = 0.0, gs_v = 0.0;
+  if constexpr (DENSE) {
+    const bool con_k = sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> kd) & 1);
+    if (!local_only && !con_k) {
+      const double* tsm = steps_of(c, m);
+      const double h_n = tsm[n + 1] - tsm[n], h_p = n > 0 ? tsm[n] - tsm[n - 1] : 0.0;
+      const int* op = dn.out_ptr + (size_t)m * dn.stride;
+      const int lo = op[n], hi = op[n + 1], plo = n > 0 ? op[n - 1] : lo;
+      const double* dwm = dn.dw + (size_t)m * dn.n_out * 8;
+      const u32 o_g = ((u32)b * 6 + kd) * 8;
+      for (int kk = lo; kk < hi; ++kk) {            // outputs inside this step
+        const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
+        const double gq = ldg<double>(Gk, o_g), gv = ldg<double>(Gk, o_g + 24);
+        const double* w = dwm + (size_t)kk * 8;
+        e_own_q += w[i] * gq; e_own_v += w[i] * gv;
+        if (i > 0) { e_nxt_q += w[i - 1] * gq; e_nxt_v += w[i - 1] * gv; }
+        else { gs_q += gq; gs_v += gv; }
+      }
+      e_own_q *= h_n; e_own_v *= h_n; e_nxt_q *= h_n; e_nxt_v *= h_n;
+      if (i <= 1) {                                 // outputs inside the previous step: its FSAL slope is this step's first slope
+        double e6q = 0.0, e6v = 0.0, e5q = 0.0, e5v = 0.0;
+        for (int kk = plo; kk < lo; ++kk) {
+          const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
+          const double gq = ldg<double>(Gk, o_g), gv = ldg<double>(Gk, o_g + 24);
+          const double* w = dwm + (size_t)kk * 8;
+          e6q += w[6] * gq; e6v += w[6] * gv;
+          e5q += w[c.s - 1] * gq; e5v += w[c.s - 1] * gv;
+        }
+        if (i == 0) { e_own_q += h_p * e6q; e_own_v += h_p * e6v; e_nxt_q = h_p * e5q; e_nxt_v = h_p * e5v; }
+        else { e_nxt_q += h_p * e6q; e_nxt_v += h_p * e6v; }
+      }
+      if (i == 0 && n == 0) {                       // the initial state is output 0 (and any output produced before the first step)
+        for (int kk = 0; kk < lo; ++kk) {
+          const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
+          gs_q += ldg<double>(Gk, o_g); gs_v += ldg<double>(Gk, o_g + 24);
+        }
+      }
+      if (!REBUILD) w_d += e_own_v * invm;
     }
   }
   LaneIn L;
@@ -1307,6 +1398,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
     const double a_i = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
     double ybq = 0.0, ybv = 0.0;
     if (!REBUILD && !local_only) kq_in = h * (ac.cur[c.s] * lq + sqc);      // (zero on constrained DOFs: their lambda and Ybar are)
+    if constexpr (DENSE) { if (!REBUILD && !local_only) kq_in += e_own_q; }
     if (!constrained) {
       ybq = -hw;
       ybv = kq_in - damp * w_d;
@@ -1323,7 +1415,8 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
       } else {
         lq += ybq + sq;
         lv += ybv + sv;
-        const bool first = (sg.j0 + j) == 0;
+        if constexpr (DENSE) { lq += gs_q; lv += gs_v; }
+        const bool first = !DENSE && (sg.j0 + j) == 0;
         if (first && c.G && !constrained) {
           const double* G = c.G + ((size_t)sg.interval * c.batch + m) * (size_t)nd6;
           lq += G[b * 6 + k]; lv += G[b * 6 + 3 + k];
@@ -1334,6 +1427,7 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
         if (REBUILD) kq = h_before * ac.col[c.s] * lq;
         kv = h_before * ac.col[c.s] * lv;
       }
+      if constexpr (DENSE) { kq += e_nxt_q; kv += e_nxt_v; }
       if (REBUILD) stg_m<double>(WT, c.KQ + (size_t)(((u32)m * 2 + (u32)(win ^ 1)) * nd), o_dof, kq);
       stg_m<double>(WT, (REBUILD ? c.W : DFX_LATE(double, W)) + (size_t)(((u32)m * 2 + (u32)(win ^ 1)) * nd), o_dof, constrained ? 0.0 : kv * invm);
     }

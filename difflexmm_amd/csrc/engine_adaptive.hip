@@ -5,9 +5,70 @@
 
 using namespace dfx_persist;
 
+// ---- the accepted steps kept for the reverse sweep (dfx_forward_adaptive_keep) -------------------------------------------------
+// Room for `cap` steps per member: stage records in the trajectory checkpoint (records level: 6 per step + the final state), step
+// boundaries and output pointers with two spare entries (the zero-size step after the last one).  Growing keeps what is there.
+template <class T>
+static hipError_t regrow(DevBuf<T>& buf, size_t count, hipStream_t st) {
+  if (count <= buf.n && buf.p) return hipSuccess;
+  T* q = nullptr;
+  hipError_t e = hipMalloc((void**)&q, count * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (buf.p) {
+    e = hipMemcpyAsync(q, buf.p, buf.n * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf.p);
+  }
+  buf.p = q; buf.n = count;
+  return e;
+}
+static const char* const kNoRoom = "forward_adaptive_keep: the stage records of the accepted steps do not fit the device (the two-pass form -- "
+                                   "dfx_forward_adaptive, then dfx_forward_grid on its step boundaries -- has the segments level to fall back on)";
+static int adaptive_room(dfx_handle* h, long long cap, bool keep_contents) {
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, rec = (size_t)pl.n_blocks * kStep;
+  const size_t want = B * ((size_t)cap * pl.tab.s + 1) * rec;
+  if ((double)B * ((double)cap * pl.tab.s + 1.0) >= 4294967296.0) { h->err = kNoRoom; return 5; }
+  const double* t0 = h->ck->traj.p;
+  hipError_t e = keep_contents ? regrow(h->ck->traj, want, h->stream) : h->ck->traj.ensure(want);
+  if (h->ck->traj.p != t0) h->ck->writer = nullptr;
+  if (e != hipSuccess) { (void)hipGetLastError(); h->err = kNoRoom; return 5; }
+  const long long stride = cap + 2;
+  if (stride > h->a_stride || !h->d_tsteps.p || !h->d_out_ptr.p || h->d_tsteps.n < B * (size_t)stride || h->d_out_ptr.n < B * (size_t)stride) {
+    DevBuf<double> nt; DevBuf<int> no;
+    if (nt.ensure(B * (size_t)stride) != hipSuccess || no.ensure(B * (size_t)stride) != hipSuccess) {
+      (void)hipGetLastError(); nt.release(); no.release(); h->err = kNoRoom; return 5;
+    }
+    if (keep_contents && h->a_stride > 0) {
+      HIP_OK(hipMemcpy2DAsync(nt.p, sizeof(double) * stride, h->d_tsteps.p, sizeof(double) * h->a_stride, sizeof(double) * h->a_stride, B,
+                              hipMemcpyDeviceToDevice, h->stream));
+      HIP_OK(hipMemcpy2DAsync(no.p, sizeof(int) * stride, h->d_out_ptr.p, sizeof(int) * h->a_stride, sizeof(int) * h->a_stride, B,
+                              hipMemcpyDeviceToDevice, h->stream));
+      HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    h->d_tsteps.release(); h->d_out_ptr.release();
+    h->d_tsteps = nt; h->d_out_ptr = no;
+    h->a_stride = stride;
+  }
+  h->a_cap = cap;
+  return 0;
+}
+
 // ---- adaptive forward (reference odeint semantics) ------------------------------------------------
+static int forward_adaptive_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                 double rtol, double atol, int64_t max_attempts, bool keep, double* fields, dfx_stats* stats);
+
 int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                          double rtol, double atol, int64_t max_attempts, double* fields, dfx_stats* stats) {
+  return forward_adaptive_impl(h, state0, timepoints, n_timepoints, rtol, atol, max_attempts, false, fields, stats);
+}
+int dfx_forward_adaptive_keep(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                              double rtol, double atol, int64_t max_attempts, int32_t keep_trajectory, double* fields, dfx_stats* stats) {
+  return forward_adaptive_impl(h, state0, timepoints, n_timepoints, rtol, atol, max_attempts, keep_trajectory != 0, fields, stats);
+}
+
+static int forward_adaptive_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
+                                 double rtol, double atol, int64_t max_attempts, bool keep, double* fields, dfx_stats* stats) {
   HIP_OK(hipSetDevice(h->device));
   h->persist_fwd = false;
   if (!h->have_params) { h->err = "forward_adaptive: set_params first"; return 1; }
@@ -20,9 +81,43 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   h->ts.assign(timepoints, timepoints + Tn);
   h->spis.clear(); h->n_total = 0;
   h->have_traj = false; h->have_fields = false;
+  h->adaptive_records = false;
   h->adaptive = true; h->rtol = rtol; h->atol = atol;
   h->have_adaptive_record = false;
-  if (ensure_work_buffers(h)) return 2;
+  if (ensure_work_buffers(h)) { h->adaptive = false; return 2; }
+  const int kAttemptsPerGraph = 32;
+  long long cap_fit = 0;
+  if (keep) {
+    // the records build of the reverse stage serves these (launch_adj_dense); everything else keeps the two-pass form
+    if (pl.n_ovf || !(pl.model == kNonlinear || pl.model == kLinearized) || pl.contact == DFX_CONTACT_DISTANCE) {
+      h->adaptive = false;
+      h->err = "forward_adaptive_keep: nonlinear / linearised ligaments with or without angle contact, one ligament per node (others: dfx_forward_adaptive, "
+               "then dfx_forward_grid on its step boundaries)";
+      return 5;
+    }
+    // room: what is free next to what this handle already holds, half of it at most (the reverse sweep's buffers come later), 5 % of the
+    // device left alone; start with a few thousand steps and grow while the solve runs.  DFX_ADAPTIVE_CAP=n: start with n steps (tests)
+    size_t free_b = 0, total_b = 0;
+    HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    const double per_step = (double)pl.batch * pl.tab.s * pl.n_blocks * kStep * sizeof(double);
+    const double usable = (double)free_b + (double)h->ck->traj.n * sizeof(double) - (double)total_b / 20.0;
+    cap_fit = (long long)std::min(1048000.0, std::max(0.0, 0.5 * usable / per_step));
+    long long cap = std::min<long long>(cap_fit, 4096);
+    if (const char* e = getenv("DFX_ADAPTIVE_CAP")) cap = std::min<long long>(cap_fit, std::max<long long>(kAttemptsPerGraph + 8, atoll(e)));
+    if (cap < kAttemptsPerGraph + 8) { h->adaptive = false; h->err = kNoRoom; return 5; }
+    if (int rc = adaptive_room(h, cap, false)) { h->adaptive = false; return rc; }
+    HIP_OK(h->d_theta.ensure(B * (size_t)n_timepoints));
+    HIP_OK(h->d_nacc.ensure(B));
+    h->have_traj = true; h->records = true; h->dense = false; h->segments = false; h->seg_chunk = 0;
+    h->ck->writer = h;
+    // rows of a solve without any step (one timepoint): the zero-size step at t_0 with the initial state as the only output
+    std::vector<double> t_init(2 * B, timepoints[0]);
+    std::vector<int> o_init(2 * B, 1);
+    HIP_OK(hipMemcpy2DAsync(h->d_tsteps.p, sizeof(double) * h->a_stride, t_init.data(), sizeof(double) * 2, sizeof(double) * 2, B, hipMemcpyHostToDevice,
+                            h->stream));
+    HIP_OK(hipMemcpy2DAsync(h->d_out_ptr.p, sizeof(int) * h->a_stride, o_init.data(), sizeof(int) * 2, sizeof(int) * 2, B, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));      // (the two host vectors go out of scope)
+  }
   const int n_wg = (pl.n_slots + kThreads - 1) / kThreads;
   const int n_partials = (pl.n_slots + 63) / 64;
   HIP_OK(h->d_fields.ensure(B * Tn * nb * 6));
@@ -54,6 +149,8 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   h->launches = 0;
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL, 0LL);
+  if (keep)
+    hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((nb * kStep + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
   hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
   // only the evaluation just made comes back (row 0 / row 1 of every member's seven stage accelerations), not all of d_A
@@ -116,34 +213,43 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
   // one of the eight launches of an attempt (p = 0..4: evaluations at S_1..S_5, the last one leaves the candidate y1 in buffer 3;
   // 5: the FSAL evaluation with the error estimate; 6: controller; 7: dense output / commit / next stage-1 record) for the members of
   // one context (the whole batch, or one member group on its own stream)
+  // keep: the attempt works in the records of step `accepted` of the trajectory checkpoint (record p + 1 -> p + 2; the candidate y1 is
+  // record 6 = record 0 of the next step), and the controller records step boundaries and output positions (AdaptRec)
+  AdaptRec ar;
+  memset(&ar, 0, sizeof(ar));
+  auto refresh_ar = [&]() { if (keep) { ar.t_steps = h->d_tsteps.p; ar.out_ptr = h->d_out_ptr.p; ar.theta = h->d_theta.p; ar.stride = h->a_stride; } };
+  refresh_ar();
   auto launch_phase = [&](int p, const DevCtx& cc, hipStream_t st, dim3 grid, unsigned nm) {
     static const int inb[6] = {0, 1, 2, 1, 2, 1}, outb[6] = {0, 2, 1, 2, 1, 3};
-    if (p < 5) { launch_fwd(h, cc, st, grid, p + 1, 0, inb[p + 1], outb[p + 1], 0, 0); return; }
+    if (p < 5) { launch_fwd(h, cc, st, grid, p + 1, 0, keep ? -1 - (p + 1) : inb[p + 1], keep ? -2 - (p + 1) : outb[p + 1], keep ? -1 : 0, 0); return; }
     if (p == 5) {
-#define DFX_ERR_CASE(M) case M: if (pl.contact == 2) hipLaunchKernelGGL((k_fwd_stage<M, 2>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, 3, -1, 0, 2); \
-    else if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, 3, -1, 0, 2); \
-    else hipLaunchKernelGGL((k_fwd_stage<M, 0>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, 3, -1, 0, 2); break;
+      const int eb = keep ? -7 : 3, yb = keep ? -1 : 0;
+#define DFX_ERR_CASE(M) case M: if (pl.contact == 2) hipLaunchKernelGGL((k_fwd_stage<M, 2>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, eb, -1, yb, 2); \
+    else if (pl.contact) hipLaunchKernelGGL((k_fwd_stage<M, 1>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, eb, -1, yb, 2); \
+    else hipLaunchKernelGGL((k_fwd_stage<M, 0>), grid, dim3(kThreads), 0, st, cc, sc_err, 6, 0, eb, -1, yb, 2); break;
       switch (pl.model) { DFX_ERR_CASE(kNonlinear) DFX_ERR_CASE(kLinearized) DFX_ERR_CASE(kSimpleSpring) DFX_ERR_CASE(kStretchTorsion) }
 #undef DFX_ERR_CASE
-    } else if (p == 6) hipLaunchKernelGGL(k_control, dim3(nm), dim3(kThreads), 0, st, cc, n_partials, 2.0 * (double)n_free, Tn);
-    else hipLaunchKernelGGL(k_prepare, grid, dim3(kThreads), 0, st, cc, dc, Tn);
+    } else if (p == 6) hipLaunchKernelGGL(k_control, dim3(nm), dim3(kThreads), 0, st, cc, n_partials, 2.0 * (double)n_free, Tn, ar);
+    else hipLaunchKernelGGL(k_prepare, grid, dim3(kThreads), 0, st, cc, dc, Tn, keep ? 1 : 0);
     h->launches++;
   };
   auto enqueue_attempt = [&]() { for (int p = 0; p < 8; ++p) launch_phase(p, c, h->stream, slot_grid(h), (unsigned)B); };
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   // stage-1 record of the first attempt (accept = 0: nothing to commit)
-  hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn);
-  const int kAttemptsPerGraph = 32;
+  hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn, keep ? 1 : 0);
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   // Same rule as the fixed grid (solve_is_eager): launches that fill the chip are issued eagerly -- instantiating the 256-node graph
   // cost 5-10 ms per call, more than a short solve runs (profiles/r02_adaptive_fixed_cost.txt); small lattices replay a graph,
   // kept in the handle while the arguments baked into it stay the same.
   const long long waves = (long long)pl.batch * ((pl.n_slots + 63) / 64);
-  if (h->use_graph && waves < 2048) {
+  auto prepare_graph = [&]() -> int {
+    exec = nullptr;
+    if (!(h->use_graph && waves < 2048)) return 0;
     dfx_handle::AdaptiveKey key;
     memset(&key, 0, sizeof(key));
     key.ctx = c; key.n_timepoints = Tn; key.n_partials = n_partials; key.two_n_free = 2.0 * (double)n_free;
+    key.keep = keep ? 1 : 0; key.ar = ar;
     if (h->adaptive_exec && memcmp(&key, &h->adaptive_key, sizeof(key)) != 0) {
       (void)hipGraphExecDestroy(h->adaptive_exec); h->adaptive_exec = nullptr;
     }
@@ -162,7 +268,9 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
       memcpy(&h->adaptive_key, &key, sizeof(key));
     }
     exec = h->adaptive_exec;
-  }
+    return 0;
+  };
+  if (int rcg = prepare_graph()) return rcg;
   long long attempts_issued = 0;
   int rc = 0;
   while (true) {
@@ -192,14 +300,35 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     }
     if (rc || all_done) break;
     if (attempts_issued >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; rc = 4; break; }
+    if (keep) {       // room for the next round of attempts (every one of them may be accepted)
+      long long most = 0;
+      for (size_t m = 0; m < B; ++m) most = std::max(most, clk[m].accepted);
+      if (most + kAttemptsPerGraph + 4 > h->a_cap) {
+        const long long cap = std::min<long long>(cap_fit, std::max<long long>(2 * h->a_cap, most + 4 * kAttemptsPerGraph));
+        if (cap < most + kAttemptsPerGraph + 4) { h->err = kNoRoom; rc = 5; break; }
+        if (int rcr = adaptive_room(h, cap, true)) { rc = rcr; break; }
+        h->ck->writer = h;
+        c = make_ctx(h);
+        refresh_ar();
+        if (int rcg = prepare_graph()) { rc = rcg; break; }
+      }
+    }
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
-  if (rc) { h->adaptive = false; return rc; }
+  if (rc) { h->adaptive = false; h->have_traj = false; return rc; }
+  if (keep) {
+    std::vector<int> nacc(B);
+    h->a_nmax = 0;
+    for (size_t m = 0; m < B; ++m) { nacc[m] = (int)clk[m].accepted; h->a_nmax = std::max<long long>(h->a_nmax, clk[m].accepted); }
+    HIP_OK(hipMemcpyAsync(h->d_nacc.p, nacc.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+  }
   if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
   h->have_fields = true;
   h->adaptive = false;
+  h->adaptive_records = keep;
   h->have_adaptive_record = true;
   h->accepted_per_member.assign(B, 0);
   for (size_t m = 0; m < B; ++m) h->accepted_per_member[m] = clk[m].accepted;
@@ -215,6 +344,7 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
     stats->kernel_ms = ms;
     stats->streams = (!exec && h->groups.size() > 1) ? (int64_t)h->groups.size() : 1;
     stats->stage_kernel_us = att ? 1e3 * ms / (double)(att * 8) : 0.0;
+    stats->checkpoint_records = keep ? 1 : 0;
   }
   return 0;
 }

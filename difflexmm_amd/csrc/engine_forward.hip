@@ -216,6 +216,7 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   HIP_OK(hipSetDevice(h->device));
   if (!h->have_params) { h->err = "forward: set_params first"; return 1; }
   h->adaptive = false;
+  h->adaptive_records = false;
   if (n_timepoints < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kStep;

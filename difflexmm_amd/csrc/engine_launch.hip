@@ -76,7 +76,7 @@ StageCoef stage_coef(const Tableau& T, int i) {
   sc.c_next = T.c[r];
   return sc;
 }
-static AdjCoef adj_coef(const Tableau& T, int i) {
+AdjCoef adj_coef(const Tableau& T, int i) {
   AdjCoef ac;
   memset(&ac, 0, sizeof(ac));
   if (i > 0) {
@@ -479,7 +479,7 @@ bool use_fn_table(const dfx_handle* h) {
   const char* e = getenv("DFX_FN_TABLE");
   return h->pl.n_fns > 0 && !h->adaptive && h->d_fn_tab.p && !(e && e[0] == '0');
 }
-static void launch_fn_table(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) {
+void launch_fn_table(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) {
   if (!c.fn_tab) return;
   StageTimes tms;
   for (int r = 0; r < kFnRows; ++r) tms.c[r] = r <= h->pl.tab.s ? h->pl.tab.c[r] : 0.0;

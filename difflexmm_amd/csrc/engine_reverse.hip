@@ -264,6 +264,11 @@ void set_grad_wishes(dfx_handle* h, const dfx_grads* g) {
 // made the next sweep skip its zeroing (round-4 advice)
 static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_grads* views, dfx_stats* stats, bool kinetic, int n_target,
                        bool accumulators_cleared = false) {
+  if (h->adaptive_records) {       // the accepted steps of an adaptive solve: engine_dense.hip (accumulators cleared by the caller's prelude
+    set_grad_wishes(h, want);      // launch, or here)
+    if (!accumulators_cleared && zero_grad_accumulators(h, nullptr, 0, -1)) return 2;
+    return run_adjoint_dense(h, want, grads, views, stats, kinetic, n_target);
+  }
   const Plan& pl = h->pl;
   const size_t B = pl.batch;
   const int Tn = (int)h->ts.size();

@@ -139,7 +139,7 @@ def check_adaptive_records_adjoint(lib, lattice="quads", n=4, nonlinear=True, co
     of = osol(y0, ts, c.oracle_cp(lv)).numpy()
     st = osol.stats["step_times"]
     e_fwd = relerr(fields, of)
-    assert e_fwd < 1e-9, ("adaptive forward", e_fwd)
+    assert e_fwd < 1e-8, ("adaptive forward", e_fwd)       # (two controllers: rounding in the error estimate moves the step sizes by ~1e-8)
     mine_t = s.engine.adaptive_step_times(0)
     # (the controller amplifies rounding: the error estimate is a difference of nearly equal numbers, so two correct implementations
     # agree on the step boundaries to ~1e-8, not to 1e-15; the decisions -- how many steps, which attempts fail -- are the same)

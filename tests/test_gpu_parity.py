@@ -185,6 +185,36 @@ def test_grid_with_caller_chosen_step_boundaries(hip_lib, lattice, n, integrator
     parity.check_trajectory_and_adjoint(None, lattice, n, integrator, spi=np.array([3, 7, 2, 5]), own_step_times=True)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(lattice="kagome", n=3, n_out=121), dict(batch=2, contact=False, nonlinear=False), dict(n=9, n_out=81)],
+                         ids=["quads-contact", "kagome-contact", "linearized-batch2", "quads9-contact"])
+def test_adaptive_solve_is_differentiable_as_it_stands(hip_lib, kw):
+    """keep_trajectory=True without a grid -- the reference's default call under jax.grad (dynamics.py:166; problems/quads_focusing.py:565):
+    ONE adaptive pass that keeps its accepted steps (dfx_forward_adaptive_keep) + the dense-output discrete adjoint, against the oracle's
+    odeint restatement (forward, step boundaries) and autograd through the oracle's replay of the same steps (gradients, 1e-9)."""
+    parity.check_adaptive_records_adjoint(None, **kw)
+
+
+def test_adaptive_records_grow_while_the_solve_runs(hip_lib, monkeypatch):
+    """The room for the accepted steps is a guess that grows (records, step boundaries, output pointers copied over): a solve started with
+    room for 40 steps gives the fields and gradients of one that never had to grow."""
+    res = []
+    for cap in (None, "40"):
+        if cap:
+            monkeypatch.setenv("DFX_ADAPTIVE_CAP", cap)
+        c = Case("quads", 5, True, True, seed=11, lib=None, cutoff_deg=42.0)
+        cp = c.cp._replace(constraint_params=dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5))
+        ts = np.linspace(0, 6e-4, 31)
+        s = c.solver
+        s.rtol = s.atol = 1e-7
+        f = s(c.random_state(0.05, 0.02, 5.0), ts, cp, keep_trajectory=True)
+        assert s.stats["step_control"] == "adaptive-records" and s.stats["steps"] > 120
+        tree, s0 = s.vjp(np.ones_like(f))
+        res.append((f, tree.geometrical_params.centroid_node_vectors, s0, s.stats["steps"]))
+    assert res[0][3] == res[1][3]
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b)
+
+
 def test_adaptive_grid_gradient_matches_cpu_port(hip_lib, cpu_lib, monkeypatch):
     """keep_trajectory=True without a grid: freeze the adaptive controller's accepted step boundaries, then forward +
     reverse on that grid.  The frozen solve stays within the tolerance of the adaptive one; on the SAME grid the CPU port
