@@ -183,7 +183,9 @@ struct dfx_handle {
   bool persist_fwd = false, persist_adj = false;
   int persist_npb = 4, persist_wpm = 0, n_cu = 0;
   int persist_fwd_members = 0, persist_adj_members = 0;     // members per launch (the rest follow in further launches of the same segment)
-  DevBuf<double> d_ring;
+  DevBuf<double> d_ring, d_err3;       // d_err3: the per-wave partials of the adaptive controller's error norm (dfx_persist_dense.h)
+  bool persist_off = false;            // a wave of a persistent launch gave up once (a workgroup was not resident): this handle keeps one launch per
+                                       // stage from then on (the solve that met it was re-run that way, in the same process)
   std::vector<int32_t> lig_slots;
   DevBuf<int32_t> d_lig_slots, d_lig_tab;
   DevBuf<double> d_lig_p, d_lig_l, d_lig_k, d_lig_phi, d_lig_g, d_lig_gphi;
@@ -225,6 +227,10 @@ bool persist_members_ok(const dfx_handle* h, int per_launch);
 void persist_plan(dfx_handle* h, const DevCtx& c);
 void persist_plan_adj(dfx_handle* h, const DevCtx& c);
 int* persist_give_up_word(dfx_handle* h);
+bool persist_adaptive_plan(dfx_handle* h);
+void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int max_attempts, AdaptLoopArgs aa);
+bool persist_plan_adj_dense(dfx_handle* h, const DevCtx& c);
+void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int n_steps, DenseCtx dn);
 int step_units(const dfx_handle* h, int kind);
 bool use_fn_table(const dfx_handle* h);
 bool solve_is_eager(const dfx_handle* h);

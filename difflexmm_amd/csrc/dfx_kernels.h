@@ -110,6 +110,19 @@ struct DenseCtx {
   int n_out, pad;
 };
 
+// arguments of the adaptive controller inside the persistent stage loop (dfx_persist_dense.h)
+struct AdaptLoopCoef {          // Dormand-Prince with embedded error and dense output (dfx_physics.h: Dopri), acceleration form
+  double a[7][7], aa[7][7], e[7], ee[7], cm[7], cma[7], c[7];
+};
+struct AdaptLoopArgs {
+  double* err;                  // 3 * batch * waves_per_member per-wave partials of the squared error ratio (poison = not yet written)
+  AdaptRec ar;                  // t_steps == nullptr: the steps are not kept
+  double two_n_free;
+  long long cap;                // steps the kept-step buffers hold per member
+  int n_timepoints, keep;
+};
+
+
 struct DevCtx {
   int n_blocks, n_slots, n_fns, batch, s, n_special, k_uniform, n_timepoints;
   int m0, nbuf;           // first member of the group this launch integrates (one stream per group); stage buffers per member

@@ -302,8 +302,12 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
 
 // (three workgroups per compute unit: 168 registers; the allocator's own choice is 170-172, the limit costs two 8-byte spills of
 // epilogue pointers OUTSIDE the stage loop)
-template <int MODEL, int CONTACT, int NPB>
-__global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_adj_persist(DevCtx c, PersistAdjCoef pc, PersistArgs pa) {
+//   DENSE: the sweep of an adaptive solve that kept its accepted steps (dfx_dense.h): every member its own number of steps N_m -- a wave
+//   runs the steps n <= N_m of the segment, of step N_m only stage 0 (the evaluation at the final state, a step of size zero) -- and the
+//   outputs' cotangents enter through the dense output (the same sums as in adj_stage_body<..., DENSE = 1>).  Builds of their own
+//   (k_adj_dense_loop, dfx_persist_dense.hip): the fixed-grid kernels carry none of it.
+template <int MODEL, int CONTACT, int NPB, int DENSE>
+__device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistAdjCoef& pc, const PersistArgs& pa, const DenseCtx& dn) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
   if (wave >= pa.waves_per_member * pa.nm) return;
   const int ml = wave / pa.waves_per_member, w = wave - ml * pa.waves_per_member;
@@ -314,6 +318,13 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
   const u32 nd = (u32)c.n_blocks * 3, nd6 = (u32)c.n_blocks * 6;
   const int s = c.s;
   const Seg sg = *c.cur;
+  long long n_m = 0;
+  int j_top = pa.n_steps - 1;
+  if constexpr (DENSE) {
+    n_m = dn.n_acc[m];
+    if (n_m - sg.base_step < (long long)j_top) j_top = (int)(n_m - sg.base_step);
+    if (j_top < 0) return;                      // this member's sweep starts in an earlier segment
+  }
   const MemberBases B = member_bases(c, m);
   LigRes g;
   load_lig_res<CONTACT>(c, B, slot, g);
@@ -349,14 +360,14 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
   const size_t ring_stride = (size_t)c.batch * c.n_blocks * kPos;
   const u32 r_own = ((u32)m * (u32)c.n_blocks + (u32)b) * (kPos * 8) + 16u * (u32)(k & 1);
   const u32 r_par = ((u32)m * (u32)c.n_blocks + (u32)(pslot >> 2)) * (kPos * 8);
-  const int total = pa.n_steps * s;
+  const int total = DENSE ? (j_top + 1) * s - ((sg.base_step + j_top == n_m) ? s - 1 : 0) : pa.n_steps * s;
   int t_ord = 0;
-  for (int j = pa.n_steps - 1; j >= 0; --j) {
+  for (int j = j_top; j >= 0; --j) {
     const long long n = sg.base_step + j;
     double h = sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
     if (c.t_steps) { const double* ts = steps_of(c, m); h = ts[n + 1] - ts[n]; h_before = n > 0 ? ts[n] - ts[n - 1] : 0.0; }
 #pragma unroll 1
-    for (int i = s - 1; i >= 0; --i) {
+    for (int i = (DENSE && n == n_m) ? 0 : s - 1; i >= 0; --i) {
       const int win = (int)((n * s + i) & 1);
       // ---- the records this stage linearises about (checkpoint), in flight while the partner's w is polled
       const double* POSin = traj_rec(c, m, -1 - i, n);
@@ -368,7 +379,8 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       double sq = 0.0, sv = 0.0, sqc = 0.0, svc = 0.0;
 #pragma unroll
       for (int jj = 1; jj < kPersistStages; ++jj) {
-        const bool on = jj > i && jj < s;
+        // (DENSE: the evaluation at the final state, stage 0 of the zero-size step N_m, has no later stages -- their places hold nothing yet)
+        const bool on = jj > i && jj < s && !(DENSE && n == n_m);
         const double2 y = on ? s_yb[jj - 1][tid] : make_double2(0.0, 0.0);
         const double cf = i > 0 ? pc.col[i][jj] : 1.0;
         sq += cf * y.x;
@@ -379,7 +391,46 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       const double col_s = pc.col[i][s], cur_s = pc.cur[i][s], col_i = pc.col[i][i];
       const double2 lam = s_lam[tid];
       const double lq = lam.x, lv = lam.y;
-      const double w_d = (h * (cur_s * lv + svc)) * invm;
+      double w_d = (h * (cur_s * lv + svc)) * invm;
+      // dense output: what the outputs inside this step and inside the previous one add to this stage's own Kbar, to the Kbar handed on,
+      // and to lambda_n -- scaled by the step sizes, zero on constrained DOFs (adj_stage_body<..., DENSE = 1>, same sums)
+      double e_own_q = 0.0, e_nxt_q = 0.0, e_nxt_v = 0.0, gs_q = 0.0, gs_v = 0.0;
+      if constexpr (DENSE) {
+        if (!constrained) {
+          const int* op = dn.out_ptr + (size_t)m * dn.stride;
+          const int lo = op[n], hi = op[n + 1], plo = n > 0 ? op[n - 1] : lo;
+          const double* dwm = dn.dw + (size_t)m * dn.n_out * 8;
+          const u32 o_g = ((u32)b * 6 + kd) * 8;
+          double e_own_v = 0.0;
+          for (int kk = lo; kk < hi; ++kk) {
+            const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
+            const double gq = ldg<double>(Gk, o_g), gv = ldg<double>(Gk, o_g + 24);
+            const double* wt = dwm + (size_t)kk * 8;
+            e_own_q += wt[i] * gq; e_own_v += wt[i] * gv;
+            if (i > 0) { e_nxt_q += wt[i - 1] * gq; e_nxt_v += wt[i - 1] * gv; }
+            else { gs_q += gq; gs_v += gv; }
+          }
+          e_own_q *= h; e_own_v *= h; e_nxt_q *= h; e_nxt_v *= h;
+          if (i <= 1) {
+            double e6q = 0.0, e6v = 0.0, e5q = 0.0, e5v = 0.0;
+            for (int kk = plo; kk < lo; ++kk) {
+              const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
+              const double gq = ldg<double>(Gk, o_g), gv = ldg<double>(Gk, o_g + 24);
+              const double* wt = dwm + (size_t)kk * 8;
+              e6q += wt[6] * gq; e6v += wt[6] * gv;
+              e5q += wt[s - 1] * gq; e5v += wt[s - 1] * gv;
+            }
+            if (i == 0) { e_own_q += h_before * e6q; e_own_v += h_before * e6v; e_nxt_q = h_before * e5q; e_nxt_v = h_before * e5v; }
+            else { e_nxt_q += h_before * e6q; e_nxt_v += h_before * e6v; }
+          }
+          if (i == 0 && n == 0)
+            for (int kk = 0; kk < lo; ++kk) {
+              const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
+              gs_q += ldg<double>(Gk, o_g); gs_v += ldg<double>(Gk, o_g + 24);
+            }
+          w_d += e_own_v * invm;
+        }
+      }
       const double wox = blk_bcast<NPB, 0>(w_d, k), woy = blk_bcast<NPB, 1>(w_d, k), woth = blk_bcast<NPB, 2>(w_d, k);
       double wp[4];
       if (t_ord == 0) {
@@ -438,7 +489,8 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
           }
         }
         const double a_i = constrained ? 0.0 : (fload - dE - damp * v_i) * invm;
-        const double kq_in = h * (cur_s * lq + sqc);
+        double kq_in = h * (cur_s * lq + sqc);
+        if constexpr (DENSE) kq_in += e_own_q;
         double ybq = 0.0, ybv = 0.0;
         if (!constrained) {
           ybq = -hw;
@@ -452,7 +504,8 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
           kv = h * (col_s * lv + col_i * ybv + sv);
         } else {
           double nlq = lq + (ybq + sq), nlv = lv + (ybv + sv);
-          const bool first = (sg.j0 + j) == 0;
+          if constexpr (DENSE) { nlq += gs_q; nlv += gs_v; }
+          const bool first = !DENSE && (sg.j0 + j) == 0;
           if (first && c.G && !constrained) {
             const double* G = c.G + ((size_t)sg.interval * c.batch + m) * (size_t)nd6;
             nlq += G[b * 6 + k]; nlv += G[b * 6 + 3 + k];
@@ -461,6 +514,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
           s_lam[tid] = make_double2(nlq, nlv);
           kv = h_before * col_s * nlv;
         }
+        if constexpr (DENSE) kv += e_nxt_v;
         w_next = constrained ? 0.0 : kv * invm;
       }
       // ---- w of the next stage to run: into the ring, or -- last stage of the launch -- where the next launch reads it
@@ -480,6 +534,11 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
     stg<double2>(LAMm, o_b6, s_lam[tid]);
     if (!constrained) { stg<double>(bmm, o_dof, s_acc[1][tid]); if (bcm) stg<double>(bcm, o_dof, s_acc[2][tid]); }
   }
+}
+
+template <int MODEL, int CONTACT, int NPB>
+__global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_adj_persist(DevCtx c, PersistAdjCoef pc, PersistArgs pa) {
+  adj_persist_body<MODEL, CONTACT, NPB, 0>(c, pc, pa, DenseCtx{});
 }
 
 }  // namespace

@@ -36,6 +36,9 @@ struct PersistAdjCoef {         // AdjCoef of every stage
 // kernels by (bond model, contact, lanes per block); nullptr: no such build
 const void* fwd_kernel(int model, int contact, int npb);
 const void* adj_kernel(int model, int contact, int npb);
+// the adaptive controller inside the stage loop and the reverse sweep of the steps it keeps (dfx_persist_dense.hip)
+const void* adaptive_fwd_kernel(int model, int contact);
+const void* adj_dense_kernel(int model, int contact, int npb);
 // places 0 .. kPAhead-1 of the ring, members [m0, m0 + nm), poisoned on `st`
 void launch_ring_poison(hipStream_t st, double* ring, int batch, int n_blocks, int m0, int nm, int width);
 

@@ -54,6 +54,45 @@ static int adaptive_room(dfx_handle* h, long long cap, bool keep_contents) {
   return 0;
 }
 
+// after the last attempt: what the solve leaves in the handle, the fields, the statistics
+static int finish_adaptive(dfx_handle* h, const std::vector<Clock>& clk, bool keep, double* fields, dfx_stats* stats, bool persist) {
+  const Plan& pl = h->pl;
+  const size_t B = pl.batch, nb = pl.n_blocks;
+  const int Tn = (int)h->ts.size();
+  if (keep) {
+    std::vector<int> nacc(B);
+    h->a_nmax = 0;
+    for (size_t m = 0; m < B; ++m) { nacc[m] = (int)clk[m].accepted; h->a_nmax = std::max<long long>(h->a_nmax, clk[m].accepted); }
+    HIP_OK(hipMemcpyAsync(h->d_nacc.p, nacc.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+  }
+  if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipGetLastError());
+  h->have_fields = true;
+  h->adaptive = false;
+  h->adaptive_records = keep;
+  h->have_adaptive_record = true;
+  h->accepted_per_member.assign(B, 0);
+  for (size_t m = 0; m < B; ++m) h->accepted_per_member[m] = clk[m].accepted;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    long long acc = 0, att = 0;
+    for (size_t m = 0; m < B; ++m) { acc = std::max(acc, clk[m].accepted); att = std::max(att, clk[m].attempts); }
+    stats->steps = acc;
+    stats->rhs_evals = 6 * att + 2;
+    stats->launches = h->launches;
+    stats->kernel_ms = ms;
+    stats->streams = (!persist && h->groups.size() > 1 && !h->adaptive_exec) ? (int64_t)h->groups.size() : 1;
+    stats->stage_kernel_us = att ? 1e3 * ms / (double)(att * (persist ? 7 : 8)) : 0.0;      // (persistent loop: 6 records + the error gather per attempt)
+    stats->checkpoint_records = keep ? 1 : 0;
+    stats->tile_kernels = persist ? 3 : 0;
+  }
+  return 0;
+}
+
 // ---- adaptive forward (reference odeint semantics) ------------------------------------------------
 static int forward_adaptive_impl(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                                  double rtol, double atol, int64_t max_attempts, bool keep, double* fields, dfx_stats* stats);
@@ -235,6 +274,55 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
   };
   auto enqueue_attempt = [&]() { for (int p = 0; p < 8; ++p) launch_phase(p, c, h->stream, slot_grid(h), (unsigned)B); };
   HIP_OK(hipEventRecord(h->ev0, h->stream));
+  // ---- the controller inside the persistent stage loop (dfx_persist_dense.h) where the solve fits the chip at once: one launch carries
+  // every member through up to kLoopAttempts attempts; the host only looks at the clocks between launches (and grows the room for kept steps)
+  HIP_OK(h->flag_stage.ensure(64));
+  *persist_give_up_word(h) = 0;
+  if (persist_adaptive_plan(h)) {
+    int kLoopAttempts = 8192;
+    if (const char* e = getenv("DFX_ADAPTIVE_LOOP_ATTEMPTS")) kLoopAttempts = std::max(1, atoi(e));
+    int rcl = 0;
+    while (true) {
+      AdaptLoopArgs la;
+      memset(&la, 0, sizeof(la));
+      la.ar = ar; la.two_n_free = 2.0 * (double)n_free; la.cap = h->a_cap; la.n_timepoints = Tn; la.keep = keep ? 1 : 0;
+      launch_adaptive_persist(h, c, h->stream, (int)std::min<long long>(kLoopAttempts, std::max<long long>(1, max_attempts)), la);
+      HIP_OK(hipMemcpyAsync(clk.data(), h->d_clock.p, sizeof(Clock) * B, hipMemcpyDeviceToHost, h->stream));
+      HIP_OK(hipStreamSynchronize(h->stream));
+      if (*persist_give_up_word(h)) break;
+      bool all_done = true;
+      long long most = 0, tried = 0;
+      for (size_t m = 0; m < B; ++m) {
+        if (clk[m].state == 2) { h->err = "forward_adaptive: non-finite error estimate (member " + std::to_string(m) + ")"; rcl = 3; }
+        if (clk[m].state == 3) { h->err = "forward_adaptive: step size underflow (member " + std::to_string(m) + ")"; rcl = 3; }
+        if (clk[m].state == 0) all_done = false;
+        most = std::max(most, clk[m].accepted); tried = std::max(tried, clk[m].attempts);
+      }
+      if (rcl || all_done) break;
+      if (tried >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; rcl = 4; break; }
+      if (keep && most + 4 > h->a_cap) {
+        const long long cap = std::min<long long>(cap_fit, std::max<long long>(2 * h->a_cap, most + 4 * kAttemptsPerGraph));
+        if (cap < most + 8) { h->err = kNoRoom; rcl = 5; break; }
+        if (int rcr = adaptive_room(h, cap, true)) { rcl = rcr; break; }
+        h->ck->writer = h;
+        c = make_ctx(h);
+        refresh_ar();
+      }
+    }
+    if (*persist_give_up_word(h)) {
+      // a workgroup was not resident (another process on the device?): this handle keeps one launch per stage from now on, and this
+      // solve starts over that way -- same process, nothing is left half done
+      h->persist_off = true;
+      static bool said = false;
+      if (!said) fprintf(stderr, "[dfx] a persistent launch could not get all its workgroups resident: this engine keeps one launch per stage from now on\n");
+      said = true;
+      h->adaptive = false; h->have_traj = false; h->persist_fwd = false;
+      return forward_adaptive_impl(h, state0 == rest.data() ? nullptr : state0, timepoints, n_timepoints, rtol, atol, max_attempts, keep, fields, stats);
+    }
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    if (rcl) { h->adaptive = false; h->have_traj = false; return rcl; }
+    return finish_adaptive(h, clk, keep, fields, stats, true);
+  }
   // stage-1 record of the first attempt (accept = 0: nothing to commit)
   hipLaunchKernelGGL(k_prepare, slot_grid(h), dim3(kThreads), 0, h->stream, c, dc, Tn, keep ? 1 : 0);
   hipGraph_t graph = nullptr;
@@ -316,37 +404,7 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   if (rc) { h->adaptive = false; h->have_traj = false; return rc; }
-  if (keep) {
-    std::vector<int> nacc(B);
-    h->a_nmax = 0;
-    for (size_t m = 0; m < B; ++m) { nacc[m] = (int)clk[m].accepted; h->a_nmax = std::max<long long>(h->a_nmax, clk[m].accepted); }
-    HIP_OK(hipMemcpyAsync(h->d_nacc.p, nacc.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
-  }
-  if (fields) HIP_OK(hipMemcpyAsync(fields, h->d_fields.p, sizeof(double) * B * Tn * nb * 6, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipGetLastError());
-  h->have_fields = true;
-  h->adaptive = false;
-  h->adaptive_records = keep;
-  h->have_adaptive_record = true;
-  h->accepted_per_member.assign(B, 0);
-  for (size_t m = 0; m < B; ++m) h->accepted_per_member[m] = clk[m].accepted;
-  if (stats) {
-    memset(stats, 0, sizeof(*stats));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-    long long acc = 0, att = 0;
-    for (size_t m = 0; m < B; ++m) { acc = std::max(acc, clk[m].accepted); att = std::max(att, clk[m].attempts); }
-    stats->steps = acc;
-    stats->rhs_evals = 6 * att + 2;
-    stats->launches = h->launches;
-    stats->kernel_ms = ms;
-    stats->streams = (!exec && h->groups.size() > 1) ? (int64_t)h->groups.size() : 1;
-    stats->stage_kernel_us = att ? 1e3 * ms / (double)(att * 8) : 0.0;
-    stats->checkpoint_records = keep ? 1 : 0;
-  }
-  return 0;
+  return finish_adaptive(h, clk, keep, fields, stats, false);
 }
 
 

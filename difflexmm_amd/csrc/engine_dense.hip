@@ -53,11 +53,16 @@ int run_adjoint_dense(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, df
   hipLaunchKernelGGL(k_adj_begin_dense, slot_grid(h), dim3(kThreads), 0, h->stream, c, dn);
   h->launches += 2;
   const dim3 grid = slot_grid(h);
+  // one launch per segment where the sweep fits the chip at once (k_adj_dense_loop), one launch per stage otherwise
+  HIP_OK(h->flag_stage.ensure(64));
+  *persist_give_up_word(h) = 0;
+  const bool persist = persist_plan_adj_dense(h, c);
   for (int si = (int)h->segs.size() - 1; si >= 0; --si) {
     const Seg& sg = h->segs[si];
     hipLaunchKernelGGL(k_set_seg, dim3(1), dim3(1), 0, h->stream, (const Seg*)h->d_segs.p, si, h->d_cur.p);
     h->launches++;
     launch_fn_table(h, c, h->stream, (int)B, sg.n_steps);
+    if (persist) { launch_adj_dense_persist(h, c, h->stream, sg.n_steps, dn); continue; }
     for (int j = sg.n_steps - 1; j >= 0; --j) {
       const long long n = sg.base_step + j;
       for (int i = (n == h->a_nmax ? 0 : s - 1); i >= 0; --i) launch_adj_dense(h, c, h->stream, grid, dn, i, j);
@@ -69,6 +74,16 @@ int run_adjoint_dense(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, df
   }
   HIP_OK(hipEventRecord(h->ev3, h->stream));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
+  if (*persist_give_up_word(h)) {
+    // a workgroup of a persistent launch was not resident (another process on the device?): this handle keeps one launch per stage from
+    // now on, and the sweep is run again that way -- same process, same records
+    h->persist_off = true;
+    static bool said = false;
+    if (!said) fprintf(stderr, "[dfx] a persistent launch could not get all its workgroups resident: this engine keeps one launch per stage from now on\n");
+    said = true;
+    if (zero_grad_accumulators(h, nullptr, 0, -1)) return 2;
+    return run_adjoint_dense(h, want, grads, views, stats, kinetic, n_target);
+  }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     float ms = 0.f;
@@ -80,7 +95,7 @@ int run_adjoint_dense(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, df
     stats->streams = 1;
     stats->stage_kernel_us = h->a_nmax ? 1e3 * ms / (double)(h->a_nmax * s * 2) : 0.0;
     stats->checkpoint_records = 1;
-    stats->tile_kernels = 0;
+    stats->tile_kernels = h->persist_adj ? 3 : 0;
   }
   return 0;
 }

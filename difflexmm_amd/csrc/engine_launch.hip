@@ -300,7 +300,7 @@ static int persist_wg_slots(const void* fn) {
 bool persist_shape_ok(const dfx_handle* h) {
   const Plan& pl = h->pl;
   const char* e = getenv("DFX_PERSIST");
-  if (e && e[0] == '0') return false;
+  if ((e && e[0] == '0') || h->persist_off) return false;
   return (pl.model == kNonlinear || pl.model == kLinearized) && pl.contact != DFX_CONTACT_DISTANCE && !pl.n_ovf && pl.tab.s <= kPersistStages &&
          (pl.n_npb == 3 || pl.n_npb == 4);
 }
@@ -439,6 +439,92 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
   }
 }
 static void launch_fwd_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) { launch_segment_persist(h, c, st, nm, n_steps, false); }
+
+// ---- the adaptive controller inside the stage loop (dfx_persist_dense.h) and the reverse sweep of the steps it keeps ------------------
+// forward: quad mapping (the controller's reductions are wave-wide), one member group; members that do not fit the chip at once run in
+// further launches (every launch carries its members through up to `max_attempts` attempts on their own clocks)
+bool persist_adaptive_plan(dfx_handle* h) {
+  h->persist_fwd = false;
+  if (!persist_shape_ok(h) || h->groups.size() != 1 || h->pl.tab.s != 6) return false;
+  const void* fn = dfx_persist::adaptive_fwd_kernel(h->pl.model, h->pl.contact);
+  if (!fn) return false;
+  h->persist_npb = 4;
+  h->persist_wpm = (h->pl.n_slots + 63) / 64;
+  h->persist_fwd_members = persist_members_that_fit(h, fn, 4);
+  if (h->persist_fwd_members <= 0 || (h->pl.batch + h->persist_fwd_members - 1) / h->persist_fwd_members > 8) return false;
+  const size_t B = h->pl.batch;
+  if (h->d_ring.ensure((size_t)kPRing * B * h->pl.n_blocks * kPos) != hipSuccess || h->d_err3.ensure(3 * B * (size_t)h->persist_wpm) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  h->persist_fwd = true;
+  return true;
+}
+void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int max_attempts, AdaptLoopArgs aa) {
+  const void* fn = dfx_persist::adaptive_fwd_kernel(h->pl.model, h->pl.contact);
+  const Dopri D = make_dopri();
+  AdaptLoopCoef pc;
+  memset(&pc, 0, sizeof(pc));
+  for (int i = 0; i < 7; ++i) {
+    pc.e[i] = D.e[i]; pc.ee[i] = D.ee[i]; pc.cm[i] = D.cm[i]; pc.cma[i] = D.cma[i]; pc.c[i] = D.c[i];
+    for (int l = 0; l < 7; ++l) { pc.a[i][l] = D.a[i][l]; pc.aa[i][l] = D.aa[i][l]; }
+  }
+  const int nm = h->pl.batch, per = h->persist_fwd_members;
+  const int n_chunks = (nm + per - 1) / per, even = (nm + n_chunks - 1) / n_chunks;
+  aa.err = h->d_err3.p;
+  (void)hipMemsetAsync(h->d_err3.p, 0xFF, sizeof(double) * 3 * (size_t)nm * h->persist_wpm, st);       // every partial: poison
+  for (int off = 0; off < nm; off += even) {
+    const int cnt = std::min(even, nm - off);
+    DevCtx cc = c;
+    cc.m0 = c.m0 + off;
+    int grid = 0, per_cu = 0;
+    persist_shape(h, 4, cnt, &grid, &per_cu);
+    dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
+    h->launches++;
+    PersistArgs pa;
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+    void* args[] = {&cc, &pc, &pa, &aa};
+    launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
+  }
+}
+// reverse: the records build's conditions (persist_plan_adj), the DENSE kernel's registers
+bool persist_plan_adj_dense(dfx_handle* h, const DevCtx& c) {
+  h->persist_adj = false;
+  if (!persist_common_ok(h, c)) return false;
+  if (c.rps <= 1 || c.g_b || c.AD || !c.lam_pairs) return false;
+  const void* fn = dfx_persist::adj_dense_kernel(h->pl.model, h->pl.contact, h->persist_npb);
+  if (!fn) return false;
+  h->persist_adj_members = persist_members_that_fit(h, fn, h->persist_npb);
+  if (h->persist_adj_members <= 0 || (h->pl.batch + h->persist_adj_members - 1) / h->persist_adj_members > 8) return false;
+  if (h->d_ring.ensure((size_t)kPRing * h->pl.batch * h->pl.n_blocks * kPos) != hipSuccess) { (void)hipGetLastError(); return false; }
+  h->persist_adj = true;
+  return true;
+}
+void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int n_steps, DenseCtx dn) {
+  const int npb = h->persist_npb, per = h->persist_adj_members, nm = h->pl.batch;
+  const void* fn = dfx_persist::adj_dense_kernel(h->pl.model, h->pl.contact, npb);
+  PersistAdjCoef pca;
+  memset(&pca, 0, sizeof(pca));
+  for (int i = 0; i < h->pl.tab.s && i < kPersistStages; ++i) {
+    const AdjCoef ac = adj_coef(h->pl.tab, i);
+    for (int jj = 0; jj <= kPersistStages; ++jj) { pca.col[i][jj] = ac.col[jj]; pca.cur[i][jj] = ac.cur[jj]; }
+    pca.c[i] = ac.c_i;
+  }
+  const int n_chunks = (nm + per - 1) / per, even = (nm + n_chunks - 1) / n_chunks;
+  for (int off = 0; off < nm; off += even) {
+    const int cnt = std::min(even, nm - off);
+    DevCtx cc = c;
+    cc.m0 = c.m0 + off;
+    int grid = 0, per_cu = 0;
+    persist_shape(h, npb, cnt, &grid, &per_cu);
+    dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
+    h->launches++;
+    PersistArgs pa;
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+    void* args[] = {&cc, &pca, &pa, &dn};
+    launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
+  }
+}
 static void launch_adj_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps) { launch_segment_persist(h, c, st, nm, n_steps, true); }
 
 // forward: stage i reads buffer fin(i), writes fout(i); buffer 0 is the step state

@@ -184,3 +184,54 @@ def test_segments_level_in_pieces_equals_whole_intervals(hip_lib, persist):
         assert np.array_equal(parts[2][k], whole[2][k]), k
         assert relerr(parts[2][k], recs[2][k]) < 1e-10, k
     assert whole[1] > 0 and np.abs(whole[2]["centroid_node_vectors"]).max() > 0
+
+
+@pytest.mark.parametrize("lattice,n,batch", [("quads", 12, 1), ("quads", 9, 3), ("kagome", 7, 2)])
+def test_adaptive_controller_in_the_loop_equals_the_stage_launch_controller(hip_lib, lattice, n, batch):
+    """jax.experimental.ode.odeint (dynamics.py:166) inside the persistent stage loop (k_adaptive_fwd_loop: error norm through an all-gather of
+    per-wave partials, every wave its member's controller) against the controller of the stage launches (k_control / k_prepare): the same
+    accepted steps -- count, accept / reject pattern, boundaries --, the same fields, and through the dense-output reverse sweep of the kept
+    steps (k_adj_dense_loop against the DENSE stage launches) the same gradients.  Bit for bit in the contraction-free build; to the
+    controller's rounding sensitivity (step boundaries 1e-9, fields 1e-9, gradients 1e-7) in the production build.  The members of a
+    batch differ (amplitudes), so they take different numbers of steps."""
+    c = Case(lattice, n, True, True, seed=17, cutoff_deg=42.0 if lattice == "quads" else 125.0, batch=batch)
+    cps = [c.cp._replace(constraint_params=dict(FAST, amplitude=7.5 / (1 + 0.6 * m))) for m in range(batch)]
+    ts = np.linspace(0.0, 6e-4, 41)
+    s = c.solver
+    s.rtol, s.atol = 1e-7, 1e-7
+    y0 = c.random_state(0.05, 0.02, 5.0)
+    mid = c.geo.n_blocks // 2
+    target = np.array([mid + 1, mid + 2], dtype=np.int32)
+
+    def run(keep):
+        f = s(y0, ts, cps if batch > 1 else cps[0], keep_trajectory=keep)
+        st = dict(s.stats)
+        counts = s.engine.adaptive_step_counts()
+        times = [s.engine.adaptive_step_times(m) for m in range(batch)]
+        if not keep:
+            return np.array(f), counts, times, st, None, None
+        obj, raw = s.kinetic_energy_value_and_raw(target)
+        return np.array(f), counts, times, st, np.array(obj, dtype=float), ({k: np.array(v) for k, v in raw.items()}, dict(s.adjoint_stats))
+
+    for keep in (False, True):
+        ref = _with_env({"DFX_PERSIST": "0"}, lambda: run(keep))
+        out = _with_env({"DFX_PERSIST": "1"}, lambda: run(keep))
+        assert ref[3]["tile_kernels"] != 3 and out[3]["tile_kernels"] == 3, (ref[3], out[3])
+        assert out[3]["launches"] < 0.05 * ref[3]["launches"]
+        assert np.array_equal(out[1], ref[1]) and out[3]["rhs_evals"] == ref[3]["rhs_evals"]          # same accepts, same rejects
+        if batch > 1:
+            assert len({int(x) for x in ref[1].sum(1)}) > 1                                             # members on their own clocks
+        print("keep", keep, "steps", [len(a) for a in ref[2]], "step boundaries", [relerr(a, b) for a, b in zip(out[2], ref[2])], "fields", relerr(out[0], ref[0]))
+        for a, b in zip(out[2], ref[2]):
+            assert len(a) == len(b) and same(a, b, 1e-5)
+        assert same(out[0], ref[0], 1e-6), relerr(out[0], ref[0])
+        if keep:
+            assert out[5][1]["tile_kernels"] == 3 and ref[5][1]["tile_kernels"] != 3
+            print("objective", relerr(out[4], ref[4]), "gradients", {k: relerr(out[5][0][k], ref[5][0][k]) for k in ref[5][0]})
+            assert same(out[4], ref[4], 1e-6)
+            for k in ref[5][0]:
+                # (3-node blocks: the loop packs five triangles per 16 lanes, the DENSE stage launches keep the quad mapping -- the block sums
+                # add in another order, so not even the contraction-free build is bit-identical there)
+                ok = relerr(out[5][0][k], ref[5][0][k]) < 1e-13 if (EXACT and lattice == "kagome") else same(out[5][0][k], ref[5][0][k], 1e-4)
+                assert ok, (k, relerr(out[5][0][k], ref[5][0][k]))
+            assert np.abs(ref[5][0]["centroid_node_vectors"]).max() > 0
