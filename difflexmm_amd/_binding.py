@@ -54,7 +54,8 @@ class dfx_stats(C.Structure):
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid", "dfx_forward_grid_members",
            "dfx_forward_adaptive", "dfx_forward_adaptive_keep", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
-           "dfx_device_count", "dfx_version", "dfx_share_checkpoint", "dfx_abi_layout"]
+           "dfx_device_count", "dfx_version", "dfx_share_checkpoint", "dfx_abi_layout", "dfx_member_status", "dfx_set_failure_policy",
+           "dfx_test_set_spin_limit"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
@@ -102,6 +103,9 @@ def declare(lib):
     lib.dfx_adaptive_step_times.argtypes = [H, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]
     lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
     lib.dfx_forward_adaptive_keep.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_member_status.argtypes = [H, _ip]
+    lib.dfx_set_failure_policy.argtypes = [H, C.c_int32]
+    lib.dfx_test_set_spin_limit.argtypes = [H, C.c_int32]
     lib.dfx_adjoint.argtypes = [H, _dp, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
     lib.dfx_objective_kinetic.argtypes = [H, _ip, C.c_int32, _dp]
     lib.dfx_adjoint_kinetic.argtypes = [H, _ip, C.c_int32, C.POINTER(dfx_grads), C.POINTER(dfx_stats)]
@@ -357,6 +361,17 @@ class Engine:
                                                       int(max_attempts), _ptr(fields), C.byref(st)), "dfx_forward_adaptive")
         self.n_timepoints = T
         return fields, _stats(st)
+
+    def member_status(self):
+        """(batch,) int32: 0 ok, 1 non-finite, 2 step size underflow, 3 step budget exceeded -- of the last forward pass."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        self._check(self.lib.dfx_member_status(self._h, st.ctypes.data_as(_ip)), "dfx_member_status")
+        return st
+
+    def set_failure_policy(self, isolate):
+        """isolate=True: a member that diverges is flagged (``member_status``; its outputs NaN) instead of failing the call for the whole
+        ensemble -- what the reference's list of forward problems does (problems/quads_focusing_multi_input.py:66-77)."""
+        self._check(self.lib.dfx_set_failure_policy(self._h, 1 if isolate else 0), "dfx_set_failure_policy")
 
     @property
     def can_keep_adaptive(self):

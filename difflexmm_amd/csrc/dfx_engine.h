@@ -184,6 +184,12 @@ struct dfx_handle {
   int persist_npb = 4, persist_wpm = 0, n_cu = 0;
   int persist_fwd_members = 0, persist_adj_members = 0;     // members per launch (the rest follow in further launches of the same segment)
   DevBuf<double> d_ring, d_err3;       // d_err3: the per-wave partials of the adaptive controller's error norm (dfx_persist_dense.h)
+  int spin_limit = 0;                  // > 0: polls before a wave of a persistent launch gives up (dfx_test_set_spin_limit; 0: kSpinLimit)
+  // failure isolation (problems/quads_focusing_multi_input.py:66-77: a member that diverges yields NaN for itself only):
+  // status of every member after the last forward pass -- 0 ok, 1 non-finite state, 2 step size underflow, 3 step budget exceeded --
+  // and whether such a member fails the call (default) or is merely flagged (dfx_set_failure_policy)
+  std::vector<int32_t> member_status;
+  bool isolate_failures = false;
   bool persist_off = false;            // a wave of a persistent launch gave up once (a workgroup was not resident): this handle keeps one launch per
                                        // stage from then on (the solve that met it was re-run that way, in the same process)
   std::vector<int32_t> lig_slots;
@@ -227,6 +233,11 @@ bool persist_members_ok(const dfx_handle* h, int per_launch);
 void persist_plan(dfx_handle* h, const DevCtx& c);
 void persist_plan_adj(dfx_handle* h, const DevCtx& c);
 int* persist_give_up_word(dfx_handle* h);
+int ensure_flags(dfx_handle* h);               // the pinned flag words: [0] non-finite (any member), [1] touched, [2] give-up, [16 + m] non-finite (member m)
+int* member_flags(dfx_handle* h);
+int persist_spin_limit(const dfx_handle* h);
+void persist_forget(dfx_handle* h);            // dfx_destroy: drop the handle's streams from the account of persistent launches in flight
+void persist_fell_back(dfx_handle* h);         // a launch could not get its workgroups resident: latch the handle onto stage launches, say so once
 bool persist_adaptive_plan(dfx_handle* h);
 void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int max_attempts, AdaptLoopArgs aa);
 bool persist_plan_adj_dense(dfx_handle* h, const DevCtx& c);

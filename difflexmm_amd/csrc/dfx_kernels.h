@@ -387,7 +387,9 @@ __global__ __launch_bounds__(kThreads) void k_init(DevCtx c, const double* state
 }
 
 // fields[m, k] <- (disp, vel) of stage buffer `buf` (or, buf < 0, of the checkpointed state of step n)
-__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad, int buf, long long n) {
+//   bad: one word, set when any output row of any member is not finite; bad_m (or null): one word per member (a member that
+//   diverges must not take the ensemble with it -- problems/quads_focusing_multi_input.py:66-77 yields NaN for that member only)
+__global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields, int k, int* bad, int buf, long long n, int* bad_m) {
   const int m = blockIdx.y + c.m0;
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   if (tid >= c.n_blocks * 3) return;
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void k_snapshot(DevCtx c, double* fields,
   const double v = vel_in(c, m, buf, n)[tid];
   f[tid] = q;
   f[(size_t)c.n_blocks * 3 + tid] = v;
-  if (!isfinite(q) || !isfinite(v)) *bad = k + 1;   // any writer wins: only "some output row is not finite" matters
+  if (!isfinite(q) || !isfinite(v)) { *bad = k + 1; if (bad_m) bad_m[m] = k + 1; }   // any writer wins: only "some output row is not finite" matters
 }
 
 // copy stage buffer 0 into record 0 of step n of the checkpoint (the initial state; the start of an interval in the segments level)

@@ -107,12 +107,12 @@ __device__ __forceinline__ void load_lig_res(const DevCtx& c, const MemberBases&
   }
 }
 // the partner's ring record of stage ordinal t: polled until none of its four doubles is poison; false: gave up
-__device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, double (&r)[4], int t_ord, int* give_up) {
+__device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, double (&r)[4], int t_ord, int* give_up, int limit) {
   for (int spins = 0;;) {
     ring_load(place, byte_off, r);
     const bool ok = !(is_poison(r[0]) || is_poison(r[1]) || is_poison(r[2]) || is_poison(r[3]));
     if (__all(ok)) return true;
-    if (++spins > kSpinLimit) { *give_up = 1 + t_ord; return false; }
+    if (++spins > limit) { *give_up = 1 + t_ord; return false; }
     __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
         // ---- the partner's record of this stage
         const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
         double pr[4];
-        if (!ring_wait(place, r_par, pr, t_ord, pa.give_up)) return;
+        if (!ring_wait(place, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
         if (k < 2 && t_ord + kPAhead <= total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
         BlockRec<double> p;
         p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];
@@ -438,7 +438,7 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
         const u32 pb = (u32)(pslot >> 2) * 24;
         const double2 wxy = ldg<double2>(Win, pb);
         wp[0] = wxy.x; wp[1] = wxy.y; wp[2] = ldg<double>(Win, pb + 16);
-      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up)) return;
+      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up, pa.spin_limit)) return;
       if (k < 2 && t_ord + kPAhead < total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
       BlockRec<double> o, p;
       o.x = o0.x; o.y = o0.y; o.th = o1.x; o.sh = o1.y; o.ch = half_cos(o.th, o.sh);

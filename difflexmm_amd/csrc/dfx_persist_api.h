@@ -14,6 +14,9 @@ constexpr int kPersistThreads = 256;
 constexpr unsigned kPoisonWord = 0xFFFFFFFFu;
 constexpr int kPersistStages = 6;   // fixed-grid tableaus of the library: 4 (RK4) and 6 (Dormand-Prince)
 constexpr int kSpinLimit = 1 << 23; // polls (>= 0.5 us each) before a wave gives up: seconds
+// what the hand-off protocol leans on (dfx_persist.h): a place is re-poisoned kPAhead ordinals ahead of its record -- at least two, so that
+// the store is complete (the owner's next poll waits for it) before a neighbour can ask -- and the ring is longer than that look-ahead
+static_assert(kPAhead >= 2 && kPRing >= kPAhead + 1, "hand-off ring: re-poison at least two ordinals ahead, ring longer than the look-ahead");
 
 struct PersistCoef {            // the whole tableau in acceleration form, by value (scalar loads at compile-time offsets)
   double cv[kPersistStages][kPersistStages];
@@ -23,7 +26,8 @@ struct PersistCoef {            // the whole tableau in acceleration form, by va
 struct PersistArgs {
   double* ring;                 // kPRing * batch * n_blocks * kPos
   int* give_up;                 // pinned host word: != 0 once a wave gave up (1 + the stage ordinal it waited for)
-  int n_steps, nm, waves_per_member, pad;
+  int n_steps, nm, waves_per_member;
+  int spin_limit;               // polls before a wave gives up (kSpinLimit; the test hook dfx_test_set_spin_limit makes it tiny)
 };
 
 

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
       }
       // ---- the partner's record S_i
       double pr[4];
-      if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up)) return;
+      if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
       if (valid && k < 2) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
       BlockRec<double> p;
       p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
         for (int spins = 0;;) {
           v = err_load(slot_now + idx);
           if (!is_poison(v)) break;
-          if (++spins > kSpinLimit) { *pa.give_up = -1 - (int)(attempt & 0xffff); return; }
+          if (++spins > pa.spin_limit) { *pa.give_up = -1 - (int)(attempt & 0xffff); return; }
           __builtin_amdgcn_s_sleep(1);
         }
       }

@@ -120,15 +120,30 @@ int dfx_create(const dfx_problem* problem, dfx_handle** out) {
     h->tiling_ok = false;          // the pair launches keep to one ligament per node
   }
   setup_lig(h);
+  // the persistent loop's hand-off assumes that the slot a lane watches watches it back (dfx_persist.h): true for every bond list with one
+  // ligament per node by construction; checked, not assumed (round-5 advice) -- a plan that breaks it keeps one launch per stage
+  for (int sl = 0; sl < pl.n_slots && !h->persist_off; ++sl) {
+    const int info = pl.slot_info[sl];
+    if (info >= 0 && (pl.slot_info[info >> 1] < 0 || (pl.slot_info[info >> 1] >> 1) != sl)) h->persist_off = true;
+  }
   *out = h;
   return 0;
 }
+
+int dfx_member_status(dfx_handle* h, int32_t* status) {
+  for (int m = 0; m < h->pl.batch; ++m) status[m] = m < (int)h->member_status.size() ? h->member_status[m] : 0;
+  return 0;
+}
+int dfx_set_failure_policy(dfx_handle* h, int32_t isolate) { h->isolate_failures = isolate != 0; return 0; }
+int dfx_test_set_spin_limit(dfx_handle* h, int32_t polls) { h->spin_limit = polls > 0 ? polls : 0; return 0; }
 
 int dfx_destroy(dfx_handle* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  persist_forget(h);           // (round-5 advice: the account of persistent launches in flight must not keep streams of a handle that is gone)
   drop_graphs(h);
+  h->d_out_ptr.release(); h->d_nacc.release(); h->d_theta.release(); h->d_dw.release(); h->d_err3.release();
   h->d_ovf_ptr.release(); h->d_ovf_info.release(); h->d_ovf_bond.release(); h->d_ovf_p.release(); h->d_ovf_g.release();
   h->d_lig_slots.release(); h->d_lig_tab.release(); h->d_lig_p.release(); h->d_lig_l.release(); h->d_lig_k.release(); h->d_lig_phi.release();
   h->d_lig_g.release(); h->d_lig_gphi.release();

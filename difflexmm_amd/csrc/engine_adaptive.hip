@@ -59,10 +59,17 @@ static int finish_adaptive(dfx_handle* h, const std::vector<Clock>& clk, bool ke
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks;
   const int Tn = (int)h->ts.size();
+  // a member that was flagged instead of failing the call: its history is NaN from row 1 on (0xFF bytes are a NaN), and the reverse
+  // sweep skips it (N_m = -1: every launch returns at once for it; its gradients stay zero and the caller sees its status)
+  for (size_t m = 0; m < B; ++m)
+    if (h->member_status[m] && Tn > 1) HIP_OK(hipMemsetAsync(h->d_fields.p + (m * Tn + 1) * nb * 6, 0xFF, sizeof(double) * (size_t)(Tn - 1) * nb * 6, h->stream));
   if (keep) {
     std::vector<int> nacc(B);
     h->a_nmax = 0;
-    for (size_t m = 0; m < B; ++m) { nacc[m] = (int)clk[m].accepted; h->a_nmax = std::max<long long>(h->a_nmax, clk[m].accepted); }
+    for (size_t m = 0; m < B; ++m) {
+      nacc[m] = h->member_status[m] ? -1 : (int)clk[m].accepted;
+      h->a_nmax = std::max<long long>(h->a_nmax, std::max(0, nacc[m]));
+    }
     HIP_OK(hipMemcpyAsync(h->d_nacc.p, nacc.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
   }
@@ -111,6 +118,8 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
   HIP_OK(hipSetDevice(h->device));
   h->persist_fwd = false;
   if (!h->have_params) { h->err = "forward_adaptive: set_params first"; return 1; }
+  if (state0) for (size_t i = 0; i < (size_t)h->pl.batch * h->pl.n_blocks * 6; ++i)
+    if (!std::isfinite(state0[i])) { h->err = "forward_adaptive: state0 holds a non-finite value"; return 1; }
   if (n_timepoints < 1) { h->err = "forward_adaptive: need >= 1 timepoint"; return 1; }
   if (h->pl.tab.s != 6) { h->err = "forward_adaptive: the adaptive controller is defined for the dopri5 tableau"; return 1; }
   const Plan& pl = h->pl;
@@ -190,7 +199,7 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
   hipLaunchKernelGGL(k_init, slot_grid(h), dim3(kThreads), 0, h->stream, c, (const double*)h->d_state0.p, timepoints[0], 0, 0LL, 0LL);
   if (keep)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((nb * kStep + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, h->d_seg_idx.p + 1, 0, 0LL, (int*)nullptr);
   launch_fwd(h, c, 0, 0, 0, -1, 0, 0);                      // A_0 = f(y0, t0)
   // only the evaluation just made comes back (row 0 / row 1 of every member's seven stage accelerations), not all of d_A
   std::vector<double> A0((size_t)B * nd), A1((size_t)B * nd);
@@ -274,9 +283,36 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
   };
   auto enqueue_attempt = [&]() { for (int p = 0; p < 8; ++p) launch_phase(p, c, h->stream, slot_grid(h), (unsigned)B); };
   HIP_OK(hipEventRecord(h->ev0, h->stream));
+  // what the clocks say after a round of attempts: a member whose error estimate is not finite or whose step size underflowed stops
+  // (its kernels return at once from then on); it fails the call -- or, dfx_set_failure_policy(h, 1), is flagged and the others go on
+  h->member_status.assign(B, 0);
+  auto judge = [&](bool& all_done) -> int {
+    int rcj = 0;
+    all_done = true;
+    for (size_t m = 0; m < B; ++m) {
+      if (clk[m].state == 2 || clk[m].state == 3) {
+        h->member_status[m] = clk[m].state == 2 ? 1 : 2;
+        if (!h->isolate_failures) {
+          h->err = std::string("forward_adaptive: ") + (clk[m].state == 2 ? "non-finite error estimate" : "step size underflow") + " (member " + std::to_string(m) +
+                   "; dfx_set_failure_policy(h, 1) flags such members instead of failing the call)";
+          rcj = 3;
+        }
+      }
+      if (clk[m].state == 0) all_done = false;
+    }
+    return rcj;
+  };
+  auto out_of_budget = [&]() -> int {
+    int first = -1;
+    for (size_t m = 0; m < B; ++m) if (clk[m].state == 0) { h->member_status[m] = 3; if (first < 0) first = (int)m; }
+    if (h->isolate_failures) return 0;
+    h->err = "forward_adaptive: step budget exceeded (member " + std::to_string(std::max(first, 0)) + " is not done after " + std::to_string((long long)max_attempts) +
+             " attempts; dfx_set_failure_policy(h, 1) flags such members instead of failing the call)";
+    return 4;
+  };
   // ---- the controller inside the persistent stage loop (dfx_persist_dense.h) where the solve fits the chip at once: one launch carries
   // every member through up to kLoopAttempts attempts; the host only looks at the clocks between launches (and grows the room for kept steps)
-  HIP_OK(h->flag_stage.ensure(64));
+  if (ensure_flags(h)) return 2;
   *persist_give_up_word(h) = 0;
   if (persist_adaptive_plan(h)) {
     int kLoopAttempts = 8192;
@@ -292,30 +328,22 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
       if (*persist_give_up_word(h)) break;
       bool all_done = true;
       long long most = 0, tried = 0;
-      for (size_t m = 0; m < B; ++m) {
-        if (clk[m].state == 2) { h->err = "forward_adaptive: non-finite error estimate (member " + std::to_string(m) + ")"; rcl = 3; }
-        if (clk[m].state == 3) { h->err = "forward_adaptive: step size underflow (member " + std::to_string(m) + ")"; rcl = 3; }
-        if (clk[m].state == 0) all_done = false;
-        most = std::max(most, clk[m].accepted); tried = std::max(tried, clk[m].attempts);
-      }
+      rcl = judge(all_done);
+      for (size_t m = 0; m < B; ++m) { most = std::max(most, clk[m].accepted); tried = std::max(tried, clk[m].attempts); }
       if (rcl || all_done) break;
-      if (tried >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; rcl = 4; break; }
+      if (tried >= max_attempts) { rcl = out_of_budget(); break; }
       if (keep && most + 4 > h->a_cap) {
         const long long cap = std::min<long long>(cap_fit, std::max<long long>(2 * h->a_cap, most + 4 * kAttemptsPerGraph));
-        if (cap < most + 8) { h->err = kNoRoom; rcl = 5; break; }
-        if (int rcr = adaptive_room(h, cap, true)) { rcl = rcr; break; }
+        if (cap < most + 8) { h->err = kNoRoom; rcl = h->isolate_failures ? out_of_budget() : 5; break; }
+        if (int rcr = adaptive_room(h, cap, true)) { rcl = h->isolate_failures ? out_of_budget() : rcr; break; }
         h->ck->writer = h;
         c = make_ctx(h);
         refresh_ar();
       }
     }
     if (*persist_give_up_word(h)) {
-      // a workgroup was not resident (another process on the device?): this handle keeps one launch per stage from now on, and this
-      // solve starts over that way -- same process, nothing is left half done
-      h->persist_off = true;
-      static bool said = false;
-      if (!said) fprintf(stderr, "[dfx] a persistent launch could not get all its workgroups resident: this engine keeps one launch per stage from now on\n");
-      said = true;
+      // a workgroup was not resident: one launch per stage from now on, and this solve starts over that way -- same process (round-5 advice)
+      persist_fell_back(h);
       h->adaptive = false; h->have_traj = false; h->persist_fwd = false;
       return forward_adaptive_impl(h, state0 == rest.data() ? nullptr : state0, timepoints, n_timepoints, rtol, atol, max_attempts, keep, fields, stats);
     }
@@ -381,20 +409,16 @@ static int forward_adaptive_impl(dfx_handle* h, const double* state0, const doub
     HIP_OK(hipMemcpyAsync(clk.data(), h->d_clock.p, sizeof(Clock) * B, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     bool all_done = true;
-    for (size_t m = 0; m < B; ++m) {
-      if (clk[m].state == 2) { h->err = "forward_adaptive: non-finite error estimate (member " + std::to_string(m) + ")"; rc = 3; }
-      if (clk[m].state == 3) { h->err = "forward_adaptive: step size underflow (member " + std::to_string(m) + ")"; rc = 3; }
-      if (clk[m].state == 0) all_done = false;
-    }
+    rc = judge(all_done);
     if (rc || all_done) break;
-    if (attempts_issued >= max_attempts) { h->err = "forward_adaptive: step budget exceeded"; rc = 4; break; }
+    if (attempts_issued >= max_attempts) { rc = out_of_budget(); break; }
     if (keep) {       // room for the next round of attempts (every one of them may be accepted)
       long long most = 0;
       for (size_t m = 0; m < B; ++m) most = std::max(most, clk[m].accepted);
       if (most + kAttemptsPerGraph + 4 > h->a_cap) {
         const long long cap = std::min<long long>(cap_fit, std::max<long long>(2 * h->a_cap, most + 4 * kAttemptsPerGraph));
-        if (cap < most + kAttemptsPerGraph + 4) { h->err = kNoRoom; rc = 5; break; }
-        if (int rcr = adaptive_room(h, cap, true)) { rc = rcr; break; }
+        if (cap < most + kAttemptsPerGraph + 4) { h->err = kNoRoom; rc = h->isolate_failures ? out_of_budget() : 5; break; }
+        if (int rcr = adaptive_room(h, cap, true)) { rc = h->isolate_failures ? out_of_budget() : rcr; break; }
         h->ck->writer = h;
         c = make_ctx(h);
         refresh_ar();

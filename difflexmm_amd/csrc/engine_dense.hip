@@ -54,7 +54,7 @@ int run_adjoint_dense(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, df
   h->launches += 2;
   const dim3 grid = slot_grid(h);
   // one launch per segment where the sweep fits the chip at once (k_adj_dense_loop), one launch per stage otherwise
-  HIP_OK(h->flag_stage.ensure(64));
+  if (ensure_flags(h)) return 2;
   *persist_give_up_word(h) = 0;
   const bool persist = persist_plan_adj_dense(h, c);
   for (int si = (int)h->segs.size() - 1; si >= 0; --si) {
@@ -75,12 +75,8 @@ int run_adjoint_dense(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, df
   HIP_OK(hipEventRecord(h->ev3, h->stream));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
   if (*persist_give_up_word(h)) {
-    // a workgroup of a persistent launch was not resident (another process on the device?): this handle keeps one launch per stage from
-    // now on, and the sweep is run again that way -- same process, same records
-    h->persist_off = true;
-    static bool said = false;
-    if (!said) fprintf(stderr, "[dfx] a persistent launch could not get all its workgroups resident: this engine keeps one launch per stage from now on\n");
-    said = true;
+    // a workgroup of a persistent launch was not resident: one launch per stage from now on, and the sweep once more -- same process, same records
+    persist_fell_back(h);
     if (zero_grad_accumulators(h, nullptr, 0, -1)) return 2;
     return run_adjoint_dense(h, want, grads, views, stats, kinetic, n_target);
   }

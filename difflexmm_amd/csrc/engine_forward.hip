@@ -168,14 +168,23 @@ int ensure_work_buffers(dfx_handle* h) {
 }
 
 
-// after the stream has been waited for: the non-finite flag of the forward pass (pinned word 0 of flag_stage) and its statistics
+// after the stream has been waited for: the non-finite flags of the forward pass (pinned words of flag_stage) and its statistics.
+// Returns -7 when a wave of a persistent launch gave up: the caller latches the handle onto stage launches and runs the solve again.
 int finish_forward(dfx_handle* h, dfx_stats* stats) {
-  if (*persist_give_up_word(h)) { h->have_traj = false; h->err = std::string("forward: ") + kPersistGaveUp; return 2; }
+  if (*persist_give_up_word(h)) { h->have_traj = false; return -7; }
   const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
+  h->member_status.assign(h->pl.batch, 0);
   if (bad) {
-    h->have_traj = false;
-    h->err = "forward: non-finite state at output " + std::to_string(bad - 1) + " (unstable step size or contact blow-up)";
-    return 3;
+    int first = -1, n_bad = 0;
+    for (int m = 0; m < h->pl.batch; ++m)
+      if (member_flags(h)[m]) { h->member_status[m] = 1; ++n_bad; if (first < 0) first = m; }
+    if (!h->isolate_failures) {
+      h->have_traj = false;
+      h->err = "forward: non-finite state at output " + std::to_string(bad - 1) + " (unstable step size or contact blow-up) of " + std::to_string(n_bad) +
+               " member(s), first: member " + std::to_string(std::max(first, 0)) + " -- dfx_member_status says which; dfx_set_failure_policy(h, 1) flags "
+               "them instead of failing the call";
+      return 3;
+    }
   }
   if (stats) {
     float ms = 0.f;
@@ -185,6 +194,13 @@ int finish_forward(dfx_handle* h, dfx_stats* stats) {
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * h->pl.tab.s) : 0.0;
   }
   return 0;
+}
+
+// a non-finite initial state would travel through the persistent loop's hand-off ring as "record not there yet" (its poison is a NaN
+// pattern) and is never a valid input: refused up front (round-5 advice)
+static bool state_is_finite(const double* p, size_t n) {
+  for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false;
+  return true;
 }
 
 int dfx_forward(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
@@ -218,6 +234,7 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   h->adaptive = false;
   h->adaptive_records = false;
   if (n_timepoints < 1) { h->err = "forward: need >= 1 timepoint and >= 1 step per interval"; return 1; }
+  if (state0 && !state_is_finite(state0, (size_t)h->pl.batch * h->pl.n_blocks * 6)) { h->err = "forward: state0 holds a non-finite value"; return 1; }
   const Plan& pl = h->pl;
   const size_t B = pl.batch, nb = pl.n_blocks, rec = nb * kStep;
   const int Tn = n_timepoints;
@@ -295,9 +312,11 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   cursors[1] = 0;
   // the non-finite flag of a fixed-grid solve lives in pinned host memory: k_snapshot stores into it directly (rare, any writer wins)
   // and the host reads it after its wait -- no device-to-host copy on the stream between the forward pass and whatever follows it
-  HIP_OK(h->flag_stage.ensure(64));
+  if (ensure_flags(h)) return 2;
   int* const bad_flag = reinterpret_cast<int*>(h->flag_stage.p);
+  int* const bad_m = member_flags(h);
   *bad_flag = 0;
+  memset(bad_m, 0, sizeof(int) * B);
   *persist_give_up_word(h) = 0;
   HIP_OK(hipMemcpyAsync(h->d_seg_idx.p, cursors.data(), cursors.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (state0) {       // through the pinned staging area (pageable DMA is slow here); NULL = every member starts at rest
@@ -322,7 +341,7 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   if (c.traj)
     hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)((rec + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads), 0, h->stream, c, 0LL);
   dim3 g3((unsigned)((nb * 3 + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, bad_flag, 0, 0LL);
+  hipLaunchKernelGGL(k_snapshot, g3, dim3(kThreads), 0, h->stream, c, h->d_fields.p, 0, bad_flag, 0, 0LL, bad_m);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   if (fork_groups(h)) return 2;
   const bool eager = solve_is_eager(h) || h->segments || h->persist_fwd;      // (a persistent segment is three launches: nothing to replay)
@@ -339,7 +358,7 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
         DevCtx cs = group_ctx(h, c, gi);
         cs.n_timepoints = h->n_restart_rows;           // k_snapshot's row stride
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, cs, h->d_restart.p, h->pieces[next_piece].row, bad_flag,
-                           pair_state_buf(h, h->segs[si + 1].base_step), (long long)h->segs[si + 1].base_step);
+                           pair_state_buf(h, h->segs[si + 1].base_step), (long long)h->segs[si + 1].base_step, bad_m);
         h->launches++;
       }
       if (sg.j0 + sg.n_steps == h->spis[sg.interval]) {   // buffer 0 holds the state at the end of the interval
@@ -347,7 +366,7 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
         // end of the interval: the state is in buffer 0, or (records checkpoint) only in the trajectory
         hipLaunchKernelGGL(k_snapshot, dim3(g3.x, gr.nm), dim3(kThreads), 0, gr.stream, group_ctx(h, c, gi), h->d_fields.p, sg.interval + 1,
                            bad_flag, c.rps > 1 ? -1 : pair_state_buf(h, h->step0[sg.interval + 1]),
-                           (long long)h->step0[sg.interval + 1]);
+                           (long long)h->step0[sg.interval + 1], bad_m);
       }
     }
   }
@@ -368,5 +387,10 @@ int forward_grid_impl(dfx_handle* h, const double* state0, const double* timepoi
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipGetLastError());
   if (timing) fprintf(stderr, "[dfx] forward: all done %.0f us after the first launch\n", since(tl0));
-  return finish_forward(h, stats);
+  const int rcf = finish_forward(h, stats);
+  if (rcf == -7) {      // a persistent launch was not fully resident: one launch per stage from now on, and this solve once more -- same process
+    persist_fell_back(h);
+    return forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, step_times, keep_trajectory, fields, stats, per_member);
+  }
+  return rcf;
 }

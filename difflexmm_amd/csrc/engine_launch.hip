@@ -297,6 +297,18 @@ static int persist_wg_slots(const void* fn) {
   const int alloc = std::max(8, ((at.numRegs + 7) / 8) * 8);
   return cache[fn] = alloc > 512 ? 0 : alloc / 8;
 }
+// workgroups of `fn` a compute unit really holds at once: the runtime's own answer (registers, the 34.8 KB of LDS of the reverse loop,
+// scratch -- round-5 advice: the register count alone ignores the latter two); 0: unknown
+static int persist_wg_per_cu(const void* fn) {
+  static std::mutex mu;
+  static std::map<const void*, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(fn);
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kPersistThreads, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+  return cache[fn] = nb;
+}
 bool persist_shape_ok(const dfx_handle* h) {
   const Plan& pl = h->pl;
   const char* e = getenv("DFX_PERSIST");
@@ -312,6 +324,7 @@ int persist_members_that_fit(dfx_handle* h, const void* fn, int npb) {
   if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return 0; h->n_cu = v; }
   const int wg_slots = persist_wg_slots(fn);
   int cap = wg_slots ? std::min(8, kPersistSlots / wg_slots) : 0;      // (8 waves per SIMD at most)
+  if (const int occ = persist_wg_per_cu(fn)) cap = std::min(cap, occ);
   if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
   const long long wpm = persist_waves_per_member(h, npb);
   if (cap <= 0 || wpm <= 0) return 0;
@@ -379,6 +392,29 @@ static PersistCoef persist_coef(const Tableau& T) {
   return pc;
 }
 int* persist_give_up_word(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 2; }   // (word 0: non-finite flag, word 1: touched flag)
+int ensure_flags(dfx_handle* h) {
+  HIP_OK(h->flag_stage.ensure(64 + sizeof(int) * (size_t)h->pl.batch));
+  return 0;
+}
+int* member_flags(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 16; }
+int persist_spin_limit(const dfx_handle* h) { return h->spin_limit > 0 ? h->spin_limit : kSpinLimit; }
+void persist_fell_back(dfx_handle* h) {
+  h->persist_off = true;
+  h->persist_fwd = h->persist_adj = false;
+  static bool said = false;
+  if (!said) fprintf(stderr, "[dfx] a persistent launch could not get all its workgroups resident (another process on the device?): this engine keeps one "
+                             "launch per stage from now on; the solve is run again that way\n");
+  said = true;
+}
+void persist_forget(dfx_handle* h) {
+  std::lock_guard<std::mutex> lk(g_persist_mu);
+  auto& fl = g_persist_inflight[h->device & 63];
+  for (size_t i = 0; i < fl.size();) {
+    bool mine = fl[i].st == h->stream;
+    for (auto& g : h->groups) mine = mine || fl[i].st == g.stream || fl[i].st == g.stream2;
+    if (mine) { (void)hipEventSynchronize(fl[i].ev); g_persist_events[h->device & 63].push_back(fl[i].ev); fl.erase(fl.begin() + i); } else ++i;
+  }
+}
 // one launch, admitted by the slot account above
 static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void** args, int grid, int need) {
   std::lock_guard<std::mutex> lk(g_persist_mu);
@@ -432,7 +468,7 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
     void* args_f[] = {&cc, &pcf, &pa};
     void* args_r[] = {&cc, &pca, &pa};
     launch_persist(h, fn, st, reverse ? args_r : args_f, grid, per_cu * persist_wg_slots(fn));
@@ -482,7 +518,7 @@ void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
     void* args[] = {&cc, &pc, &pa, &aa};
     launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
   }
@@ -520,7 +556,7 @@ void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, in
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.pad = 0;
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
     void* args[] = {&cc, &pca, &pa, &dn};
     launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
   }

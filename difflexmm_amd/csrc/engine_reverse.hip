@@ -123,7 +123,7 @@ int collect_grads(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, dfx_gr
   // gets a view of a zero buffer that is never written
   bool phi_zero = false;
   if (w_phi) {
-    HIP_OK(h->flag_stage.ensure(64));
+    if (ensure_flags(h)) return 2;
     // (word 0: the forward pass's flag)
     HIP_OK(hipMemcpyAsync(reinterpret_cast<int32_t*>(h->flag_stage.p) + 1, h->d_touch.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -344,7 +344,15 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   HIP_OK(hipEventRecord(h->ev3, h->stream));
   if (timing) fprintf(stderr, "[dfx] adjoint: sweep enqueued %.0f us after entry\n", since(ta0));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
-  if (*persist_give_up_word(h)) { h->err = std::string("adjoint: ") + kPersistGaveUp; return 2; }
+  if (*persist_give_up_word(h)) {
+    // a wave of a persistent launch gave up.  A give-up inside the forward pass of the fused call (its flag is read only now) invalidates the
+    // trajectory: the fused call runs everything again (-7).  Otherwise the records are good: the sweep alone is run again on stage launches
+    if (h->defer_forward_sync) return -7;
+    persist_fell_back(h);
+    *persist_give_up_word(h) = 0;
+    if (zero_grad_accumulators(h, nullptr, 0, nseg)) return 2;
+    return run_adjoint(h, want, grads, views, stats, kinetic, n_target, true);
+  }
   if (timing) {
     float ms0 = 0.f;
     (void)hipEventElapsedTime(&ms0, h->ev2, h->ev3);
@@ -456,14 +464,19 @@ int dfx_forward_kinetic_value_and_grad(dfx_handle* h, const double* state0, cons
                                        const int32_t* steps_per_interval, const int32_t* target_blocks, int32_t n_target,
                                        double* objective, const dfx_grads* want, dfx_grads* views, int32_t device_views,
                                        dfx_stats* forward_stats, dfx_stats* adjoint_stats) {
-  h->defer_forward_sync = true;
-  int rc = forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, nullptr, 1, nullptr, nullptr, false);
-  h->defer_forward_sync = false;
-  if (rc) return rc;
-  h->device_views = device_views != 0;
-  rc = adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, views, adjoint_stats);
-  h->device_views = false;
-  HIP_OK(hipStreamSynchronize(h->stream));          // (already idle when the sweep returned normally)
-  const int rcf = finish_forward(h, forward_stats);
-  return rcf ? rcf : rc;
+  for (int pass = 0; pass < 2; ++pass) {
+    h->defer_forward_sync = true;
+    int rc = forward_grid_impl(h, state0, timepoints, n_timepoints, steps_per_interval, nullptr, 1, nullptr, nullptr, false);
+    if (rc) { h->defer_forward_sync = false; return rc; }
+    h->device_views = device_views != 0;
+    rc = adjoint_kinetic(h, target_blocks, n_target, objective, want, nullptr, views, adjoint_stats);
+    h->device_views = false;
+    h->defer_forward_sync = false;
+    HIP_OK(hipStreamSynchronize(h->stream));          // (already idle when the sweep returned normally)
+    const int rcf = finish_forward(h, forward_stats);
+    if ((rc == -7 || rcf == -7) && pass == 0) { persist_fell_back(h); continue; }      // not fully resident: once more, one launch per stage
+    if (rc == -7 || rcf == -7) { h->err = kPersistGaveUp; return 2; }
+    return rcf ? rcf : rc;
+  }
+  return 2;
 }

@@ -51,6 +51,7 @@ class DynamicSolver:
         if int(grid_refine) < 1:
             raise ValueError("grid_refine must be >= 1")
         self.grid_refine = int(grid_refine)
+        self.max_attempts = 10_000_000          # budget of the adaptive controller (attempted steps per member): jax's mxstep is unbounded
         self.batch = int(batch)
         self.damped_blocks = None if damped_blocks is None else np.asarray(damped_blocks, dtype=np.int64)
         self.constrained_pairs = np.asarray(constrained_block_DOF_pairs, dtype=np.int64).reshape(-1, 2)
@@ -183,7 +184,7 @@ class DynamicSolver:
         ts = np.asarray(timepoints, dtype=float)
         if len(ts) < 2:
             return np.zeros(0, dtype=np.int32), None
-        _, st = self.engine.forward_adaptive(state0, ts, self.rtol, self.atol)
+        _, st = self.engine.forward_adaptive(state0, ts, self.rtol, self.atol, max_attempts=self.max_attempts)
         self.adaptive_stats = st
         counts = self.engine.adaptive_step_counts()
         acc = self.engine.adaptive_step_times(int(counts.sum(1).argmax()))
@@ -244,7 +245,7 @@ class DynamicSolver:
             state0 = np.broadcast_to(state0, (self.batch,) + state0.shape)
         if spi is None and not keep_trajectory:
             # reference behaviour: adaptive Dormand-Prince controlled by rtol / atol (dynamics.py:166)
-            fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol)
+            fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol, max_attempts=self.max_attempts)
             self._last = None
             self.stats = dict(stats, steps_per_interval=None, step_control="adaptive")
             return fields
@@ -253,11 +254,18 @@ class DynamicSolver:
             # the reference's call, differentiable as it stands: the adaptive pass keeps its accepted steps and the reverse sweep is their
             # exact discrete adjoint, output cotangents entering through the dense output -- one forward pass, one reverse sweep, and the
             # gradient belongs to exactly the fields returned (dfx_forward_adaptive_keep; DFX_ADAPTIVE_RECORDS=0: the frozen grid below)
-            fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol, keep_trajectory=True, want_fields=want_fields)
-            self._last = (cps, flats, np.asarray(timepoints, dtype=float))
-            self._last_fields = fields
-            self.stats = dict(stats, steps_per_interval=None, step_times=None, step_control="adaptive-records")
-            return fields
+            try:
+                fields, stats = self.engine.forward_adaptive(state0, timepoints, self.rtol, self.atol, max_attempts=self.max_attempts,
+                                                             keep_trajectory=True, want_fields=want_fields)
+            except RuntimeError as e:
+                if "forward_adaptive_keep:" not in str(e):
+                    raise
+                fields = stats = None        # the kept steps do not fit the device (or this physics keeps the two-pass form): frozen grid below
+            if stats is not None:
+                self._last = (cps, flats, np.asarray(timepoints, dtype=float))
+                self._last_fields = fields
+                self.stats = dict(stats, steps_per_interval=None, step_times=None, step_control="adaptive-records")
+                return fields
         if spi is None:   # the reverse sweep needs a fixed grid: freeze the one the adaptive controller chooses
             spi, step_times = self.adaptive_grid(state0, timepoints, flats)
             control = "adaptive-grid"

@@ -301,21 +301,69 @@ def sum_shared_gradients(arrays, comm=None):
     return out
 
 
-def evaluate_ensemble(objective, designs, comm=None):
+def _engine_of(objective):
+    fw = getattr(objective, "forward", None)
+    sd = getattr(fw, "solve_dynamics", None)
+    return getattr(sd, "engine", None)
+
+
+def evaluate_ensemble(objective, designs, comm=None, with_status=False):
     """Every rank evaluates ``objective.value_and_grad`` on its chunk of ``designs`` (as one batch if the forward
     problem was set up with ``batch`` = chunk size, else one by one) and returns (all objectives, local gradients,
-    (lo, hi))."""
+    (lo, hi)) -- with ``with_status=True`` also the status of every design, on every rank.
+
+    Failure isolation (in the reference a diverging member of the list of forward problems,
+    problems/quads_focusing_multi_input.py:66-77, yields NaN for that member only): the engine flags a member whose state
+    becomes non-finite or whose step underflows instead of failing the call (``dfx_set_failure_policy``), its objective
+    comes back as NaN with status 1 / 2 / 3 (``dfx_member_status``), the others are untouched.  A rank whose evaluation
+    RAISES still enters the collective -- with NaN objectives and status -1 for its designs -- so no peer is left blocked in
+    the all-gather; the exception is raised again after the collective unless ``with_status`` asked for the statuses."""
     c = _comm(comm)
     lo, hi = shard_bounds(len(designs), c.rank, c.world)
     mine = list(designs[lo:hi])
     batch = getattr(objective.forward, "batch", 1)
     vals, grads = [], []
-    if batch > 1:
-        assert len(mine) == batch, "chunk size must equal the solver's batch"
-        v, g = objective.value_and_grad(mine)
-        vals, grads = list(np.atleast_1d(v)), list(g)
-    else:
-        for dsg in mine:
-            v, g = objective.value_and_grad(dsg)
-            vals.append(float(v)); grads.append(g)
-    return gather_objectives(vals, len(designs), c), grads, (lo, hi)
+    status = np.zeros(len(mine))
+    eng = _engine_of(objective)
+    if eng is not None and hasattr(eng, "set_failure_policy"):
+        eng.set_failure_policy(True)
+    err = None
+    try:
+        if batch > 1:
+            assert len(mine) == batch, "chunk size must equal the solver's batch"
+            v, g = objective.value_and_grad(mine)
+            vals, grads = list(np.atleast_1d(v)), list(g)
+            if eng is not None and hasattr(eng, "member_status"):
+                status[:] = eng.member_status()
+        else:
+            for i, dsg in enumerate(mine):
+                v, g = objective.value_and_grad(dsg)
+                vals.append(float(v)); grads.append(g)
+                if eng is not None and hasattr(eng, "member_status"):
+                    status[i] = eng.member_status()[0]
+    except Exception as e:          # noqa: BLE001 -- reported through the statuses (and raised again below), never swallowed
+        err = e
+        vals = list(vals) + [np.nan] * (len(mine) - len(vals))
+        grads = list(grads) + [None] * (len(mine) - len(grads))
+        status[:] = np.where(np.isnan(np.asarray(vals, dtype=float)), -1, status)
+    vals = np.asarray(vals, dtype=float)
+    vals = np.where(status != 0, np.nan, vals)            # a flagged member's objective is NaN whatever arithmetic produced
+    all_vals = gather_objectives(vals, len(designs), c) if c.world == 1 else None
+    if c.world == 1:
+        all_status = status.astype(int)
+    else:       # ONE all-gather carries (value, status) of every design
+        width = -(-len(designs) // c.world)
+        buf = np.zeros(2 * width)
+        buf[:len(vals)] = vals
+        buf[width:width + len(status)] = status
+        out = c.all_gather(buf)
+        pv, ps = [], []
+        for r in range(c.world):
+            rlo, rhi = shard_bounds(len(designs), r, c.world)
+            pv.append(out[r][:rhi - rlo]); ps.append(out[r][width:width + rhi - rlo])
+        all_vals, all_status = np.concatenate(pv), np.concatenate(ps).astype(int)
+    if with_status:
+        return all_vals, grads, (lo, hi), all_status
+    if err is not None:
+        raise err
+    return all_vals, grads, (lo, hi)

@@ -204,6 +204,15 @@ int dfx_forward_adaptive(dfx_handle* h, const double* state0, const double* time
 int dfx_forward_adaptive_keep(dfx_handle* h, const double* state0, const double* timepoints, int32_t n_timepoints,
                               double rtol, double atol, int64_t max_attempts, int32_t keep_trajectory, double* fields, dfx_stats* stats);
 
+/* Failure isolation.  In the reference a member of an ensemble that diverges -- the list of forward problems of
+ * problems/quads_focusing_multi_input.py:66-77, the pmap of quads_kinetic_energy_static_tuning.py:473-478 -- yields NaN for itself only.
+ * dfx_member_status: status of every member after the last forward pass, (batch,): 0 ok, 1 non-finite state / error estimate, 2 step size
+ * underflow, 3 step budget exceeded.  dfx_set_failure_policy(h, 1): such a member no longer fails the call (return 3 / 4) -- the call
+ * returns 0, the member's outputs are NaN from the point of failure on (adaptive: from row 1 on), its status says why, the other members are
+ * untouched, and a reverse sweep leaves NaN (fixed grid) or zeros (adaptive) in its gradients.  Default: 0, the call fails. */
+int dfx_member_status(dfx_handle* h, int32_t* status);
+int dfx_set_failure_policy(dfx_handle* h, int32_t isolate);
+
 /* Accepted steps of the last dfx_forward_adaptive per member and output interval: counts (batch, n_timepoints - 1);
  * a step is counted in the interval that contains its start. */
 int dfx_adaptive_step_counts(dfx_handle* h, int32_t* counts);
@@ -266,6 +275,11 @@ int dfx_rhs_vjp(dfx_handle* h, const double* y, double t, const double* lam, dou
 
 /* Potential energy of a full-DOF configuration, (batch, n_blocks, 3) -> (batch,)  (test hook) */
 int dfx_energy(dfx_handle* h, const double* u, double* energy);
+
+/* Test hook: polls after which a wave of the persistent stage loop gives up waiting for a neighbour's record (0: the default, seconds).
+ * A tiny value makes a launch give up at once, which exercises what happens when a workgroup of such a launch is not resident (another
+ * process on the device): the handle latches onto one launch per stage and the solve is run again that way, in the same process. */
+int dfx_test_set_spin_limit(dfx_handle* h, int32_t polls);
 
 int dfx_device_count(void);
 const char* dfx_version(void);

@@ -11,6 +11,7 @@
 // the torch-autograd restatement in oracle/ref_*.py.  Parallelism: OpenMP over blocks.
 #define DFX_ABI_LAYOUT_IMPL
 #include <math.h>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -866,6 +867,18 @@ int dfx_energy(dfx_handle* h, const double* u, double* energy) {
   return 0;
 }
 
+// failure isolation (include/dfx.h): the port judges a member by its output rows
+int dfx_member_status(dfx_handle* h, int32_t* status) {
+  const Plan& pl = h->pl;
+  const size_t per = h->fields.size() / std::max(1, pl.batch);
+  for (int m = 0; m < pl.batch; ++m) {
+    status[m] = 0;
+    for (size_t i = 0; i < per && !h->fields.empty(); ++i) if (!std::isfinite(h->fields[(size_t)m * per + i])) { status[m] = 1; break; }
+  }
+  return 0;
+}
+int dfx_set_failure_policy(dfx_handle*, int32_t) { return 0; }      // (the port never fails a fixed-grid call for a non-finite member)
+int dfx_test_set_spin_limit(dfx_handle*, int32_t) { return 0; }
 int dfx_device_count(void) { return 0; }
 const char* dfx_version(void) { return "dfx-cpu-port 0.1.0"; }
 int dfx_abi_layout(int32_t* out, int32_t n) { return dfxabi_fill(out, n); }

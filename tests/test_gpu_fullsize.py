@@ -248,6 +248,7 @@ def test_adaptive_solve_on_member_group_streams_equals_one_stream(hip_lib, monke
     their own streams against all members on one stream -- every member carries its own clock, the fields must agree bit for bit."""
     import bench
     out = {}
+    monkeypatch.setenv("DFX_PERSIST", "0")       # (one member group would take the controller inside the persistent loop: tests/test_gpu_persistent.py)
     for streams in ("1", "2"):
         monkeypatch.setenv("DFX_STREAMS", streams)
         fw, obj, designs = bench.c3_problem(128, 3, 2)

@@ -94,6 +94,68 @@ def test_two_ranks_shard_designs_and_gather_objectives(tmp_path, cpu_lib, kind):
         assert float(d["slowest"][0]) == 1.0
 
 
+def _collapsed(fw, design, blk=14, keep=1e-5):
+    """`design` with block `blk` of the 6 x 6 lattice shrunk to (almost) a point: its mass is ~1e-10 of its neighbours', the explicit
+    integrator blows up within a few steps -- a member that diverges for a physical reason, not a malformed input."""
+    d = tuple(np.array(a) for a in design)
+    cnv = fw.geometry.centroid_node_vectors(*d)[blk]
+    f = 1 - keep
+    d[0][3, 2] -= f * cnv[0]; d[1][2, 3] -= f * cnv[1]; d[0][2, 2] -= f * cnv[2]; d[1][2, 2] -= f * cnv[3]
+    return d
+
+
+def _isolation_worker(rank, world_size, port, out_dir, mode):
+    sys.path.insert(0, ROOT)
+    from difflexmm_amd import ensemble
+    from oracle.cpu import load
+    comm = GlooComm(rank, world_size, port)
+    ensemble.set_default(comm)
+    fw, obj, designs = _make(load())
+    designs = list(designs)
+    if mode == "diverges":
+        designs[3] = _collapsed(fw, designs[3])                      # member 1 of rank 1
+    else:
+        bad = tuple(np.array(a) for a in designs[2]); bad[0][1, 1, 0] = np.nan
+        designs[2] = bad                                             # rank 1's first evaluation raises (set_params refuses the NaN)
+    values, grads, (lo, hi), status = ensemble.evaluate_ensemble(obj, designs, with_status=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), values=values, status=status, lo=lo, hi=hi)
+    raised = ""
+    if mode == "raises":      # without with_status the exception comes back -- AFTER the collective, so the peer is not left blocked in it
+        try:
+            ensemble.evaluate_ensemble(obj, designs)
+        except Exception as e:      # noqa: BLE001
+            raised = type(e).__name__
+    with open(os.path.join(out_dir, f"raised{rank}"), "w") as f:
+        f.write(raised)
+    comm.barrier()
+    comm.close()
+
+
+@pytest.mark.parametrize("mode", ["diverges", "raises"])
+def test_a_failing_member_does_not_take_the_ensemble_with_it(tmp_path, cpu_lib, mode):
+    """SURVEY section 5 / round-5 verdict item 4: in the reference a diverging member of the list of forward problems
+    (problems/quads_focusing_multi_input.py:66-77) yields NaN for that member only.  world_size 2 over gloo: one member of rank 1
+    diverges (a block with almost no mass: the state overflows) -- both ranks return, the member is NaN and flagged on BOTH ranks, the
+    other three objectives equal the serial run.  And a rank whose evaluation raises still enters the all-gather (status -1 for its
+    designs): the peer is not left waiting in the collective."""
+    import torch.multiprocessing as mp
+    port = 35000 + (os.getpid() % 2000) + (0 if mode == "diverges" else 7)
+    mp.spawn(_isolation_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    fw, obj, designs = _make(cpu_lib)
+    ref_vals = np.array([obj.value_and_grad(d)[0] for d in designs])
+    for rank in range(2):
+        d = np.load(tmp_path / f"rank{rank}.npz")
+        if mode == "diverges":
+            assert d["status"].tolist() == [0, 0, 0, 1]
+            assert np.isnan(d["values"][3])
+            np.testing.assert_allclose(d["values"][:3], ref_vals[:3], rtol=1e-12)
+        else:
+            assert d["status"].tolist() == [0, 0, -1, -1]                      # rank 1 raised at its first design: both of its are void
+            assert np.all(np.isnan(d["values"][2:]))
+            np.testing.assert_allclose(d["values"][:2], ref_vals[:2], rtol=1e-12)
+            assert open(tmp_path / f"raised{rank}").read() == ("" if rank == 0 else "RuntimeError")
+
+
 def test_shard_bounds_cover_everything():
     from difflexmm_amd.ensemble import shard_bounds
     for n in (1, 7, 64, 256):
