@@ -177,8 +177,13 @@ class QuadsFocusingForward:
         self._lib = _lib
     _drive_cls = L.Pulse          # problems/quads_focusing.py:211-222
 
+    def _make_geometry(self):
+        return QuadGeometry(self.n1_blocks, self.n2_blocks, self.spacing, self.bond_length)
+
     def setup(self, excited_blocks_fn=None):
-        g = self.geometry = QuadGeometry(self.n1_blocks, self.n2_blocks, self.spacing, self.bond_length)
+        """problems/quads_focusing.py:82-317 (and, through ``_make_geometry``, problems/reference_design.py): geometry, boundary
+        conditions, energy, solver.  ``excited_blocks_fn``: a recorded input signal (``loading.Table``) instead of the synthetic pulse."""
+        g = self.geometry = self._make_geometry()
         self.bond_connectivity = g.bond_connectivity()
         self.reference_bond_vectors = g.reference_bond_vectors()
         pairs, vec, self.driven_blocks_ids, self.clamped_blocks_ids = quads_focusing_constraints(
@@ -237,29 +242,11 @@ class RotatedSquaresForward(QuadsFocusingForward):
     initial_angle: Any = None
     name: str = "rotated_squares"
 
-    def setup(self, excited_blocks_fn=None):
+    def _make_geometry(self):
         from .geometry import RotatedSquareGeometry
         if self.initial_angle is None:
             raise ValueError("RotatedSquaresForward needs initial_angle")
-        g = self.geometry = RotatedSquareGeometry(self.n1_blocks // 2, self.n2_blocks // 2, self.spacing, self.bond_length)
-        self.bond_connectivity = g.bond_connectivity()
-        self.reference_bond_vectors = g.reference_bond_vectors()
-        pairs, vec, self.driven_blocks_ids, self.clamped_blocks_ids = quads_focusing_constraints(
-            g, self.n_excited_blocks, self.loaded_side, self.input_shift, self.n_blocks_clamped_corner)
-        self.constrained_block_DOF_pairs = pairs
-        self.moving_blocks_ids = np.setdiff1d(np.arange(g.n_blocks), self.clamped_blocks_ids)
-        strain = E.build_strain_energy(self.bond_connectivity,
-                                       E.ligament_energy_linearized if self.linearized_strains else E.ligament_energy)
-        energy = E.combine_block_energies(strain, E.build_contact_energy(self.bond_connectivity)) if self.use_contact else strain
-        self.solve_dynamics = setup_dynamic_solver(
-            g, energy, constrained_block_DOF_pairs=pairs, constrained_DOFs_fn=_make_drive(self, vec, excited_blocks_fn),
-            damped_blocks=np.arange(g.n_blocks), rtol=self.rtol, atol=self.atol, integrator=self.integrator,
-            steps_per_interval=self.steps_per_interval, batch=self.batch, device=self.device, streams=self.streams,
-            grid_refine=getattr(self, "grid_refine", 1), _lib=self._lib)
-        self.timepoints = np.linspace(0, self.simulation_time, self.n_timepoints)
-        self.state0 = np.zeros((2, g.n_blocks, 3))
-        self.signed_amplitude = self.amplitude if self.loaded_side in ("left", "bottom") else -self.amplitude
-        self.is_setup = True
+        return RotatedSquareGeometry(self.n1_blocks // 2, self.n2_blocks // 2, self.spacing, self.bond_length)
 
     def control_params(self, design=None):
         g = self.geometry

@@ -199,10 +199,10 @@ def test_persistent_kernels_fit_their_occupancy(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) or not os.environ.get("DFX_TEST_EXPERIMENTAL_ISA"), reason="opt-in experiments: set DFX_TEST_EXPERIMENTAL_ISA=1")
 def test_tile_kernels_have_no_scratch_and_no_barrier(tmp_path):
-    """The opt-in tile kernels (dfx_tile.h, -DDFX_EXPERIMENTAL builds only): no scratch, no workgroup barrier (wave-private tiles; the
+    """The opt-in tile kernels (variants/experimental/dfx_tile.h, -DDFX_EXPERIMENTAL builds only): no scratch, no workgroup barrier (wave-private tiles; the
     exchange through LDS is ordered by wavefront-scope fences, which emit no instruction)."""
     out = tmp_path / "exp.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-DDFX_EXPERIMENTAL", "-S", "--cuda-device-only", "-o", str(out),
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-DDFX_EXPERIMENTAL", "-I" + os.path.join(ROOT, "variants", "experimental"), "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "difflexmm_amd", "csrc", "engine_launch.hip")], stderr=subprocess.DEVNULL)
     txt = out.read_text()
     for nm in ("_ZN12_GLOBAL__N_110k_fwd_tileILi1ELi1EE", "_ZN12_GLOBAL__N_110k_adj_tileILi1ELi1EE"):

@@ -1,4 +1,4 @@
-// dfx_experimental_host.h -- host side of the two measured-slower experiments that stay in the tree behind -DDFX_EXPERIMENTAL (make experimental):
+// variants/experimental/dfx_experimental_host.h -- host side of the two measured-slower experiments that stay in the tree behind -DDFX_EXPERIMENTAL (make experimental):
 // two Runge-Kutta stages per launch on lattice windows (dfx_pair.h, DFX_PAIR=1) and every ligament evaluated once on lattice tiles
 // (dfx_tile.h, DFX_TILE=1).  Included by engine_launch.hip only; the default libdfx.so contains none of it.
 #pragma once

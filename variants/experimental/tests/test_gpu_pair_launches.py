@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from .common import Case, relerr
+from tests.common import Case, relerr
 
 pytestmark = pytest.mark.gpu
 

@@ -8,8 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from .common import Case, relerr
-from .test_gpu_pair_launches import FAST, _solve
+from tests.common import Case, relerr
+from test_gpu_pair_launches import FAST, _solve
 
 pytestmark = pytest.mark.gpu
 
