@@ -507,12 +507,19 @@ def run_c2(args, comm, comm_info, world, rank, local_rank):
         fw.solve_dynamics.engine.close()
     if rank == 0:
         one = legs["one_member"]
-        line = {"metric": "timesteps*rigid-units/s (forward)", "value": one["value"], "unit": "timesteps*units/s", "n_gpus": world, "steps": K,
+        bat = legs["batched"]
+        # the line leads with BOTH widths (round-5 verdict): the config as written is ONE 32x32 member -- 64 waves on a 1 024-SIMD chip, bound by the
+        # hand-off latency of the stage loop, not by bytes -- and the same lattice batched is what the engine is designed for
+        line = {"metric": "timesteps*rigid-units/s (forward)", "value": one["value"], "value_batched": bat["value"],
+                "roofline_frac_one_member": one["roofline"]["frac"], "roofline_frac_batched": bat["roofline"]["frac"],
+                "unit": "timesteps*units/s", "n_gpus": world, "steps": K,
                 "warmup": W, "ms_per_step": one["wall_ms"] / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                 "data": "synthetic",
                 "config": {"workload": f"C2: 32x32 quads (1024 units), nonlinear ligaments + damping, no contact, pulse drive, fixed-step Dopri5 "
-                                       f"dt={C2_DT:.3e}s, {K} of 10000 steps, forward only, 1 member per GPU",
-                           "members_per_gpu": 1, "collective": comm_info["collective"], "ranks_seen": comm_info.get("ranks_seen")},
+                                       f"dt={C2_DT:.3e}s, {K} of 10000 steps, forward only; `value`: 1 member per GPU as the config is written "
+                                       f"(launch-latency bound: 64 waves), `value_batched`: {bat['members_per_gpu']} members side by side",
+                           "members_per_gpu": 1, "members_per_gpu_batched": bat["members_per_gpu"], "collective": comm_info["collective"],
+                           "ranks_seen": comm_info.get("ranks_seen")},
                 "roofline": one["roofline"], "one_member": one, "batched": legs["batched"], "csrc": source_ids()}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(32, 2, n_steps=2000, repeats=3, budget_s=30.0, make=lambda lib: c2_problem(1, lib=lib), adjoint=False,

@@ -179,7 +179,7 @@ def long_horizon():
         print(lattice, "objective", obj.item(), "contact energy", contact[0], "->", contact[-1], flush=True)
 
 
-def long_horizon_32(steps=2000, n=32, seed=23, cut=42.0, intervals=8):
+def long_horizon_32(steps=2000, n=32, seed=23, cut=42.0, intervals=8, name="long_horizon_quads32", keep=None, dt=1.5e-6):
     """The same at a size where the engine's size-dependent code runs (round-4 verdict #5): 32 x 32 quads (1 024 blocks: 64 waves, several
     workgroups, the XCD-banded order, more than one segment), contact engaged everywhere, 2 000 fixed Dopri5 steps.  Two thousand steps
     of 1 024 blocks do not fit on one autograd tape (33 MB per step), so the gradient is assembled interval by interval: a first pass
@@ -191,7 +191,7 @@ def long_horizon_32(steps=2000, n=32, seed=23, cut=42.0, intervals=8):
     c = Case("quads", n, True, True, seed=seed, lib=load(), cutoff_deg=cut)
     nb = c.geo.n_blocks
     lv = dict(loading_rate=T64(3000.0), input_delay=T64(1e-5))
-    ts = np.linspace(0.0, 1.5e-6 * steps, intervals + 1)
+    ts = np.linspace(0.0, dt * steps, intervals + 1)
     spi = steps // intervals
     osol = c.oracle_solver(integrator="fixed", steps_per_interval=spi)
     free = torch.as_tensor(osol.free_DOF_ids, dtype=torch.long)
@@ -238,7 +238,7 @@ def long_horizon_32(steps=2000, n=32, seed=23, cut=42.0, intervals=8):
         obj += e.item()
         print("reverse interval", k, time.time() - t0, "s", flush=True)
     # (output 0 is the state at rest: its kinetic energy and gradient are zero)
-    np.savez_compressed("/tmp/long32_partial.npz", states=torch.stack(states).numpy(), objective=obj, **{f"grad_{i}": a.numpy() for i, a in enumerate(grads)})
+    np.savez_compressed(f"/tmp/{name}_partial.npz", states=torch.stack(states).numpy(), objective=obj, **{f"grad_{i}": a.numpy() for i, a in enumerate(grads)})
     cp = c.oracle_cp(lv)
     fields = osol(np.zeros((2, nb, 3)), ts, cp).detach()     # the oracle's ordinary (tape-free) fixed-grid solve: all DOFs, prescribed ones with their rate
     # the two oracle paths restart their first stage differently at an interval boundary (f(y, t_k) against the carried k_7): the same
@@ -254,11 +254,11 @@ def long_horizon_32(steps=2000, n=32, seed=23, cut=42.0, intervals=8):
     with torch.no_grad():
         ce = OE.build_contact_energy(c.bonds)
         contact = np.array([float(ce(fields[k, 0], cp)) for k in range(len(ts))])
-    keep = np.arange(0, intervals + 1, 2)          # every other output row travels (file size)
-    np.savez_compressed(os.path.join(OUT, "long_horizon_quads32.npz"), timepoints=ts, spi=spi, target=target, seed=seed, n=n, cutoff_deg=cut,
+    keep = np.arange(0, intervals + 1, 2) if keep is None else np.asarray(keep)          # every other output row travels (file size)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), timepoints=ts, spi=spi, target=target, seed=seed, n=n, cutoff_deg=cut,
                         rows=keep, fields=fields.numpy()[keep], objective=obj, contact_energy=contact, oracle_paths_agree=np.array(drift),
                         **{f"design_{i}": d for i, d in enumerate(c.design)}, **{f"grad_{i}": a.numpy() for i, a in enumerate(grads)})
-    print("quads32 objective", obj, "contact energy", contact[0], "->", contact[-1], "total", time.time() - t0, "s", flush=True)
+    print(name, "objective", obj, "contact energy", contact[0], "->", contact[-1], "total", time.time() - t0, "s", flush=True)
 
 
 def pulse_rs_script(n1_cells=20, n2_cells=10, name="pulse_rs"):
@@ -291,7 +291,18 @@ def pulse_rs_script(n1_cells=20, n2_cells=10, name="pulse_rs"):
                         n1_cells=n1_cells, n2_cells=n2_cells, inertia=np.asarray(inertia))
 
 
+def long_horizon_128():
+    """BASELINE config 3's lattice at full size (round-5 verdict item 5): 128 x 128 quads (16 384 blocks: 1 024 waves, every XCD band, four
+    workgroups per compute unit), contact engaged everywhere, 500 fixed Dopri5 steps in 25 intervals of 20 (a tape of 20 steps of this
+    lattice is ~10 GB) -- so that full-size long-horizon parity no longer leans on the C++ port, which shares the engine's physics headers.
+    Two output rows travel (the middle one and the last: 786 KB each)."""
+    long_horizon_32(steps=500, n=128, seed=29, cut=42.0, intervals=25, name="long_horizon_quads128", keep=[0, 13, 25])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "long_horizon_128":
+        long_horizon_128()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "problems":
         problem_layer()
         sys.exit(0)

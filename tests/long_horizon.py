@@ -19,9 +19,11 @@ def check(lib, lattice, tol_fields=TOL_FIELDS, tol_objective=TOL_OBJECTIVE, tol_
     """`lattice`: "quads" (8 x 8, 1 200 steps), "kagome" (4 x 4 cells, 800 steps), or "quads32": 32 x 32 quads, 2 000 steps -- a size
     at which the engine's size-dependent code runs (several workgroups, XCD-banded order, more than one segment, the persistent loop's
     ring wrapping 1 500 times); its gradient was assembled interval by interval (make_golden.py long_horizon_32) and every other
-    output row travels."""
+    output row travels; "quads128": BASELINE config 3's lattice at full size, 128 x 128 quads, 500 contact-engaged steps in 25 intervals
+    (make_golden.py long_horizon_128): full-size long-horizon parity against the TORCH oracle, not against the port that shares the
+    engine's physics headers."""
     g = np.load(os.path.join(GOLD, f"long_horizon_{lattice}.npz"))
-    lattice = "quads" if lattice == "quads32" else lattice
+    lattice = "quads" if lattice.startswith("quads") else lattice
     c = Case(lattice, int(g["n"]), True, True, seed=int(g["seed"]), lib=lib, cutoff_deg=float(g["cutoff_deg"]))
     design = tuple(g[f"design_{i}"] for i in range(len(c.design)))
     for a, b in zip(design, c.design):
