@@ -51,11 +51,16 @@ class dfx_stats(C.Structure):
                 ("stage_checkpoint", C.c_int64), ("checkpoint_records", C.c_int64), ("tile_kernels", C.c_int64)]
 
 
+class dfx_design_map(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("n_npb", C.c_int32), ("n_bonds", C.c_int32), ("n_design", C.c_int32),
+                ("base", _dp), ("gather", _ip), ("ref_points", _dp), ("bonds", _ip)]
+
+
 EXPORTS = ["dfx_create", "dfx_destroy", "dfx_last_error", "dfx_set_params", "dfx_reserve", "dfx_forward", "dfx_forward_grid", "dfx_forward_grid_members",
            "dfx_forward_adaptive", "dfx_forward_adaptive_keep", "dfx_adaptive_step_counts", "dfx_adaptive_step_times", "dfx_adjoint",
            "dfx_objective_kinetic", "dfx_adjoint_kinetic", "dfx_kinetic_value_and_grad", "dfx_response_data", "dfx_rhs", "dfx_rhs_vjp", "dfx_energy",
            "dfx_device_count", "dfx_version", "dfx_share_checkpoint", "dfx_abi_layout", "dfx_member_status", "dfx_set_failure_policy",
-           "dfx_test_set_spin_limit"]
+           "dfx_test_set_spin_limit", "dfx_design_forward", "dfx_design_vjp"]
 # multi-GPU collective (RCCL inside libdfx) and device helpers: HIP library only
 COMM_EXPORTS = ["dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_rccl_version", "dfx_comm_rank", "dfx_comm_size",
                 "dfx_gather_objectives", "dfx_reduce_grads", "dfx_comm_allreduce", "dfx_comm_barrier", "dfx_comm_last_error",
@@ -103,6 +108,8 @@ def declare(lib):
     lib.dfx_adaptive_step_times.argtypes = [H, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]
     lib.dfx_forward_adaptive.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, C.POINTER(dfx_stats)]
     lib.dfx_forward_adaptive_keep.argtypes = [H, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int32, _dp, C.POINTER(dfx_stats)]
+    lib.dfx_design_forward.argtypes = [C.POINTER(dfx_design_map), _dp, C.c_int32, C.c_double, _dp, _dp, _dp, _dp]
+    lib.dfx_design_vjp.argtypes = [C.POINTER(dfx_design_map), _dp, C.c_int32, C.c_double, _dp, _dp, _dp, _dp, _dp]
     lib.dfx_member_status.argtypes = [H, _ip]
     lib.dfx_set_failure_policy.argtypes = [H, C.c_int32]
     lib.dfx_test_set_spin_limit.argtypes = [H, C.c_int32]

@@ -3,10 +3,21 @@
 // post-processing, downloads
 // (one of five translation units; shared declarations in dfx_engine.h, the design in DESIGN.md section 3)
 #include "dfx_engine.h"
+#include "dfx_design.h"
 
 using namespace dfx_persist;
 
 static std::string g_create_error;
+
+// design -> geometry and its cotangent, on the host (dfx_design.h)
+int dfx_design_forward(const dfx_design_map* map, const double* design, int32_t batch, double density, double* block_centroids,
+                       double* centroid_node_vectors, double* inertia, double* void_angle0) {
+  return dfx_design::forward(map, design, batch, density, block_centroids, centroid_node_vectors, inertia, void_angle0);
+}
+int dfx_design_vjp(const dfx_design_map* map, const double* design, int32_t batch, double density, const double* centroid_node_vectors_bar,
+                   const double* block_centroids_bar, const double* inertia_bar, const double* void_angle0_bar, double* design_bar) {
+  return dfx_design::vjp(map, design, batch, density, centroid_node_vectors_bar, block_centroids_bar, inertia_bar, void_angle0_bar, design_bar);
+}
 
 
 int dfx_device_count(void) {

@@ -30,6 +30,16 @@ from .utils import (ContactParams, ControlParams, GeometricalParams, MechanicalP
 _FLAT_CACHE = {}      # id(centroid_node_vectors) -> (weakref, bonds, density, inertia, void_angle0)
 
 
+def remember_flat(cnv, bonds, density, inertia, void_angle0):
+    """What a solver derives from a design's node vectors, computed elsewhere (the native design map, problems.prefetch_designs): kept for
+    ``DynamicSolver._flatten`` under the identity of the (read-only) array, like the entries it makes itself."""
+    import weakref
+    key = id(cnv)
+    if len(_FLAT_CACHE) > 1024:
+        _FLAT_CACHE.clear()
+    _FLAT_CACHE[key] = (weakref.ref(cnv, lambda _r, k=key: _FLAT_CACHE.pop(k, None)), bonds, np.array(density, copy=True), inertia, void_angle0)
+
+
 def _bcast(x, n):
     return np.broadcast_to(np.asarray(x, dtype=float), (n,)).copy()
 
@@ -111,7 +121,7 @@ class DynamicSolver:
                                 _bcast(bp.k_rot, nbd) if self.spec.bond_model != _b.BOND_SIMPLE_SPRING else zero], 1),
         }
         cached = _FLAT_CACHE.get(id(cnv)) if mp.inertia is None else None
-        if cached is not None and cached[0]() is cnv and cached[1] is self.bonds and np.array_equal(cached[2], mp.density):
+        if cached is not None and cached[0]() is cnv and (cached[1] is self.bonds or np.array_equal(cached[1], self.bonds)) and np.array_equal(cached[2], mp.density):
             out["inertia"] = cached[3]        # same design seen through another solver (multi-input problems): reuse
             if self.spec.contact == _b.CONTACT_ANGLE and cached[4] is not None:
                 out["void_angle0"] = cached[4]

@@ -304,6 +304,81 @@ def compute_edge_angles(nodes, bonds):
     return _angle(e2m, e1p), _angle(e1m, e2p), _angle(e1p, e1m), _angle(e2p, e2m)
 
 
+# -- the same maps, fused, in native code (include/dfx.h: dfx_design_forward / dfx_design_vjp) -------------------------------------
+
+class NativeDesignMap:
+    """Design -> (block_centroids, centroid_node_vectors, inertia, undeformed void angles) and the cotangent of all of it in ONE native loop
+    over the blocks (``csrc/dfx_design.h``, host code in libdfx -- no device involved), for any lattice class whose nodes are "a static base
+    vector + one row of the design" (QuadGeometry, KagomeGeometry: geometry.py:607-952).  The static tables are derived from the class itself:
+    ``base`` = the node vectors of the zero design, ``gather`` = which design row each node takes, found by pushing the row numbers through
+    ``reference_node_vectors``.  The NumPy functions of this module stay as the checker (tests/test_host_helpers.py, 1e-13)."""
+
+    def __init__(self, geometry, bonds=None):
+        shapes = geometry.design_shapes()
+        self.shapes = shapes
+        self.sizes = [int(np.prod(sh[:-1])) for sh in shapes]
+        self.n_design = int(sum(self.sizes))
+        zeros = [np.zeros(sh) for sh in shapes]
+        base = np.ascontiguousarray(geometry.reference_node_vectors(*zeros), dtype=np.float64)
+        rows, start = [], 0
+        for sh, n in zip(shapes, self.sizes):
+            a = np.zeros(sh)
+            a.reshape(-1, 2)[:, 0] = np.arange(start, start + n)
+            rows.append(a)
+            start += n
+        gather = np.rint(geometry.reference_node_vectors(*rows)[..., 0] - base[..., 0]).astype(np.int32)
+        self.base, self.gather = base, np.ascontiguousarray(gather)
+        self.ref_points = np.ascontiguousarray(geometry.reference_points(), dtype=np.float64)
+        self.n_blocks, self.n_npb = base.shape[0], base.shape[1]
+        self.bonds = None if bonds is None else np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
+
+    def _map(self):
+        from ._binding import _dp, _ip, dfx_design_map
+        m = dfx_design_map()
+        m.n_blocks, m.n_npb, m.n_design = self.n_blocks, self.n_npb, self.n_design
+        m.n_bonds = 0 if self.bonds is None else len(self.bonds)
+        m.base, m.gather, m.ref_points = self.base.ctypes.data_as(_dp), self.gather.ctypes.data_as(_ip), self.ref_points.ctypes.data_as(_dp)
+        m.bonds = None if self.bonds is None else self.bonds.ctypes.data_as(_ip)
+        return m
+
+    def flatten(self, designs):
+        """list of design tuples -> (batch, n_design, 2)."""
+        return np.ascontiguousarray(np.stack([np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, 2) for a in d]) for d in designs]))
+
+    def unflatten(self, flat):
+        out, start = [], 0
+        for sh, n in zip(self.shapes, self.sizes):
+            out.append(flat[start:start + n].reshape(sh))
+            start += n
+        return tuple(out)
+
+    def forward(self, lib, designs, density, void_angles=True):
+        """-> block_centroids (B, n, 2), cnv (B, n, npb, 2), inertia (B, n, 3), void_angle0 (B, n_bonds, 2) or None."""
+        import ctypes as C
+        from ._binding import _ptr
+        flat = self.flatten(designs)
+        B, nb, n = len(designs), self.n_blocks, self.n_npb
+        cen, cnv, inertia = np.empty((B, nb, 2)), np.empty((B, nb, n, 2)), np.empty((B, nb, 3))
+        va = np.empty((B, len(self.bonds), 2)) if (void_angles and self.bonds is not None) else None
+        m = self._map()
+        if lib.dfx_design_forward(C.byref(m), _ptr(flat), B, float(density), _ptr(cen), _ptr(cnv), _ptr(inertia), _ptr(va)) != 0:
+            raise RuntimeError("dfx_design_forward failed")
+        return cen, cnv, inertia, va
+
+    def vjp(self, lib, designs, density, cnv_bar, centroid_bar=None, inertia_bar=None, void_bar=None):
+        """Cotangents (batch-leading arrays; None = zero) -> list of design-gradient tuples."""
+        import ctypes as C
+        from ._binding import _ptr, _f64
+        flat = self.flatten(designs)
+        B = len(designs)
+        out = np.empty_like(flat)
+        m = self._map()
+        args = [None if a is None else _f64(a) for a in (cnv_bar, centroid_bar, inertia_bar, void_bar)]
+        if lib.dfx_design_vjp(C.byref(m), _ptr(flat), B, float(density), _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]), _ptr(out)) != 0:
+            raise RuntimeError("dfx_design_vjp failed")
+        return [self.unflatten(out[i]) for i in range(B)]
+
+
 # -- lattices ---------------------------------------------------------------------------------------
 
 class Geometry:

@@ -8,6 +8,8 @@
 from dataclasses import InitVar, dataclass
 from typing import Any, Optional, Tuple
 
+import os
+
 import numpy as np
 
 from . import energy as E
@@ -20,9 +22,7 @@ from .utils import (ContactParams, ControlParams, GeometricalParams, LigamentPar
 _GEOMETRY_CACHE = {}   # (lattice signature, ids of the design arrays) -> (design arrays, block_centroids, centroid_node_vectors)
 
 
-def geometry_from_design_cached(geometry, design):
-    """``geometry.geometry_from_design(*design)`` remembered per design OBJECT: the forward problems of a multi-input
-    objective (one solver per input) all ask for the geometry of the same design tuple in the same round."""
+def _signature(geometry):
     sig = getattr(geometry, "_signature", None)
     if sig is None:
         # every public attribute that defines the lattice: scalars by value, arrays (kagome direct_basis) by content
@@ -30,17 +30,74 @@ def geometry_from_design_cached(geometry, design):
             sorted((k, float(v) if isinstance(v, (int, float)) else (np.asarray(v).shape, np.asarray(v, dtype=float).tobytes()))
                    for k, v in vars(geometry).items()
                    if isinstance(v, (int, float, np.ndarray, list, tuple)) and not k.startswith("_")))
-    key = (sig,) + tuple(id(a) for a in design)
-    hit = _GEOMETRY_CACHE.get(key)
-    if hit is not None and all(a is b for a, b in zip(hit[0], design)):
-        return hit[1], hit[2]
-    centroids, cnv = geometry.geometry_from_design(*design)
+    return sig
+
+
+def _remember_geometry(geometry, design, centroids, cnv):
     centroids.flags.writeable = False
     cnv.flags.writeable = False
     if len(_GEOMETRY_CACHE) > 1024:
         _GEOMETRY_CACHE.clear()
-    _GEOMETRY_CACHE[key] = (tuple(design), centroids, cnv)      # holds the design arrays: their ids cannot be reused meanwhile
+    _GEOMETRY_CACHE[(_signature(geometry),) + tuple(id(a) for a in design)] = (tuple(design), centroids, cnv)   # (holds the design arrays: ids stay unique)
+
+
+def geometry_from_design_cached(geometry, design):
+    """``geometry.geometry_from_design(*design)`` remembered per design OBJECT: the forward problems of a multi-input
+    objective (one solver per input) all ask for the geometry of the same design tuple in the same round."""
+    key = (_signature(geometry),) + tuple(id(a) for a in design)
+    hit = _GEOMETRY_CACHE.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], design)):
+        return hit[1], hit[2]
+    centroids, cnv = geometry.geometry_from_design(*design)
+    _remember_geometry(geometry, design, centroids, cnv)
     return centroids, cnv
+
+
+def _native_design_map(fw):
+    """(library, NativeDesignMap) of a forward problem whose lattice map runs in native code (include/dfx.h: dfx_design_forward / _vjp), or None:
+    a scalar density, a lattice class with ``design_shapes`` / ``reference_node_vectors``, a library that exports the two entry points."""
+    hit = getattr(fw, "_native_map", None)
+    if hit is not None:
+        return hit or None
+    fw._native_map = False
+    try:
+        if np.ndim(fw.density) != 0 or not hasattr(fw.geometry, "design_shapes") or os.environ.get("DFX_NATIVE_DESIGN", "1") == "0":
+            return None
+        from ._binding import load_library
+        from .geometry import NativeDesignMap
+        lib = fw._lib if getattr(fw, "_lib", None) is not None else load_library()
+        if not hasattr(lib, "dfx_design_forward"):
+            return None
+        spec_contact = getattr(fw.solve_dynamics.spec, "contact", 0)
+        fw._native_map = (lib, NativeDesignMap(fw.geometry, fw.solve_dynamics.bonds), spec_contact)
+    except Exception:       # noqa: BLE001 -- the NumPy maps are always there
+        return None
+    return fw._native_map
+
+
+def prefetch_designs(fw, designs):
+    """The geometry of every design of a batch in ONE native pass (lattice map + polygon pass + inertia + undeformed void angles, fused:
+    csrc/dfx_design.h), left where ``control_params`` / ``DynamicSolver._flatten`` look for it -- the geometry cache above and the solver's
+    cache of what it derives from a design.  No-op when the native map does not apply or everything is cached already."""
+    nm = _native_design_map(fw)
+    if nm is None:
+        return
+    lib, ndm, contact = nm
+    sig = _signature(fw.geometry)
+    todo = []
+    for d in designs:
+        hit = _GEOMETRY_CACHE.get((sig,) + tuple(id(a) for a in d))
+        if not (hit is not None and all(a is b for a, b in zip(hit[0], d))):
+            todo.append(d)
+    if not todo:
+        return
+    from . import _binding as _b
+    from .dynamics import remember_flat
+    cen, cnv, inertia, va = ndm.forward(lib, todo, float(fw.density), void_angles=contact == _b.CONTACT_ANGLE)
+    for i, d in enumerate(todo):
+        ci, vi = cen[i], cnv[i]
+        _remember_geometry(fw.geometry, d, ci, vi)
+        remember_flat(vi, fw.solve_dynamics.bonds, fw.density, inertia[i], None if va is None else va[i])
 
 
 def _tile3(blocks):
@@ -204,6 +261,7 @@ class QuadsFocusingForward:
         self.is_setup = True
 
     def control_params(self, design):
+        prefetch_designs(self, [design])           # (native lattice map when it applies: geometry, inertia, void angles in one pass)
         centroids, cnv = geometry_from_design_cached(self.geometry, design)
         return ControlParams(
             geometrical_params=GeometricalParams(block_centroids=centroids, centroid_node_vectors=cnv),
@@ -217,6 +275,8 @@ class QuadsFocusingForward:
         """design = (horizontal_shifts, vertical_shifts), or a list of ``batch`` such tuples.
         want_fields=False leaves the histories on the device (for objectives the engine evaluates there) and returns None."""
         many = isinstance(design, list)
+        if many:
+            prefetch_designs(self, design)         # all designs of the batch in one native pass
         cps = [self.control_params(d) for d in design] if many else self.control_params(design)
         fields = self.solve_dynamics(self.state0, self.timepoints, cps, keep_trajectory=keep_trajectory, want_fields=want_fields)
         self._last_design = design
@@ -691,9 +751,17 @@ class StaticTuningKineticEnergy:
 
 def design_gradients(fw, designs, raw):
     """The engine's raw gradients (batch-leading arrays for centroid_node_vectors, void_angle0, inertia[, block_centroids]) mapped
-    back to the designs: void-angle and inertia chain rules, then the lattice map (all linear in the cotangent)."""
+    back to the designs: void-angle and inertia chain rules, then the lattice map (all linear in the cotangent) -- one native pass over the
+    blocks of all designs (``dfx_design_vjp``) where the native map applies, the NumPy maps of geometry.py otherwise."""
     from .geometry import compute_inertia_vjp, void_angles0_vjp
     geo, bonds = fw.geometry, fw.solve_dynamics.bonds
+    nm = _native_design_map(fw)
+    if nm is not None:
+        lib, ndm, _ = nm
+        va = raw.get("void_angle0")
+        if va is not None and not np.any(va):
+            va = None           # (contacts are rare: an identically zero cotangent maps to exact zeros)
+        return ndm.vjp(lib, designs, float(fw.density), raw["centroid_node_vectors"], raw.get("block_centroids"), raw["inertia"], va)
     grads = []
     for m, d in enumerate(designs):
         _, cnv = geometry_from_design_cached(geo, d)

@@ -290,6 +290,26 @@ const char* dfx_version(void);
  * them with its own before the first call (tests/test_abi.py).  Writes min(n, 53) values, returns 53. */
 int dfx_abi_layout(int32_t* out, int32_t n);
 
+/* ---- design -> geometry on the host, fused (the per-evaluation prologue of the design loop) -------------------------------------------
+ * The lattice maps of the reference (geometry.py:607-952: QuadGeometry / KagomeGeometry -- every node of every block = a static base vector
+ * + one row of the design), the polygon pass (geometry.py:71-127), compute_inertia (geometry.py:144-160) and the undeformed void angles
+ * (energy.py:204-219 + geometry.py:181-253 at rest) in one loop over the blocks; dfx_design_vjp is the cotangent of all of it.  Plain host
+ * code (no handle, no device): `design` (batch, n_design, 2) holds the design arrays of a lattice flattened and concatenated, `gather[b*n_npb+k]`
+ * the row node k of block b takes.  Outputs / cotangents may be NULL where noted.  Equal to difflexmm_amd/geometry.py (NumPy) to 1e-13. */
+typedef struct dfx_design_map {
+  int32_t n_blocks, n_npb, n_bonds, n_design;
+  const double* base;                     /* (n_blocks, n_npb, 2) node vectors of the zero design                  */
+  const int32_t* gather;                  /* (n_blocks, n_npb)    row of `design` added to each node                */
+  const double* ref_points;               /* (n_blocks, 2)        lattice points the centroids are measured from    */
+  const int32_t* bonds;                   /* (n_bonds, 2) node ids, or NULL (no void angles)                        */
+} dfx_design_map;
+int dfx_design_forward(const dfx_design_map* map, const double* design, int32_t batch, double density,
+                       double* block_centroids /* (batch, n_blocks, 2) or NULL */, double* centroid_node_vectors /* (batch, n_blocks, n_npb, 2) */,
+                       double* inertia /* (batch, n_blocks, 3) or NULL */, double* void_angle0 /* (batch, n_bonds, 2) or NULL */);
+int dfx_design_vjp(const dfx_design_map* map, const double* design, int32_t batch, double density,
+                   const double* centroid_node_vectors_bar, const double* block_centroids_bar /* or NULL */, const double* inertia_bar /* or NULL */,
+                   const double* void_angle0_bar /* or NULL */, double* design_bar /* (batch, n_design, 2) */);
+
 /* ---- multi-GPU: one process per GPU, independent members per rank, ONE collective per evaluation -------------
  * Replaces the reference's pmap over forward inputs + host sum (problems/quads_kinetic_energy_static_tuning.py:454-478) and the
  * sequential list of forward problems of problems/quads_focusing_multi_input.py:66-86.  RCCL over xGMI inside the library;

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../difflexmm_amd/csrc/dfx_stage.h"
+#include "../../difflexmm_amd/csrc/dfx_design.h"
 
 using namespace dfx;
 
@@ -879,6 +880,15 @@ int dfx_member_status(dfx_handle* h, int32_t* status) {
 }
 int dfx_set_failure_policy(dfx_handle*, int32_t) { return 0; }      // (the port never fails a fixed-grid call for a non-finite member)
 int dfx_test_set_spin_limit(dfx_handle*, int32_t) { return 0; }
+// design -> geometry and its cotangent (host code shared with libdfx: dfx_design.h)
+int dfx_design_forward(const dfx_design_map* map, const double* design, int32_t batch, double density, double* block_centroids,
+                       double* centroid_node_vectors, double* inertia, double* void_angle0) {
+  return dfx_design::forward(map, design, batch, density, block_centroids, centroid_node_vectors, inertia, void_angle0);
+}
+int dfx_design_vjp(const dfx_design_map* map, const double* design, int32_t batch, double density, const double* centroid_node_vectors_bar,
+                   const double* block_centroids_bar, const double* inertia_bar, const double* void_angle0_bar, double* design_bar) {
+  return dfx_design::vjp(map, design, batch, density, centroid_node_vectors_bar, block_centroids_bar, inertia_bar, void_angle0_bar, design_bar);
+}
 int dfx_device_count(void) { return 0; }
 const char* dfx_version(void) { return "dfx-cpu-port 0.1.0"; }
 int dfx_abi_layout(int32_t* out, int32_t n) { return dfxabi_fill(out, n); }

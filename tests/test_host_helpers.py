@@ -3,6 +3,7 @@
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from difflexmm_amd import geometry as G
@@ -86,3 +87,37 @@ def test_cross_correlation_measures():
     peak, delay = O.compute_space_time_xcorr(A, B)
     assert delay == 6 and 0.5 < peak <= 1.0
     assert O.compute_max_xcorr2d_at_shift(A, A, 0, shift_axis=1)[1] == 0
+
+
+@pytest.mark.parametrize("lattice", ["quads", "kagome"])
+def test_native_design_map_equals_the_numpy_maps(cpu_lib, lattice):
+    """dfx_design_forward / dfx_design_vjp (csrc/dfx_design.h: lattice map + polygon pass + compute_inertia + undeformed void angles fused in
+    native code, and the cotangent of all of it) against the NumPy functions of difflexmm_amd/geometry.py they replace in the design loop
+    (geometry.py:607-952, 71-160, 181-253 of the reference), 1e-13; a batch of designs in one call."""
+    import math
+    from difflexmm_amd import geometry as G
+    if lattice == "quads":
+        geo = G.QuadGeometry(7, 5, 15.0, 2.25)
+        base = geo.get_design_from_rotated_square(25 * math.pi / 180)
+    else:
+        geo = G.KagomeGeometry(4, 3, 20.0 * np.array([[1.0, 0.0], [math.cos(math.pi / 3), math.sin(math.pi / 3)]]), 2.25)
+        base = tuple(np.zeros(sh) for sh in geo.design_shapes())
+    rng = np.random.default_rng(0)
+    bonds, rho = geo.bond_connectivity(), 6.18e-9
+    nm = G.NativeDesignMap(geo, bonds)
+    designs = [tuple(b + rng.uniform(-0.3, 0.3, b.shape) for b in base) for _ in range(3)]
+    cen, cnv, inertia, va = nm.forward(cpu_lib, designs, rho)
+    cb, gb, ib, vb = rng.normal(size=cnv.shape), rng.normal(size=cen.shape), rng.normal(size=inertia.shape) * 1e8, rng.normal(size=va.shape)
+    mine = nm.vjp(cpu_lib, designs, rho, cb, gb, ib, vb)
+    for i, d in enumerate(designs):
+        c0, v0 = geo.geometry_from_design(*d)
+        assert np.abs(cen[i] - c0).max() < 1e-13 and np.abs(cnv[i] - v0).max() < 1e-13
+        assert np.abs(inertia[i] - G.compute_inertia(v0, rho)).max() < 1e-13 * np.abs(inertia[i]).max()
+        assert np.abs(va[i] - G.void_angles0(v0, bonds)).max() < 1e-13
+        ref = geo.vjp(d, cb[i] + G.void_angles0_vjp(v0, bonds, vb[i]), gb[i], props_bar=(rho * (ib[i][:, 0] + ib[i][:, 1]), rho * ib[i][:, 2]))
+        for a, b in zip(mine[i], ref):
+            assert np.abs(a - b).max() < 1e-13 * np.abs(b).max()
+    # cotangents that are absent (None) are zeros
+    only = nm.vjp(cpu_lib, designs, rho, cb)
+    ref0 = geo.vjp(designs[0], cb[0])
+    assert all(np.abs(a - b).max() < 1e-13 * np.abs(b).max() for a, b in zip(only[0], ref0))
