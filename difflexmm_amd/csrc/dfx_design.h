@@ -10,28 +10,18 @@
 #include <math.h>
 #include <stdint.h>
 
-#include <algorithm>
-#include <thread>
 #include <vector>
 
 #include "../../include/dfx.h"
+#include "dfx_hostpar.h"
 
 namespace dfx_design {
 
 constexpr int kMaxNpb = 4;
 
-// the designs of a batch are independent: a handful of host threads, one contiguous chunk of designs each (no OpenMP runtime in libdfx)
+// (the designs of a batch are independent: dfx_hostpar.h)
 template <class F>
-inline void for_each_design(int batch, size_t work_per_design, F&& body) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
-  nt = std::max(1, std::min(nt, batch));
-  if (nt == 1 || work_per_design * (size_t)batch < 200000) { for (int m = 0; m < batch; ++m) body(m); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&, t]() { for (int m = (int)((long long)batch * t / nt); m < (int)((long long)batch * (t + 1) / nt); ++m) body(m); });
-  for (auto& x : th) x.join();
-}
+inline void for_each_design(int batch, size_t work_per_design, F&& body) { dfx_hostpar::for_each(batch, work_per_design, body); }
 
 struct Poly {            // one block's polygon pass
   double area, cx, cy, ip, sgn_s, sgn_m;

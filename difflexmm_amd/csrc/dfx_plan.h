@@ -9,6 +9,7 @@
 // of quantities it owns, so forces and parameter gradients are accumulated without atomics and
 // bit-reproducibly.  Ligament parameters are duplicated to both slots (coalesced loads).
 #pragma once
+#include "dfx_hostpar.h"
 #include <stdint.h>
 #include <string.h>
 
@@ -143,6 +144,9 @@ struct PackedParams {
   bool damping_uniform = true;  // the three per-DOF damping coefficients are the same for every block of a member (cst[6..8])
 };
 
+// ControlParams arrays -> the packed images.  The members of an ensemble are independent: a handful of host threads, one contiguous chunk
+// of members each (dfx_hostpar.h), every entry of every image written (nothing is zero-filled first: at 16 x 128 x 128 the images are
+// 150 MB, and filling them twice was most of the 12 ms this function took before round 6).
 inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, std::string& err, bool gpu_image = true) {
   if (!q || !q->centroid_node_vectors || !q->reference_vector || !q->k_bond || !q->inertia) {
     err = "set_params: centroid_node_vectors, reference_vector, k_bond and inertia are required"; return 1;
@@ -151,22 +155,34 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
   if (pl.contact == DFX_CONTACT_DISTANCE && (!q->block_centroids || !q->contact)) { err = "set_params: distance-based contact needs block_centroids and contact"; return 1; }
   if (pl.n_fns && !q->fn_params) { err = "set_params: fn_params required"; return 1; }
   const int B = pl.batch, NS = pl.n_slots, NB = pl.n_blocks;
-  out.slot.assign((size_t)B * NS * kSlotParams, 0.0);
-  out.inv_m.assign((size_t)B * NB * 3, 0.0);
-  out.damping.assign((size_t)B * NB * 3, 0.0);
+  out.slot.resize((size_t)B * NS * kSlotParams);
+  out.inv_m.resize((size_t)B * NB * 3);
+  out.damping.resize((size_t)B * NB * 3);
   out.contact.assign((size_t)B * 3, 0.0);
-  out.centroid.assign((size_t)B * NB * 2, 0.0);
   if (q->block_centroids) out.centroid.assign(q->block_centroids, q->block_centroids + (size_t)B * NB * 2);
+  else out.centroid.assign((size_t)B * NB * 2, 0.0);
   out.fns.assign((size_t)B * DFX_MAX_FNS, TimeFn{0, 0, {0, 0, 0, 0, 0}});
-  for (int m = 0; m < B; ++m) {
+  if (pl.n_ovf) out.ovf.resize((size_t)B * pl.n_ovf * kOvfParams);
+  if (gpu_image) {
+    out.p_r.resize((size_t)B * NS * 2); out.p_l.resize((size_t)B * NS * 2);
+    out.p_k.resize((size_t)B * NS * 4); out.p_phi.resize((size_t)B * NS * 2);
+    out.cst.assign((size_t)B * 16, 0.0);
+    out.l_idx.resize((size_t)B * NS); out.l_dict.assign((size_t)B * 1024, 0.0);
+  }
+  struct Flags { bool k_uniform = true, l_dict_ok = true, damping_uniform = true; int n_dict = 0, bad = 0; };
+  std::vector<Flags> flags(B);
+  auto member = [&](int m) {
+    Flags& F = flags[m];
     const double* cnv = q->centroid_node_vectors + (size_t)m * NB * pl.n_npb * 2;
     const double* l0 = q->reference_vector + (size_t)m * pl.n_bonds * 2;
     const double* kb = q->k_bond + (size_t)m * pl.n_bonds * 3;
     const double* ph = q->void_angle0 ? q->void_angle0 + (size_t)m * pl.n_bonds * 2 : nullptr;
     double* sp = out.slot.data() + (size_t)m * NS * kSlotParams;
     for (int b = 0; b < NB; ++b)
-      for (int k = 0; k < pl.n_npb; ++k) {
+      for (int k = 0; k < kSlots; ++k) {
         double* s = sp + (size_t)(b * kSlots + k) * kSlotParams;
+        for (int i = 0; i < kSlotParams; ++i) s[i] = 0.0;
+        if (k >= pl.n_npb) continue;
         s[0] = cnv[(b * pl.n_npb + k) * 2];
         s[1] = cnv[(b * pl.n_npb + k) * 2 + 1];
         int bond = pl.slot_bond[b * kSlots + k];
@@ -176,20 +192,18 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
           if (ph) { s[7] = ph[2 * bond]; s[8] = ph[2 * bond + 1]; }
         }
       }
-    if (pl.n_ovf) {
-      if (m == 0) out.ovf.assign((size_t)B * pl.n_ovf * kOvfParams, 0.0);
-      for (int e = 0; e < pl.n_ovf; ++e) {
-        double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
-        const int bond = pl.ovf_bond[e];
-        o[0] = l0[2 * bond]; o[1] = l0[2 * bond + 1];
-        if (!(o[0] * o[0] + o[1] * o[1] > 0.0)) { err = "set_params: zero-length reference vector"; return 1; }
-        o[2] = kb[3 * bond]; o[3] = kb[3 * bond + 1]; o[4] = kb[3 * bond + 2];
-        if (ph) { o[5] = ph[2 * bond]; o[6] = ph[2 * bond + 1]; }
-      }
+    for (int e = 0; e < pl.n_ovf; ++e) {
+      double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
+      for (int i = 0; i < kOvfParams; ++i) o[i] = 0.0;
+      const int bond = pl.ovf_bond[e];
+      o[0] = l0[2 * bond]; o[1] = l0[2 * bond + 1];
+      if (!(o[0] * o[0] + o[1] * o[1] > 0.0)) { F.bad = 1; return; }
+      o[2] = kb[3 * bond]; o[3] = kb[3 * bond + 1]; o[4] = kb[3 * bond + 2];
+      if (ph) { o[5] = ph[2 * bond]; o[6] = ph[2 * bond + 1]; }
     }
     for (int i = 0; i < NB * 3; ++i) {
       double mass = q->inertia[(size_t)m * NB * 3 + i];
-      if (!(mass > 0.0)) { err = "set_params: inertia must be positive"; return 1; }
+      if (!(mass > 0.0)) { F.bad = 2; return; }
       out.inv_m[(size_t)m * NB * 3 + i] = 1.0 / mass;
       out.damping[(size_t)m * NB * 3 + i] = q->damping ? q->damping[(size_t)m * NB * 3 + i] : 0.0;
     }
@@ -202,34 +216,28 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       for (int i = 0; i < DFX_FN_PARAMS; ++i) tf.p[i] = q->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i];
     }
     // ---- GPU structure-of-arrays image
-    if (!gpu_image) continue;
-    if (m == 0) {
-      out.p_r.assign((size_t)B * NS * 2, 0.0); out.p_l.assign((size_t)B * NS * 2, 0.0);
-      out.p_k.assign((size_t)B * NS * 4, 0.0); out.p_phi.assign((size_t)B * NS * 2, 0.0);
-      out.cst.assign((size_t)B * 16, 0.0);
-      out.k_uniform = true;
-      out.l_idx.assign((size_t)B * NS, 0); out.l_dict.assign((size_t)B * 1024, 0.0);
-      out.l_dict_ok = true; out.damping_uniform = true; out.n_dict_max = 0;
-    }
+    if (!gpu_image) return;
     for (int s_ = 0; s_ < NS; ++s_) {
       const double* s = sp + (size_t)s_ * kSlotParams;
       double* r = out.p_r.data() + ((size_t)m * NS + s_) * 2;
       double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
       double* k = out.p_k.data() + ((size_t)m * NS + s_) * 4;
-      double* ph = out.p_phi.data() + ((size_t)m * NS + s_) * 2;
+      double* ph2 = out.p_phi.data() + ((size_t)m * NS + s_) * 2;
       r[0] = s[0]; r[1] = s[1];
+      l[0] = l[1] = 0.0; k[0] = k[1] = k[2] = k[3] = 0.0; ph2[0] = ph2[1] = 0.0;
+      out.l_idx[(size_t)m * NS + s_] = 0;
       int info = pl.slot_info[s_];
       if (info >= 0) {
-        if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { err = "set_params: zero-length reference vector"; return 1; }
+        if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { F.bad = 1; return; }
         l[0] = s[2]; l[1] = s[3];
         k[0] = s[4]; k[1] = s[5]; k[2] = s[6];
-        ph[0] = s[7]; ph[1] = s[8];
-        if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) out.k_uniform = false;
+        ph2[0] = s[7]; ph2[1] = s[8];
+        if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) F.k_uniform = false;
       }
     }
     for (int e = 0; e < pl.n_ovf; ++e) {
       const double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
-      if (o[2] != kb[0] || o[3] != kb[1] || o[4] != kb[2]) out.k_uniform = false;
+      if (o[2] != kb[0] || o[3] != kb[1] || o[4] != kb[2]) F.k_uniform = false;
     }
     if (q->contact) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + i] = q->contact[m * 3 + i];
     if (q->contact && pl.contact == 1) {
@@ -249,25 +257,36 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     {  // dictionary of reference vectors
       int n_dict = 0;
       double* dict = out.l_dict.data() + (size_t)m * 1024;
-      for (int s_ = 0; s_ < NS && out.l_dict_ok; ++s_) {
+      for (int s_ = 0; s_ < NS && F.l_dict_ok; ++s_) {
         if (pl.slot_info[s_] < 0) continue;
         const double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
         int hit = -1;
         for (int d = 0; d < n_dict; ++d) if (dict[4 * d] == l[0] && dict[4 * d + 1] == l[1]) { hit = d; break; }
         if (hit < 0) {
-          if (n_dict == 256) { out.l_dict_ok = false; break; }
+          if (n_dict == 256) { F.l_dict_ok = false; break; }
           hit = n_dict++; dict[4 * hit] = l[0]; dict[4 * hit + 1] = l[1];
           dict[4 * hit + 2] = sqrt(l[0] * l[0] + l[1] * l[1]); dict[4 * hit + 3] = 1.0 / dict[4 * hit + 2];
         }
         out.l_idx[(size_t)m * NS + s_] = (uint8_t)hit;
       }
-      if (n_dict > out.n_dict_max) out.n_dict_max = n_dict;
+      F.n_dict = n_dict;
     }
     for (int d = 0; d < 3; ++d) {
       const double d0 = out.damping[(size_t)m * NB * 3 + d];
       out.cst[(size_t)m * 16 + 6 + d] = d0;
-      for (int b = 1; b < NB && out.damping_uniform; ++b) if (out.damping[(size_t)m * NB * 3 + b * 3 + d] != d0) out.damping_uniform = false;
+      for (int b = 1; b < NB && F.damping_uniform; ++b) if (out.damping[(size_t)m * NB * 3 + b * 3 + d] != d0) F.damping_uniform = false;
     }
+  };
+  dfx_hostpar::for_each(B, (size_t)NS * 16, member);
+  out.k_uniform = true; out.l_dict_ok = true; out.damping_uniform = true; out.n_dict_max = 0;
+  for (int m = 0; m < B; ++m) {
+    const Flags& F = flags[m];
+    if (F.bad == 1) { err = "set_params: zero-length reference vector"; return 1; }
+    if (F.bad == 2) { err = "set_params: inertia must be positive"; return 1; }
+    out.k_uniform = out.k_uniform && F.k_uniform;
+    out.l_dict_ok = out.l_dict_ok && F.l_dict_ok;
+    out.damping_uniform = out.damping_uniform && F.damping_uniform;
+    if (F.n_dict > out.n_dict_max) out.n_dict_max = F.n_dict;
   }
   return 0;
 }

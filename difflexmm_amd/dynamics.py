@@ -40,6 +40,17 @@ def remember_flat(cnv, bonds, density, inertia, void_angle0):
     _FLAT_CACHE[key] = (weakref.ref(cnv, lambda _r, k=key: _FLAT_CACHE.pop(k, None)), bonds, np.array(density, copy=True), inertia, void_angle0)
 
 
+def _same_scalars(a, b):
+    try:
+        if isinstance(a, tuple) or isinstance(b, tuple):
+            return isinstance(a, tuple) and isinstance(b, tuple) and len(a) == len(b) and all(_same_scalars(x, y) for x, y in zip(a, b))
+        if a is None or b is None:
+            return a is b
+        return np.ndim(a) == 0 and np.ndim(b) == 0 and float(a) == float(b)
+    except (TypeError, ValueError):
+        return False
+
+
 def _bcast(x, n):
     return np.broadcast_to(np.asarray(x, dtype=float), (n,)).copy()
 
@@ -105,6 +116,37 @@ class DynamicSolver:
         self.solve_count = 0          # forward solves run so far (what the engine's resident history belongs to)
 
     # -- ControlParams -> engine arrays -------------------------------------------------------------
+    def _memo(self, name, source, build):
+        """The flattened form of a ControlParams leaf that rarely changes between members and evaluations (stiffnesses, reference vectors,
+        damping): rebuilt only when the leaf is another object (arrays) or another value (scalars / tuples of scalars)."""
+        cache = self.__dict__.setdefault("_memo_cache", {})
+        hit = cache.get(name)
+        same = hit is not None and (hit[0] is source or (not isinstance(source, np.ndarray) and not isinstance(hit[0], np.ndarray) and _same_scalars(hit[0], source)))
+        if same:
+            return hit[1]
+        arr = build()
+        arr.flags.writeable = False
+        cache[name] = (source, arr)
+        return arr
+
+    def _stack(self, flats):
+        """The members' flattened arrays as batch-leading arrays in buffers this solver keeps: a row is copied only when its source is
+        another object than last time (the static leaves above, and designs that did not change, cost nothing)."""
+        bufs = self.__dict__.setdefault("_batch_bufs", {})
+        out = {}
+        for k in flats[0]:
+            rows = [f[k] for f in flats]
+            shape = (len(rows),) + np.shape(rows[0])
+            buf = bufs.get(k)
+            if buf is None or buf[0].shape != shape:
+                buf = bufs[k] = [np.empty(shape), [None] * len(rows)]
+            for m, r in enumerate(rows):
+                if buf[1][m] is not r or not isinstance(r, np.ndarray) or r.flags.writeable:
+                    buf[0][m] = r
+                    buf[1][m] = r if isinstance(r, np.ndarray) and not r.flags.writeable else None     # (only read-only arrays are trusted to be unchanged)
+            out[k] = buf[0]
+        return out
+
     def _flatten(self, cp: ControlParams):
         gp, mp = cp.geometrical_params, cp.mechanical_params
         cnv = np.asarray(gp.centroid_node_vectors, dtype=float)
@@ -115,10 +157,12 @@ class DynamicSolver:
         zero = np.zeros(nbd)
         out = {
             "centroid_node_vectors": cnv,
-            "reference_vector": np.broadcast_to(np.asarray(getattr(bp, "reference_vector", np.array([1.0, 0.0])), dtype=float), (nbd, 2)),
-            "k_bond": np.stack([_bcast(bp.k_stretch, nbd),
-                                _bcast(bp.k_shear, nbd) if self.spec.bond_model in (_b.BOND_LINEARIZED, _b.BOND_NONLINEAR) else zero,
-                                _bcast(bp.k_rot, nbd) if self.spec.bond_model != _b.BOND_SIMPLE_SPRING else zero], 1),
+            "reference_vector": self._memo("reference_vector", getattr(bp, "reference_vector", None), lambda: np.ascontiguousarray(np.broadcast_to(
+                np.asarray(getattr(bp, "reference_vector", np.array([1.0, 0.0])), dtype=float), (nbd, 2)))),
+            "k_bond": self._memo("k_bond", (bp.k_stretch, getattr(bp, "k_shear", None), getattr(bp, "k_rot", None)), lambda: np.stack(
+                [_bcast(bp.k_stretch, nbd),
+                 _bcast(bp.k_shear, nbd) if self.spec.bond_model in (_b.BOND_LINEARIZED, _b.BOND_NONLINEAR) else zero,
+                 _bcast(bp.k_rot, nbd) if self.spec.bond_model != _b.BOND_SIMPLE_SPRING else zero], 1)),
         }
         cached = _FLAT_CACHE.get(id(cnv)) if mp.inertia is None else None
         if cached is not None and cached[0]() is cnv and (cached[1] is self.bonds or np.array_equal(cached[1], self.bonds)) and np.array_equal(cached[2], mp.density):
@@ -129,10 +173,12 @@ class DynamicSolver:
             out["inertia"] = compute_inertia(cnv, mp.density)
         else:
             out["inertia"] = np.asarray(mp.inertia, dtype=float).reshape(self.n_blocks, 3)
-        damping = np.zeros((self.n_blocks, 3))
-        if self.damped_blocks is not None:   # loading.py:71-106
-            damping[self.damped_blocks] = np.broadcast_to(np.asarray(mp.damping, dtype=float), (len(self.damped_blocks), 3))
-        out["damping"] = damping
+        def _damping():
+            damping = np.zeros((self.n_blocks, 3))
+            if self.damped_blocks is not None:   # loading.py:71-106
+                damping[self.damped_blocks] = np.broadcast_to(np.asarray(mp.damping, dtype=float), (len(self.damped_blocks), 3))
+            return damping
+        out["damping"] = self._memo("damping", mp.damping, _damping)
         if self.spec.contact:
             c = mp.contact_params
             if self.spec.contact == _b.CONTACT_DISTANCE:      # energy.py:397-404: absolute node positions enter
@@ -218,7 +264,7 @@ class DynamicSolver:
         :meth:`solve_resident` are resident in HBM."""
         cps = self._members(control_params)
         flats = [self._flatten(cp) for cp in cps]
-        self.engine.set_params(**{k: np.stack([f[k] for f in flats]) for k in flats[0]})
+        self.engine.set_params(**self._stack(flats))
         self._prepared = (cps, flats)
         return cps, flats
 

@@ -95,9 +95,12 @@ def prefetch_designs(fw, designs):
     from .dynamics import remember_flat
     cen, cnv, inertia, va = ndm.forward(lib, todo, float(fw.density), void_angles=contact == _b.CONTACT_ANGLE)
     for i, d in enumerate(todo):
-        ci, vi = cen[i], cnv[i]
+        ci, vi, ii, ai = cen[i], cnv[i], inertia[i], (None if va is None else va[i])
+        ii.flags.writeable = False
+        if ai is not None:
+            ai.flags.writeable = False
         _remember_geometry(fw.geometry, d, ci, vi)
-        remember_flat(vi, fw.solve_dynamics.bonds, fw.density, inertia[i], None if va is None else va[i])
+        remember_flat(vi, fw.solve_dynamics.bonds, fw.density, ii, ai)
 
 
 def _tile3(blocks):
