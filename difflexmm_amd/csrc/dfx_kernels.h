@@ -1281,6 +1281,26 @@ __device__ __forceinline__ void adj_stage_body(const DevCtx& c_arg, const AdjCoe
   double ex = 0.0, ey = 0.0, eth = 0.0;   // dE/du of this slot (value parts): gives the stage acceleration without re-reading it
   double d_rx = 0.0, d_ry = 0.0, d_phi = 0.0;   // this launch's contributions to the node-vector / void-angle gradients
   double dn_x = 0.0, dn_y = 0.0, dp_x = 0.0, dp_y = 0.0, d_cx = 0.0, d_cy = 0.0;   // distance contact: next / previous node, centroid
+  // The builds that accumulate only what a design reaches (node vectors, void angles, inertia) take the Hessian-vector product written out
+  // by hand (bond_hvp / contact_hvp, dfx_physics.h): a third of the multiply-adds of the dual-number evaluation, on a kernel bound by
+  // instruction issue.  Per-ligament gradients, the spring models and the distance-based contact keep the dual numbers.
+  constexpr bool kHandHvp = !BOND_GRADS && CONTACT != 2 && (MODEL == kNonlinear || MODEL == kLinearized);
+  if constexpr (kHandHvp) {
+    if (L.info >= 0) {
+      BondHvp hv;
+      bond_hvp<MODEL>(L.o, L.p, wox, woy, woth, wpx, wpy, wpth, L.rox, L.roy, L.rpx, L.rpy, L.lx, L.ly, L.l0, L.il0, L.ks, L.ksh, L.kr, L.sgn, hv);
+      hx = hv.hx; hy = hv.hy; hth = hv.hth;
+      ex = hv.fx; ey = hv.fy; eth = hv.fth;
+      d_rx = hv.rx; d_ry = hv.ry;
+      if (CONTACT == 1) {
+        double dk, dke, p1e, p2e;
+        contact_hvp(L.sgn * (L.o.th - L.p.th), L.sgn * (woth - wpth), L.phi1, L.phi2, L.am, L.ac, L.kc, dk, dke, p1e, p2e);
+        hth += L.sgn * dke;
+        eth += L.sgn * dk;
+        d_phi = (L.info & 1) ? p2e : p1e;      // both ends hold the same penalty: each accumulates one of the two void-angle derivatives
+      }
+    }
+  } else
   if (L.info >= 0) {
     BlockRec<Dual> o = seed_rec(L.o, wox, woy, woth);
     BlockRec<Dual> p = seed_rec(L.p, wpx, wpy, wpth);

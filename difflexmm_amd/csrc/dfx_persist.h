@@ -446,20 +446,19 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
       // ---- Hessian-vector product + mixed parameter derivatives of this slot
       double hx = 0.0, hy = 0.0, hth = 0.0, ex = 0.0, ey = 0.0, eth = 0.0, d_rx = 0.0, d_ry = 0.0, d_phi = 0.0;
       if (info >= 0) {
-        BlockRec<Dual> od = seed_rec(o, wox, woy, woth);
-        BlockRec<Dual> pd = seed_rec(p, wp[0], wp[1], wp[2]);
-        BondGrad<Dual> bg;
-        bond_grad<MODEL, Dual>(od, pd, g.rox, g.roy, g.rpx, g.rpy, g.lx, g.ly, g.l0, g.il0, g.ks, g.ksh, g.kr, g.sgn, bg);
-        hx = bg.fx.e; hy = bg.fy.e; hth = bg.fth.e;
-        ex = bg.fx.v; ey = bg.fy.v; eth = bg.fth.v;
-        d_rx = bg.rx.e; d_ry = bg.ry.e;
+        // (the Hessian-vector product written out by hand, as in the records build of the stage kernel: bond_hvp / contact_hvp, dfx_physics.h)
+        BondHvp hv;
+        bond_hvp<MODEL>(o, p, wox, woy, woth, wp[0], wp[1], wp[2], g.rox, g.roy, g.rpx, g.rpy, g.lx, g.ly, g.l0, g.il0, g.ks, g.ksh, g.kr, g.sgn, hv);
+        hx = hv.hx; hy = hv.hy; hth = hv.hth;
+        ex = hv.fx; ey = hv.fy; eth = hv.fth;
+        d_rx = hv.rx; d_ry = hv.ry;
         if (CONTACT == 1) {
           const bool far = !(fabs(o.th - p.th) <= g.kap_safe);
-          ContactGrad<Dual> cg;
-          contact_grad<Dual>(g.sgn * (od.th - pd.th), far ? g.phi1 : g.phi_min, far ? g.phi2 : g.phi_min, g.am, g.ac, g.kc, cg);
-          hth += g.sgn * cg.dkap.e;
-          eth += g.sgn * cg.dkap.v;
-          d_phi = (info & 1) ? cg.p2.e : cg.p1.e;
+          double dk, dke, p1e, p2e;
+          contact_hvp(g.sgn * (o.th - p.th), g.sgn * (woth - wp[2]), far ? g.phi1 : g.phi_min, far ? g.phi2 : g.phi_min, g.am, g.ac, g.kc, dk, dke, p1e, p2e);
+          hth += g.sgn * dke;
+          eth += g.sgn * dk;
+          d_phi = (info & 1) ? p2e : p1e;
         }
         const double2 r_old = s_racc[tid];
         s_racc[tid] = make_double2(r_old.x - d_rx, r_old.y - d_ry);

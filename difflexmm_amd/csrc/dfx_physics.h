@@ -367,6 +367,115 @@ DFX_HD void contact_grad(T kap, P phi1, P phi2, P am, P ac, P kc, ContactGrad<T>
 }
 
 // ---------------------------------------------------------------------------------------
+// Hessian-vector product by hand (round 6): what the reverse stage needs from a ligament -- dE/d(own DOFs) (value), (H w)_own and the
+// epsilon part of dE/d(own node vector) for the direction w = (w_o, w_p) on the six DOFs of the two blocks -- written out instead of pushed
+// through the gradient as dual numbers.  Same formulas as bond_grad / contact_grad (energy.py:70-176, 333-361), differentiated once more:
+// in the ligament's own coordinates  b = dU + l  (length L, direction bh, angle phi_b), mean rotation tb, relative rotation kap
+//     E = ks (L - l0)^2 / 2 + ksh l0^2 gam^2 / 2 + kr kap^2 / 2,   gam = phi_b - tb - angle(l)      (d gam / d tb = -1 exactly)
+//     Ldot = bh . bdot,  phidot_b = (b x bdot) / L^2,  gamdot = phidot_b - tbdot,  Sdot = ksh l0^2 gamdot
+// so the second derivative costs ~70 multiply-adds where the dual-number evaluation of the whole gradient costs ~300 (the reverse stage
+// kernel is bound by instruction issue: profiles/LABNOTES.md, round 4).  The per-ligament gradients (reference vector, stiffnesses,
+// contact constants), the spring models and the distance-based contact keep the dual-number path.  Checked against that path on random
+// ligaments to 1e-13 (tests/test_physics_hvp.py) and, inside the kernels, by every gradient test of the GPU suite.
+// ---------------------------------------------------------------------------------------
+struct BondHvp {
+  double fx, fy, fth;    // dE/d(x, y, theta) of the own block                    (bond_grad: fx, fy, fth)
+  double hx, hy, hth;    // (H w) on the own block's DOFs                          (their epsilon parts)
+  double rx, ry;         // epsilon part of dE/d(centroid_node_vector of own node) (rx.e, ry.e)
+};
+
+template <int MODEL>
+DFX_HD void bond_hvp(const BlockRec<double>& o, const BlockRec<double>& p, double wox, double woy, double woth, double wpx, double wpy, double wpth,
+                     double rox, double roy, double rpx, double rpy, double lx, double ly, double l0, double il0, double ks, double ksh, double kr,
+                     double sgn, BondHvp& h) {
+  static_assert(MODEL == kNonlinear || MODEL == kLinearized, "bond_hvp: the two ligament models");
+  const double co = o.ch * o.ch - o.sh * o.sh, so = 2.0 * (o.sh * o.ch);
+  const double cp = p.ch * p.ch - p.sh * p.sh, sp = 2.0 * (p.sh * p.ch);
+  const double qox = co * rox - so * roy, qoy = so * rox + co * roy;
+  const double qpx = cp * rpx - sp * rpy, qpy = sp * rpx + cp * rpy;
+  const double dUx = sgn * ((o.x + qox - rox) - (p.x + qpx - rpx));
+  const double dUy = sgn * ((o.y + qoy - roy) - (p.y + qpy - rpy));
+  // direction: d(dU)/d eps, mean and relative rotation rates
+  const double bdx = sgn * ((wox - woth * qoy) - (wpx - wpth * qpy));
+  const double bdy = sgn * ((woy + woth * qox) - (wpy + wpth * qpx));
+  const double tbd = 0.5 * (woth + wpth);
+  const double kapd = sgn * (woth - wpth);
+  const double kap = sgn * (o.th - p.th);
+  double gbx, gby, gtb, gbxd, gbyd, gtbd;
+  if (MODEL == kNonlinear) {
+    const double l02 = lx * lx + ly * ly;
+    const double cb = o.ch * p.ch - o.sh * p.sh, sb = o.sh * p.ch + o.ch * p.sh;
+    const double bx = dUx + lx, by = dUy + ly;
+    const double L2 = bx * bx + by * by;
+    const double Lb = sqrt(L2);            // (correctly rounded: a lattice at rest has Lb == l0 bit for bit, as in bond_grad)
+    const double iLb = trcp(Lb), iL2 = iLb * iLb;
+    const double px = cb * lx - sb * ly, py = sb * lx + cb * ly;
+    const double gam = fast_atan2(px * by - py * bx, px * bx + py * by);
+    const double es = Lb - l0;
+    const double kse = ks * es, S = ksh * gam * l02;
+    gbx = kse * bx * iLb - S * by * iL2;
+    gby = kse * by * iLb + S * bx * iL2;
+    gtb = -S;
+    const double u = (bx * bdx + by * bdy) * iLb;            // Ldot
+    const double gamd = (bx * bdy - by * bdx) * iL2 - tbd;
+    const double Sd = ksh * l02 * gamd;
+    const double ui = u * iLb;
+    const double a1 = ks * u - kse * ui;                     // d(kse / L) * L
+    const double a2 = Sd - 2.0 * (S * ui);                   // d(S / L^2) * L^2
+    gbxd = iLb * (a1 * bx + kse * bdx) - iL2 * (a2 * by + S * bdy);
+    gbyd = iLb * (a1 * by + kse * bdy) + iL2 * (a2 * bx + S * bdx);
+    gtbd = -Sd;
+  } else {
+    const double tb = 0.5 * (o.th + p.th);
+    const double es = (dUx * lx + dUy * ly) * il0;
+    const double esh = (lx * dUy - ly * dUx) * il0 - tb * l0;
+    const double kse = ks * es, kshe = ksh * esh;
+    gbx = (kse * lx - kshe * ly) * il0;
+    gby = (kse * ly + kshe * lx) * il0;
+    gtb = -(kshe * l0);
+    const double ksed = ks * ((bdx * lx + bdy * ly) * il0);
+    const double kshed = ksh * ((lx * bdy - ly * bdx) * il0 - tbd * l0);
+    gbxd = (ksed * lx - kshed * ly) * il0;
+    gbyd = (ksed * ly + kshed * lx) * il0;
+    gtbd = -(kshed * l0);
+  }
+  h.fx = sgn * gbx;
+  h.fy = sgn * gby;
+  h.fth = sgn * (gby * qox - gbx * qoy) + 0.5 * gtb + sgn * (kr * kap);
+  h.hx = sgn * gbxd;
+  h.hy = sgn * gbyd;
+  // d(qo)/d eps = woth * (-qoy, qox)
+  h.hth = sgn * (gbyd * qox - gbxd * qoy - woth * (gby * qoy + gbx * qox)) + 0.5 * gtbd + sgn * (kr * kapd);
+  // d(co, so)/d eps = woth * (-so, co)
+  h.rx = sgn * (co * gbxd + so * gbyd - gbxd + woth * (co * gby - so * gbx));
+  h.ry = sgn * (co * gbyd - so * gbxd - gbyd - woth * (so * gby + co * gbx));
+}
+
+// Angle-based contact, the same way: dE/dkap (value), its epsilon part for kapdot, and the epsilon parts of dE/dphi1, dE/dphi2.
+//   e'(a) = qD hp(x), x = (a - ac) / D, qD = kc D / 4   =>   e''(a) = kc (ip^3 - im^3) / 2,  ip = 1 / (x + 1), im = 1 / (x - 1)
+DFX_HD void contact_hvp_one(double a, double am, double ac, double kc, double& da, double& dda) {
+  a = twrap(a);
+  da = 0.0; dda = 0.0;
+  if (a >= am && a < ac) {
+    const double D = ac - am;
+    const double x = (a - ac) * trcp(D);
+    const double ip = trcp(x + 1.0), im = trcp(x - 1.0);
+    da = 0.25 * (kc * D) * (im * im - ip * ip);
+    dda = 0.5 * kc * (ip * ip * ip - im * im * im);
+  }
+}
+DFX_HD void contact_hvp(double kap, double kapd, double phi1, double phi2, double am, double ac, double kc, double& dkap, double& dkap_e, double& p1_e,
+                        double& p2_e) {
+  double d1, dd1, d2, dd2;
+  contact_hvp_one(phi1 - kap, am, ac, kc, d1, dd1);
+  contact_hvp_one(phi2 + kap, am, ac, kc, d2, dd2);
+  dkap = d2 - d1;
+  p1_e = -(dd1 * kapd);
+  p2_e = dd2 * kapd;
+  dkap_e = p2_e - p1_e;
+}
+
+// ---------------------------------------------------------------------------------------
 // distance-based contact (energy.py:222-330; build_contact_energy(angle_based=False) :364-407)
 // ---------------------------------------------------------------------------------------
 // point_to_edge_distance (energy.py:222-251) in closest-point form: with t = (p - a).(b - a) / |b - a|^2 clamped to [0, 1] the

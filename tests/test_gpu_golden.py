@@ -47,18 +47,20 @@ def test_golden_focusing_gradient(hip_lib):
     assert relerr(gh, gold["grad_h"]) < 1e-9 and relerr(gv, gold["grad_v"]) < 1e-9
 
 
-@pytest.mark.parametrize("lattice", ["quads", "kagome", "quads32"])
+@pytest.mark.parametrize("lattice", ["quads", "kagome", "quads32", "quads128"])
 def test_long_horizon_trajectory_and_gradient_against_the_oracle(hip_lib, lattice):
     """1200 (quads 8x8) / 800 (kagome 4x4) / 2000 (quads 32x32: several workgroups, several segments; by default the persistent stage
-    loop, whose ring wraps 1 500 times) steps with the contact engaged throughout: trajectory, objective and design gradient of the HIP
-    engine against the torch oracle's taped solve (tests/golden/long_horizon_*.npz) -- an oracle that shares no header with the product."""
+    loop, whose ring wraps 1 500 times) / 500 (quads 128x128: BASELINE config 3's lattice at FULL SIZE, 1 024 waves, every XCD band) steps
+    with the contact engaged throughout: trajectory, objective and design gradient of the HIP engine against the torch oracle's taped solve
+    (tests/golden/long_horizon_*.npz) -- an oracle that shares no header with the product."""
     long_horizon.check(None, lattice)
 
 
-def test_long_horizon_32x32_with_one_launch_per_stage(hip_lib, monkeypatch):
-    """The same 2 000-step golden through the stage launches (DFX_PERSIST=0): both forms of the stage loop are pinned to the oracle."""
+@pytest.mark.parametrize("lattice", ["quads32", "quads128"])
+def test_long_horizon_with_one_launch_per_stage(hip_lib, monkeypatch, lattice):
+    """The same goldens through the stage launches (DFX_PERSIST=0): both forms of the stage loop are pinned to the oracle."""
     monkeypatch.setenv("DFX_PERSIST", "0")
-    long_horizon.check(None, "quads32")
+    long_horizon.check(None, lattice)
 
 
 def test_pulse_rs_script_as_written(hip_lib):

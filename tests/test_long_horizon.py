@@ -4,7 +4,7 @@ import pytest
 from . import long_horizon
 
 
-@pytest.mark.parametrize("lattice", ["quads", "kagome", "quads32"])
+@pytest.mark.parametrize("lattice", ["quads", "kagome", "quads32", "quads128"])
 def test_cpu_port_follows_the_oracle_over_a_long_horizon(cpu_lib, lattice):
     long_horizon.check(cpu_lib, lattice)
 
