@@ -394,7 +394,7 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
       double w_d = (h * (cur_s * lv + svc)) * invm;
       // dense output: what the outputs inside this step and inside the previous one add to this stage's own Kbar, to the Kbar handed on,
       // and to lambda_n -- scaled by the step sizes, zero on constrained DOFs (adj_stage_body<..., DENSE = 1>, same sums)
-      double e_own_q = 0.0, e_nxt_q = 0.0, e_nxt_v = 0.0, gs_q = 0.0, gs_v = 0.0;
+      double e_own_q = 0.0, e_nxt_v = 0.0, gs_q = 0.0, gs_v = 0.0;
       if constexpr (DENSE) {
         if (!constrained) {
           const int* op = dn.out_ptr + (size_t)m * dn.stride;
@@ -407,21 +407,21 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
             const double gq = ldg<double>(Gk, o_g), gv = ldg<double>(Gk, o_g + 24);
             const double* wt = dwm + (size_t)kk * 8;
             e_own_q += wt[i] * gq; e_own_v += wt[i] * gv;
-            if (i > 0) { e_nxt_q += wt[i - 1] * gq; e_nxt_v += wt[i - 1] * gv; }
+            if (i > 0) e_nxt_v += wt[i - 1] * gv;
             else { gs_q += gq; gs_v += gv; }
           }
-          e_own_q *= h; e_own_v *= h; e_nxt_q *= h; e_nxt_v *= h;
+          e_own_q *= h; e_own_v *= h; e_nxt_v *= h;
           if (i <= 1) {
-            double e6q = 0.0, e6v = 0.0, e5q = 0.0, e5v = 0.0;
+            double e6q = 0.0, e6v = 0.0, e5v = 0.0;
             for (int kk = plo; kk < lo; ++kk) {
               const double* Gk = c.G + ((size_t)kk * c.batch + m) * (size_t)nd6;
               const double gq = ldg<double>(Gk, o_g), gv = ldg<double>(Gk, o_g + 24);
               const double* wt = dwm + (size_t)kk * 8;
               e6q += wt[6] * gq; e6v += wt[6] * gv;
-              e5q += wt[s - 1] * gq; e5v += wt[s - 1] * gv;
+              e5v += wt[s - 1] * gv;
             }
-            if (i == 0) { e_own_q += h_before * e6q; e_own_v += h_before * e6v; e_nxt_q = h_before * e5q; e_nxt_v = h_before * e5v; }
-            else { e_nxt_q += h_before * e6q; e_nxt_v += h_before * e6v; }
+            if (i == 0) { e_own_q += h_before * e6q; e_own_v += h_before * e6v; e_nxt_v = h_before * e5v; }
+            else e_nxt_v += h_before * e6v;
           }
           if (i == 0 && n == 0)
             for (int kk = 0; kk < lo; ++kk) {

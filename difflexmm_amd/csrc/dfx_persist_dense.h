@@ -38,7 +38,7 @@ __device__ __forceinline__ void err_store(double* p, double v) {
 }
 
 template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c, AdaptLoopCoef pc, PersistArgs pa, AdaptLoopArgs aa) {
+__global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_adaptive_fwd_loop(DevCtx c, AdaptLoopCoef pc, PersistArgs pa, AdaptLoopArgs aa) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
   if (wave >= pa.waves_per_member * pa.nm) return;
   const int W = pa.waves_per_member;
@@ -95,12 +95,48 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
   long long attempt = 0;
   for (; attempt < pa.n_steps; ++attempt) {
     if (keep && n_acc + 3 > aa.cap) break;                         // no room for another kept step: the host grows the buffers
+    // ---- the time functions of this attempt at its stage times t + c_j h, j = 0 .. 6: lane j (mod 8) of every wave that holds a driven or
+    // loaded block evaluates time j -- the wave pays for ONE evaluation (a software sin / cos) instead of one per stage, and the stages
+    // below fetch their values with a lane broadcast.  Same function, same argument as the stage launches: same bits.
+    double fg[DFX_MAX_FNS], fgt[DFX_MAX_FNS];
+    const bool need_fn = c.n_fns > 0 && __any(sidx >= 0);
+    if (need_fn) {
+      const int jj = min(lane & 7, 6);
+      const double cj = jj == 0 ? pc.c[0] : (jj == 1 ? pc.c[1] : (jj == 2 ? pc.c[2] : (jj == 3 ? pc.c[3] : (jj == 4 ? pc.c[4] : (jj == 5 ? pc.c[5] : pc.c[6])))));
+      double gp[kMaxFnParams];
+#pragma unroll
+      for (int f = 0; f < DFX_MAX_FNS; ++f) {
+        fg[f] = 0.0; fgt[f] = 0.0;
+        if (f < c.n_fns) eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + cj * h, fg[f], fgt[f], gp);
+      }
+    }
+    // value and rate of this lane's prescribed DOF at stage time j (all lanes call: the broadcasts are wave-wide)
+    auto prescribed = [&](int j, double& q, double& v) {
+      if (!need_fn) return;
+      double sq_ = 0.0, sv_ = 0.0;
+#pragma unroll
+      for (int f = 0; f < DFX_MAX_FNS; ++f) {
+        const double gj = __shfl(fg[f], j, 64), gtj = __shfl(fgt[f], j, 64);
+        if (constrained && f < c.n_fns) { sq_ += c.special[sidx].con_coef[k][f] * gj; sv_ += c.special[sidx].con_coef[k][f] * gtj; }
+      }
+      if (constrained) { q = sq_; v = sv_; }
+    };
+    auto load_at = [&](int j) -> double {
+      double fl = 0.0;
+      if (!need_fn) return fl;
+#pragma unroll
+      for (int f = 0; f < DFX_MAX_FNS; ++f) {
+        const double gj = __shfl(fg[f], j, 64);
+        if (k < 3 && sidx >= 0 && !constrained && f < c.n_fns) fl += c.special[sidx].load_coef[k][f] * gj;
+      }
+      return fl;
+    };
     // ---- record S_1 = y_n + h a_10 k_0 (prescribed DOFs: c(t + c_1 h)), published as ordinal 6 * attempt
-    double v_i, q_i;
+    double v_i;
     {
       double qx = qn + h * pc.a[1][0] * vn, vx = vn + h * pc.a[1][0] * al[0];
-      if (constrained) { const TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + pc.c[1] * h); qx = tv.g; vx = tv.gt; }
-      q_i = qx; v_i = vx;
+      prescribed(1, qx, vx);
+      v_i = vx;
       const double y1 = blk_bcast<4, 1>(qx, k), th2 = blk_bcast<4, 2>(qx, k), x0 = blk_bcast<4, 0>(qx, k);
       double sn, cs;
       fast_sincos(0.5 * th2, &sn, &cs);
@@ -124,16 +160,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
         sv += (i < 6 ? pc.a[i + 1][l] : pc.e[l]) * a_l;
         sq += (i < 6 ? pc.aa[i + 1][l] : pc.ee[l]) * a_l;
       }
-      if (k < 3 && sidx >= 0 && !constrained) {
-        const dfx_special& sp = c.special[sidx];
-        double gp[kMaxFnParams];
-        for (int f = 0; f < c.n_fns; ++f)
-          if (sp.load_coef[k][f] != 0.0) {
-            double gg, gt;
-            eval_time_fn(c.fns[(u32)m * DFX_MAX_FNS + f], t + pc.c[i] * h, gg, gt, gp);
-            fload += sp.load_coef[k][f] * gg;
-          }
-      }
+      fload = load_at(i);
       // ---- the partner's record S_i
       double pr[4];
       if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
@@ -162,7 +189,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
 #pragma unroll
         for (int l = 1; l < 7; ++l) al[l] = l == i ? a : al[l];
         double qx = qn + h * (pc.c[i + 1] * vn + h * sq), vx = vn + h * sv;
-        if (constrained) { const TimeVals tv = constrained_value(c, m, c.special[sidx], k, t + pc.c[i + 1] * h); qx = tv.g; vx = tv.gt; }
+        prescribed(i + 1, qx, vx);
         const double y1 = blk_bcast<4, 1>(qx, k), th2 = blk_bcast<4, 2>(qx, k), x0 = blk_bcast<4, 0>(qx, k);
         double sn, cs;
         fast_sincos(0.5 * th2, &sn, &cs);
@@ -173,7 +200,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
           if (k < 2) stg<double2>(tr, o_chunk, k == 0 ? make_double2(x0, y1) : make_double2(th2, sn));
           stg<double>(tr + (size_t)c.n_blocks * kPos, o_dof, vx);
         }
-        q_i = qx; v_i = vx;
+        v_i = vx;
         if (i == 5) { q1 = qx; v1 = vx; }
       } else {
         // the evaluation at the candidate: A_6, and with (e, ee) the embedded error estimate (k_fwd_stage, error mode)
