@@ -124,6 +124,10 @@ struct dfx_handle {
   DevBuf<int> d_seg_idx;
   std::vector<Seg> segs;
   DevBuf<double> d_POS, d_VEL, d_A, d_state0, d_fields, d_fn_tab, d_restart;
+  // segments level, the re-run of piece k-1 beside the reverse stages of piece k (run_adjoint): the second record buffer, hand-off ring and
+  // time-function table, and the events that order the two streams (per buffer: records rebuilt / reverse stages done)
+  DevBuf<double> d_traj2, d_ring2, d_fn_tab2;
+  hipEvent_t ev_rebuilt[2] = {nullptr, nullptr}, ev_reversed[2] = {nullptr, nullptr};
   DevBuf<double> d_YB, d_LAM, d_W, d_KQ, d_G, d_g_r, d_g_phi, d_g_b, d_blk_m, d_blk_c, d_fn_g, d_tmp, d_obj;
   DevBuf<int32_t> d_target;
   std::vector<double> ts;
@@ -246,6 +250,8 @@ int step_units(const dfx_handle* h, int kind);
 bool use_fn_table(const dfx_handle* h);
 bool solve_is_eager(const dfx_handle* h);
 void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int kind, int seg_index = -1);
+bool seg_overlap_plan(dfx_handle* h, const DevCtx& c);
+void enqueue_rerun_segment(dfx_handle* h, const DevCtx& cf, hipStream_t st, int seg_index);
 int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int kind);
 int fork_groups(dfx_handle* h);
 int join_groups(dfx_handle* h);

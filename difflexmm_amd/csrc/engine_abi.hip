@@ -166,6 +166,8 @@ int dfx_destroy(dfx_handle* h) {
   h->d_segs.release(); h->d_cur.release(); h->d_seg_idx.release(); h->d_clock.release(); h->d_err_partial.release(); h->d_ts.release();
       h->d_step_counts.release(); h->d_acc_times.release(); h->d_tsteps.release();
   if (--h->ck->users == 0) { h->ck->traj.release(); h->ck->AD.release(); delete h->ck; }
+  h->d_traj2.release(); h->d_ring2.release(); h->d_fn_tab2.release();
+  for (int b = 0; b < 2; ++b) { if (h->ev_rebuilt[b]) (void)hipEventDestroy(h->ev_rebuilt[b]); if (h->ev_reversed[b]) (void)hipEventDestroy(h->ev_reversed[b]); }
   h->d_ring.release(); h->d_fn_tab.release(); h->d_POS.release(); h->d_VEL.release(); h->d_A.release(); h->d_state0.release(); h->d_fields.release();
   h->d_YB.release(); h->d_LAM.release(); h->d_W.release(); h->d_KQ.release(); h->d_G.release(); h->d_restart.release();
   h->d_g_r.release(); h->d_g_phi.release(); h->d_g_b.release(); h->d_blk_m.release(); h->d_blk_c.release(); h->d_fn_g.release();

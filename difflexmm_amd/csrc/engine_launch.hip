@@ -447,7 +447,8 @@ static void launch_persist(dfx_handle* h, const void* fn, hipStream_t st, void**
   h->launches++;
 }
 // one segment of the group's members: the first ring places poisoned, then the whole segment in one launch per `per_launch` members
-static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps, bool reverse) {
+static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int n_steps, bool reverse, double* ring = nullptr) {
+  if (!ring) ring = h->d_ring.p;
   const int npb = h->persist_npb, per = reverse ? h->persist_adj_members : h->persist_fwd_members;
   const void* fn = reverse ? dfx_persist::adj_kernel(h->pl.model, h->pl.contact, npb) : dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, npb);
   PersistCoef pcf = persist_coef(h->pl.tab);
@@ -465,10 +466,10 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     cc.m0 = c.m0 + off;
     int grid = 0, per_cu = 0;
     persist_shape(h, npb, cnt, &grid, &per_cu);
-    dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
+    dfx_persist::launch_ring_poison(st, ring, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
     void* args_f[] = {&cc, &pcf, &pa};
     void* args_r[] = {&cc, &pca, &pa};
     launch_persist(h, fn, st, reverse ? args_r : args_f, grid, per_cu * persist_wg_slots(fn));
@@ -606,7 +607,7 @@ void launch_fn_table(dfx_handle* h, const DevCtx& c, hipStream_t st, int nm, int
   StageTimes tms;
   for (int r = 0; r < kFnRows; ++r) tms.c[r] = r <= h->pl.tab.s ? h->pl.tab.c[r] : 0.0;
   const int total = n_steps * (h->pl.tab.s + 1) * h->pl.n_fns;
-  hipLaunchKernelGGL(k_fn_table, dim3((total + 63) / 64, nm), dim3(64), 0, st, c, tms, n_steps, h->d_fn_tab.p);
+  hipLaunchKernelGGL(k_fn_table, dim3((total + 63) / 64, nm), dim3(64), 0, st, c, tms, n_steps, const_cast<double*>(c.fn_tab));
   h->launches++;
 }
 
@@ -706,6 +707,50 @@ void enqueue_interleaved(dfx_handle* h, const DevCtx& cbase, int n_steps, int ki
         for (int gi = 0; gi < ng; ++gi)
           launch_adj_unit(h, cg[gi], h->groups[gi].stream, slot_grid(h, h->groups[gi]), u, j);
   }
+}
+
+// ---- segments level where the persistent loop serves both sweeps: the re-run of piece k-1 beside the reverse stages of piece k ---------
+// A piece's records are rebuilt by one cheap forward launch per segment and then read by its reverse launches; neither fills the chip
+// (one 128x128 design: one wave per SIMD each), so the re-run of the NEXT piece (the one before it in time) runs on a second stream into
+// a second record buffer while this piece is reversed.  Both launches must be resident together: the slot account of launch_persist
+// would otherwise queue one behind the other (correct, but then the second buffer buys nothing) -- asked here, before anything is
+// allocated.  DFX_SEG_OVERLAP=0 switches it off (A/B runs, and the bit-identity test against the serial order).
+bool seg_overlap_plan(dfx_handle* h, const DevCtx& c) {
+  const char* e = getenv("DFX_SEG_OVERLAP");
+  if ((e && e[0] == '0') || !h->segments || !h->persist_fwd || !h->persist_adj || h->groups.size() != 1 || h->pieces.size() < 2) return false;
+  const int npb = h->persist_npb, nm = h->pl.batch;
+  const void* ff = dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, npb);
+  const void* fr = dfx_persist::adj_kernel(h->pl.model, h->pl.contact, npb);
+  if (h->persist_fwd_members < nm || h->persist_adj_members < nm) return false;       // one launch per segment each
+  int grid = 0, per_cu = 0;
+  persist_shape(h, npb, nm, &grid, &per_cu);
+  if (per_cu * (persist_wg_slots(ff) + persist_wg_slots(fr)) > kPersistSlots) return false;
+  const int of = persist_wg_per_cu(ff), orv = persist_wg_per_cu(fr);
+  if ((of && 2 * per_cu > of) || (orv && 2 * per_cu > orv)) return false;       // (occupancy by LDS / scratch: room for both with a margin)
+  size_t steps = 0;
+  for (const auto& pc : h->pieces) { size_t n = 0; for (int si = pc.first; si <= pc.last; ++si) n += h->segs[si].n_steps; steps = std::max(steps, n); }
+  const size_t rec = (size_t)h->pl.n_blocks * kStep;
+  const size_t want = (size_t)nm * (steps * h->pl.tab.s + 1) * rec;
+  if (h->d_traj2.n < want) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if ((want - h->d_traj2.n) * sizeof(double) + total_b / 20 > free_b) return false;
+  }
+  if (h->d_traj2.ensure(want) != hipSuccess || h->d_ring2.ensure((size_t)kPRing * nm * h->pl.n_blocks * kPos) != hipSuccess ||
+      (c.fn_tab && h->d_fn_tab2.ensure(h->d_fn_tab.n) != hipSuccess)) { (void)hipGetLastError(); return false; }
+  for (int b = 0; b < 2; ++b) {
+    if (!h->ev_rebuilt[b] && hipEventCreateWithFlags(&h->ev_rebuilt[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!h->ev_reversed[b] && hipEventCreateWithFlags(&h->ev_reversed[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  }
+  return true;
+}
+// one segment of the re-run on the second stream: its own cursor, time-function table and ring (cf carries cursor, table and record base)
+void enqueue_rerun_segment(dfx_handle* h, const DevCtx& cf, hipStream_t st, int seg_index) {
+  const int n_steps = h->segs[seg_index].n_steps;
+  hipLaunchKernelGGL(k_set_seg, dim3(1), dim3(1), 0, st, (const Seg*)h->d_segs.p, seg_index, const_cast<Seg*>(cf.cur));
+  h->launches++;
+  launch_fn_table(h, cf, st, h->pl.batch, n_steps);
+  launch_segment_persist(h, cf, st, h->pl.batch, n_steps, false, h->d_ring2.p);
 }
 
 int run_segment(dfx_handle* h, const DevCtx& c, int gi, int n_steps, int kind) {

@@ -300,6 +300,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   }
   if (fork_groups(h)) return 2;
   const bool eager = solve_is_eager(h) || h->persist_adj;
+  bool overlapped = false;
   if (h->segments) {
     // output intervals backwards: records of interval k rebuilt by re-running its forward pass from the resident output row k
     // (bit-identical to the first pass: same state, same arithmetic), then its reverse stages read them
@@ -322,9 +323,53 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     // kernel two hot-path spills: profiles/r02_fwd_spill_regression.txt).  The records of a piece are rebuilt by re-running its forward pass
     // from the resident output row of its interval, or from the restart row the forward pass left (bit-identical to the first pass: a step
     // starts from nothing but its state, same arithmetic), then its reverse stages read them.
-    for (int pi = (int)h->pieces.size() - 1; pi >= 0; --pi) {
+    const int np = (int)h->pieces.size();
+    auto shifted = [&](double* buf, const dfx_handle::Piece& pc) {
+      return buf - (size_t)h->segs[pc.first].base_step * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
+    };
+    if (seg_overlap_plan(h, c)) {
+      // Persistent loop, launches that leave room for each other: piece k-1 is re-run on the group's second stream into the OTHER record
+      // buffer while piece k is reversed on the first (engine_launch.hip, seg_overlap_plan).  Per buffer two events: records rebuilt ->
+      // its reverse launches may start; reverse stages done -> the re-run after next may overwrite it.  The re-run has its own cursor,
+      // time-function table and ring; the stage buffers belong to it alone (the reverse launches of the records level read records).
+      Group& g0 = h->groups[0];
+      const hipStream_t sf = g0.stream2, sr = g0.stream;
+      double* bufs[2] = {h->ck->traj.p, h->d_traj2.p};
+      DevCtx cf = group_ctx(h, c, 0);
+      cf.cur = h->d_cur.p + 1;
+      if (c.fn_tab) cf.fn_tab = h->d_fn_tab2.p;
+      HIP_OK(hipEventRecord(h->ev_fork2, sr));
+      HIP_OK(hipStreamWaitEvent(sf, h->ev_fork2, 0));
+      auto rerun = [&](int pi) {
+        const dfx_handle::Piece& pc = h->pieces[pi];
+        const int b = (np - 1 - pi) & 1;
+        if (np - 1 - pi >= 2) (void)hipStreamWaitEvent(sf, h->ev_reversed[b], 0);
+        cf.traj = shifted(bufs[b], pc);
+        const Seg& s0 = h->segs[pc.first];
+        const double* rows = pc.row < 0 ? h->d_fields.p + (size_t)pc.interval * nb6 : h->d_restart.p + (size_t)pc.row * nb6;
+        const long long stride = pc.row < 0 ? (long long)((size_t)Tn * nb6) : (long long)((size_t)h->n_restart_rows * nb6);
+        hipLaunchKernelGGL(k_init, slot_grid(h, g0), dim3(kThreads), 0, sf, cf, rows, s0.t_interval + s0.j0 * s0.h, 0, stride, (long long)s0.base_step);
+        hipLaunchKernelGGL(k_checkpoint0, dim3((unsigned)(((size_t)pl.n_blocks * kStep + kThreads - 1) / kThreads), (unsigned)g0.nm), dim3(kThreads), 0,
+                           sf, cf, (long long)s0.base_step);
+        h->launches += 2;
+        for (int si = pc.first; si <= pc.last; ++si) enqueue_rerun_segment(h, cf, sf, si);
+        (void)hipEventRecord(h->ev_rebuilt[b], sf);
+      };
+      rerun(np - 1);
+      for (int pi = np - 1; pi >= 0; --pi) {
+        if (pi > 0) rerun(pi - 1);
+        const dfx_handle::Piece& pc = h->pieces[pi];
+        const int b = (np - 1 - pi) & 1;
+        (void)hipStreamWaitEvent(sr, h->ev_rebuilt[b], 0);
+        c.traj = shifted(bufs[b], pc);
+        for (int si = pc.last; si >= pc.first; --si) enqueue_interleaved(h, c, h->segs[si].n_steps, 1, si);
+        (void)hipEventRecord(h->ev_reversed[b], sr);
+      }
+      overlapped = true;
+    } else
+    for (int pi = np - 1; pi >= 0; --pi) {
       const dfx_handle::Piece& pc = h->pieces[pi];
-      c.traj = h->ck->traj.p - (size_t)h->segs[pc.first].base_step * (size_t)c.rps * pl.batch * ((size_t)pl.n_blocks * kStep);
+      c.traj = shifted(h->ck->traj.p, pc);
       if (pc.row < 0) restart(c, h->d_fields.p + (size_t)pc.interval * nb6, (long long)((size_t)Tn * nb6), pc.first);
       else restart(c, h->d_restart.p + (size_t)pc.row * nb6, (long long)((size_t)h->n_restart_rows * nb6), pc.first);
       for (int si = pc.first; si <= pc.last; ++si) enqueue_interleaved(h, c, h->segs[si].n_steps, 0, si);
@@ -366,7 +411,7 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
     stats->rhs_evals = h->n_total * pl.tab.s;
     stats->launches = h->launches;
     stats->kernel_ms = ms;
-    stats->streams = (int64_t)h->groups.size();
+    stats->streams = overlapped ? 2 : (int64_t)h->groups.size();     // (segments level, re-run beside the reverse stages: two streams)
     stats->stage_kernel_us = h->n_total ? 1e3 * ms / (double)(h->n_total * pl.tab.s * 2) : 0.0;
     stats->stage_checkpoint = c.AD ? 1 : 0;
     stats->checkpoint_records = h->segments ? 2 : (c.rps > 1 ? 1 : 0);

@@ -122,7 +122,8 @@ typedef struct dfx_stats {
   int64_t launches;                       /* kernel launches issued                              */
   double kernel_ms;                       /* device time of the integration loop (HIP events)    */
   double stage_kernel_us;                 /* mean duration of one stage-kernel launch incl. gap  */
-  int64_t streams;                        /* member groups integrated concurrently (one HIP stream each) */
+  int64_t streams;                        /* member groups integrated concurrently (one HIP stream each); reverse sweep at the segments level
+                                             with the re-run of the next piece beside the reverse stages of this one: 2 */
   int64_t stage_checkpoint;               /* 1: the forward pass also kept the stage accelerations of every step, so the
                                              reverse sweep runs without recompute launches (chosen when it fits in HBM) */
   int64_t checkpoint_records;             /* 1: the forward pass kept EVERY stage record of every step (56 s B per unit and step): the

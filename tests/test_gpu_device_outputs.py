@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from .common import Case
-from .test_gpu_pair_launches import FAST
+FAST = dict(amplitude=7.5, loading_rate=3000.0, input_delay=1e-5)
 
 pytestmark = pytest.mark.gpu
 

@@ -184,6 +184,14 @@ def test_segments_level_in_pieces_equals_whole_intervals(hip_lib, persist):
         assert np.array_equal(parts[2][k], whole[2][k]), k
         assert relerr(parts[2][k], recs[2][k]) < 1e-10, k
     assert whole[1] > 0 and np.abs(whole[2]["centroid_node_vectors"]).max() > 0
+    if persist == "1":
+        # persistent loop: the re-run of piece k-1 ran on a second stream into a second record buffer beside the reverse stages of piece k
+        # (seg_overlap_plan); the serial order gives the same bits
+        assert parts[3]["adjoint"]["streams"] == 2 and whole[3]["adjoint"]["streams"] == 2
+        serial = _solve(c, ts, spi, target, {"DFX_PERSIST": "1", "DFX_CHECKPOINT": "segments", "DFX_SEG_CHUNK_STEPS": "256", "DFX_SEG_OVERLAP": "0"})
+        assert serial[3]["adjoint"]["streams"] == 1 and serial[1] == parts[1]
+        for k in parts[2]:
+            assert np.array_equal(serial[2][k], parts[2][k]), k
 
 
 @pytest.mark.parametrize("lattice,n,batch", [("quads", 12, 1), ("quads", 9, 3), ("kagome", 7, 2)])
