@@ -155,7 +155,7 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
   if (pl.contact == DFX_CONTACT_DISTANCE && (!q->block_centroids || !q->contact)) { err = "set_params: distance-based contact needs block_centroids and contact"; return 1; }
   if (pl.n_fns && !q->fn_params) { err = "set_params: fn_params required"; return 1; }
   const int B = pl.batch, NS = pl.n_slots, NB = pl.n_blocks;
-  out.slot.resize((size_t)B * NS * kSlotParams);
+  if (!gpu_image) out.slot.resize((size_t)B * NS * kSlotParams);      // (the GPU image is built from a per-thread scratch copy of one member's)
   out.inv_m.resize((size_t)B * NB * 3);
   out.damping.resize((size_t)B * NB * 3);
   out.contact.assign((size_t)B * 3, 0.0);
@@ -171,27 +171,44 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
   }
   struct Flags { bool k_uniform = true, l_dict_ok = true, damping_uniform = true; int n_dict = 0, bad = 0; };
   std::vector<Flags> flags(B);
-  auto member = [&](int m) {
-    Flags& F = flags[m];
+  // the nine per-slot values (r, l0, k, phi) of slot (b, k) of member m, straight from the ControlParams arrays
+  auto slot_values = [&](int m, int b, int k, double* s) {
     const double* cnv = q->centroid_node_vectors + (size_t)m * NB * pl.n_npb * 2;
     const double* l0 = q->reference_vector + (size_t)m * pl.n_bonds * 2;
     const double* kb = q->k_bond + (size_t)m * pl.n_bonds * 3;
     const double* ph = q->void_angle0 ? q->void_angle0 + (size_t)m * pl.n_bonds * 2 : nullptr;
-    double* sp = out.slot.data() + (size_t)m * NS * kSlotParams;
-    for (int b = 0; b < NB; ++b)
-      for (int k = 0; k < kSlots; ++k) {
-        double* s = sp + (size_t)(b * kSlots + k) * kSlotParams;
-        for (int i = 0; i < kSlotParams; ++i) s[i] = 0.0;
-        if (k >= pl.n_npb) continue;
-        s[0] = cnv[(b * pl.n_npb + k) * 2];
-        s[1] = cnv[(b * pl.n_npb + k) * 2 + 1];
-        int bond = pl.slot_bond[b * kSlots + k];
-        if (bond >= 0) {
-          s[2] = l0[2 * bond]; s[3] = l0[2 * bond + 1];
-          s[4] = kb[3 * bond]; s[5] = kb[3 * bond + 1]; s[6] = kb[3 * bond + 2];
-          if (ph) { s[7] = ph[2 * bond]; s[8] = ph[2 * bond + 1]; }
-        }
-      }
+    for (int i = 0; i < kSlotParams; ++i) s[i] = 0.0;
+    if (k >= pl.n_npb) return;
+    s[0] = cnv[(b * pl.n_npb + k) * 2];
+    s[1] = cnv[(b * pl.n_npb + k) * 2 + 1];
+    const int bond = pl.slot_bond[b * kSlots + k];
+    if (bond >= 0) {
+      s[2] = l0[2 * bond]; s[3] = l0[2 * bond + 1];
+      s[4] = kb[3 * bond]; s[5] = kb[3 * bond + 1]; s[6] = kb[3 * bond + 2];
+      if (ph) { s[7] = ph[2 * bond]; s[8] = ph[2 * bond + 1]; }
+    }
+  };
+  // GPU image, the two arrays that are uploaded only when a member's ligaments do NOT share their stiffnesses / have > 256 distinct reference
+  // vectors: filled in a second pass when that turns out to be so (they are 3 of the 5 MB a member's images take)
+  auto fill_l_k = [&](int m, bool want_l, bool want_k) {
+    double s[kSlotParams];
+    for (int s_ = 0; s_ < NS; ++s_) {
+      slot_values(m, s_ / kSlots, s_ % kSlots, s);
+      const bool lig = pl.slot_info[s_] >= 0;
+      if (want_l) { double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2; l[0] = lig ? s[2] : 0.0; l[1] = lig ? s[3] : 0.0; }
+      if (want_k) { double* k = out.p_k.data() + ((size_t)m * NS + s_) * 4; k[0] = lig ? s[4] : 0.0; k[1] = lig ? s[5] : 0.0; k[2] = lig ? s[6] : 0.0; k[3] = 0.0; }
+    }
+  };
+  auto member = [&](int m) {
+    Flags& F = flags[m];
+    const double* l0 = q->reference_vector + (size_t)m * pl.n_bonds * 2;
+    const double* kb = q->k_bond + (size_t)m * pl.n_bonds * 3;
+    const double* ph = q->void_angle0 ? q->void_angle0 + (size_t)m * pl.n_bonds * 2 : nullptr;
+    if (!gpu_image) {
+      double* sp = out.slot.data() + (size_t)m * NS * kSlotParams;
+      for (int b = 0; b < NB; ++b)
+        for (int k = 0; k < kSlots; ++k) slot_values(m, b, k, sp + (size_t)(b * kSlots + k) * kSlotParams);
+    }
     for (int e = 0; e < pl.n_ovf; ++e) {
       double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
       for (int i = 0; i < kOvfParams; ++i) o[i] = 0.0;
@@ -215,26 +232,40 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       tf.tab = pl.fn_table_ptr[f];
       for (int i = 0; i < DFX_FN_PARAMS; ++i) tf.p[i] = q->fn_params[((size_t)m * pl.n_fns + f) * DFX_FN_PARAMS + i];
     }
-    // ---- GPU structure-of-arrays image
+    // ---- GPU structure-of-arrays image: one pass over the slots -- node vector, void angles, dictionary index of the reference vector, the
+    // range of the void angles (culling bound), and whether the stiffnesses are uniform
     if (!gpu_image) return;
+    int n_dict = 0;
+    double* dict = out.l_dict.data() + (size_t)m * 1024;
+    double lo = 1e300, hi = -1e300;
+    double s[kSlotParams];
     for (int s_ = 0; s_ < NS; ++s_) {
-      const double* s = sp + (size_t)s_ * kSlotParams;
+      slot_values(m, s_ / kSlots, s_ % kSlots, s);
       double* r = out.p_r.data() + ((size_t)m * NS + s_) * 2;
-      double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
-      double* k = out.p_k.data() + ((size_t)m * NS + s_) * 4;
       double* ph2 = out.p_phi.data() + ((size_t)m * NS + s_) * 2;
       r[0] = s[0]; r[1] = s[1];
-      l[0] = l[1] = 0.0; k[0] = k[1] = k[2] = k[3] = 0.0; ph2[0] = ph2[1] = 0.0;
+      ph2[0] = ph2[1] = 0.0;
       out.l_idx[(size_t)m * NS + s_] = 0;
-      int info = pl.slot_info[s_];
-      if (info >= 0) {
-        if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { F.bad = 1; return; }
-        l[0] = s[2]; l[1] = s[3];
-        k[0] = s[4]; k[1] = s[5]; k[2] = s[6];
-        ph2[0] = s[7]; ph2[1] = s[8];
-        if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) F.k_uniform = false;
+      if (pl.slot_info[s_] < 0) continue;
+      if (!(s[2] * s[2] + s[3] * s[3] > 0.0)) { F.bad = 1; return; }
+      ph2[0] = s[7]; ph2[1] = s[8];
+      lo = s[7] < lo ? s[7] : lo; hi = s[7] > hi ? s[7] : hi;
+      lo = s[8] < lo ? s[8] : lo; hi = s[8] > hi ? s[8] : hi;
+      if (s[4] != kb[0] || s[5] != kb[1] || s[6] != kb[2]) F.k_uniform = false;
+      if (F.l_dict_ok) {      // dictionary of reference vectors
+        int hit = -1;
+        for (int d = 0; d < n_dict; ++d) if (dict[4 * d] == s[2] && dict[4 * d + 1] == s[3]) { hit = d; break; }
+        if (hit < 0) {
+          if (n_dict == 256) F.l_dict_ok = false;
+          else {
+            hit = n_dict++; dict[4 * hit] = s[2]; dict[4 * hit + 1] = s[3];
+            dict[4 * hit + 2] = sqrt(s[2] * s[2] + s[3] * s[3]); dict[4 * hit + 3] = 1.0 / dict[4 * hit + 2];
+          }
+        }
+        if (hit >= 0) out.l_idx[(size_t)m * NS + s_] = (uint8_t)hit;
       }
     }
+    F.n_dict = n_dict;
     for (int e = 0; e < pl.n_ovf; ++e) {
       const double* o = out.ovf.data() + ((size_t)m * pl.n_ovf + e) * kOvfParams;
       if (o[2] != kb[0] || o[3] != kb[1] || o[4] != kb[2]) F.k_uniform = false;
@@ -245,32 +276,12 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
       // = min(phi_lo - cutoff, pi - phi_hi) leaves both void angles wrap(phi -+ kappa) in [cutoff, pi]: the penalty and all its
       // derivatives are exactly zero whatever phi is, so the kernels do not load phi for such ligaments (cst[9] = kappa_safe with a
       // rounding margin, <= 0: never skip; cst[10] = phi_lo, the stand-in value).
-      double lo = 1e300, hi = -1e300;
-      for (int s_ = 0; s_ < NS; ++s_) if (pl.slot_info[s_] >= 0)
-        for (int a = 0; a < 2; ++a) { const double v = out.p_phi[((size_t)m * NS + s_) * 2 + a]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
       double safe = -1.0;
       if (lo <= hi) { const double a = lo - q->contact[m * 3 + 1], b2 = 3.14159265358979323846 - hi; safe = (a < b2 ? a : b2) * (1.0 - 1e-12) - 1e-12; }
       out.cst[(size_t)m * 16 + 9] = safe;
       out.cst[(size_t)m * 16 + 10] = lo <= hi ? lo : 0.0;
     }
     if (pl.n_bonds > 0) for (int i = 0; i < 3; ++i) out.cst[(size_t)m * 16 + 3 + i] = kb[i];
-    {  // dictionary of reference vectors
-      int n_dict = 0;
-      double* dict = out.l_dict.data() + (size_t)m * 1024;
-      for (int s_ = 0; s_ < NS && F.l_dict_ok; ++s_) {
-        if (pl.slot_info[s_] < 0) continue;
-        const double* l = out.p_l.data() + ((size_t)m * NS + s_) * 2;
-        int hit = -1;
-        for (int d = 0; d < n_dict; ++d) if (dict[4 * d] == l[0] && dict[4 * d + 1] == l[1]) { hit = d; break; }
-        if (hit < 0) {
-          if (n_dict == 256) { F.l_dict_ok = false; break; }
-          hit = n_dict++; dict[4 * hit] = l[0]; dict[4 * hit + 1] = l[1];
-          dict[4 * hit + 2] = sqrt(l[0] * l[0] + l[1] * l[1]); dict[4 * hit + 3] = 1.0 / dict[4 * hit + 2];
-        }
-        out.l_idx[(size_t)m * NS + s_] = (uint8_t)hit;
-      }
-      F.n_dict = n_dict;
-    }
     for (int d = 0; d < 3; ++d) {
       const double d0 = out.damping[(size_t)m * NB * 3 + d];
       out.cst[(size_t)m * 16 + 6 + d] = d0;
@@ -287,6 +298,10 @@ inline int pack_params(const Plan& pl, const dfx_params* q, PackedParams& out, s
     out.l_dict_ok = out.l_dict_ok && F.l_dict_ok;
     out.damping_uniform = out.damping_uniform && F.damping_uniform;
     if (F.n_dict > out.n_dict_max) out.n_dict_max = F.n_dict;
+  }
+  if (gpu_image && (!out.l_dict_ok || !out.k_uniform)) {
+    const bool want_l = !out.l_dict_ok, want_k = !out.k_uniform;
+    dfx_hostpar::for_each(B, (size_t)NS * 16, [&](int m) { fill_l_k(m, want_l, want_k); });
   }
   return 0;
 }
