@@ -309,7 +309,7 @@ def c3_as_written_leg(args, device, sync, steps=50000):
     os.environ["DFX_CHECKPOINT"] = "segments"
     os.environ["DFX_STREAMS"] = str(args.streams)
     try:
-        members = min(args.members, 16)             # (16 designs, whatever width the short-window job chose)
+        members = min(args.members, args.as_written_members)     # (16 designs: 32 measured the same rate -- 8.22e8 vs 8.17e8 -- in twice the time)
         fw, obj, designs = c3_problem(args.size, 3, members, device=device, input_delay=t_d,
                                       target_shift=(args.size // 6, args.size // 5))
         eng = fw.solve_dynamics.engine
@@ -835,6 +835,7 @@ def main():
     ap.add_argument("--c5-iterations", type=int, default=4)
     ap.add_argument("--no-as-written", action="store_true", help="skip the extra C3-as-written leg (segments checkpoint, paper's pulse "
                                                                  "delay and target placement, 2500 steps)")
+    ap.add_argument("--as-written-members", type=int, default=16, help="designs per GPU of the C3-as-written leg (at most the job's own width)")
     ap.add_argument("--as-written-steps", type=int, default=50000, help="steps of the C3-as-written leg (default: the whole 50 000-step horizon, ~18 s)")
     ap.add_argument("--all-ranks-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     ap.add_argument("--input-delay", type=float, default=0.0, help="pulse delay in s (C3 text: 0.1/f = 3.33e-3)")
