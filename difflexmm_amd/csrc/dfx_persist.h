@@ -107,7 +107,8 @@ __device__ __forceinline__ void load_lig_res(const DevCtx& c, const MemberBases&
   }
 }
 // the partner's ring record of stage ordinal t: polled until none of its four doubles is poison; false: gave up
-__device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, double (&r)[4], int t_ord, int* give_up, int limit) {
+__device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, double (&r)[4], int t_ord, int* give_up, int limit, int pre = 0) {
+  for (int q = 0; q < pre; ++q) __builtin_amdgcn_s_sleep(1);
   for (int spins = 0;;) {
     ring_load(place, byte_off, r);
     const bool ok = !(is_poison(r[0]) || is_poison(r[1]) || is_poison(r[2]) || is_poison(r[3]));
@@ -116,6 +117,19 @@ __device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, dou
     __builtin_amdgcn_s_sleep(1);
   }
 }
+
+#ifdef DFX_PERSIST_TIMING
+// diagnostic build (make timing -> variants/libdfx_timing.so): where one wave's stage goes, in ticks of the shader clock counter, summed over a
+// launch by wave 0 and left in the pinned words behind the give-up word (engine_forward.hip prints them)
+__device__ __forceinline__ unsigned long long tick() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define DFX_TICK(k) { const unsigned long long t_ = tick(); acc_t[k] += (unsigned)(t_ - t_prev); t_prev = t_; }
+#else
+#define DFX_TICK(k)
+#endif
 
 // lane -> (slot, block, node) of wave w of a member (lane_pos of dfx_kernels.h without the workgroup arithmetic)
 template <int NPB>
@@ -165,6 +179,13 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
   const double invm = ldg<double>(c.inv_m + (size_t)((u32)m * nd), o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
   const bool constrained = k < 3 && sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> k) & 1);
+  // a driven / loaded DOF's coefficients of the <= 2 time functions, resident (prescribed motion: con_coef, load: load_coef -- a DOF is one or
+  // the other); their table values are fetched in FRONT of the poll.  The wave that owns the driven edge would otherwise add two dependent
+  // round trips to every stage of its own, and over a segment every wave runs at the pace of the slowest (profiles/r06_persistent_phase_timing.txt)
+  double tf_coef[DFX_MAX_FNS];
+#pragma unroll
+  for (int f = 0; f < DFX_MAX_FNS; ++f)
+    tf_coef[f] = (k < 3 && sidx >= 0 && f < c.n_fns) ? (constrained ? c.special[sidx].con_coef[k][f] : c.special[sidx].load_coef[k][f]) : 0.0;
   const bool recs = c.rps > 1;
   const long long n0 = sg.base_step;
   double qn, vn;
@@ -188,6 +209,11 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
   const int total = pa.n_steps * s;
   int t_ord = 0;
   double v_i = vn;
+#ifdef DFX_PERSIST_TIMING
+  unsigned acc_t[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = tick();
+  const unsigned long long t_first = t_prev, w_first = wall_clock64();
+#endif
   for (int j = 0; j < pa.n_steps; ++j) {
     const long long n = n0 + j;
     double h = sg.h;
@@ -208,20 +234,34 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
           sv += pc.cv[i][l] * a_l;
           sq += pc.cq[i][l] * a_l;
         }
-        if (k < 3 && sidx >= 0 && !constrained) {
-          const dfx_special& sp = c.special[sidx];
-          const double* ft_i = fn_tab_row(c, m, j, i);
+        // the time functions' table values a driven / loaded DOF needs (prescribed value and rate at the NEXT stage time, or the load at this
+        // one): ASKED FOR here, used after the poll -- the two round trips overlap
+        double tv0[DFX_MAX_FNS], tv1[DFX_MAX_FNS];
+#pragma unroll
+        for (int f = 0; f < DFX_MAX_FNS; ++f) { tv0[f] = 0.0; tv1[f] = 0.0; }
+        if (k < 3 && sidx >= 0) {
+          const double* ft = fn_tab_row(c, m, j, constrained ? i + 1 : i);
           const u32 z = lane_zero();
-          for (int f = 0; f < c.n_fns; ++f) fload += sp.load_coef[k][f] * fn_tab_get(ft_i, f, 0, z);
+#pragma unroll
+          for (int f = 0; f < DFX_MAX_FNS; ++f)
+            if (f < c.n_fns) { tv0[f] = fn_tab_get(ft, f, 0, z); if (constrained) tv1[f] = fn_tab_get(ft, f, 1, z); }
         }
+        DFX_TICK(0)
         // ---- the partner's record of this stage
         const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
         double pr[4];
-        if (!ring_wait(place, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
+        if (!ring_wait(place, r_par, pr, t_ord, pa.give_up, pa.spin_limit, pa.pre_poll)) return;
+        DFX_TICK(1)
         if (k < 2 && t_ord + kPAhead <= total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
         BlockRec<double> p;
         p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];
         p.ch = half_cos(p.th, p.sh);
+        double q_pre = 0.0, v_pre = 0.0;
+#pragma unroll
+        for (int f = 0; f < DFX_MAX_FNS; ++f) {
+          if (constrained) { q_pre += tf_coef[f] * tv0[f]; v_pre += tf_coef[f] * tv1[f]; }
+          else fload += tf_coef[f] * tv0[f];
+        }
         // ---- ligament + contact of this slot (k_fwd_stage's arithmetic)
         double fx = 0.0, fy = 0.0, fth = 0.0;
         if (info >= 0) {
@@ -237,6 +277,7 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
             fth += g.sgn * cg.dkap;
           }
         }
+        DFX_TICK(2)
         const double dE = blk_reduce3<NPB>(fx, fy, fth, k);
         // ---- DOF epilogue
         double qnext = 0.0, vnext = 0.0;
@@ -250,23 +291,16 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
           for (int l = 0; l < kPersistStages; ++l) al[l] = l == i ? a : al[l];
           qnext = qn + h * (pc.c[i + 1] * vn + h * sq);
           vnext = vn + h * sv;
-          if (constrained) {
-            const dfx_special& sp = c.special[sidx];
-            const double* ft_n = fn_tab_row(c, m, j, i + 1);
-            const u32 z = lane_zero();
-            qnext = 0.0; vnext = 0.0;
-            for (int f = 0; f < c.n_fns; ++f) {
-              qnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 0, z);
-              vnext += sp.con_coef[k][f] * fn_tab_get(ft_n, f, 1, z);
-            }
-          }
+          if (constrained) { qnext = q_pre; vnext = v_pre; }
         }
+        DFX_TICK(3)
         // ---- the next stage record: into the ring for the neighbours, into the checkpoint for the reverse sweep
         const double y1 = blk_bcast<NPB, 1>(qnext, k), th2 = blk_bcast<NPB, 2>(qnext, k), x0 = blk_bcast<NPB, 0>(qnext, k);
         double sn, cs;
         fast_sincos(0.5 * th2, &sn, &cs);
         o.x = x0; o.y = y1; o.th = th2; o.sh = sn;
         ++t_ord;
+        DFX_TICK(4)
         const bool last = i == s - 1;
         if (k < 2) ring_store(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_own, k == 0 ? x0 : th2, k == 0 ? y1 : sn);
         if (k < 3) {
@@ -283,9 +317,18 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
         }
         v_i = vnext;
         if (last) { qn = qnext; vn = vnext; }
+        DFX_TICK(5)
       }
     }
   }
+#ifdef DFX_PERSIST_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int q = 0; q < 6; ++q) pa.give_up[1 + q] = (int)acc_t[q];
+    pa.give_up[7] = (int)(tick() - t_first);
+    pa.give_up[8] = (int)(wall_clock64() - w_first);       // 100 MHz
+    pa.give_up[9] = total;
+  }
+#endif
 }
 
 
@@ -335,6 +378,10 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
   const double invm = ldg<double>(c.inv_m + (size_t)((u32)m * nd), o_dof);
   const int sidx = ldg<int>(c.block_special, (u32)b * 4);
   const bool constrained = k < 3 && sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> k) & 1);
+  double tf_coef[DFX_MAX_FNS];      // k_fwd_persist: a driven / loaded DOF's coefficients of the time functions, resident
+#pragma unroll
+  for (int f = 0; f < DFX_MAX_FNS; ++f)
+    tf_coef[f] = (k < 3 && sidx >= 0 && f < c.n_fns) ? (constrained ? c.special[sidx].con_coef[k][f] : c.special[sidx].load_coef[k][f]) : 0.0;
   // ---- resident: lambda, accumulators
   double* LAMm = c.LAM + (size_t)((u32)m * nd6);
   const u32 ms = (u32)m * (u32)c.n_slots;
@@ -388,6 +435,16 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
         sqc += pc.cur[i][jj] * y.x;
         svc += pc.cur[i][jj] * y.y;
       }
+      // the load of a loaded DOF at this stage time (tabulated per segment): fetched here, in front of the poll
+      double tv0[DFX_MAX_FNS];
+#pragma unroll
+      for (int f = 0; f < DFX_MAX_FNS; ++f) tv0[f] = 0.0;
+      if (k < 3 && sidx >= 0 && !constrained) {
+        const double* ft = fn_tab_row(c, m, j, i);
+        const u32 z = lane_zero();
+#pragma unroll
+        for (int f = 0; f < DFX_MAX_FNS; ++f) if (f < c.n_fns) tv0[f] = fn_tab_get(ft, f, 0, z);
+      }
       const double col_s = pc.col[i][s], cur_s = pc.cur[i][s], col_i = pc.col[i][i];
       const double2 lam = s_lam[tid];
       const double lq = lam.x, lv = lam.y;
@@ -438,7 +495,7 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
         const u32 pb = (u32)(pslot >> 2) * 24;
         const double2 wxy = ldg<double2>(Win, pb);
         wp[0] = wxy.x; wp[1] = wxy.y; wp[2] = ldg<double>(Win, pb + 16);
-      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up, pa.spin_limit)) return;
+      } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up, pa.spin_limit, pa.pre_poll)) return;
       if (k < 2 && t_ord + kPAhead < total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
       BlockRec<double> o, p;
       o.x = o0.x; o.y = o0.y; o.th = o1.x; o.sh = o1.y; o.ch = half_cos(o.th, o.sh);
@@ -470,20 +527,17 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
       double w_next = 0.0;
       if (k < 3) {
         double fload = 0.0;
-        if (sidx >= 0) {
-          const dfx_special& sp = c.special[sidx];
+#pragma unroll
+        for (int f = 0; f < DFX_MAX_FNS; ++f) if (!constrained) fload += tf_coef[f] * tv0[f];
+        if (c.fn_g && sidx >= 0) {        // gradients w.r.t. the time functions' parameters (asked for explicitly: not the design loop's path)
           const double* ft = fn_tab_row(c, m, j, i);
-          for (int f = 0; f < c.n_fns; ++f) {
-            const double coef = constrained ? -hw * sp.con_coef[k][f] : w_d * sp.load_coef[k][f];
-            const bool loaded = !constrained && sp.load_coef[k][f] != 0.0;
-            if ((coef != 0.0 && c.fn_g) || loaded) {
+#pragma unroll
+          for (int f = 0; f < DFX_MAX_FNS; ++f) {
+            const double coef = f < c.n_fns ? (constrained ? -hw * tf_coef[f] : w_d * tf_coef[f]) : 0.0;
+            if (coef != 0.0) {
               const u32 z = lane_zero();
-              const double gv = fn_tab_get(ft, f, 0, z);
-              if (loaded) fload += sp.load_coef[k][f] * gv;
-              if (coef != 0.0 && c.fn_g) {
-                double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
-                for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * fn_tab_get(ft, f, 2 + kk, z));
-              }
+              double* q = c.fn_g + (((size_t)m * c.n_special + sidx) * DFX_MAX_FNS + f) * DFX_FN_PARAMS;
+              for (int kk = 0; kk < DFX_FN_PARAMS; ++kk) acc_add(q + kk, coef * fn_tab_get(ft, f, 2 + kk, z));
             }
           }
         }

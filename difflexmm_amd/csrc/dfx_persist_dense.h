@@ -65,6 +65,10 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
   const bool constrained = k < 3 && sidx >= 0 && ((c.special[sidx >= 0 ? sidx : 0].con_mask >> k) & 1);
   const bool dof_lane = valid && k < 3;
   const bool keep = aa.keep != 0;
+  double tf_coef[DFX_MAX_FNS];      // k_fwd_persist: a driven / loaded DOF's coefficients of the time functions, resident
+#pragma unroll
+  for (int f = 0; f < DFX_MAX_FNS; ++f)
+    tf_coef[f] = (valid && k < 3 && sidx >= 0 && f < c.n_fns) ? (constrained ? c.special[sidx].con_coef[k][f] : c.special[sidx].load_coef[k][f]) : 0.0;
   double* Am = c.A + (size_t)((u32)m * (u32)(c.s + 1) * nd);
   // ---- the state the launch starts from: y_n (record 0 of step `accepted`, or stage buffer 0) and the FSAL slope A_0
   long long n_acc = ck.accepted;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int f = 0; f < DFX_MAX_FNS; ++f) {
         const double gj = __shfl(fg[f], j, 64), gtj = __shfl(fgt[f], j, 64);
-        if (constrained && f < c.n_fns) { sq_ += c.special[sidx].con_coef[k][f] * gj; sv_ += c.special[sidx].con_coef[k][f] * gtj; }
+        if (constrained && f < c.n_fns) { sq_ += tf_coef[f] * gj; sv_ += tf_coef[f] * gtj; }
       }
       if (constrained) { q = sq_; v = sv_; }
     };
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int f = 0; f < DFX_MAX_FNS; ++f) {
         const double gj = __shfl(fg[f], j, 64);
-        if (k < 3 && sidx >= 0 && !constrained && f < c.n_fns) fl += c.special[sidx].load_coef[k][f] * gj;
+        if (k < 3 && sidx >= 0 && !constrained && f < c.n_fns) fl += tf_coef[f] * gj;
       }
       return fl;
     };
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       fload = load_at(i);
       // ---- the partner's record S_i
       double pr[4];
-      if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
+      if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up, pa.spin_limit, pa.pre_poll)) return;
       if (valid && k < 2) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
       BlockRec<double> p;
       p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];

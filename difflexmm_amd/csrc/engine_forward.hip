@@ -171,6 +171,12 @@ int ensure_work_buffers(dfx_handle* h) {
 // after the stream has been waited for: the non-finite flags of the forward pass (pinned words of flag_stage) and its statistics.
 // Returns -7 when a wave of a persistent launch gave up: the caller latches the handle onto stage launches and runs the solve again.
 int finish_forward(dfx_handle* h, dfx_stats* stats) {
+#ifdef DFX_PERSIST_TIMING
+  { const int* w = persist_give_up_word(h);
+    if (w[9] > 0) { const double tk = 10.0 * w[8] / std::max(1, w[7]);      // ns per tick
+      fprintf(stderr, "[dfx] forward loop, wave 0, last launch (%d stages, %.3f us per stage, %.2f ns per tick): pre-poll %.0f  poll %.0f  ligament %.0f  reduce+epilogue %.0f  sincos+ring store %.0f  checkpoint stores %.0f ns per stage\n",
+              w[9], 1e-3 * 10.0 * w[8] / w[9], tk, tk * (unsigned)w[1] / w[9], tk * (unsigned)w[2] / w[9], tk * (unsigned)w[3] / w[9], tk * (unsigned)w[4] / w[9], tk * (unsigned)w[5] / w[9], tk * (unsigned)w[6] / w[9]); } }
+#endif
   if (*persist_give_up_word(h)) { h->have_traj = false; return -7; }
   const int bad = *reinterpret_cast<const int*>(h->flag_stage.p);
   h->member_status.assign(h->pl.batch, 0);

@@ -397,6 +397,7 @@ int ensure_flags(dfx_handle* h) {
   return 0;
 }
 int* member_flags(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 16; }
+static int persist_pre_poll() { const char* e = getenv("DFX_PREPOLL"); return e ? atoi(e) : 0; }
 int persist_spin_limit(const dfx_handle* h) { return h->spin_limit > 0 ? h->spin_limit : kSpinLimit; }
 void persist_fell_back(dfx_handle* h) {
   h->persist_off = true;
@@ -469,7 +470,7 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     dfx_persist::launch_ring_poison(st, ring, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
     void* args_f[] = {&cc, &pcf, &pa};
     void* args_r[] = {&cc, &pca, &pa};
     launch_persist(h, fn, st, reverse ? args_r : args_f, grid, per_cu * persist_wg_slots(fn));
@@ -519,7 +520,7 @@ void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
     void* args[] = {&cc, &pc, &pa, &aa};
     launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
   }
@@ -557,7 +558,7 @@ void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, in
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
     void* args[] = {&cc, &pca, &pa, &dn};
     launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
   }
