@@ -126,7 +126,11 @@ __device__ __forceinline__ unsigned long long tick() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+#if DFX_PERSIST_TIMING == 2      // light: the poll against everything else, no waits added
+#define DFX_TICK(k) if ((k) < 4) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); acc_t[k] += (unsigned)(t_ - t_prev); t_prev = t_; }
+#else
 #define DFX_TICK(k) { const unsigned long long t_ = tick(); acc_t[k] += (unsigned)(t_ - t_prev); t_prev = t_; }
+#endif
 #else
 #define DFX_TICK(k)
 #endif
@@ -322,6 +326,11 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
     }
   }
 #ifdef DFX_PERSIST_TIMING
+  if (pa.dbg && (threadIdx.x & 63) == 0) {
+    unsigned* d = pa.dbg + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    for (int q = 0; q < 6; ++q) d[q] = acc_t[q];
+    d[6] = (unsigned)(tick() - t_first); d[7] = (unsigned)total;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int q = 0; q < 6; ++q) pa.give_up[1 + q] = (int)acc_t[q];
     pa.give_up[7] = (int)(tick() - t_first);

@@ -172,6 +172,17 @@ int ensure_work_buffers(dfx_handle* h) {
 // Returns -7 when a wave of a persistent launch gave up: the caller latches the handle onto stage launches and runs the solve again.
 int finish_forward(dfx_handle* h, dfx_stats* stats) {
 #ifdef DFX_PERSIST_TIMING
+  { extern unsigned* persist_dbg_buffer();
+    const unsigned* d = persist_dbg_buffer();
+    const int nw = std::min(4096, (int)h->pl.batch * ((h->pl.n_slots + 63) / 64));
+    if (getenv("DFX_TIMING_WAVES") && d[7] > 0) {
+      const int* w0 = persist_give_up_word(h);
+      const double tk = 10.0 * w0[8] / std::max(1, w0[7]);
+      fprintf(stderr, "[dfx] per wave: poll / ligament+contact / reduce+epilogue / rest ns per stage:");
+      for (int w = 0; w < nw; ++w) { const unsigned* q = d + (size_t)w * 8; if (!q[7]) continue;
+        fprintf(stderr, "%s%d:%.0f/%.0f/%.0f/%.0f", w % 6 ? "  " : "\n   ", w, tk * q[1] / q[7], tk * q[2] / q[7], tk * q[3] / q[7], tk * (q[0] + q[4] + q[5]) / q[7]); }
+      fprintf(stderr, "\n");
+    } }
   { const int* w = persist_give_up_word(h);
     if (w[9] > 0) { const double tk = 10.0 * w[8] / std::max(1, w[7]);      // ns per tick
       fprintf(stderr, "[dfx] forward loop, wave 0, last launch (%d stages, %.3f us per stage, %.2f ns per tick): pre-poll %.0f  poll %.0f  ligament %.0f  reduce+epilogue %.0f  sincos+ring store %.0f  checkpoint stores %.0f ns per stage\n",

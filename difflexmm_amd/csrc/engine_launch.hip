@@ -397,6 +397,9 @@ int ensure_flags(dfx_handle* h) {
   return 0;
 }
 int* member_flags(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p) + 16; }
+#ifdef DFX_PERSIST_TIMING
+unsigned* persist_dbg_buffer() { static unsigned* p = nullptr; if (!p) { (void)hipHostMalloc((void**)&p, 8 * 4 * 8192 * sizeof(unsigned), hipHostMallocDefault); memset(p, 0, 8 * 4 * 8192 * sizeof(unsigned)); } return p; }
+#endif
 static int persist_pre_poll() { const char* e = getenv("DFX_PREPOLL"); return e ? atoi(e) : 0; }
 int persist_spin_limit(const dfx_handle* h) { return h->spin_limit > 0 ? h->spin_limit : kSpinLimit; }
 void persist_fell_back(dfx_handle* h) {
@@ -471,6 +474,9 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     h->launches++;
     PersistArgs pa;
     pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
+#ifdef DFX_PERSIST_TIMING
+    pa.dbg = (!reverse && grid <= 8192) ? persist_dbg_buffer() : nullptr;
+#endif
     void* args_f[] = {&cc, &pcf, &pa};
     void* args_r[] = {&cc, &pca, &pa};
     launch_persist(h, fn, st, reverse ? args_r : args_f, grid, per_cu * persist_wg_slots(fn));
@@ -521,6 +527,9 @@ void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int
     h->launches++;
     PersistArgs pa;
     pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
+#ifdef DFX_PERSIST_TIMING
+    pa.dbg = nullptr;
+#endif
     void* args[] = {&cc, &pc, &pa, &aa};
     launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
   }
@@ -559,6 +568,9 @@ void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, in
     h->launches++;
     PersistArgs pa;
     pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
+#ifdef DFX_PERSIST_TIMING
+    pa.dbg = nullptr;
+#endif
     void* args[] = {&cc, &pca, &pa, &dn};
     launch_persist(h, fn, st, args, grid, per_cu * persist_wg_slots(fn));
   }
