@@ -26,6 +26,45 @@
 #include "dfx_persist.h"
 #include "dfx_dense.h"
 
+// ---- wave-wide helpers of the controller.  The sums keep the ORDER of the shfl_down tree (32, 16, .. 1) the stage launches use, so the bits
+// agree, but not its cost: a 64-bit __shfl_down is two ds_bpermute round trips per level (~0.3 us for the tree, twice per attempt, on every
+// wave's critical path); gfx950's permlane swaps bring lanes i+32 / i+16 to lane i, DPP row shifts the rest (tools/mock/permlane_probe.hip:
+// identical bits)
+template <int CTRL> __device__ __forceinline__ double dpp_row_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lanes_plus_32(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double lanes_plus_16(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+// lane 0 receives what `for (off = 32; off; off >>= 1) v += __shfl_down(v, off, 64)` leaves there, bit for bit (other lanes: no meaning)
+__device__ __forceinline__ double wave_sum_lane0(double v) {
+  v += lanes_plus_32(v);
+  v += lanes_plus_16(v);
+  v += dpp_row_mov<0x108>(v);      // row_shl:8
+  v += dpp_row_mov<0x104>(v);
+  v += dpp_row_mov<0x102>(v);
+  v += dpp_row_mov<0x101>(v);
+  return v;
+}
+__device__ __forceinline__ double lane_value(double v, int lane_uniform) {       // v of one lane (a wave-uniform index), to all
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform), __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
+}
+
+#ifndef DFX_DENSE_OCC
+#define DFX_DENSE_OCC __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 namespace {
 
 __device__ __forceinline__ double err_load(const double* p) {
@@ -38,7 +77,9 @@ __device__ __forceinline__ void err_store(double* p, double v) {
 }
 
 template <int MODEL, int CONTACT>
-__global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_adaptive_fwd_loop(DevCtx c, AdaptLoopCoef pc, PersistArgs pa, AdaptLoopArgs aa) {
+// (no occupancy pin: at three workgroups per compute unit the loop spills 44 B per lane into its stage chain, 31.0 against 27.7 ms for the paper
+// workload; 174-182 registers = two workgroups per compute unit = 2 048 waves per launch, wider ensembles follow in further launches)
+__global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c, AdaptLoopCoef pc, PersistArgs pa, AdaptLoopArgs aa) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
   if (wave >= pa.waves_per_member * pa.nm) return;
   const int W = pa.waves_per_member;
@@ -95,6 +136,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
   const double* ts_out = c.ts_dev;
   const int Tn = aa.n_timepoints;
   double t = ck.t, h = ck.h;
+  double t_out_next = ck.out_idx < Tn ? ts_out[ck.out_idx] : 1.7976931348623157e308;
   int t_ord = 0;
   long long attempt = 0;
   for (; attempt < pa.n_steps; ++attempt) {
@@ -120,7 +162,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       double sq_ = 0.0, sv_ = 0.0;
 #pragma unroll
       for (int f = 0; f < DFX_MAX_FNS; ++f) {
-        const double gj = __shfl(fg[f], j, 64), gtj = __shfl(fgt[f], j, 64);
+        const double gj = lane_value(fg[f], j), gtj = lane_value(fgt[f], j);
         if (constrained && f < c.n_fns) { sq_ += tf_coef[f] * gj; sv_ += tf_coef[f] * gtj; }
       }
       if (constrained) { q = sq_; v = sv_; }
@@ -130,7 +172,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       if (!need_fn) return fl;
 #pragma unroll
       for (int f = 0; f < DFX_MAX_FNS; ++f) {
-        const double gj = __shfl(fg[f], j, 64);
+        const double gj = lane_value(fg[f], j);
         if (k < 3 && sidx >= 0 && !constrained && f < c.n_fns) fl += tf_coef[f] * gj;
       }
       return fl;
@@ -219,7 +261,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       }
     }
     // ---- error norm: per-wave sum (the order of k_fwd_stage's error mode), all-gather of the member's partials, k_control's order
-    for (int off = 32; off > 0; off >>= 1) r2 += __shfl_down(r2, off, 64);
+    r2 = wave_sum_lane0(r2);
     double* slot_now = err_m + (size_t)(attempt % 3) * err_stride;
     if (lane == 0) err_store(slot_now + w, r2);
     double acc_a = 0.0, acc_b = 0.0;
@@ -238,8 +280,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
     }
     if (lane == 0) err_store(err_m + (size_t)((attempt + 2) % 3) * err_stride + w, __hiloint2double((int)kPoisonWord, (int)kPoisonWord));
     double red = acc_a + acc_b;
-    for (int off = 32; off > 0; off >>= 1) red += __shfl_down(red, off, 64);
-    red = __shfl(red, 0, 64);
+    red = lane_value(wave_sum_lane0(red), 0);
     const double ratio = sqrt(red / aa.two_n_free);
     ck.attempts++;
     if (!(ratio == ratio)) { ck.state = 2; break; }
@@ -248,7 +289,10 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
       const double t_new = t + h;
       const int out_lo = ck.out_idx;
       int out_hi = out_lo;
-      while (out_hi < Tn && ts_out[out_hi] <= t_new) ++out_hi;
+      if (t_out_next <= t_new) {        // (the next output time rides in a register: no load on the path of a step that crosses none)
+        while (out_hi < Tn && ts_out[out_hi] <= t_new) ++out_hi;
+        t_out_next = out_hi < Tn ? ts_out[out_hi] : 1.7976931348623157e308;
+      }
       if (dof_lane && out_hi > out_lo) {          // dense output for the outputs this step crosses (k_prepare)
         double sm = pc.cm[0] * al[0] + pc.cm[6] * al[6], sma = pc.cma[0] * al[0] + pc.cma[6] * al[6];
 #pragma unroll
@@ -302,7 +346,7 @@ __global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu
 
 // the reverse sweep of the kept steps without kernel boundaries: adj_persist_body<..., DENSE = 1> (dfx_persist.h)
 template <int MODEL, int CONTACT, int NPB>
-__global__ __launch_bounds__(kPersistThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_adj_dense_loop(DevCtx c, PersistAdjCoef pc, PersistArgs pa,
+__global__ __launch_bounds__(kPersistThreads) DFX_DENSE_OCC void k_adj_dense_loop(DevCtx c, PersistAdjCoef pc, PersistArgs pa,
                                                                                                            DenseCtx dn) {
   adj_persist_body<MODEL, CONTACT, NPB, 1>(c, pc, pa, dn);
 }
