@@ -28,7 +28,6 @@ struct PersistArgs {
   int* give_up;                 // pinned host word: != 0 once a wave gave up (1 + the stage ordinal it waited for)
   int n_steps, nm, waves_per_member;
   int spin_limit;               // polls before a wave gives up (kSpinLimit; the test hook dfx_test_set_spin_limit makes it tiny)
-  int pre_poll;                 // s_sleep(1) units in front of the first poll of a hand-off (experiment: DFX_PREPOLL)
 #ifdef DFX_PERSIST_TIMING
   unsigned* dbg;                // diagnostic build: 8 words per wave (six phase sums, total ticks, stages)
 #endif

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c,
       fload = load_at(i);
       // ---- the partner's record S_i
       double pr[4];
-      if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up, pa.spin_limit, pa.pre_poll)) return;
+      if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
       if (valid && k < 2) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
       BlockRec<double> p;
       p.x = pr[0]; p.y = pr[1]; p.th = pr[2]; p.sh = pr[3];

@@ -400,7 +400,6 @@ int* member_flags(dfx_handle* h) { return reinterpret_cast<int*>(h->flag_stage.p
 #ifdef DFX_PERSIST_TIMING
 unsigned* persist_dbg_buffer() { static unsigned* p = nullptr; if (!p) { (void)hipHostMalloc((void**)&p, 8 * 4 * 8192 * sizeof(unsigned), hipHostMallocDefault); memset(p, 0, 8 * 4 * 8192 * sizeof(unsigned)); } return p; }
 #endif
-static int persist_pre_poll() { const char* e = getenv("DFX_PREPOLL"); return e ? atoi(e) : 0; }
 int persist_spin_limit(const dfx_handle* h) { return h->spin_limit > 0 ? h->spin_limit : kSpinLimit; }
 void persist_fell_back(dfx_handle* h) {
   h->persist_off = true;
@@ -473,7 +472,7 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     dfx_persist::launch_ring_poison(st, ring, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
+    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
 #ifdef DFX_PERSIST_TIMING
     pa.dbg = (!reverse && grid <= 8192) ? persist_dbg_buffer() : nullptr;
 #endif
@@ -526,7 +525,7 @@ void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
 #ifdef DFX_PERSIST_TIMING
     pa.dbg = nullptr;
 #endif
@@ -567,7 +566,7 @@ void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, in
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.pre_poll = persist_pre_poll();
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
 #ifdef DFX_PERSIST_TIMING
     pa.dbg = nullptr;
 #endif
