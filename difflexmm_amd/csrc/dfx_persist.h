@@ -417,26 +417,10 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
   const u32 r_par = ((u32)m * (u32)c.n_blocks + (u32)(pslot >> 2)) * (kPos * 8);
   const int total = DENSE ? (j_top + 1) * s - ((sg.base_step + j_top == n_m) ? s - 1 : 0) : pa.n_steps * s;
   int t_ord = 0;
-  // dense output: which outputs lie in step n ([op_lo, op_hi)) and in the step before it ([op_plo, op_lo)) -- carried from step to step, the
-  // one new entry a step needs asked for a step ahead (six stages each waited for these loads before: 2.9 against 2.3 us per stage)
-  int op_plo = 0, op_lo = 0, op_hi = 0, op_next = 0;
-  if constexpr (DENSE) {
-    const int* op = dn.out_ptr + (size_t)m * dn.stride;
-    const long long n1 = sg.base_step + j_top;
-    op_lo = op[n1]; op_hi = op[n1 + 1]; op_plo = n1 > 0 ? op[n1 - 1] : op_lo;
-  }
-  // caller-chosen / kept step boundaries: t_{n+1}, t_n, t_{n-1} carried the same way
-  double ts_hi = 0.0, ts_lo = 0.0, ts_plo = 0.0, ts_next = 0.0;
-  if (c.t_steps) {
-    const double* ts = steps_of(c, m);
-    const long long n1 = sg.base_step + j_top;
-    ts_hi = ts[n1 + 1]; ts_lo = ts[n1]; ts_plo = n1 > 0 ? ts[n1 - 1] : ts_lo;
-  }
   for (int j = j_top; j >= 0; --j) {
     const long long n = sg.base_step + j;
-    if constexpr (DENSE) { const int* op = dn.out_ptr + (size_t)m * dn.stride; op_next = n > 1 ? op[n - 2] : op_plo; }
     double h = sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
-    if (c.t_steps) { ts_next = n > 1 ? steps_of(c, m)[n - 2] : ts_plo; h = ts_hi - ts_lo; h_before = n > 0 ? ts_lo - ts_plo : 0.0; }
+    if (c.t_steps) { const double* ts = steps_of(c, m); h = ts[n + 1] - ts[n]; h_before = n > 0 ? ts[n] - ts[n - 1] : 0.0; }
 #pragma unroll 1
     for (int i = (DENSE && n == n_m) ? 0 : s - 1; i >= 0; --i) {
       const int win = (int)((n * s + i) & 1);
@@ -478,7 +462,8 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
       double e_own_q = 0.0, e_nxt_v = 0.0, gs_q = 0.0, gs_v = 0.0;
       if constexpr (DENSE) {
         if (!constrained) {
-          const int lo = op_lo, hi = op_hi, plo = op_plo;
+          const int* op = dn.out_ptr + (size_t)m * dn.stride;
+          const int lo = op[n], hi = op[n + 1], plo = n > 0 ? op[n - 1] : lo;
           const double* dwm = dn.dw + (size_t)m * dn.n_out * 8;
           const u32 o_g = ((u32)b * 6 + kd) * 8;
           double e_own_v = 0.0;
@@ -602,8 +587,6 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
         stg<double>(c.W + (size_t)(((u32)m * 2 + (u32)(win ^ 1)) * nd), o_dof, w_next);
       }
     }
-    if constexpr (DENSE) { op_hi = op_lo; op_lo = op_plo; op_plo = op_next; }
-    if (c.t_steps) { ts_hi = ts_lo; ts_lo = ts_plo; ts_plo = ts_next; }
   }
   // ---- what the segment leaves behind
   if (info >= 0) stg<double2>(grm, (u32)slot * 16, s_racc[tid]);
