@@ -106,18 +106,6 @@ __device__ __forceinline__ void load_lig_res(const DevCtx& c, const MemberBases&
     g.phi1 = ph.x; g.phi2 = ph.y;
   }
 }
-// A first look at the partner's record that does NOT wait: four 8-byte loads past the L1 (relaxed, device scope: sc1) the compiler knows about,
-// so that what a stage can do without the partner's record runs while they are in flight.  A wave's stage is  poll + arithmetic + store;
-// the poll used to start only after that independent work, i.e. one full load round trip (~0.45 us) sat on the chain of EVERY stage although
-// the neighbour's record had long arrived (profiles/r06_persistent_phase_timing.txt).  Poison in any word: the blocking poll below takes over.
-__device__ __forceinline__ void ring_probe(const double* place, u32 byte_off, double (&r)[4]) {
-  const double* p = reinterpret_cast<const double*>(reinterpret_cast<const char*>(place) + byte_off);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) r[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool ring_ready(const double (&r)[4]) {
-  return __all(!(is_poison(r[0]) || is_poison(r[1]) || is_poison(r[2]) || is_poison(r[3])));
-}
 // the partner's ring record of stage ordinal t: polled until none of its four doubles is poison; false: gave up
 __device__ __forceinline__ bool ring_wait(const double* place, u32 byte_off, double (&r)[4], int t_ord, int* give_up, int limit) {
   for (int spins = 0;;) {
@@ -239,12 +227,8 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
 #pragma unroll 1
     for (int i = 0; i < s; ++i) {
       {
-        // ---- the partner's record of this stage: asked for first (ring_probe) ...
-        const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
-        double pr[4];
-        ring_probe(place, r_par, pr);
-        // ---- ... then what does not need it (a wave alone on its SIMD has nothing else to do while it waits): the own half-angle
-        // cosine, the Runge-Kutta sums over the EARLIER stages' accelerations, the load of a loaded block
+        // ---- what does not need the partner's record, in front of the poll (a wave alone on its SIMD has nothing else to do while it
+        // waits): the own half-angle cosine, the Runge-Kutta sums over the EARLIER stages' accelerations, the load of a loaded block
         o.ch = half_cos(o.th, o.sh);
         double sv = 0.0, sq = 0.0, fload = 0.0;
 #pragma unroll
@@ -266,7 +250,10 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
             if (f < c.n_fns) { tv0[f] = fn_tab_get(ft, f, 0, z); if (constrained) tv1[f] = fn_tab_get(ft, f, 1, z); }
         }
         DFX_TICK(0)
-        if (!ring_ready(pr) && !ring_wait(place, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
+        // ---- the partner's record of this stage
+        const double* place = pa.ring + (size_t)(t_ord % kPRing) * ring_stride;
+        double pr[4];
+        if (!ring_wait(place, r_par, pr, t_ord, pa.give_up, pa.spin_limit)) return;
         DFX_TICK(1)
         if (k < 2 && t_ord + kPAhead <= total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
         BlockRec<double> p;
