@@ -417,6 +417,11 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
   const u32 r_par = ((u32)m * (u32)c.n_blocks + (u32)(pslot >> 2)) * (kPos * 8);
   const int total = DENSE ? (j_top + 1) * s - ((sg.base_step + j_top == n_m) ? s - 1 : 0) : pa.n_steps * s;
   int t_ord = 0;
+#ifdef DFX_PERSIST_TIMING
+  unsigned acc_t[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = tick();
+  const unsigned long long t_first = t_prev;
+#endif
   for (int j = j_top; j >= 0; --j) {
     const long long n = sg.base_step + j;
     double h = sg.h, h_before = (sg.j0 + j) == 0 ? sg.h_prev : sg.h;
@@ -498,12 +503,14 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
       }
       const double wox = blk_bcast<NPB, 0>(w_d, k), woy = blk_bcast<NPB, 1>(w_d, k), woth = blk_bcast<NPB, 2>(w_d, k);
       double wp[4];
+      DFX_TICK(0)
       if (t_ord == 0) {
         const double* Win = c.W + (size_t)(((u32)m * 2 + (u32)win) * nd);
         const u32 pb = (u32)(pslot >> 2) * 24;
         const double2 wxy = ldg<double2>(Win, pb);
         wp[0] = wxy.x; wp[1] = wxy.y; wp[2] = ldg<double>(Win, pb + 16);
       } else if (!ring_wait(pa.ring + (size_t)(t_ord % kPRing) * ring_stride, r_par, wp, t_ord, pa.give_up, pa.spin_limit)) return;
+      DFX_TICK(1)
       if (k < 2 && t_ord + kPAhead < total) ring_poison(pa.ring + (size_t)((t_ord + kPAhead) % kPRing) * ring_stride, r_own);
       BlockRec<double> o, p;
       o.x = o0.x; o.y = o0.y; o.th = o1.x; o.sh = o1.y; o.ch = half_cos(o.th, o.sh);
@@ -529,6 +536,7 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
         s_racc[tid] = make_double2(r_old.x - d_rx, r_old.y - d_ry);
       }
       if (CONTACT == 1 && d_phi != 0.0) { s_acc[0][tid] -= d_phi; phi_any = true; }
+      DFX_TICK(2)
       const double hw = blk_reduce3<NPB>(hx, hy, hth, k);
       const double dE = blk_reduce3<NPB>(ex, ey, eth, k);
       // ---- DOF epilogue
@@ -578,6 +586,7 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
         if constexpr (DENSE) kv += e_nxt_v;
         w_next = constrained ? 0.0 : kv * invm;
       }
+      DFX_TICK(3)
       // ---- w of the next stage to run: into the ring, or -- last stage of the launch -- where the next launch reads it
       ++t_ord;
       if (t_ord < total) {
@@ -588,6 +597,13 @@ __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistA
       }
     }
   }
+#ifdef DFX_PERSIST_TIMING
+  if (pa.dbg && (threadIdx.x & 63) == 0) {
+    unsigned* d = pa.dbg + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    for (int q = 0; q < 6; ++q) d[q] = acc_t[q];
+    d[6] = (unsigned)(tick() - t_first); d[7] = (unsigned)total;
+  }
+#endif
   // ---- what the segment leaves behind
   if (info >= 0) stg<double2>(grm, (u32)slot * 16, s_racc[tid]);
   if (CONTACT == 1 && phi_any) { stg<double>(gpm, (u32)slot * 8, s_acc[0][tid]); c.touch[0] = 1; }

@@ -474,7 +474,7 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     PersistArgs pa;
     pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
 #ifdef DFX_PERSIST_TIMING
-    pa.dbg = (!reverse && grid <= 8192) ? persist_dbg_buffer() : nullptr;
+    pa.dbg = ((reverse ? getenv("DFX_TIMING_REVERSE") != nullptr : getenv("DFX_TIMING_REVERSE") == nullptr) && grid <= 8192) ? persist_dbg_buffer() : nullptr;
 #endif
     void* args_f[] = {&cc, &pcf, &pa};
     void* args_r[] = {&cc, &pca, &pa};

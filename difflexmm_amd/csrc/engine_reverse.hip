@@ -389,6 +389,18 @@ static int run_adjoint(dfx_handle* h, const dfx_grads* want, dfx_grads* grads, d
   HIP_OK(hipEventRecord(h->ev3, h->stream));
   if (timing) fprintf(stderr, "[dfx] adjoint: sweep enqueued %.0f us after entry\n", since(ta0));
   if (int rc = collect_grads(h, want, grads, views, true)) return rc;
+#ifdef DFX_PERSIST_TIMING
+  if (getenv("DFX_TIMING_REVERSE") && getenv("DFX_TIMING_WAVES")) {
+    extern unsigned* persist_dbg_buffer();
+    const unsigned* d = persist_dbg_buffer();
+    const int nw = std::min(4096, (int)h->pl.batch * ((h->pl.n_slots + 63) / 64));
+    float ms1 = 0.f; (void)hipEventElapsedTime(&ms1, h->ev2, h->ev3);
+    fprintf(stderr, "[dfx] reverse loop per wave, last launch: before the poll / poll / Hessian-vector product / epilogue + rest, in counter ticks per stage (sweep %.3f us per stage):", 1e3 * ms1 / std::max<long long>(1, h->n_total * pl.tab.s));
+    for (int w = 0; w < nw; ++w) { const unsigned* q = d + (size_t)w * 8; if (!q[7]) continue;
+      fprintf(stderr, "%s%d:%u/%u/%u/%u", w % 6 ? "  " : "\n   ", w, q[0] / q[7], q[1] / q[7], q[2] / q[7], (q[3] + q[4] + q[5]) / q[7]); }
+    fprintf(stderr, "\n");
+  }
+#endif
   if (*persist_give_up_word(h)) {
     // a wave of a persistent launch gave up.  A give-up inside the forward pass of the fused call (its flag is read only now) invalidates the
     // trajectory: the fused call runs everything again (-7).  Otherwise the records are good: the sweep alone is run again on stage launches
