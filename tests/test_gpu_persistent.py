@@ -290,3 +290,22 @@ def test_a_launch_that_cannot_get_resident_falls_back_in_process(hip_lib, mode):
         assert res[1] == ref[1]
         for k in ref[2]:
             assert np.array_equal(res[2][k], ref[2][k]), k
+
+
+def test_the_second_record_buffer_of_the_overlapped_segments_level_is_released(hip_lib):
+    """Engines that ran the segments level with the re-run beside the reverse stages (second record buffer, ring and time-function table:
+    seg_overlap_plan) give their device memory back when they are closed."""
+    from difflexmm_amd._binding import mem_info
+    ts = np.array([0.0, 4e-4, 6e-4])
+    target = np.array([44, 45], dtype=np.int32)
+    free = []
+    for it in range(6):
+        c = Case("quads", 10, True, True, seed=4, cutoff_deg=42.0, batch=1)
+        c.cp = c.cp._replace(constraint_params=FAST)
+        out = _solve(c, ts, [600, 300], target, {"DFX_PERSIST": "1", "DFX_CHECKPOINT": "segments", "DFX_SEG_CHUNK_STEPS": "256"})
+        assert out[3]["adjoint"]["streams"] == 2
+        c.solver.engine.close()
+        del c
+        free.append(mem_info(0)[0])
+    assert free[-1] >= free[2] - (1 << 20), free          # (the first cycles grow the runtime's own pools)
+
