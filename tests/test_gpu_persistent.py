@@ -309,3 +309,29 @@ def test_the_second_record_buffer_of_the_overlapped_segments_level_is_released(h
         free.append(mem_info(0)[0])
     assert free[-1] >= free[2] - (1 << 20), free          # (the first cycles grow the runtime's own pools)
 
+
+def test_adaptive_loop_with_the_members_in_several_launches(hip_lib):
+    """Members that do not fit the chip at once follow in further launches of the adaptive loop, every launch carrying its members through
+    their own attempts (launch_adaptive_persist; forced here with DFX_PERSIST_MAX_WG=1: six 64 x 64 systems are 1 536 waves against
+    1 024 places).  Same accepted steps as the stage-launch controller, fields and gradients to the controller's rounding sensitivity."""
+    batch = 6
+    c = Case("quads", 64, True, True, seed=17, cutoff_deg=42.0, batch=batch)
+    cps = [c.cp._replace(constraint_params=dict(FAST, amplitude=7.5 / (1 + 0.6 * m))) for m in range(batch)]
+    ts = np.linspace(0.0, 2e-4, 11)
+    mid = c.geo.n_blocks // 2
+    target = np.array([mid + 1, mid + 2], dtype=np.int32)
+
+    def run():
+        f = np.array(c.solver(np.zeros((2, c.geo.n_blocks, 3)), ts, cps, keep_trajectory=True))
+        st = dict(c.solver.stats)
+        obj, raw = c.solver.kinetic_energy_value_and_raw(target)
+        return f, st, np.array(c.solver.engine.adaptive_step_counts()), np.atleast_1d(obj).copy(), {k: np.array(v) for k, v in raw.items()}, dict(c.solver.adjoint_stats)
+    ref = _with_env({"DFX_PERSIST": "0"}, run)
+    out = _with_env({"DFX_PERSIST": "1", "DFX_PERSIST_MAX_WG": "1"}, run)
+    assert ref[1]["tile_kernels"] == 0 and out[1]["tile_kernels"] == 3 and out[5]["tile_kernels"] == 3
+    assert out[1]["launches"] >= 4                                   # (two launches of three members, each with its ring poison)
+    assert np.array_equal(out[2], ref[2]) and len({int(x) for x in out[2].sum(axis=1)}) > 1
+    assert relerr(out[0], ref[0]) < 1e-8 and relerr(out[3], ref[3]) < 1e-8
+    for k in ("centroid_node_vectors", "inertia"):
+        assert relerr(out[4][k], ref[4][k]) < 1e-6, k
+
