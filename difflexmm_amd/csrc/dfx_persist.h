@@ -134,6 +134,26 @@ __device__ __forceinline__ unsigned long long tick() {
 #define DFX_TICK(k)
 #endif
 
+// which member and which of its waves this wave is.  Dense: waves packed one after the other.  XCD-aware (pa.xcd_wg workgroups per member, small
+// lattices): the dispatcher deals workgroups round-robin over the eight XCDs (tools/mock/handoff_scope_mock.hip: workgroup b on XCD b % 8,
+// 256 of 256), so member  8 * mi + x  takes workgroups  (mi * xcd_wg + j) * 8 + x,  j < xcd_wg -- all on XCD x: its hand-offs stay under one L2
+// (0.34 against 0.45 us per hand-off).  Only the latency depends on the placement really being so; the protocol does not.
+__device__ __forceinline__ bool persist_wave(const PersistArgs& pa, int& ml, int& w) {
+  const int wv = (int)(threadIdx.x >> 6);
+  if (pa.xcd_wg > 0) {
+    const int xcd = (int)(blockIdx.x & 7), pos = (int)(blockIdx.x >> 3);
+    const int mi = pos / pa.xcd_wg, j = pos - mi * pa.xcd_wg;
+    ml = __builtin_amdgcn_readfirstlane(mi * 8 + xcd);
+    w = __builtin_amdgcn_readfirstlane(j * (kPersistThreads / 64) + wv);
+    return ml < pa.nm && w < pa.waves_per_member;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64)) + wv);
+  if (wave >= pa.waves_per_member * pa.nm) return false;
+  ml = wave / pa.waves_per_member;
+  w = wave - ml * pa.waves_per_member;
+  return true;
+}
+
 // lane -> (slot, block, node) of wave w of a member (lane_pos of dfx_kernels.h without the workgroup arithmetic)
 template <int NPB>
 __device__ __forceinline__ LanePos wave_lane_pos(int w, int n_blocks) {
@@ -161,9 +181,8 @@ __device__ __forceinline__ LanePos wave_lane_pos(int w, int n_blocks) {
 #endif
 template <int MODEL, int CONTACT, int NPB>
 __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist(DevCtx c, PersistCoef pc, PersistArgs pa) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
-  if (wave >= pa.waves_per_member * pa.nm) return;
-  const int ml = wave / pa.waves_per_member, w = wave - ml * pa.waves_per_member;
+  int ml, w;
+  if (!persist_wave(pa, ml, w)) return;
   const int m = c.m0 + ml;
   const LanePos lp = wave_lane_pos<NPB>(w, c.n_blocks);
   if (!lp.valid) return;
@@ -359,9 +378,8 @@ __global__ __launch_bounds__(kPersistThreads) DFX_PERSIST_OCC void k_fwd_persist
 //   (k_adj_dense_loop, dfx_persist_dense.hip): the fixed-grid kernels carry none of it.
 template <int MODEL, int CONTACT, int NPB, int DENSE>
 __device__ __forceinline__ void adj_persist_body(const DevCtx& c, const PersistAdjCoef& pc, const PersistArgs& pa, const DenseCtx& dn) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
-  if (wave >= pa.waves_per_member * pa.nm) return;
-  const int ml = wave / pa.waves_per_member, w = wave - ml * pa.waves_per_member;
+  int ml, w;
+  if (!persist_wave(pa, ml, w)) return;
   const int m = c.m0 + ml;
   const LanePos lp = wave_lane_pos<NPB>(w, c.n_blocks);
   if (!lp.valid) return;

@@ -28,6 +28,7 @@ struct PersistArgs {
   int* give_up;                 // pinned host word: != 0 once a wave gave up (1 + the stage ordinal it waited for)
   int n_steps, nm, waves_per_member;
   int spin_limit;               // polls before a wave gives up (kSpinLimit; the test hook dfx_test_set_spin_limit makes it tiny)
+  int xcd_wg;                   // > 0: workgroups per member, every member on ONE XCD (workgroup b sits on XCD b % 8: persist_wave); 0: waves packed densely
 #ifdef DFX_PERSIST_TIMING
   unsigned* dbg;                // diagnostic build: 8 words per wave (six phase sums, total ticks, stages)
 #endif

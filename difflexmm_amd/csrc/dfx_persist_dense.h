@@ -80,10 +80,9 @@ template <int MODEL, int CONTACT>
 // (no occupancy pin: at three workgroups per compute unit the loop spills 44 B per lane into its stage chain, 31.0 against 27.7 ms for the paper
 // workload; 174-182 registers = two workgroups per compute unit = 2 048 waves per launch, wider ensembles follow in further launches)
 __global__ __launch_bounds__(kPersistThreads) void k_adaptive_fwd_loop(DevCtx c, AdaptLoopCoef pc, PersistArgs pa, AdaptLoopArgs aa) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kPersistThreads / 64) + (threadIdx.x >> 6)));
-  if (wave >= pa.waves_per_member * pa.nm) return;
+  int ml, w;
+  if (!persist_wave(pa, ml, w)) return;
   const int W = pa.waves_per_member;
-  const int ml = wave / W, w = wave - ml * W;
   const int m = c.m0 + ml;
   Clock ck = c.clock[m];
   if (ck.state) return;

@@ -319,19 +319,39 @@ bool persist_shape_ok(const dfx_handle* h) {
 static int persist_waves_per_member(const dfx_handle* h, int npb) {
   return npb == 3 ? (h->pl.n_blocks + 19) / 20 : (h->pl.n_slots + 63) / 64;
 }
+static int persist_cap(const void* fn);
 // how many members fit on the chip at once (0: not even one), and the launch shape for `nm` of them
 int persist_members_that_fit(dfx_handle* h, const void* fn, int npb) {
   if (!h->n_cu) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) return 0; h->n_cu = v; }
-  const int wg_slots = persist_wg_slots(fn);
-  int cap = wg_slots ? std::min(8, kPersistSlots / wg_slots) : 0;      // (8 waves per SIMD at most)
-  if (const int occ = persist_wg_per_cu(fn)) cap = std::min(cap, occ);
-  if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
+  const int cap = persist_cap(fn);
   const long long wpm = persist_waves_per_member(h, npb);
   if (cap <= 0 || wpm <= 0) return 0;
   return (int)std::min<long long>(h->pl.batch, ((long long)cap * h->n_cu * 4) / wpm);
 }
-static void persist_shape(const dfx_handle* h, int npb, int nm, int* grid, int* per_cu) {
-  const long long waves = (long long)nm * persist_waves_per_member(h, npb);
+// workgroups of `fn` a compute unit may hold in a persistent launch (registers, the runtime's occupancy, DFX_PERSIST_MAX_WG)
+static int persist_cap(const void* fn) {
+  const int wg_slots = persist_wg_slots(fn);
+  int cap = wg_slots ? std::min(8, kPersistSlots / wg_slots) : 0;      // (8 waves per SIMD at most)
+  if (const int occ = persist_wg_per_cu(fn)) cap = std::min(cap, occ);
+  if (const char* e = getenv("DFX_PERSIST_MAX_WG")) cap = std::min(cap, atoi(e));
+  return cap;
+}
+// the launch shape for `nm` members.  *xcd_wg > 0: every member on one XCD (persist_wave, dfx_persist.h) -- taken where a member's workgroups fit
+// the 32 compute units of an XCD one each and the members fit the launch that way; DFX_PERSIST_XCD=0 keeps the dense packing
+static void persist_shape(const dfx_handle* h, int npb, int nm, int* grid, int* per_cu, const void* fn = nullptr, int* xcd_wg = nullptr) {
+  const long long wpm = persist_waves_per_member(h, npb);
+  if (xcd_wg) {
+    *xcd_wg = 0;
+    const char* e = getenv("DFX_PERSIST_XCD");
+    const int wg = (int)((wpm + 3) / 4), cus = h->n_cu / 8, per_xcd = (nm + 7) / 8, cap = fn ? persist_cap(fn) : 0;
+    if (!(e && e[0] == '0') && h->n_cu % 8 == 0 && wg <= cus && (long long)per_xcd * wg <= (long long)cap * cus) {
+      *xcd_wg = wg;
+      *grid = 8 * per_xcd * wg;
+      *per_cu = std::max(1, (per_xcd * wg + cus - 1) / cus);
+      return;
+    }
+  }
+  const long long waves = (long long)nm * wpm;
   const long long g = (waves + 3) / 4;
   *grid = (int)g;
   *per_cu = (int)std::max<long long>(1, (g + h->n_cu - 1) / h->n_cu);
@@ -468,11 +488,12 @@ static void launch_segment_persist(dfx_handle* h, const DevCtx& c, hipStream_t s
     DevCtx cc = c;
     cc.m0 = c.m0 + off;
     int grid = 0, per_cu = 0;
-    persist_shape(h, npb, cnt, &grid, &per_cu);
+    int xcd_wg = 0;
+    persist_shape(h, npb, cnt, &grid, &per_cu, fn, &xcd_wg);
     dfx_persist::launch_ring_poison(st, ring, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = ring; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.xcd_wg = xcd_wg;
 #ifdef DFX_PERSIST_TIMING
     pa.dbg = ((reverse ? getenv("DFX_TIMING_REVERSE") != nullptr : getenv("DFX_TIMING_REVERSE") == nullptr) && grid <= 8192) ? persist_dbg_buffer() : nullptr;
 #endif
@@ -521,11 +542,12 @@ void launch_adaptive_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, int
     DevCtx cc = c;
     cc.m0 = c.m0 + off;
     int grid = 0, per_cu = 0;
-    persist_shape(h, 4, cnt, &grid, &per_cu);
+    int xcd_wg = 0;
+    persist_shape(h, 4, cnt, &grid, &per_cu, fn, &xcd_wg);
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = max_attempts; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.xcd_wg = xcd_wg;
 #ifdef DFX_PERSIST_TIMING
     pa.dbg = nullptr;
 #endif
@@ -562,11 +584,12 @@ void launch_adj_dense_persist(dfx_handle* h, const DevCtx& c, hipStream_t st, in
     DevCtx cc = c;
     cc.m0 = c.m0 + off;
     int grid = 0, per_cu = 0;
-    persist_shape(h, npb, cnt, &grid, &per_cu);
+    int xcd_wg = 0;
+    persist_shape(h, npb, cnt, &grid, &per_cu, fn, &xcd_wg);
     dfx_persist::launch_ring_poison(st, h->d_ring.p, h->pl.batch, h->pl.n_blocks, cc.m0, cnt, kPos);
     h->launches++;
     PersistArgs pa;
-    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h);
+    pa.ring = h->d_ring.p; pa.give_up = persist_give_up_word(h); pa.n_steps = n_steps; pa.nm = cnt; pa.waves_per_member = h->persist_wpm; pa.spin_limit = persist_spin_limit(h); pa.xcd_wg = xcd_wg;
 #ifdef DFX_PERSIST_TIMING
     pa.dbg = nullptr;
 #endif
@@ -734,10 +757,11 @@ bool seg_overlap_plan(dfx_handle* h, const DevCtx& c) {
   const void* ff = dfx_persist::fwd_kernel(h->pl.model, h->pl.contact, npb);
   const void* fr = dfx_persist::adj_kernel(h->pl.model, h->pl.contact, npb);
   if (h->persist_fwd_members < nm || h->persist_adj_members < nm) return false;       // one launch per segment each
-  int grid = 0, per_cu = 0;
-  persist_shape(h, npb, nm, &grid, &per_cu);
-  if (per_cu * (persist_wg_slots(ff) + persist_wg_slots(fr)) > kPersistSlots) return false;
-  const int of = persist_wg_per_cu(ff), orv = persist_wg_per_cu(fr);
+  int grid = 0, per_cu_f = 0, per_cu_r = 0, xf = 0, xr = 0;
+  persist_shape(h, npb, nm, &grid, &per_cu_f, ff, &xf);
+  persist_shape(h, npb, nm, &grid, &per_cu_r, fr, &xr);
+  if (per_cu_f * persist_wg_slots(ff) + per_cu_r * persist_wg_slots(fr) > kPersistSlots) return false;
+  const int of = persist_wg_per_cu(ff), orv = persist_wg_per_cu(fr), per_cu = std::max(per_cu_f, per_cu_r);
   if ((of && 2 * per_cu > of) || (orv && 2 * per_cu > orv)) return false;       // (occupancy by LDS / scratch: room for both with a margin)
   size_t steps = 0;
   for (const auto& pc : h->pieces) { size_t n = 0; for (int si = pc.first; si <= pc.last; ++si) n += h->segs[si].n_steps; steps = std::max(steps, n); }
