@@ -322,7 +322,7 @@ __device__ __forceinline__ TimeVals constrained_value(const DevCtx& c, int m, co
 // Every lane of a driven or loaded block needs g_f(t) at the stage time of its launch (and, constrained DOFs, at the next stage
 // time for the record it publishes): a dependent load of the function's parameters, a sin / cos pair in software, a second
 // evaluation -- a few hundred instructions and three memory round trips on a handful of lanes.  Invisible when launches fill the
-// chip; 2.8 of the 7.1 us of a launch-bound forward stage (one 128x128 system: profiles/r03_time_function_table.txt), because a
+// chip; 2.8 of the 7.1 us of a launch-bound forward stage (one 128x128 system: profiles/LABNOTES.md, "Time functions tabulated per segment"), because a
 // launch ends with its slowest workgroup.  All those lanes ask for the same numbers, so one small launch per segment computes them
 // for every (step, stage time, function, member) and the stage kernels read them with scalar loads issued at the top of the kernel.
 //   entry (m, j, r, f): 8 doubles = g, dg/dt, dg/dp[0..4], pad;  r = 0 .. s: stage times t_n + c_r h with c_s = 1
